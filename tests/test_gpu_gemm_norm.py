@@ -1,0 +1,87 @@
+"""GPU parity of the GEMM and LayerNorm kernels (through the C-ABI) against plain fp32 torch on the same inputs."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from walkgpt_amd import ops
+
+
+def _ref_act(y, act):
+    if act == ops.ACT_GELU:
+        return torch.nn.functional.gelu(y)
+    if act == ops.ACT_QUICK_GELU:
+        return y * torch.sigmoid(1.702 * y)
+    if act == ops.ACT_RELU:
+        return torch.relu(y)
+    return y
+
+
+@pytest.mark.parametrize("tile", [1, 2])
+def test_gemm_exact_integer_asymmetric(dev, tile):
+    # small integers: every product and partial sum is exact in bf16 x bf16 -> fp32, so the result must be
+    # bit-exact; W is asymmetric so a transposed / permuted fragment map cannot pass.
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 300, 272, 128
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float()
+    w[:, 0] += torch.arange(N).float() % 5
+    ref = a @ w.t()
+    out = ops.linear(a.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out_f32=True, tile=tile)
+    assert torch.equal(out.cpu(), ref)
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(8200, 1024, 1024, 1), (8200, 3072, 1024, 2), (4096, 768, 3072, 2),
+                                        (77, 256, 256, 1), (1, 512, 4096, 1), (1000, 2304, 768, 0)])
+@pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_GELU, ops.ACT_QUICK_GELU, ops.ACT_RELU])
+def test_gemm_epilogues(dev, M, N, K, tile, act):
+    g = torch.Generator().manual_seed(M + N + K + act)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16)
+    r = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    ref = _ref_act(a.float() @ w.float().t() + b.float(), act) + r.float()
+    out = ops.linear(a.to(dev), w.to(dev), b.to(dev), act=act, residual=r.to(dev), tile=tile)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err <= 0.02 * max(1.0, ref.abs().max().item()), err
+    # fp32 output path: only the accumulation order differs
+    out32 = ops.linear(a.to(dev), w.to(dev), b.to(dev), act=act, residual=r.to(dev), out_f32=True, tile=tile)
+    err32 = (out32.cpu() - ref).abs().max().item()
+    assert err32 <= 2e-3, err32
+
+
+def test_gemm_residual_row_modulo_and_strided(dev):
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 512, 128, 192
+    a_full = torch.randn(M, 3 * K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    pos = torch.randn(128, N, generator=g).to(torch.bfloat16)
+    a = a_full[:, K:2 * K]
+    ref = a.float() @ w.float().t() + pos.float().repeat(4, 1)
+    ad = a_full.to(dev)[:, K:2 * K]
+    out = ops.linear(ad, w.to(dev), residual=pos.to(dev), res_row_mod=128, out_f32=True)
+    assert (out.cpu() - ref).abs().max().item() <= 2e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(13, 1, 128), (7, 4, 256), (20, 32, 256), (5, 36, 100)])
+def test_gemm_rowwave_fallback(dev, M, N, K):
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16)
+    ref = torch.relu(a.float() @ w.float().t() + b.float())
+    out = ops.linear(a.to(dev), w.to(dev), b.to(dev), act=ops.ACT_RELU, out_f32=True)
+    assert (out.cpu() - ref).abs().max().item() <= 1e-3
+
+
+@pytest.mark.parametrize("M,D,eps", [(4100, 768, 1e-6), (1025, 1024, 1e-5), (37, 256, 1e-6), (9, 4096, 1e-5),
+                                     (3, 5120, 1e-5), (50, 64, 1e-6)])
+def test_layernorm_rows(dev, M, D, eps):
+    g = torch.Generator().manual_seed(D)
+    x = (torch.randn(M, D, generator=g) * 3 + 1).to(torch.bfloat16)
+    gm = torch.randn(D, generator=g).to(torch.bfloat16)
+    bt = torch.randn(D, generator=g).to(torch.bfloat16)
+    ref = torch.nn.functional.layer_norm(x.float(), (D,), gm.float(), bt.float(), eps)
+    out = ops.layernorm(x.to(dev), gm.to(dev), bt.to(dev), eps)
+    # output is rounded to bf16: half an ulp of the largest value
+    assert (out.float().cpu() - ref).abs().max().item() <= 0.004 * ref.abs().max().item() + 1e-3

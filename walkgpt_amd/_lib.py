@@ -1,0 +1,60 @@
+"""ctypes binding of libwalkgpt_hip.so (the C-ABI declared in include/walkgpt_hip.h).
+
+There is NO fallback: if the shared library is missing or an entry point returns an error, the product path
+raises.  (The CPU oracle lives under oracle/ and is only ever imported by tests, smoke() and bench.py's
+cpu_baseline leg.)"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwalkgpt_hip.so")
+
+c_void_p, c_int, c_long, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
+
+# name -> argtypes; every function returns int (0 ok / negative error) unless listed in _SPECIAL.
+SIGNATURES = {
+    "wg_gemm_bias_act_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_void_p, c_long,
+                              c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "wg_layernorm_rows": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_int,
+                          c_void_p],
+}
+_SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, [])}
+
+
+class WalkgptHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise WalkgptHipError(
+            "libwalkgpt_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `python walkgpt_amd/_build.py`. There is no CPU fallback." % LIB_PATH)
+    h = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(h, name)
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    for name, (res, argtypes) in _SPECIAL.items():
+        fn = getattr(h, name)
+        fn.argtypes = argtypes
+        fn.restype = res
+    _lib = h
+    return h
+
+
+def exported_symbols():
+    return list(SIGNATURES) + list(_SPECIAL)
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().wg_last_error()
+        raise WalkgptHipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))

@@ -1,0 +1,229 @@
+// bf16 GEMM with fused epilogue for gfx950:  C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ R)
+//
+// Replaces every nn.Linear / 1x1-conv / patchify-conv on the hot path (SURVEY.md §8a rows a1,a2,a4,a6,a7,
+// a8,a9,a11,a13,a14): qkv/proj/MLP of the SAM and CLIP blocks, the neck convolutions (after im2row), the
+// MSQP/CTP linears and the mask decoder linears.
+//
+// Design (MI355X_MICROARCH.md / cdna_hip_programming.md §5):
+//   * both operands are K-contiguous ("B^T" form: nn.Linear weights are [N,K]) so A and W tiles are staged
+//     the same way: 64-deep K slabs, 128-byte LDS rows, LDS-DMA (global_load_lds_dwordx4, 1 KiB per
+//     wave-instruction = 8 rows), double-buffered.
+//   * the LDS image is lane-linear (hardware constraint of LDS-DMA), so the bank-conflict swizzle is applied
+//     to the per-lane SOURCE address and undone on the ds_read_b128: 16-byte chunk c of row r lives in slot
+//     c ^ ((r >> 1) & 7).  16 rows x one chunk then cover all 16 slots of the 256-byte bank row.
+//   * MFMA 16x16x32 bf16, operands swapped (W fragment as the A operand) so that each lane ends with four
+//     consecutive N elements of one output row: the epilogue packs them into one 8-byte store and reads
+//     bias / residual with the same shape.
+//   * workgroup -> tile map is XCD-aware: blocks that share an XCD (same id mod 8) walk one contiguous
+//     stripe of the tile grid, so the A row panel and the weight slab are re-read from that XCD's L2.
+#include "wg_common.h"
+
+struct GemmArgs {
+    const bf16* A; long lda;
+    const bf16* W; long ldw;
+    const bf16* bias;
+    const bf16* R; long ldr; int res_mod;
+    void* C; long ldc;
+    int M, N, K;
+    int act;
+    int out_f32;
+    int tiles_m, tiles_n;
+};
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void wg_gemm_kernel(GemmArgs g) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int FI = WTM / 16, FJ = WTN / 16;
+    constexpr int STAGE = (BM + BN) * 128;
+    constexpr int ROWS_PER_ROUND = NT / 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware, bijective remap of the linear block id (cdna_hip_programming.md §5 "XCD swizzle").
+    const int nwg = g.tiles_m * g.tiles_n;
+    int wgid;
+    {
+        const int orig = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tile_m = wgid / g.tiles_n, tile_n = wgid % g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    auto stage = [&](int kt, int buf) {
+        char* ldsA = smem + buf * STAGE;
+        char* ldsW = ldsA + BM * 128;
+        const int k0 = kt * 64;
+#pragma unroll
+        for (int i = 0; i < BM / ROWS_PER_ROUND; ++i) {
+            const int rbase = i * ROWS_PER_ROUND + wave * 8;
+            const int r = rbase + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gr = m0 + r;
+            gr = gr < g.M ? gr : g.M - 1;
+            const bf16* src = g.A + (long)gr * g.lda + k0 + c * 8;
+            __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(src), WG_LDS_PTR(ldsA + rbase * 128), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < BN / ROWS_PER_ROUND; ++i) {
+            const int rbase = i * ROWS_PER_ROUND + wave * 8;
+            const int r = rbase + (lane >> 3);
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            int gr = n0 + r;
+            gr = gr < g.N ? gr : g.N - 1;
+            const bf16* src = g.W + (long)gr * g.ldw + k0 + c * 8;
+            __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(src), WG_LDS_PTR(ldsW + rbase * 128), 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[FI][FJ];
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / 64;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        const char* ldsA = smem + buf * STAGE;
+        const char* ldsW = ldsA + BM * 128;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[FI], wf[FJ];
+            const int c = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const int r = wm * WTM + i * 16 + fr;
+                af[i] = *(const bf16x8*)(ldsA + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                const int r = wn * WTN + j * 16 + fr;
+                wf[j] = *(const bf16x8*)(ldsW + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // Epilogue. acc[i][j][e]: output row m = .. + i*16 + (lane&15), column n = .. + j*16 + (lane>>4)*4 + e.
+#pragma unroll
+    for (int i = 0; i < FI; ++i) {
+        const int m = m0 + wm * WTM + i * 16 + fr;
+        if (m >= g.M) continue;
+        const long rrow = g.R ? (long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr : 0;
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            const int n = n0 + wn * WTN + j * 16 + fq * 4;
+            if (n >= g.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (g.bias) {
+                const bf16x4 b = *(const bf16x4*)(g.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
+            }
+            if (g.act != WG_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = wg_act(v[e], g.act);
+            }
+            if (g.R) {
+                const bf16x4 rr = *(const bf16x4*)(g.R + rrow + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+            }
+            if (g.out_f32) {
+                *(f32x4*)((float*)g.C + (long)m * g.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
+            } else {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+                *(bf16x4*)((bf16*)g.C + (long)m * g.ldc + n) = o;
+            }
+        }
+    }
+}
+
+// Small / ragged shapes (N of 1, 4, 32 ..., K not a multiple of 64): one wave per output row, lanes split K.
+// Used by the gate's 128->1 linear, the IoU head, the hyper-network output layers; never on the FLOP-heavy path.
+__global__ __launch_bounds__(256) void wg_gemm_rowwave_kernel(GemmArgs g) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= g.M) return;
+    const bf16* a = g.A + (long)m * g.lda;
+    const long rrow = g.R ? (long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr : 0;
+    for (int n = 0; n < g.N; ++n) {
+        const bf16* w = g.W + (long)n * g.ldw;
+        float s = 0.f;
+        for (int k = lane; k < g.K; k += 64) s += (float)a[k] * (float)w[k];
+        s = wg_wave_sum(s);
+        if (lane == 0) {
+            if (g.bias) s += (float)g.bias[n];
+            s = wg_act(s, g.act);
+            if (g.R) s += (float)g.R[rrow + n];
+            if (g.out_f32) ((float*)g.C)[(long)m * g.ldc + n] = s;
+            else ((bf16*)g.C)[(long)m * g.ldc + n] = (bf16)s;
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_tile(GemmArgs& g, hipStream_t st) {
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    constexpr int lds = 2 * (BM + BN) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)wg_gemm_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((wg_gemm_kernel<BM, BN, WM, WN>), dim3(g.tiles_m * g.tiles_n), dim3(WM * WN * 64), lds, st, g);
+    return wg_check_launch("wg_gemm_bias_act_bf16");
+}
+
+extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, const void* bias,
+                                     const void* residual, long ldr, int res_row_mod, void* C, long ldc, int M, int N,
+                                     int K, int act, int out_f32, int tile_hint, void* stream) {
+    WG_REQUIRE(A && W && C, "gemm: null operand");
+    WG_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    WG_REQUIRE(act >= 0 && act <= 3, "gemm: bad activation %d", act);
+    WG_REQUIRE(lda >= K && ldw >= K && ldc >= N, "gemm: leading dimension smaller than the row");
+    WG_REQUIRE(!residual || ldr >= N, "gemm: residual leading dimension smaller than N");
+    GemmArgs g;
+    g.A = (const bf16*)A; g.lda = lda; g.W = (const bf16*)W; g.ldw = ldw;
+    g.bias = (const bf16*)bias; g.R = (const bf16*)residual; g.ldr = ldr; g.res_mod = res_row_mod;
+    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act; g.out_f32 = out_f32;
+    g.tiles_m = g.tiles_n = 0;
+    hipStream_t st = (hipStream_t)stream;
+    const bool mfma_ok = (K % 64 == 0) && (N % 4 == 0) && (lda % 8 == 0) && (ldw % 8 == 0) && (ldc % 4 == 0) &&
+                         (!residual || ldr % 4 == 0) && (((uintptr_t)A | (uintptr_t)W) % 16 == 0) &&
+                         ((uintptr_t)C % 16 == 0) && (!bias || (uintptr_t)bias % 8 == 0) &&
+                         (!residual || (uintptr_t)residual % 8 == 0) && N >= 16;
+    if (!mfma_ok || tile_hint == 3) {
+        hipLaunchKernelGGL(wg_gemm_rowwave_kernel, dim3((M + 3) / 4), dim3(256), 0, st, g);
+        return wg_check_launch("wg_gemm_bias_act_bf16(rowwave)");
+    }
+    int tile = tile_hint;
+    if (tile <= 0) {
+        // 256x256 tiles once they fill the chip at least ~1.5 times, else 128x128 (2 blocks per CU).
+        const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+        tile = (t256 >= 384 && N % 256 == 0) ? 2 : 1;
+    }
+    if (tile == 2) return launch_tile<256, 256, 2, 4>(g, st);
+    return launch_tile<128, 128, 2, 2>(g, st);
+}

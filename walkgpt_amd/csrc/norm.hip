@@ -1,0 +1,85 @@
+// Row LayerNorm (bf16 in/out, fp32 statistics), one wave per row.
+//
+// Replaces nn.LayerNorm in the SAM blocks (eps 1e-6, image_encoder.py:177-193 via build_sam.py:73), the CLIP
+// layers (eps 1e-5), MSQP/CTP (utils_walkgpt.py:163-185,302-327), the two-way transformer
+// (transformer.py:151-182) and -- because the build keeps activations channels-last -- LayerNorm2d
+// (common.py:31-43: biased variance over C, eps inside the sqrt), including the neck and the mask-decoder upscaler.
+//
+// HBM-bound: 2 bytes read + 2 bytes written per element.  The row stays in registers between the
+// statistics and the normalisation, loads/stores are 16 bytes per lane.
+#include "wg_common.h"
+
+struct LnArgs {
+    const bf16* x; long ldx;
+    const bf16* gamma; const bf16* beta;
+    bf16* y; long ldy;
+    int M, D;
+    float eps;
+    int act;  // optional activation fused behind the affine (upscaler: LN2d -> GELU)
+};
+
+template <int MAXC>
+__global__ __launch_bounds__(256) void wg_layernorm_kernel(LnArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const bf16* x = a.x + (long)m * a.ldx;
+    float v[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int d = c * 512 + lane * 8;
+        if (d < a.D) {
+            const bf16x8 t = *(const bf16x8*)(x + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[c][e] = (float)t[e]; s += v[c][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+        }
+    }
+    const float mean = wg_wave_sum(s) / (float)a.D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int d = c * 512 + lane * 8;
+        if (d < a.D) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float t = v[c][e] - mean; q += t * t; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wg_wave_sum(q) / (float)a.D + a.eps);
+    bf16* y = a.y + (long)m * a.ldy;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int d = c * 512 + lane * 8;
+        if (d < a.D) {
+            const bf16x8 gm = *(const bf16x8*)(a.gamma + d);
+            const bf16x8 bt = *(const bf16x8*)(a.beta + d);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = (v[c][e] - mean) * rstd * (float)gm[e] + (float)bt[e];
+                if (a.act != WG_ACT_NONE) t = wg_act(t, a.act);
+                o[e] = (bf16)t;
+            }
+            *(bf16x8*)(y + d) = o;
+        }
+    }
+}
+
+extern "C" int wg_layernorm_rows(const void* x, long ldx, const void* gamma, const void* beta, void* y, long ldy,
+                                 int M, int D, float eps, int act, void* stream) {
+    WG_REQUIRE(x && gamma && beta && y, "layernorm: null operand");
+    WG_REQUIRE(M > 0 && D > 0 && D % 8 == 0, "layernorm: D=%d must be a positive multiple of 8", D);
+    WG_REQUIRE(D <= 8192, "layernorm: D=%d exceeds 8192", D);
+    WG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= D && ldy >= D, "layernorm: bad leading dimension");
+    LnArgs a{(const bf16*)x, ldx, (const bf16*)gamma, (const bf16*)beta, (bf16*)y, ldy, M, D, eps, act};
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((M + 3) / 4), block(256);
+    if (D <= 1024) hipLaunchKernelGGL(wg_layernorm_kernel<2>, grid, block, 0, st, a);
+    else if (D <= 2048) hipLaunchKernelGGL(wg_layernorm_kernel<4>, grid, block, 0, st, a);
+    else if (D <= 4096) hipLaunchKernelGGL(wg_layernorm_kernel<8>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(wg_layernorm_kernel<16>, grid, block, 0, st, a);
+    return wg_check_launch("wg_layernorm_rows");
+}

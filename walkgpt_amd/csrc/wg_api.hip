@@ -1,0 +1,25 @@
+// Host-side plumbing of the C-ABI: version, last-error string, launch check.  No allocation, no sync.
+#include <stdarg.h>
+#include <stdio.h>
+#include "wg_common.h"
+
+static thread_local char g_err[512] = "";
+
+void wg_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int wg_check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        wg_set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return WG_ERR_LAUNCH;
+    }
+    return WG_OK;
+}
+
+extern "C" const char* wg_last_error(void) { return g_err; }
+extern "C" int wg_version(void) { return 100; }  // 0.1.0
