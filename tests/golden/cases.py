@@ -1,0 +1,208 @@
+"""Golden-vector case table, shared by make_golden.py (which runs the reference) and by the tests (which run the
+oracle / the HIP path).  Inputs and weights are regenerated from walkgpt_amd/synth.py; only outputs are on disk."""
+import os
+
+import numpy as np
+import torch
+
+from walkgpt_amd import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# --- SAM image encoder ---------------------------------------------------------------------------------------
+# "tiny": 512 px -> 32x32 grid: windowed blocks pad 32 -> 42 (3x3 windows, bias-valued pad keys), global blocks
+#         at S=32.  "vit_b": the real SAM-B geometry (1024 px, 64x64 grid, pad to 70 = 5x5 windows), one image.
+SAM_ENCODERS = {
+    "tiny": dict(img=512, patch=16, embed_dim=128, depth=4, heads=2, global_idx=(1, 3), window=14, out=256,
+                 batch=2, seed=11, tap_blocks=(0, 1, 3)),
+    "tiny_hd32": dict(img=448, patch=16, embed_dim=64, depth=2, heads=2, global_idx=(1,), window=14, out=256,
+                      batch=1, seed=12, tap_blocks=(0, 1)),
+    "vit_b": dict(img=1024, patch=16, embed_dim=768, depth=12, heads=12, global_idx=(2, 5, 8, 11), window=14,
+                  out=256, batch=1, seed=13, tap_blocks=(0, 2, 11)),
+}
+
+
+def sam_encoder_input(c):
+    return torch.from_numpy(synth.normal(c["seed"], "input.images", (c["batch"], 3, c["img"], c["img"])))
+
+
+def sam_encoder_weights(c, prefix="image_encoder."):
+    D, p, g = c["embed_dim"], c["patch"], c["img"] // c["patch"]
+    hd = D // c["heads"]
+    shapes = {"pos_embed": (1, g, g, D), "patch_embed.proj.weight": (D, 3, p, p), "patch_embed.proj.bias": (D,),
+              "neck.0.weight": (c["out"], D, 1, 1), "neck.1.weight": (c["out"],), "neck.1.bias": (c["out"],),
+              "neck.2.weight": (c["out"], c["out"], 3, 3), "neck.3.weight": (c["out"],), "neck.3.bias": (c["out"],)}
+    for i in range(c["depth"]):
+        S = g if i in c["global_idx"] else c["window"]
+        b = "blocks.%d." % i
+        shapes.update({b + "norm1.weight": (D,), b + "norm1.bias": (D,), b + "norm2.weight": (D,), b + "norm2.bias": (D,),
+                       b + "attn.rel_pos_h": (2 * S - 1, hd), b + "attn.rel_pos_w": (2 * S - 1, hd),
+                       b + "attn.qkv.weight": (3 * D, D), b + "attn.qkv.bias": (3 * D,),
+                       b + "attn.proj.weight": (D, D), b + "attn.proj.bias": (D,),
+                       b + "mlp.lin1.weight": (4 * D, D), b + "mlp.lin1.bias": (4 * D,),
+                       b + "mlp.lin2.weight": (D, 4 * D), b + "mlp.lin2.bias": (D,)})
+    return {prefix + k: torch.from_numpy(synth.param(c["seed"], prefix + k, s)) for k, s in shapes.items()}
+
+
+def tap_tokens(h):
+    """[B,H,W,D] block output -> strided slice."""
+    return h[:, ::2, ::2, ::4].contiguous()
+
+
+def tap_embedding(out):
+    """[B,C,h,w] encoder output -> strided slice."""
+    return out[:, ::4, ::2, ::2].contiguous()
+
+
+# --- prompt encoder + mask decoder + postprocess -----------------------------------------------------------------
+DECODERS = {
+    "g32": dict(grid=32, tokens=3, seed=21, input_size=(384, 512), original_size=(75, 111)),
+    "g64": dict(grid=64, tokens=2, seed=22, input_size=(1024, 683), original_size=(448, 299)),
+}
+
+
+def decoder_inputs(c):
+    g = c["grid"]
+    emb = torch.from_numpy(synth.normal(c["seed"], "input.image_embedding", (1, 256, g, g)))
+    text = torch.from_numpy(synth.normal(c["seed"], "input.text_embeds", (c["tokens"], 1, 256)))
+    text = torch.nn.functional.normalize(text, dim=-1)
+    return emb, text
+
+
+def _mlp3_shapes(prefix, din, dh, dout):
+    return {prefix + "layers.0.weight": (dh, din), prefix + "layers.0.bias": (dh,),
+            prefix + "layers.1.weight": (dh, dh), prefix + "layers.1.bias": (dh,),
+            prefix + "layers.2.weight": (dout, dh), prefix + "layers.2.bias": (dout,)}
+
+
+def decoder_weight_shapes():
+    """Hot-path subset of the prompt-encoder + mask-decoder state_dict."""
+    s = {"prompt_encoder.pe_layer.positional_encoding_gaussian_matrix": (2, 128),
+         "prompt_encoder.no_mask_embed.weight": (1, 256),
+         "mask_decoder.iou_token.weight": (1, 256), "mask_decoder.mask_tokens.weight": (4, 256)}
+    T = "mask_decoder.transformer."
+
+    def attn(p, inner):
+        for n in ("q_proj", "k_proj", "v_proj"):
+            s[p + n + ".weight"] = (inner, 256)
+            s[p + n + ".bias"] = (inner,)
+        s[p + "out_proj.weight"] = (256, inner)
+        s[p + "out_proj.bias"] = (256,)
+
+    for i in range(2):
+        L = T + "layers.%d." % i
+        attn(L + "self_attn.", 256)
+        attn(L + "cross_attn_token_to_image.", 128)
+        attn(L + "cross_attn_image_to_token.", 128)
+        for n in ("norm1", "norm2", "norm3", "norm4"):
+            s[L + n + ".weight"] = (256,)
+            s[L + n + ".bias"] = (256,)
+        s[L + "mlp.lin1.weight"] = (2048, 256)
+        s[L + "mlp.lin1.bias"] = (2048,)
+        s[L + "mlp.lin2.weight"] = (256, 2048)
+        s[L + "mlp.lin2.bias"] = (256,)
+    attn(T + "final_attn_token_to_image.", 128)
+    s[T + "norm_final_attn.weight"] = (256,)
+    s[T + "norm_final_attn.bias"] = (256,)
+    s["mask_decoder.output_upscaling.0.weight"] = (256, 64, 2, 2)
+    s["mask_decoder.output_upscaling.0.bias"] = (64,)
+    s["mask_decoder.output_upscaling.1.weight"] = (64,)
+    s["mask_decoder.output_upscaling.1.bias"] = (64,)
+    s["mask_decoder.output_upscaling.3.weight"] = (64, 32, 2, 2)
+    s["mask_decoder.output_upscaling.3.bias"] = (32,)
+    for i in range(4):
+        s.update(_mlp3_shapes("mask_decoder.output_hypernetworks_mlps.%d." % i, 256, 256, 32))
+    s.update(_mlp3_shapes("mask_decoder.iou_prediction_head.", 256, 256, 4))
+    return s
+
+
+def decoder_weights(seed):
+    return {k: torch.from_numpy(synth.param(seed, k, sh)) for k, sh in decoder_weight_shapes().items()}
+
+
+# --- MSQP + CTP ----------------------------------------------------------------------------------------------
+PROJECTORS = {
+    "h64": dict(llama_dim=64, grid=32, batch=2, seed=31, ctp_shape=(3, 5)),
+}
+
+
+def msqp_weight_shapes(llama_dim, d=1024, sam_dim=256):
+    s = {"pad_token": (1, 1, d), "sam_to_proj.weight": (d, sam_dim), "sam_to_proj.bias": (d,),
+         "q_x1": (1, 12, d), "q_x2": (1, 8, d), "q_x4": (1, 8, d), "q_global": (1, 4, d),
+         "gate.net.0.weight": (d,), "gate.net.0.bias": (d,), "gate.net.1.weight": (128, d), "gate.net.1.bias": (128,),
+         "gate.net.3.weight": (1, 128), "gate.net.3.bias": (1,),
+         "to_llama.weight": (llama_dim, d), "to_llama.bias": (llama_dim,)}
+    for c in ("cross_x1", "cross_x2", "cross_x4", "cross_glb"):
+        for i in range(2):
+            p = "%s.%d." % (c, i)
+            s.update({p + "q_norm.weight": (d,), p + "q_norm.bias": (d,), p + "kv_norm.weight": (d,), p + "kv_norm.bias": (d,),
+                      p + "attn.in_proj_weight": (3 * d, d), p + "attn.in_proj_bias": (3 * d,),
+                      p + "attn.out_proj.weight": (d, d), p + "attn.out_proj.bias": (d,),
+                      p + "ffn.0.weight": (d,), p + "ffn.0.bias": (d,), p + "ffn.1.weight": (4 * d, d),
+                      p + "ffn.1.bias": (4 * d,), p + "ffn.3.weight": (d, 4 * d), p + "ffn.3.bias": (d,)})
+    return s
+
+
+def ctp_weight_shapes(in_dim, out_dim=256):
+    mid = out_dim * 2
+    return {"net.0.weight": (in_dim,), "net.0.bias": (in_dim,), "net.1.weight": (mid, in_dim), "net.1.bias": (mid,),
+            "net.3.weight": (out_dim, mid), "net.3.bias": (out_dim,), "net.4.weight": (out_dim,), "net.4.bias": (out_dim,),
+            "text_type": (1, 1, out_dim), "log_temp": (1,)}
+
+
+def projector_weights(c):
+    m = {k: torch.from_numpy(synth.param(c["seed"], "out_mm_projector." + k, s))
+         for k, s in msqp_weight_shapes(c["llama_dim"]).items()}
+    t = {k: torch.from_numpy(synth.param(c["seed"], "text_hidden_fcs.0." + k, s))
+         for k, s in ctp_weight_shapes(c["llama_dim"]).items()}
+    return m, t
+
+
+def projector_inputs(c):
+    g = c["grid"]
+    toks = torch.from_numpy(synth.normal(c["seed"], "input.sam_tokens", (c["batch"], g * g, 256)))
+    hid = torch.from_numpy(synth.normal(c["seed"], "input.hidden", c["ctp_shape"] + (c["llama_dim"],)))
+    return toks, hid
+
+
+# --- CLIP tower (stand-in pin) ---------------------------------------------------------------------------------
+CLIPS = {
+    "tiny": dict(dim=128, heads=2, layers=12, img=112, select_layer=-2, batch=2, seed=41,
+                 clip_resize_list=[(112, 112), (70, 98)]),
+}
+
+
+def clip_weight_shapes(c):
+    D, P = c["dim"], (c["img"] // 14) ** 2
+    s = {"vision_model.embeddings.class_embedding": (D,),
+         "vision_model.embeddings.patch_embedding.weight": (D, 3, 14, 14),
+         "vision_model.embeddings.position_embedding.weight": (P + 1, D),
+         "vision_model.pre_layrnorm.weight": (D,), "vision_model.pre_layrnorm.bias": (D,),
+         "vision_model.post_layernorm.weight": (D,), "vision_model.post_layernorm.bias": (D,)}
+    for i in range(c["layers"]):
+        L = "vision_model.encoder.layers.%d." % i
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            s[L + "self_attn." + n + ".weight"] = (D, D)
+            s[L + "self_attn." + n + ".bias"] = (D,)
+        for n in ("layer_norm1", "layer_norm2"):
+            s[L + n + ".weight"] = (D,)
+            s[L + n + ".bias"] = (D,)
+        s[L + "mlp.fc1.weight"] = (4 * D, D)
+        s[L + "mlp.fc1.bias"] = (4 * D,)
+        s[L + "mlp.fc2.weight"] = (D, 4 * D)
+        s[L + "mlp.fc2.bias"] = (D,)
+    return s
+
+
+def clip_weights(c):
+    return {k: torch.from_numpy(synth.param(c["seed"], k, sh)) for k, sh in clip_weight_shapes(c).items()}
+
+
+def clip_inputs(c):
+    from oracle.clip import patch_key_mask
+    x = torch.from_numpy(synth.normal(c["seed"], "input.images_clip", (c["batch"], 3, c["img"], c["img"])))
+    return x, patch_key_mask(c["batch"], (c["img"], c["img"]), c["clip_resize_list"])
+
+
+def load(name):
+    return dict(np.load(os.path.join(HERE, name + ".npz")))

@@ -1,0 +1,166 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (imported from /root/reference, this
+container only) on synthetic weights/inputs from walkgpt_amd/synth.py.
+
+Only outputs (or strided slices of them) are stored; weights and inputs are regenerated from (seed, key, shape).
+Nothing from the reference -- source, bytecode or weights -- is written into the repo.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py [case ...]
+
+The CLIP case uses transformers (5.15 here) CLIPVisionModel as a stand-in for the pinned 4.31 the reference
+expects (its own wrapper no longer imports); see oracle/clip.py for what that does and does not pin.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+REF = "/root/reference"
+
+from tests.golden import cases  # noqa: E402
+from walkgpt_amd import synth  # noqa: E402
+
+
+def _import_reference():
+    import transformers  # noqa: F401  (must be imported before the torchvision stub is registered)
+    for n in ["torchvision", "torchvision.ops", "torchvision.ops.boxes", "torchvision.transforms",
+              "torchvision.transforms.functional"]:
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules["torchvision.ops.boxes"].batched_nms = None
+    sys.modules["torchvision.ops.boxes"].box_area = None
+    sys.modules["torchvision.transforms.functional"].resize = None
+    sys.modules["torchvision.transforms.functional"].to_pil_image = None
+    sys.path.insert(0, REF)
+    from model.segment_anything import modeling as sam_modeling
+    from utils import utils_walkgpt
+    return sam_modeling, utils_walkgpt
+
+
+def _load(module, seed, prefix):
+    sd = module.state_dict()
+    new = {k: torch.from_numpy(synth.param(seed, prefix + k, tuple(v.shape))) for k, v in sd.items()}
+    module.load_state_dict(new, strict=True)
+    module.eval()
+    return module
+
+
+def make_sam_encoder(name):
+    sam_modeling, _ = _import_reference()
+    c = cases.SAM_ENCODERS[name]
+    from functools import partial
+    enc = sam_modeling.ImageEncoderViT(
+        img_size=c["img"], patch_size=c["patch"], embed_dim=c["embed_dim"], depth=c["depth"], num_heads=c["heads"],
+        mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), qkv_bias=True, use_rel_pos=True,
+        global_attn_indexes=c["global_idx"], window_size=c["window"], out_chans=c["out"])
+    _load(enc, c["seed"], "image_encoder.")
+    x = cases.sam_encoder_input(c)
+    taps = {}
+    with torch.no_grad():
+        h = enc.patch_embed(x) + enc.pos_embed
+        for i, blk in enumerate(enc.blocks):
+            h = blk(h)
+            if i in c["tap_blocks"]:
+                taps["block%d" % i] = cases.tap_tokens(h).numpy()
+        out = enc.neck(h.permute(0, 3, 1, 2))
+        assert torch.equal(out, enc(x))
+    taps["out"] = cases.tap_embedding(out).numpy()
+    taps["out_stats"] = np.array([out.mean().item(), out.std().item(), out.abs().max().item()], np.float64)
+    np.savez_compressed(os.path.join(HERE, "sam_encoder_%s.npz" % name), **taps)
+
+
+def make_decoder(name):
+    sam_modeling, _ = _import_reference()
+    c = cases.DECODERS[name]
+    g = c["grid"]
+    pe = sam_modeling.PromptEncoder(embed_dim=256, image_embedding_size=(g, g), input_image_size=(g * 16, g * 16),
+                                    mask_in_chans=16)
+    dec = sam_modeling.MaskDecoder(num_multimask_outputs=3, transformer=sam_modeling.TwoWayTransformer(
+        depth=2, embedding_dim=256, mlp_dim=2048, num_heads=8), transformer_dim=256, iou_head_depth=3,
+        iou_head_hidden_dim=256)
+    _load(pe, c["seed"], "prompt_encoder.")
+    _load(dec, c["seed"], "mask_decoder.")
+    emb, text = cases.decoder_inputs(c)
+    out = {}
+    with torch.no_grad():
+        sparse, dense = pe(points=None, boxes=None, masks=None, text_embeds=text)
+        dpe = pe.get_dense_pe()
+        masks, iou = dec(image_embeddings=emb, image_pe=dpe, sparse_prompt_embeddings=sparse,
+                         dense_prompt_embeddings=dense, multimask_output=False)
+        # Sam.postprocess_masks (sam.py:137-172) needs a whole Sam object only for image_encoder.img_size
+        holder = types.SimpleNamespace(image_encoder=types.SimpleNamespace(img_size=g * 16))
+        post = sam_modeling.Sam.postprocess_masks(holder, masks, input_size=c["input_size"], original_size=c["original_size"])
+    out["dense_pe"] = dpe[0, ::8].numpy()
+    out["masks"] = masks.numpy()
+    out["iou"] = iou.numpy()
+    out["post"] = post.numpy()
+    np.savez_compressed(os.path.join(HERE, "decoder_%s.npz" % name), **out)
+
+
+def make_projectors(name):
+    _, uw = _import_reference()
+    c = cases.PROJECTORS[name]
+    msqp = uw.MultiScaleQFormerProjector(sam_dim=256, llama_dim=c["llama_dim"], target_square_side=6)
+    ctp = uw.CalibratedTextProjector(in_dim=c["llama_dim"], out_dim=256)
+    _load(msqp, c["seed"], "out_mm_projector.")
+    _load(ctp, c["seed"], "text_hidden_fcs.0.")
+    toks, hid = cases.projector_inputs(c)
+    with torch.no_grad():
+        a = msqp(toks)
+        b = ctp(hid)
+    np.savez_compressed(os.path.join(HERE, "projectors_%s.npz" % name), msqp=a.numpy(), ctp=b.numpy())
+
+
+def make_clip(name):
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    c = cases.CLIPS[name]
+    cfg = CLIPVisionConfig(hidden_size=c["dim"], intermediate_size=4 * c["dim"], num_hidden_layers=c["layers"],
+                           num_attention_heads=c["heads"], image_size=c["img"], patch_size=14, hidden_act="quick_gelu")
+    cfg._attn_implementation = "eager"
+    model = CLIPVisionModel(cfg).eval()
+    vm = model.vision_model if hasattr(model, "vision_model") else model
+    w = cases.clip_weights(c)  # `vision_model.*` names, position table already at the run size
+    sd = vm.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if k.endswith("position_ids"):
+            new[k] = v
+            continue
+        new[k] = w["vision_model." + k].reshape(v.shape)
+    vm.load_state_dict(new, strict=True)
+    x, key_mask = cases.clip_inputs(c)
+    bias = ((1.0 - key_mask) * torch.finfo(torch.float32).min)[:, None, None, :]
+    with torch.no_grad():
+        h = vm.pre_layrnorm(vm.embeddings(x))
+        states = [h]
+        for layer in vm.encoder.layers:
+            h = layer(h, attention_mask=bias)
+            if isinstance(h, tuple):
+                h = h[0]
+            states.append(h)
+    np.savez_compressed(os.path.join(HERE, "clip_%s.npz" % name),
+                        sel=states[c["select_layer"]][:, 1:].numpy(), pre=states[-11][:, 1:].numpy(),
+                        emb=states[0].numpy())
+
+
+ALL = {
+    "sam_encoder": (make_sam_encoder, cases.SAM_ENCODERS),
+    "decoder": (make_decoder, cases.DECODERS),
+    "projectors": (make_projectors, cases.PROJECTORS),
+    "clip": (make_clip, cases.CLIPS),
+}
+
+if __name__ == "__main__":
+    want = sys.argv[1:]
+    torch.set_num_threads(8)
+    for kind, (fn, table) in ALL.items():
+        for name in table:
+            tag = "%s:%s" % (kind, name)
+            if want and tag not in want and kind not in want:
+                continue
+            print("generating", tag, flush=True)
+            fn(name)

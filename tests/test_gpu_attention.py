@@ -1,0 +1,117 @@
+"""GPU parity of the fused attention kernels (through the C-ABI) against fp32 references built from the oracle's
+own pieces (oracle.sam.rel_pos_bias) on the same bf16-rounded inputs."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sam as osam
+from walkgpt_amd import ops
+
+
+def _rand(shape, seed, std=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * std).to(torch.bfloat16)
+
+
+def _ref_mha(q, k, v, heads, scale, key_bias=None):
+    B, Lq, D = q.shape
+    hd = D // heads
+    sp = lambda t: t.float().reshape(B, -1, heads, hd).transpose(1, 2)
+    a = (sp(q) @ sp(k).transpose(2, 3)) * scale
+    if key_bias is not None:
+        a = a + key_bias[:, None, None, :]
+    return (a.softmax(-1) @ sp(v)).transpose(1, 2).reshape(B, Lq, D)
+
+
+def _ref_sam_attention(qkv, bias, rel_h, rel_w, B, grid, window, heads):
+    """image_encoder.py:177-193 + 235-260 on an already-projected qkv buffer: zero-padded positions carry q=k=v=bias."""
+    D = qkv.shape[-1] // 3
+    hd = D // heads
+    x = qkv.float().reshape(B, grid, grid, 3 * D)
+    pad = (-grid) % window
+    Hp = grid + pad
+    full = bias.float().reshape(1, 1, 1, 3 * D).repeat(B, Hp, Hp, 1)
+    full[:, :grid, :grid] = x
+    nw = Hp // window
+    w = full.reshape(B, nw, window, nw, window, 3 * D).permute(0, 1, 3, 2, 4, 5).reshape(-1, window * window, 3, heads, hd)
+    w = w.permute(2, 0, 3, 1, 4)
+    q, k, v = [t.reshape(-1, window * window, hd) for t in w]
+    logits = (q * hd ** -0.5) @ k.transpose(1, 2) + osam.rel_pos_bias(q, rel_h.float(), rel_w.float(), window)
+    o = logits.softmax(-1) @ v
+    o = o.reshape(B * nw * nw, heads, window, window, hd).permute(0, 2, 3, 1, 4).reshape(B, nw, nw, window, window, D)
+    o = o.permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Hp, D)[:, :grid, :grid]
+    return o.reshape(B * grid * grid, D)
+
+
+@pytest.mark.parametrize("B,grid,window,heads,hd", [
+    (2, 64, 14, 3, 64),   # SAM windows: 64 -> 70 padding, bias-valued pad keys
+    (1, 64, 64, 2, 64),   # SAM global attention (row-tile rel-pos path)
+    (2, 32, 14, 2, 64),   # tiny golden geometry: 32 -> 42
+    (2, 32, 32, 2, 64),
+    (1, 28, 14, 2, 32),   # hd 32, no padding
+    (1, 28, 28, 2, 32),
+])
+def test_sam_attention_relpos(dev, B, grid, window, heads, hd):
+    D = heads * hd
+    qkv = _rand((B * grid * grid, 3 * D), 1)
+    bias = _rand((3 * D,), 2, 0.5)
+    rel_h = _rand((2 * window - 1, hd), 3, 0.2)
+    rel_w = _rand((2 * window - 1, hd), 4, 0.2)
+    ref = _ref_sam_attention(qkv, bias, rel_h, rel_w, B, grid, window, heads)
+    out = ops.sam_attention(qkv.to(dev), bias.to(dev), rel_h.to(dev), rel_w.to(dev), B, grid, window, heads)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < 0.03, err
+
+
+@pytest.mark.parametrize("B,Lq,Lk,heads,hd,masked", [
+    (2, 1025, 1025, 4, 64, True),    # CLIP ViT-L geometry (fewer heads), key-padding mask
+    (1, 1025, 1025, 2, 64, False),
+    (2, 65, 65, 2, 64, True),        # tiny CLIP golden geometry
+    (2, 300, 77, 2, 128, False),
+    (1, 200, 1000, 2, 32, False),
+])
+def test_mha_plain_and_keymask(dev, B, Lq, Lk, heads, hd, masked):
+    D = heads * hd
+    q, k, v = _rand((B, Lq, D), 5), _rand((B, Lk, D), 6), _rand((B, Lk, D), 7)
+    kb = None
+    if masked:
+        keep = (torch.rand(B, Lk, generator=torch.Generator().manual_seed(8)) > 0.3).float()
+        keep[:, 0] = 1
+        kb = (1 - keep) * torch.finfo(torch.float32).min
+    ref = _ref_mha(q, k, v, heads, hd ** -0.5, kb)
+    out = ops.mha(q.to(dev), k.to(dev), v.to(dev), heads, hd ** -0.5, None if kb is None else kb.to(dev), small=False)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < 0.03, err
+
+
+def test_mha_packed_qkv_views(dev):
+    # q/k/v as column slices of one packed [B, L, 3D] buffer (CLIP layout)
+    B, L, heads, hd = 2, 130, 2, 64
+    D = heads * hd
+    qkv = _rand((B, L, 3 * D), 9)
+    ref = _ref_mha(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], heads, 0.125)
+    d = qkv.to(dev)
+    out = ops.mha(d[..., :D], d[..., D:2 * D], d[..., 2 * D:], heads, 0.125, small=False)
+    assert (out.float().cpu() - ref).abs().max().item() < 0.03
+
+
+@pytest.mark.parametrize("B,Lq,Lk,heads,hd", [
+    (3, 7, 4096, 8, 16),    # mask decoder token -> image
+    (3, 4096, 7, 8, 16),    # image -> token
+    (3, 7, 7, 8, 32),       # token self-attention
+    (2, 12, 4096, 8, 128),  # MSQP x1 scale
+    (2, 4, 1, 8, 128),      # MSQP global token
+    (2, 8, 256, 8, 128),
+    (1, 5, 100, 2, 64),
+])
+def test_mha_small(dev, B, Lq, Lk, heads, hd):
+    D = heads * hd
+    q, k, v = _rand((B, Lq, D), 10), _rand((B, Lk, D), 11), _rand((B, Lk, D), 12)
+    scale = 1.0 / math.sqrt(hd)
+    ref = _ref_mha(q, k, v, heads, scale)
+    out = ops.mha(q.to(dev), k.to(dev), v.to(dev), heads, scale, small=True)
+    assert (out.float().cpu() - ref).abs().max().item() < 0.03

@@ -1,0 +1,95 @@
+"""GPU parity of the layout / elementwise kernels against torch fp32 (exact where the op is data movement)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sam as osam
+from walkgpt_amd import ops
+
+
+def _rand(shape, seed, std=1.0, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * std).to(dtype)
+
+
+@pytest.mark.parametrize("B,C,H,P", [(2, 3, 64, 16), (1, 3, 1024, 16), (2, 3, 112, 14), (1, 3, 448, 14)])
+def test_patchify_matches_unfold(dev, B, C, H, P):
+    img = _rand((B, C, H, H), 1)
+    K = C * P * P
+    rows = ops.patchify(img.to(dev), P).cpu()
+    ref = F.unfold(img.float(), P, stride=P).transpose(1, 2).reshape(-1, K).to(torch.bfloat16)
+    assert torch.equal(rows[:, :K], ref)
+    assert rows.shape[1] % 64 == 0 and (rows[:, K:] == 0).all()
+
+
+def test_patchify_gemm_equals_conv(dev):
+    img = _rand((2, 3, 64, 64), 2)
+    w = _rand((128, 3, 16, 16), 3, 0.05)
+    b = _rand((128,), 4, 0.1)
+    ref = F.conv2d(img.float(), w.float(), b.float(), stride=16).permute(0, 2, 3, 1).reshape(-1, 128)
+    out = ops.linear(ops.patchify(img.to(dev), 16), w.reshape(128, -1).to(dev), b.to(dev), out_f32=True)
+    assert (out.cpu() - ref).abs().max().item() < 2e-3
+
+
+def test_im2row3x3_gemm_equals_conv(dev):
+    B, H, C, O = 2, 16, 64, 32
+    x = _rand((B, H, H, C), 5)
+    w = _rand((O, C, 3, 3), 6, 0.05)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float(), padding=1).permute(0, 2, 3, 1).reshape(-1, O)
+    rows = ops.im2row3x3(x.to(dev), B, H, H)
+    wr = w.permute(0, 2, 3, 1).reshape(O, 9 * C).contiguous()
+    out = ops.linear(rows, wr.to(dev), out_f32=True)
+    assert (out.cpu() - ref).abs().max().item() < 2e-3
+
+
+def test_add_rows_broadcast(dev):
+    a = _rand((3, 50, 256), 7)
+    b = _rand((50, 256), 8)
+    out = ops.add_rows(a.to(dev), b.to(dev)).cpu()
+    assert torch.equal(out, (a.float() + b.float()).to(torch.bfloat16))
+
+
+def test_layout_transposes_roundtrip(dev):
+    x = _rand((2, 100, 48), 9)
+    y = ops.tokens_to_nchw(x.to(dev), 2, 100, 48)
+    assert torch.equal(y.cpu(), x.transpose(1, 2).contiguous())
+    assert torch.equal(ops.nchw_to_tokens(y).cpu(), x)
+
+
+def test_dense_pe_matches_oracle(dev):
+    G = _rand((2, 128), 10, 1.0, torch.float32)
+    ref = osam.dense_pe({"prompt_encoder.pe_layer.positional_encoding_gaussian_matrix": G}, (64, 64))
+    pe = ops.dense_pe_tokens(G.to(dev), 64, 64).cpu()
+    assert (pe - ref[0].flatten(1).t()).abs().max().item() < 2e-4
+
+
+def test_hyper_mask_dot_pixel_shuffle(dev):
+    # build `up` by running the two transposed convs in torch, then re-lay it the way the GEMMs emit it
+    T, h, w = 2, 8, 8
+    x = _rand((T, 64, 2 * h, 2 * w), 11)                       # after the first ConvT + LN + GELU (NCHW)
+    w2 = _rand((64, 32, 2, 2), 12, 0.1)
+    b2 = _rand((32,), 13, 0.1)
+    up_ref = F.gelu(F.conv_transpose2d(x.float(), w2.float(), b2.float(), stride=2))   # [T,32,4h,4w]
+    hyper = _rand((T, 4, 32), 14)
+    ref = (hyper.float() @ up_ref.flatten(2)).reshape(T, 4, 4 * h, 4 * w)
+    # rows = t, y, x, (dy,dx); cols = (dy2,dx2), c
+    u = up_ref.reshape(T, 32, h, 2, 2, w, 2, 2)                # t c y dy dy2 x dx dx2
+    u = u.permute(0, 2, 5, 3, 6, 4, 7, 1).reshape(T * h * w * 4, 4 * 32).to(torch.bfloat16)
+    out = ops.hyper_mask_dot(u.to(dev), hyper.to(dev), T, h, w, 0, 4).cpu()
+    assert (out - ref).abs().max().item() < 0.05 * ref.abs().max().item()
+    one = ops.hyper_mask_dot(u.to(dev), hyper.to(dev), T, h, w, 2, 1).cpu()
+    assert torch.equal(one[:, 0], out[:, 2])
+
+
+@pytest.mark.parametrize("lh,img,inp,orig", [(128, 512, (384, 512), (75, 111)), (256, 1024, (1024, 683), (448, 299)),
+                                             (256, 1024, (1024, 1024), (448, 448)), (256, 1024, (768, 1024), (1080, 1440))])
+def test_postprocess_and_score(dev, lh, img, inp, orig):
+    m = _rand((3, 1, lh, lh), 15, 4.0, torch.float32)
+    ref = osam.postprocess_masks(m, img, inp, orig)
+    out = ops.postprocess_masks(m.to(dev), img, inp, orig)
+    # fp32 both sides; the tolerance covers a different (but equally valid) association of the 4-tap blends
+    assert (out.cpu() - ref).abs().max().item() < 2e-5 * ref.abs().max().item() + 1e-5
+    sc = ops.mask_score(out[:, 0].contiguous()).cpu()
+    assert torch.allclose(sc, osam.mask_score(ref[:, 0]), atol=1e-5)

@@ -1,0 +1,119 @@
+"""The oracle (CPU fp32 restatement) against golden vectors produced by the reference's own modules
+(tests/golden/make_golden.py).  Runs without a GPU."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import clip as oclip
+from oracle import projectors as oproj
+from oracle import sam as osam
+from tests.golden import cases
+
+
+def _close(a, b, tol):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b).max()
+    assert err <= tol * max(1.0, np.abs(b).max()), "max abs err %g (ref max %g)" % (err, np.abs(b).max())
+
+
+def _encoder_cfg(c):
+    return dict(patch=c["patch"], depth=c["depth"], heads=c["heads"], global_idx=c["global_idx"], window=c["window"])
+
+
+def _run_encoder_with_taps(w, x, c):
+    """Same composition as oracle.sam.image_encoder, tapping the block outputs the fixture holds."""
+    import torch.nn.functional as F
+    p = "image_encoder"
+    h = F.conv2d(x, w[p + ".patch_embed.proj.weight"], w[p + ".patch_embed.proj.bias"], stride=c["patch"]).permute(0, 2, 3, 1)
+    h = h + w[p + ".pos_embed"]
+    taps = {}
+    for i in range(c["depth"]):
+        h = osam.vit_block(w, "%s.blocks.%d" % (p, i), h, c["heads"], 0 if i in c["global_idx"] else c["window"])
+        if i in c["tap_blocks"]:
+            taps["block%d" % i] = cases.tap_tokens(h)
+    return taps
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_hd32", "vit_b"])
+def test_sam_encoder_matches_reference(name):
+    c = cases.SAM_ENCODERS[name]
+    gold = cases.load("sam_encoder_" + name)
+    w = cases.sam_encoder_weights(c)
+    x = cases.sam_encoder_input(c)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        out = osam.image_encoder(w, x, _encoder_cfg(c))
+        if name != "vit_b":
+            for k, v in _run_encoder_with_taps(w, x, c).items():
+                _close(v.numpy(), gold[k], 2e-5)
+    _close(cases.tap_embedding(out).numpy(), gold["out"], 5e-5)
+    stats = np.array([out.mean().item(), out.std().item(), out.abs().max().item()])
+    assert np.allclose(stats, gold["out_stats"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["g32", "g64"])
+def test_prompt_decoder_postprocess_match_reference(name):
+    c = cases.DECODERS[name]
+    gold = cases.load("decoder_" + name)
+    w = cases.decoder_weights(c["seed"])
+    emb, text = cases.decoder_inputs(c)
+    g = c["grid"]
+    with torch.no_grad():
+        dpe = osam.dense_pe(w, (g, g))
+        sparse, dense = osam.prompt_encoder_text(w, text, (g, g))
+        masks, iou = osam.mask_decoder(w, emb, dpe, sparse, dense)
+        post = osam.postprocess_masks(masks, g * 16, c["input_size"], c["original_size"])
+    _close(dpe[0, ::8].numpy(), gold["dense_pe"], 1e-5)
+    _close(masks.numpy(), gold["masks"], 5e-5)
+    _close(iou.numpy(), gold["iou"], 5e-5)
+    _close(post.numpy(), gold["post"], 5e-5)
+
+
+def test_projectors_match_reference():
+    c = cases.PROJECTORS["h64"]
+    gold = cases.load("projectors_h64")
+    wm, wt = cases.projector_weights(c)
+    toks, hid = cases.projector_inputs(c)
+    with torch.no_grad():
+        a = oproj.msqp(wm, toks)
+        b = oproj.ctp(wt, hid)
+    _close(a.numpy(), gold["msqp"], 5e-5)
+    _close(b.numpy(), gold["ctp"], 1e-5)
+    assert np.allclose(np.linalg.norm(b.numpy(), axis=-1), np.exp(wt["log_temp"].item()), rtol=1e-5)
+
+
+def test_clip_blocks_match_transformers_standin():
+    c = cases.CLIPS["tiny"]
+    gold = cases.load("clip_tiny")
+    w = cases.clip_weights(c)
+    x, key_mask = cases.clip_inputs(c)
+    with torch.no_grad():
+        hs = oclip.clip_hidden_states(w, x, key_mask, heads=c["heads"], layers=c["layers"])
+        sel, pre = oclip.clip_tower(w, x, key_mask, c["select_layer"], heads=c["heads"], layers=c["layers"])
+    _close(hs[0].numpy(), gold["emb"], 1e-5)
+    _close(sel.numpy(), gold["sel"], 5e-5)
+    _close(pre[0].numpy(), gold["pre"], 5e-5)
+
+
+def test_clip_wrapper_quirks():
+    # resize_position_table keeps the reference's row bookkeeping: last row carried over, rest interpolated
+    t = torch.arange(17 * 4, dtype=torch.float32).reshape(17, 4)
+    r = oclip.resize_position_table(t, 8)
+    assert r.shape == (65, 4)
+    assert torch.equal(r[-1], t[-1])
+    expect = torch.nn.functional.interpolate(t[:-1].t().reshape(1, 4, 4, 4), (8, 8), mode="bilinear", align_corners=False)
+    assert torch.allclose(r[:-1], expect[0].flatten(1).t())
+    m = oclip.patch_key_mask(2, (112, 112), [(112, 112), (70, 98)])
+    assert m.shape == (2, 65) and m[0].all() and m[1, 0] == 1
+    grid = m[1, 1:].reshape(8, 8)
+    assert grid[:5, :7].all() and not grid[5:].any() and not grid[:, 7:].any()
+
+
+def test_resample_tokens_matches_torch():
+    x = torch.from_numpy(np.random.RandomState(0).randn(2, 36, 8).astype(np.float32))
+    y = oproj.resample_tokens(x)
+    assert y.shape == (2, 256, 8)
+    # corners are preserved by align_corners=False bilinear at the 4 extreme cells (clamped)
+    assert torch.allclose(y[:, 0], x[:, 0]) and torch.allclose(y[:, -1], x[:, -1])

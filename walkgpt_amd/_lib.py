@@ -17,6 +17,22 @@ SIGNATURES = {
                               c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_layernorm_rows": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_int,
                           c_void_p],
+    "wg_mha_bf16": [c_void_p, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_void_p, c_long, c_long,
+                    c_void_p, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "wg_mha_small_bf16": [c_void_p, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_void_p, c_long,
+                          c_long, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "wg_sam_attn_relpos_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                c_float, c_void_p],
+    "wg_patchify_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "wg_im2row3x3_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "wg_add_rows_bf16": [c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_long, c_int, c_void_p],
+    "wg_tokens_to_nchw_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "wg_nchw_to_tokens_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "wg_dense_pe_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "wg_cast_f32_to_bf16": [c_void_p, c_void_p, c_long, c_void_p],
+    "wg_hyper_mask_dot": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "wg_postprocess_masks_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "wg_mask_score_f32": [c_void_p, c_void_p, c_int, c_long, c_void_p],
 }
 _SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, [])}
 

@@ -1,0 +1,431 @@
+// Fused multi-head attention for gfx950 (flash style: the score matrix never leaves registers).
+//
+// One kernel template, three users on the hot path:
+//   S == 0  "plain"  : CLIP ViT-L/14 self-attention, 1025 keys + additive key-padding mask
+//                      (custom_clip.py:27-38,50-104; HF CLIPAttention), MSQP cross-attention.
+//   S == 14 "window" : SAM 14x14 windowed attention incl. decomposed rel-pos and the 64->70 zero padding whose
+//                      pad tokens carry q=k=v=qkv-bias and take part in the softmax as keys
+//                      (image_encoder.py:177-193, 235-260, 263-318, 321-392).
+//   S == grid side   : SAM global attention (4096 keys at S=64) with decomposed rel-pos.
+// window_partition / window_unpartition are pure address arithmetic here (no copies): keys and queries are fetched
+// from / written to their natural [B*H*W, 3D] / [B*H*W, D] rows.
+//
+// Structure per workgroup: NW waves, each owning 32 query rows; K/V tiles of 64 keys are staged into LDS by
+// LDS-DMA (double-buffered, one barrier per tile) and shared by all waves.
+//   S^T = K . Q^T   (mfma 32x32x16, K fragment = A operand)  -> each lane holds 32 scores of ONE query column,
+//                    so the running max / sum / rescale are per-lane scalars (no cross-lane traffic except one
+//                    exchange with lane^32).
+//   O^T += V^T . P^T (P^T is the S^T accumulator converted to bf16 in place: "accumulator as the next MFMA's
+//                    B operand", k order permuted; the matching V^T fragment is read with ds_read_b64_tr_b16.)
+//   rel-pos: T^T = Rel . Q^T by MFMA (table rows straight from global as the A operand), scattered into a
+//            per-wave key-space table relh[q][kh], relw[q][kw] in LDS (pre-multiplied by log2 e); the main loop adds
+//            relh[q][k / S] + relw[q][k % S].  For S == 64 a key tile is exactly one grid row: relw lives in 32
+//            registers and relh costs one LDS read per tile.
+// LDS swizzles (source-side, undone on the read): K rows for ds_read_b128, V rows for the transposed read.
+#include "wg_common.h"
+
+#define LOG2E 1.4426950408889634f
+#define NEG_BIG (-1.0e30f)
+
+struct AttnArgs {
+    const bf16* Q; const bf16* K; const bf16* V; bf16* O;
+    long ldq, ldk, ldv, ldo;     // row strides (elements)
+    long q_bs, k_bs, o_bs;       // rows per batch item (plain mode)
+    const bf16* padK; const bf16* padV;  // grid mode: bias rows used for zero-padded window positions
+    const bf16* rel_h; const bf16* rel_w;  // [2S-1, HD]
+    const float* key_bias;       // plain mode: [B, Lk] additive, may be null
+    int B, heads, Lq, Lk;
+    int Hg;                      // grid mode: tokens per image side
+    int nW;                      // windows per side
+    int qchunks;                 // workgroups per (batch, window, head)
+    float scale;
+};
+
+template <int HD> __device__ __forceinline__ int swzK(int row) {
+    if (HD == 128) return row & 15;
+    if (HD == 64) return (row >> 1) & 7;
+    return (row >> 2) & 3;  // HD == 32
+}
+template <int HD> __device__ __forceinline__ int swzV(int row) {
+    if (HD == 128) return (row & 3) << 2;
+    if (HD == 64) return ((row >> 1) & 1) << 2;
+    return 0;
+}
+
+template <int HD, int S, int NW>
+__global__ __launch_bounds__(NW * 64) void wg_attn_kernel(AttnArgs a) {
+    constexpr int CPR = HD / 8;            // 16-byte chunks per K/V row
+    constexpr int ROWB = HD * 2;           // bytes per row
+    constexpr int TILE = 64 * ROWB;        // bytes per K (or V) tile
+    constexpr int KSTEPS = HD / 16;
+    constexpr int DB = HD / 32;
+    constexpr bool GRID = (S > 0);
+    constexpr int SS = GRID ? S * S : 0;
+    constexpr int SP = S + 1;              // padded table row (fp32 words)
+    constexpr bool ROWTILE = (S == 64);    // a 64-key tile is one grid row
+    constexpr int NTAB = GRID ? (ROWTILE ? 1 : 2) : 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* kv = smem;                                  // [2 buffers][K tile | V tile]
+    float* tab = (float*)(smem + 4 * TILE);           // grid: per-wave rel tables; plain: key bias row
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql_lane = lane & 31, hi = lane >> 5;
+
+    // ---- decode the block id -> (batch, window, head, q chunk) ------------------------------------------------
+    int bid = blockIdx.x;
+    const int groups = a.B * (GRID ? a.nW * a.nW : 1) * a.heads;  // (batch, window, head) triples
+    int grp, qc;
+    if (a.qchunks > 1 && (groups & 7) == 0) {
+        // XCD-aware: the 8 XCDs work on 8 different triples, all q chunks of a triple stay on one XCD's L2
+        const int per = 8 * a.qchunks;
+        const int blk = bid / per, rem = bid % per;
+        grp = blk * 8 + (rem & 7);
+        qc = rem >> 3;
+    } else {
+        grp = bid / a.qchunks;
+        qc = bid % a.qchunks;
+    }
+    const int head = grp % a.heads;
+    const int bw = grp / a.heads;
+    int b, wy = 0, wx = 0;
+    if (GRID) {
+        const int nw2 = a.nW * a.nW;
+        b = bw / nw2;
+        const int wi = bw % nw2;
+        wy = wi / a.nW;
+        wx = wi % a.nW;
+    } else {
+        b = bw;
+    }
+    const int Lq = GRID ? SS : a.Lq;
+    const int Lk = GRID ? SS : a.Lk;
+    const int hcol = head * HD;
+
+    // ---- this lane's query ---------------------------------------------------------------------------------------
+    const int ql_raw = (qc * NW + wave) * 32 + ql_lane;
+    const int ql = ql_raw < Lq ? ql_raw : Lq - 1;
+    long qrow;
+    bool qvalid = ql_raw < Lq;
+    int qh = 0, qw = 0;
+    if (GRID) {
+        qh = ql / S;
+        qw = ql % S;
+        const int gy = wy * S + qh, gx = wx * S + qw;
+        const bool inside = gy < a.Hg && gx < a.Hg;
+        qvalid = qvalid && inside;
+        qrow = (long)b * a.Hg * a.Hg + (inside ? gy * a.Hg + gx : 0);
+    } else {
+        qrow = (long)b * a.q_bs + ql;
+    }
+    bf16x8 qf[KSTEPS];
+    {
+        const bf16* qp = a.Q + qrow * a.ldq + hcol + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
+    }
+
+    // ---- K/V staging (LDS-DMA, swizzle on the source address) -----------------------------------------------
+    auto stage = [&](int t, int buf) {
+        char* kbuf = kv + buf * 2 * TILE;
+        char* vbuf = kbuf + TILE;
+        constexpr int NINST = TILE / 1024;  // wave-instructions per tile
+        for (int i = wave; i < 2 * NINST; i += NW) {
+            const bool isV = i >= NINST;
+            const int ii = isV ? i - NINST : i;
+            const int ci = ii * 64 + lane;
+            const int row = ci / CPR;
+            const int cs = ci % CPR;
+            const int c = cs ^ (isV ? swzV<HD>(row) : swzK<HD>(row));
+            int kl = t * 64 + row;
+            kl = kl < Lk ? kl : Lk - 1;
+            const bf16* src;
+            if (GRID) {
+                const int kh = kl / S, kw = kl % S;
+                const int gy = wy * S + kh, gx = wx * S + kw;
+                if (gy < a.Hg && gx < a.Hg) {
+                    const long r = (long)b * a.Hg * a.Hg + gy * a.Hg + gx;
+                    src = (isV ? a.V + r * a.ldv : a.K + r * a.ldk) + hcol + c * 8;
+                } else {
+                    src = (isV ? a.padV : a.padK) + hcol + c * 8;
+                }
+            } else {
+                const long r = (long)b * a.k_bs + kl;
+                src = (isV ? a.V + r * a.ldv : a.K + r * a.ldk) + hcol + c * 8;
+            }
+            __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(src), WG_LDS_PTR((isV ? vbuf : kbuf) + ii * 1024), 16, 0, 0);
+        }
+    };
+
+    const int nt = (Lk + 63) / 64;
+    stage(0, 0);
+
+    // ---- rel-pos tables (grid) / key bias row (plain) -----------------------------------------------------------
+    float relw_reg[ROWTILE ? 32 : 1];
+    float* mytab = tab + wave * 32 * SP * NTAB;
+    if constexpr (GRID) {
+        constexpr int NJB = (2 * S - 1 + 31) / 32;
+        // which == 0: width table (for S == 64 it is consumed into registers, then the slot is reused for height)
+        for (int which = 0; which < 2; ++which) {
+            const bf16* rel = which == 0 ? a.rel_w : a.rel_h;
+            float* dst = ROWTILE ? mytab : mytab + (which == 0 ? 32 * SP : 0);
+            const int qpos = which == 0 ? qw : qh;
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb) {
+                int j = jb * 32 + ql_lane;
+                j = j < 2 * S - 1 ? j : 2 * S - 2;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) {
+                    const bf16x8 rf = *(const bf16x8*)(rel + (long)j * HD + 16 * s + 8 * hi);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf, qf[s], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jj = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // table row held in acc[r]
+                    const int kpos = qpos + S - 1 - jj;                        // key coordinate it belongs to
+                    if (jj < 2 * S - 1 && kpos >= 0 && kpos < S) dst[ql_lane * SP + kpos] = acc[r] * LOG2E;
+                }
+            }
+            if (ROWTILE && which == 0) {
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < 32; ++r) {
+                    const int kw = (r & 3) + 8 * ((r & 15) >> 2) + 4 * hi + 32 * (r >> 4);
+                    relw_reg[r] = dst[ql_lane * SP + kw];
+                }
+                __syncthreads();
+            }
+        }
+    } else {
+        if (a.key_bias) {
+            for (int k = tid; k < nt * 64; k += NW * 64) {
+                float v = k < Lk ? a.key_bias[(long)b * Lk + k] * LOG2E : NEG_BIG;
+                tab[k] = fmaxf(v, NEG_BIG);
+            }
+        }
+    }
+    const float* relh_tab = mytab + ql_lane * SP;
+    const float* relw_tab = mytab + 32 * SP + ql_lane * SP;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // ---- main loop ---------------------------------------------------------------------------------------------------
+    f32x16 ot[DB];
+#pragma unroll
+    for (int d = 0; d < DB; ++d)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+    float m_run = NEG_BIG, l_run = 0.f;
+    const float sc2 = a.scale * LOG2E;
+
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < nt) stage(t + 1, buf ^ 1);
+        const char* kbuf = kv + buf * 2 * TILE;
+        const char* vbuf = kbuf + TILE;
+
+        // S^T (two 32-key blocks)
+        f32x16 st[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
+            const int row = kb * 32 + ql_lane;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                const int c = (2 * s + hi) ^ swzK<HD>(row);
+                const bf16x8 kf = *(const bf16x8*)(kbuf + row * ROWB + c * 16);
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kb], 0, 0, 0);
+            }
+        }
+
+        // scores in the exp2 domain + bias + masking
+        float rowh = 0.f;
+        if constexpr (ROWTILE) rowh = relh_tab[t];
+        float mt = NEG_BIG;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kin = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // key index inside the tile
+                float v = st[kb][r] * sc2;
+                if constexpr (ROWTILE) {
+                    v += relw_reg[kb * 16 + r] + rowh;
+                } else if constexpr (GRID) {
+                    int kl = t * 64 + kin;
+                    kl = kl < SS ? kl : SS - 1;
+                    v += relh_tab[kl / S] + relw_tab[kl % S];
+                } else {
+                    if (a.key_bias) v += tab[t * 64 + kin];
+                }
+                if (t * 64 + kin >= Lk) v = NEG_BIG;
+                st[kb][r] = v;
+                mt = fmaxf(mt, v);
+            }
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = exp2f(m_run - m_new);
+        m_run = m_new;
+        float ls = 0.f;
+        bf16x8 pf[4];  // P^T fragments: k-step (kb, s2) uses registers 8*s2 .. 8*s2+7 of block kb
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(st[kb][r] - m_new);
+                ls += p;
+                pf[kb * 2 + (r >> 3)][r & 7] = (bf16)p;
+            }
+        }
+        l_run = l_run * alpha + ls;
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+
+        // O^T += V^T . P^T
+        {
+            const int g = lane >> 4;           // 16-lane group
+            const int i16 = lane & 15;
+            const int rq = i16 >> 2, cp = i16 & 3;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {   // 16 keys per step: keys 16*ks + {4hi..4hi+3, 8+4hi..8+4hi+3}
+#pragma unroll
+                for (int d = 0; d < DB; ++d) {
+                    const int col = 32 * d + 16 * (g & 1) + 4 * cp;  // first of this lane's 4 d-columns
+                    const int chunk = col >> 3;
+                    const int within = (col & 7) * 2;
+                    const int key0 = 16 * ks + 4 * hi + rq;
+                    const int key1 = key0 + 8;
+                    const char* p0 = vbuf + key0 * ROWB + ((chunk ^ swzV<HD>(key0)) << 4) + within;
+                    const char* p1 = vbuf + key1 * ROWB + ((chunk ^ swzV<HD>(key1)) << 4) + within;
+                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
+                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+                    ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], ot[d], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: O = O^T / l, 8-byte stores ---------------------------------------------------------------------------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (qvalid) {
+        const float inv = 1.0f / l_tot;
+        long orow;
+        if (GRID) orow = qrow;
+        else orow = (long)b * a.o_bs + ql;
+        bf16* op = a.O + orow * a.ldo + hcol;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (bf16)(ot[d][g4 * 4 + e] * inv);
+                *(bf16x4*)(op + 32 * d + 8 * g4 + 4 * hi) = o;
+            }
+        }
+    }
+}
+
+template <int HD, int S, int NW>
+static int launch_attn(const AttnArgs& a, int groups, hipStream_t st) {
+    constexpr int TILE = 64 * HD * 2;
+    constexpr bool ROWTILE = (S == 64);
+    size_t lds = 4 * TILE;
+    if (S > 0) lds += (size_t)NW * 32 * (S + 1) * 4 * (ROWTILE ? 1 : 2);
+    else lds += (size_t)((a.Lk + 63) / 64) * 64 * 4;
+    if (lds > 160 * 1024) {
+        wg_set_error("attention: LDS request %zu exceeds 160 KiB", lds);
+        return WG_ERR_UNSUPPORTED;
+    }
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)wg_attn_kernel<HD, S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((wg_attn_kernel<HD, S, NW>), dim3(groups * a.qchunks), dim3(NW * 64), lds, st, a);
+    return wg_check_launch("wg_attn");
+}
+
+// Plain multi-head attention (optionally cross attention, optionally with an additive per-key bias).
+// Q rows: (b*q_rows_per_batch + i), head h at columns [h*hd, (h+1)*hd); same for K, V, O.
+extern "C" int wg_mha_bf16(const void* Q, long ldq, long q_rows_per_batch, const void* K, long ldk, const void* V, long ldv,
+                           long k_rows_per_batch, void* O, long ldo, long o_rows_per_batch, const float* key_bias,
+                           int B, int heads, int head_dim, int Lq, int Lk, float scale, void* stream) {
+    WG_REQUIRE(Q && K && V && O, "mha: null operand");
+    WG_REQUIRE(B > 0 && heads > 0 && Lq > 0 && Lk > 0, "mha: bad shape");
+    WG_REQUIRE(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0, "mha: leading dimensions must be multiples of 8");
+    WG_REQUIRE((((uintptr_t)Q | (uintptr_t)K | (uintptr_t)V) & 15) == 0 && ((uintptr_t)O & 7) == 0, "mha: misaligned operand");
+    AttnArgs a{};
+    a.Q = (const bf16*)Q; a.K = (const bf16*)K; a.V = (const bf16*)V; a.O = (bf16*)O;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo;
+    a.q_bs = q_rows_per_batch; a.k_bs = k_rows_per_batch; a.o_bs = o_rows_per_batch;
+    a.key_bias = key_bias; a.B = B; a.heads = heads; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = B * heads;
+    if (Lq > 512) {
+        a.qchunks = (Lq + 255) / 256;
+        if (head_dim == 64) return launch_attn<64, 0, 8>(a, groups, st);
+        if (head_dim == 128) return launch_attn<128, 0, 8>(a, groups, st);
+        if (head_dim == 32) return launch_attn<32, 0, 8>(a, groups, st);
+    } else if (Lq > 32) {
+        a.qchunks = (Lq + 127) / 128;
+        if (head_dim == 64) return launch_attn<64, 0, 4>(a, groups, st);
+        if (head_dim == 128) return launch_attn<128, 0, 4>(a, groups, st);
+        if (head_dim == 32) return launch_attn<32, 0, 4>(a, groups, st);
+    } else {
+        a.qchunks = 1;
+        if (head_dim == 64) return launch_attn<64, 0, 1>(a, groups, st);
+        if (head_dim == 128) return launch_attn<128, 0, 1>(a, groups, st);
+        if (head_dim == 32) return launch_attn<32, 0, 1>(a, groups, st);
+    }
+    wg_set_error("mha: head_dim %d not supported (32, 64, 128)", head_dim);
+    return WG_ERR_UNSUPPORTED;
+}
+
+// SAM ViT attention over a packed qkv buffer [B*Hg*Hg, 3*D] (q | k | v, heads contiguous inside each third).
+// window == Hg: global attention; window < Hg: non-overlapping windows with zero padding to a multiple of
+// `window`, pad positions acting as keys/values equal to qkv_bias (their outputs are dropped).
+extern "C" int wg_sam_attn_relpos_bf16(const void* qkv, const void* qkv_bias, const void* rel_pos_h, const void* rel_pos_w,
+                                       void* out, int B, int grid, int window, int heads, int head_dim, float scale,
+                                       void* stream) {
+    WG_REQUIRE(qkv && qkv_bias && rel_pos_h && rel_pos_w && out, "sam_attn: null operand");
+    WG_REQUIRE(B > 0 && grid > 0 && window > 0 && window <= grid && heads > 0, "sam_attn: bad shape");
+    const long D = (long)heads * head_dim;
+    WG_REQUIRE((((uintptr_t)qkv | (uintptr_t)qkv_bias | (uintptr_t)rel_pos_h | (uintptr_t)rel_pos_w) & 15) == 0 &&
+                   ((uintptr_t)out & 7) == 0, "sam_attn: misaligned operand");
+    AttnArgs a{};
+    const bf16* base = (const bf16*)qkv;
+    a.Q = base; a.K = base + D; a.V = base + 2 * D; a.O = (bf16*)out;
+    a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
+    a.padK = (const bf16*)qkv_bias + D; a.padV = (const bf16*)qkv_bias + 2 * D;
+    a.rel_h = (const bf16*)rel_pos_h; a.rel_w = (const bf16*)rel_pos_w;
+    a.B = B; a.heads = heads; a.Hg = grid; a.nW = (grid + window - 1) / window; a.scale = scale;
+    hipStream_t st = (hipStream_t)stream;
+    const int groups = B * a.nW * a.nW * heads;
+    const int qblocks = (window * window + 31) / 32;
+#define WG_SAM_CASE(HD_, S_, NW_)                                  \
+    if (head_dim == HD_ && window == S_) {                         \
+        a.qchunks = (qblocks + NW_ - 1) / NW_;                     \
+        return launch_attn<HD_, S_, NW_>(a, groups, st);           \
+    }
+    WG_SAM_CASE(64, 14, 7)
+    WG_SAM_CASE(64, 64, 8)
+    WG_SAM_CASE(64, 32, 8)
+    WG_SAM_CASE(32, 14, 7)
+    WG_SAM_CASE(32, 28, 5)
+#undef WG_SAM_CASE
+    wg_set_error("sam_attn: (head_dim %d, window %d) has no compiled kernel", head_dim, window);
+    return WG_ERR_UNSUPPORTED;
+}

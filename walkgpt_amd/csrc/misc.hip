@@ -1,0 +1,337 @@
+// HBM-bound data-layout and elementwise kernels of the hot path (no GEMM shape -> no MFMA): patch gathering,
+// 3x3 im2row, broadcast adds, layout transposes, the dense positional encoding, the hyper-network mask product,
+// the fused double-bilinear mask post-processing and the mask score.
+#include "wg_common.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// Patch gather ("im2row" of a stride == kernel conv): images NCHW bf16 -> rows [B*gh*gw, Kpad], column order
+// (c, ky, kx) = the flattened Conv2d weight [D, C, P, P] (PatchEmbed image_encoder.py:422-426; CLIP patch conv).
+// Columns >= C*P*P (CLIP: 588 -> 640) are zero so the GEMM can run 64-deep K slabs.
+// One thread produces 8 consecutive columns (16-byte store); for P % 8 == 0 they come from one 16-byte load.
+// ------------------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void wg_patchify_kernel(const bf16* img, bf16* rows, int B, int C, int H, int W, int P,
+                                                          int Kpad) {
+    const int gh = H / P, gw = W / P;
+    const int cpr = Kpad / 8;
+    const long total = (long)B * gh * gw * cpr;
+    const int K = C * P * P;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr);
+        const long r = i / cpr;
+        const int px = (int)(r % gw), py = (int)((r / gw) % gh), b = (int)(r / ((long)gw * gh));
+        bf16x8 v;
+        const int k0 = ch * 8;
+        if (VEC) {
+            if (k0 < K) {
+                const int c = k0 / (P * P), ky = (k0 / P) % P, kx = k0 % P;
+                v = *(const bf16x8*)(img + (((long)b * C + c) * H + py * P + ky) * W + px * P + kx);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + e;
+                if (k < K) {
+                    const int c = k / (P * P), ky = (k / P) % P, kx = k % P;
+                    v[e] = img[(((long)b * C + c) * H + py * P + ky) * W + px * P + kx];
+                } else {
+                    v[e] = (bf16)0.f;
+                }
+            }
+        }
+        *(bf16x8*)(rows + r * Kpad + k0) = v;
+    }
+}
+
+extern "C" int wg_patchify_bf16(const void* images, void* rows, int B, int C, int H, int W, int P, int Kpad, void* stream) {
+    WG_REQUIRE(images && rows, "patchify: null operand");
+    WG_REQUIRE(B > 0 && C > 0 && P > 0 && H % P == 0 && W % P == 0, "patchify: image %dx%d not a multiple of patch %d", H, W, P);
+    WG_REQUIRE(Kpad % 8 == 0 && Kpad >= C * P * P, "patchify: Kpad=%d too small or not a multiple of 8", Kpad);
+    const long total = (long)B * (H / P) * (W / P) * (Kpad / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    const bool vec = (P % 8 == 0) && (W % 8 == 0) && (((uintptr_t)images & 15) == 0);
+    if (vec) hipLaunchKernelGGL(wg_patchify_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)images, (bf16*)rows, B, C, H, W, P, Kpad);
+    else hipLaunchKernelGGL(wg_patchify_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)images, (bf16*)rows, B, C, H, W, P, Kpad);
+    return wg_check_launch("wg_patchify_bf16");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 / pad 1 im2row on channels-last tokens: x [B, H, W, C] -> rows [B*H*W, 9*C], column order (ky, kx, c);
+// the neck's second conv (image_encoder.py:99-106) then is one GEMM against the weight re-laid as [O, (ky,kx,c)].
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wg_im2row3x3_kernel(const bf16* x, bf16* rows, int B, int H, int W, int C) {
+    const int cpr = 9 * C / 8;
+    const int cpc = C / 8;
+    const long total = (long)B * H * W * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpr);
+        const long r = i / cpr;
+        const int xx = (int)(r % W), yy = (int)((r / W) % H), b = (int)(r / ((long)W * H));
+        const int tap = ch / cpc, c0 = (ch % cpc) * 8;
+        const int sy = yy + tap / 3 - 1, sx = xx + tap % 3 - 1;
+        bf16x8 v;
+        if (sy >= 0 && sy < H && sx >= 0 && sx < W) {
+            v = *(const bf16x8*)(x + (((long)b * H + sy) * W + sx) * C + c0);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16)0.f;
+        }
+        *(bf16x8*)(rows + r * 9 * C + ch * 8) = v;
+    }
+}
+
+extern "C" int wg_im2row3x3_bf16(const void* x, void* rows, int B, int H, int W, int C, void* stream) {
+    WG_REQUIRE(x && rows && B > 0 && H > 0 && W > 0 && C % 8 == 0, "im2row3x3: bad arguments");
+    const long total = (long)B * H * W * (9 * C / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(wg_im2row3x3_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (bf16*)rows, B, H, W, C);
+    return wg_check_launch("wg_im2row3x3_bf16");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// out[r, :] = a[r, :] + b[r % b_rows, :]    (queries + query_pe, keys + key_pe, src + no_mask_embed, cls + pos ...)
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wg_add_rows_kernel(const bf16* a, long lda, const bf16* b, long ldb, int b_rows,
+                                                          bf16* out, long ldo, long rows, int cols) {
+    const int cpr = cols / 8;
+    const long total = rows * cpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cpr;
+        const int c = (int)(i % cpr) * 8;
+        const bf16x8 x = *(const bf16x8*)(a + r * lda + c);
+        const bf16x8 y = *(const bf16x8*)(b + (r % b_rows) * ldb + c);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)x[e] + (float)y[e]);
+        *(bf16x8*)(out + r * ldo + c) = o;
+    }
+}
+
+extern "C" int wg_add_rows_bf16(const void* a, long lda, const void* b, long ldb, int b_rows, void* out, long ldo, long rows,
+                                int cols, void* stream) {
+    WG_REQUIRE(a && b && out && rows > 0 && cols > 0 && cols % 8 == 0 && b_rows > 0, "add_rows: bad arguments");
+    WG_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && ldo % 8 == 0, "add_rows: leading dimensions must be multiples of 8");
+    const long total = rows * (cols / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(wg_add_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)a, lda, (const bf16*)b, ldb,
+                       b_rows, (bf16*)out, ldo, rows, cols);
+    return wg_check_launch("wg_add_rows_bf16");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Channels-last tokens [B, HW, C] -> NCHW [B, C, HW] (the [B,256,64,64] embedding the reference API returns).
+// 32x32 tiles through LDS so both sides are coalesced.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wg_tokens_to_nchw_kernel(const bf16* x, bf16* y, int HW, int C) {
+    __shared__ bf16 tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int k = ty; k < 32; k += 8) {
+        const int t = t0 + k, c = c0 + tx;
+        tile[k][tx] = (t < HW && c < C) ? x[((long)b * HW + t) * C + c] : (bf16)0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, t = t0 + tx;
+        if (t < HW && c < C) y[((long)b * C + c) * HW + t] = tile[tx][k];
+    }
+}
+
+extern "C" int wg_tokens_to_nchw_bf16(const void* x, void* y, int B, int HW, int C, void* stream) {
+    WG_REQUIRE(x && y && B > 0 && HW > 0 && C > 0, "tokens_to_nchw: bad arguments");
+    hipLaunchKernelGGL(wg_tokens_to_nchw_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, (bf16*)y, HW, C);
+    return wg_check_launch("wg_tokens_to_nchw_bf16");
+}
+
+__global__ __launch_bounds__(256) void wg_nchw_to_tokens_kernel(const bf16* x, bf16* y, int HW, int C) {
+    __shared__ bf16 tile[32][33];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int k = ty; k < 32; k += 8) {
+        const int c = c0 + k, t = t0 + tx;
+        tile[k][tx] = (t < HW && c < C) ? x[((long)b * C + c) * HW + t] : (bf16)0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int t = t0 + k, c = c0 + tx;
+        if (t < HW && c < C) y[((long)b * HW + t) * C + c] = tile[tx][k];
+    }
+}
+
+extern "C" int wg_nchw_to_tokens_bf16(const void* x, void* y, int B, int HW, int C, void* stream) {
+    WG_REQUIRE(x && y && B > 0 && HW > 0 && C > 0, "nchw_to_tokens: bad arguments");
+    hipLaunchKernelGGL(wg_nchw_to_tokens_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16*)x, (bf16*)y, HW, C);
+    return wg_check_launch("wg_nchw_to_tokens_bf16");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Dense positional encoding as token rows (prompt_encoder.py:203-229): pe[y*w+x, :] = [sin | cos](2 pi ((2c-1) @ G)),
+// c = ((x+0.5)/w, (y+0.5)/h), G = positional_encoding_gaussian_matrix [2, F] (fp32 buffer).  Input independent:
+// computed once per model.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wg_dense_pe_kernel(const float* G, float* pe, int h, int w, int F) {
+    const long total = (long)h * w * F;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int f = (int)(i % F);
+        const int t = (int)(i / F);
+        const int x = t % w, y = t / w;
+        const float cx = 2.0f * ((x + 0.5f) / w) - 1.0f, cy = 2.0f * ((y + 0.5f) / h) - 1.0f;
+        const float v = 6.283185307179586f * (cx * G[f] + cy * G[F + f]);
+        pe[(long)t * 2 * F + f] = sinf(v);
+        pe[(long)t * 2 * F + F + f] = cosf(v);
+    }
+}
+
+extern "C" int wg_dense_pe_f32(const float* gaussian, float* pe_tokens, int h, int w, int num_feats, void* stream) {
+    WG_REQUIRE(gaussian && pe_tokens && h > 0 && w > 0 && num_feats > 0, "dense_pe: bad arguments");
+    const long total = (long)h * w * num_feats;
+    hipLaunchKernelGGL(wg_dense_pe_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gaussian,
+                       pe_tokens, h, w, num_feats);
+    return wg_check_launch("wg_dense_pe_f32");
+}
+
+__global__ __launch_bounds__(256) void wg_cast_f32_bf16_kernel(const float* x, bf16* y, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = (bf16)x[i];
+}
+extern "C" int wg_cast_f32_to_bf16(const float* x, void* y, long n, void* stream) {
+    WG_REQUIRE(x && y && n > 0, "cast: bad arguments");
+    const int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wg_cast_f32_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (bf16*)y, n);
+    return wg_check_launch("wg_cast_f32_to_bf16");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Hyper-network mask product (mask_decoder.py:150-160): masks[t, k, Y, X] = sum_c hyper[t, k, c] * up[t, c, Y, X].
+// `up` arrives as the pixel-shuffled output of the two transposed-conv GEMMs:
+//   rows  = t*h*w*4 + (y*w + x)*4 + (dy*2 + dx)        (first ConvT sub-pixel)
+//   cols  = (dy2*2 + dx2)*Cu + c                        (second ConvT sub-pixel, Cu = 32 channels)
+// and lands at Y = 4y + 2dy + dy2, X = 4x + 2dx + dx2.  One thread per (row, second sub-pixel): a 32-long dot.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wg_hyper_mask_kernel(const bf16* up, const bf16* hyper, float* masks, int T, int h,
+                                                            int w, int Cu, int nmask_total, int k0, int nk) {
+    const long total = (long)T * h * w * 4 * 4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int sub2 = (int)(i & 3);
+        const long row = i >> 2;
+        const int sub1 = (int)(row & 3);
+        const long pix = row >> 2;
+        const int x = (int)(pix % w), y = (int)((pix / w) % h), t = (int)(pix / ((long)w * h));
+        const int Y = 4 * y + 2 * (sub1 >> 1) + (sub2 >> 1), X = 4 * x + 2 * (sub1 & 1) + (sub2 & 1);
+        const bf16* u = up + row * (4 * Cu) + sub2 * Cu;
+        float uf[32];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const bf16x8 v = *(const bf16x8*)(u + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) uf[8 * c + e] = (float)v[e];
+        }
+        for (int k = 0; k < nk; ++k) {
+            const bf16* hp = hyper + ((long)t * nmask_total + k0 + k) * Cu;
+            float s = 0.f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) s += uf[c] * (float)hp[c];
+            masks[(((long)t * nk + k) * (4 * h) + Y) * (4 * w) + X] = s;
+        }
+    }
+}
+
+extern "C" int wg_hyper_mask_dot(const void* up, const void* hyper, float* masks, int T, int h, int w, int channels,
+                                 int nmask_total, int first_mask, int num_masks, void* stream) {
+    WG_REQUIRE(up && hyper && masks && T > 0 && h > 0 && w > 0, "hyper_mask_dot: bad arguments");
+    WG_REQUIRE(channels == 32, "hyper_mask_dot: %d channels (only 32 = transformer_dim/8 compiled)", channels);
+    WG_REQUIRE(first_mask >= 0 && num_masks > 0 && first_mask + num_masks <= nmask_total, "hyper_mask_dot: bad mask slice");
+    const long total = (long)T * h * w * 16;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(wg_hyper_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)up, (const bf16*)hyper,
+                       masks, T, h, w, channels, nmask_total, first_mask, num_masks);
+    return wg_check_launch("wg_hyper_mask_dot");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Sam.postprocess_masks (sam.py:137-172) as ONE pass: bilinear low-res -> img_size^2, crop to (in_h, in_w), bilinear
+// -> (out_h, out_w); the img_size^2 intermediate (4 MB / mask) is never materialised: each output pixel evaluates
+// its 4 taps of the second resample, each of which evaluates 4 taps of the first.  PyTorch's align_corners=False
+// source-index rule is reproduced exactly: src = max(scale*(dst+0.5)-0.5, 0), i0 = floor, i1 = i0 + (i0 < in-1).
+// Algorithmic bytes: read N*lh*lw*4, write N*out_h*out_w*4.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wg_src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
+    // separate roundings (no FMA contraction) so the source index and weight match PyTorch's CPU kernel bit for bit
+    float s = __fsub_rn(__fmul_rn(scale, (float)dst + 0.5f), 0.5f);
+    s = s < 0.f ? 0.f : s;
+    i0 = (int)s;
+    i0 = i0 < in_size - 1 ? i0 : in_size - 1;
+    i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+    l1 = s - (float)i0;
+}
+
+__device__ __forceinline__ float wg_up1(const float* m, int lh, int lw, int img, float sc_y, float sc_x, int yy, int xx) {
+    int y0, y1, x0, x1;
+    float ly, lx;
+    wg_src_index(yy, sc_y, lh, y0, y1, ly);
+    wg_src_index(xx, sc_x, lw, x0, x1, lx);
+    const float a = m[y0 * lw + x0], b = m[y0 * lw + x1], c = m[y1 * lw + x0], d = m[y1 * lw + x1];
+    return __fadd_rn(__fmul_rn(1.f - ly, __fadd_rn(__fmul_rn(1.f - lx, a), __fmul_rn(lx, b))),
+                     __fmul_rn(ly, __fadd_rn(__fmul_rn(1.f - lx, c), __fmul_rn(lx, d))));
+}
+
+__global__ __launch_bounds__(256) void wg_postprocess_kernel(const float* low, float* out, int N, int lh, int lw, int img,
+                                                             int in_h, int in_w, int out_h, int out_w) {
+    const long total = (long)N * out_h * out_w;
+    const float s1y = (float)lh / (float)img, s1x = (float)lw / (float)img;
+    const float s2y = (float)in_h / (float)out_h, s2x = (float)in_w / (float)out_w;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % out_w), oy = (int)((i / out_w) % out_h), n = (int)(i / ((long)out_w * out_h));
+        const float* m = low + (long)n * lh * lw;
+        int y0, y1, x0, x1;
+        float ly, lx;
+        wg_src_index(oy, s2y, in_h, y0, y1, ly);
+        wg_src_index(ox, s2x, in_w, x0, x1, lx);
+        const float a = wg_up1(m, lh, lw, img, s1y, s1x, y0, x0), b = wg_up1(m, lh, lw, img, s1y, s1x, y0, x1);
+        const float c = wg_up1(m, lh, lw, img, s1y, s1x, y1, x0), d = wg_up1(m, lh, lw, img, s1y, s1x, y1, x1);
+        out[i] = __fadd_rn(__fmul_rn(1.f - ly, __fadd_rn(__fmul_rn(1.f - lx, a), __fmul_rn(lx, b))),
+                           __fmul_rn(ly, __fadd_rn(__fmul_rn(1.f - lx, c), __fmul_rn(lx, d))));
+    }
+}
+
+extern "C" int wg_postprocess_masks_f32(const float* low_res, float* out, int N, int low_h, int low_w, int img_size,
+                                        int in_h, int in_w, int out_h, int out_w, void* stream) {
+    WG_REQUIRE(low_res && out && N > 0 && low_h > 0 && low_w > 0 && img_size > 0, "postprocess: bad arguments");
+    WG_REQUIRE(in_h > 0 && in_w > 0 && in_h <= img_size && in_w <= img_size && out_h > 0 && out_w > 0,
+               "postprocess: crop (%d,%d) must lie inside the %d^2 padded image", in_h, in_w, img_size);
+    const long total = (long)N * out_h * out_w;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(wg_postprocess_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, low_res, out, N, low_h, low_w,
+                       img_size, in_h, in_w, out_h, out_w);
+    return wg_check_launch("wg_postprocess_masks_f32");
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Mask score (walkgpt.py:540-542, :737): sum(sigmoid(x) [x>0]) / (count[x>0] + 1e-6) per mask.  One block per mask.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wg_mask_score_kernel(const float* masks, float* score, long hw) {
+    __shared__ float ssum[4], scnt[4];
+    const float* m = masks + (long)blockIdx.x * hw;
+    float s = 0.f, c = 0.f;
+    for (long i = threadIdx.x; i < hw; i += 256) {
+        const float x = m[i];
+        if (x > 0.f) { s += 1.0f / (1.0f + __expf(-x)); c += 1.f; }
+    }
+    s = wg_wave_sum(s);
+    c = wg_wave_sum(c);
+    if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; scnt[threadIdx.x >> 6] = c; }
+    __syncthreads();
+    if (threadIdx.x == 0) score[blockIdx.x] = (ssum[0] + ssum[1] + ssum[2] + ssum[3]) / (scnt[0] + scnt[1] + scnt[2] + scnt[3] + 1e-6f);
+}
+
+extern "C" int wg_mask_score_f32(const float* masks, float* score, int N, long hw, void* stream) {
+    WG_REQUIRE(masks && score && N > 0 && hw > 0, "mask_score: bad arguments");
+    hipLaunchKernelGGL(wg_mask_score_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, masks, score, hw);
+    return wg_check_launch("wg_mask_score_f32");
+}

@@ -69,3 +69,164 @@ def layernorm(x, gamma, beta, eps, act=ACT_NONE, out=None):
                                       float(eps), act, _stream())
     _lib.check(rc, "wg_layernorm_rows")
     return out
+
+
+def _rows_per_batch(t):
+    """[B, L, D] (contiguous rows, possibly a column slice of a wider buffer) -> (B, L, ld, rows per batch)."""
+    assert t.dim() == 3 and t.stride(2) == 1
+    B, L, _ = t.shape
+    ld = t.stride(1)
+    assert t.stride(0) % ld == 0 or B == 1
+    return B, L, ld, (t.stride(0) // ld if B > 1 else L)
+
+
+def mha(q, k, v, heads, scale, key_bias=None, out=None, small=None):
+    """softmax(scale * q k^T + key_bias) v per head.  q [B,Lq,D], k/v [B,Lk,D] (bf16, may be column slices of a
+    packed buffer); key_bias [B,Lk] fp32 additive or None.  `small` forces / forbids the one-wave-per-query kernel."""
+    _need_gpu(q, k, v, key_bias, out)
+    B, Lq, ldq, qbs = _rows_per_batch(q)
+    _, Lk, ldk, kbs = _rows_per_batch(k)
+    _, _, ldv, vbs = _rows_per_batch(v)
+    assert kbs == vbs
+    D = q.shape[2]
+    hd = D // heads
+    if out is None:
+        out = torch.empty(B, Lq, D, device=q.device, dtype=_BF16)
+    _, _, ldo, obs = _rows_per_batch(out)
+    if small is None:
+        small = hd < 32 or Lq <= 32 or Lk <= 32
+    if small:
+        assert key_bias is None
+        rc = _lib.lib().wg_mha_small_bf16(q.data_ptr(), ldq, qbs, k.data_ptr(), ldk, v.data_ptr(), ldv, kbs,
+                                          out.data_ptr(), ldo, obs, B, heads, hd, Lq, Lk, float(scale), _stream())
+        _lib.check(rc, "wg_mha_small_bf16")
+    else:
+        if key_bias is not None:
+            assert key_bias.dtype == torch.float32 and key_bias.is_contiguous() and key_bias.shape == (B, Lk)
+        rc = _lib.lib().wg_mha_bf16(q.data_ptr(), ldq, qbs, k.data_ptr(), ldk, v.data_ptr(), ldv, kbs, out.data_ptr(),
+                                    ldo, obs, _ptr(key_bias), B, heads, hd, Lq, Lk, float(scale), _stream())
+        _lib.check(rc, "wg_mha_bf16")
+    return out
+
+
+def sam_attention(qkv, qkv_bias, rel_pos_h, rel_pos_w, B, grid, window, heads, out=None):
+    """SAM ViT attention over packed qkv rows [B*grid*grid, 3D]; window == grid means global attention."""
+    _need_gpu(qkv, qkv_bias, rel_pos_h, rel_pos_w, out)
+    D = qkv.shape[-1] // 3
+    hd = D // heads
+    assert qkv.is_contiguous() and qkv.shape[0] == B * grid * grid and qkv.dtype == _BF16
+    assert rel_pos_h.shape == (2 * window - 1, hd) and rel_pos_h.is_contiguous() and rel_pos_w.is_contiguous()
+    if out is None:
+        out = torch.empty(B * grid * grid, D, device=qkv.device, dtype=_BF16)
+    rc = _lib.lib().wg_sam_attn_relpos_bf16(qkv.data_ptr(), qkv_bias.data_ptr(), rel_pos_h.data_ptr(),
+                                            rel_pos_w.data_ptr(), out.data_ptr(), B, grid, window, heads, hd,
+                                            float(hd) ** -0.5, _stream())
+    _lib.check(rc, "wg_sam_attn_relpos_bf16")
+    return out
+
+
+def patchify(images, patch, kpad=None):
+    """NCHW bf16 images -> [B*gh*gw, kpad] rows in conv-weight column order, zero padded to kpad columns."""
+    _need_gpu(images)
+    assert images.dtype == _BF16 and images.is_contiguous()
+    B, C, H, W = images.shape
+    K = C * patch * patch
+    kpad = kpad or ((K + 63) // 64) * 64
+    rows = torch.empty(B * (H // patch) * (W // patch), kpad, device=images.device, dtype=_BF16)
+    rc = _lib.lib().wg_patchify_bf16(images.data_ptr(), rows.data_ptr(), B, C, H, W, patch, kpad, _stream())
+    _lib.check(rc, "wg_patchify_bf16")
+    return rows
+
+
+def im2row3x3(x, B, H, W):
+    _need_gpu(x)
+    C = x.shape[-1]
+    assert x.is_contiguous() and x.numel() == B * H * W * C
+    rows = torch.empty(B * H * W, 9 * C, device=x.device, dtype=_BF16)
+    rc = _lib.lib().wg_im2row3x3_bf16(x.data_ptr(), rows.data_ptr(), B, H, W, C, _stream())
+    _lib.check(rc, "wg_im2row3x3_bf16")
+    return rows
+
+
+def add_rows(a, b, out=None):
+    """a [..., C] + b [rb, C] broadcast by row index modulo rb."""
+    _need_gpu(a, b, out)
+    rows, cols, lda = _rows(a)
+    rb, cb, ldb = _rows(b)
+    assert cb == cols
+    if out is None:
+        out = torch.empty(a.shape, device=a.device, dtype=_BF16)
+    _, _, ldo = _rows(out)
+    rc = _lib.lib().wg_add_rows_bf16(a.data_ptr(), lda, b.data_ptr(), ldb, rb, out.data_ptr(), ldo, rows, cols, _stream())
+    _lib.check(rc, "wg_add_rows_bf16")
+    return out
+
+
+def tokens_to_nchw(x, B, HW, C):
+    _need_gpu(x)
+    assert x.is_contiguous()
+    y = torch.empty(B, C, HW, device=x.device, dtype=_BF16)
+    _lib.check(_lib.lib().wg_tokens_to_nchw_bf16(x.data_ptr(), y.data_ptr(), B, HW, C, _stream()), "wg_tokens_to_nchw_bf16")
+    return y
+
+
+def nchw_to_tokens(x):
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dtype == _BF16
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    y = torch.empty(B, HW, C, device=x.device, dtype=_BF16)
+    _lib.check(_lib.lib().wg_nchw_to_tokens_bf16(x.data_ptr(), y.data_ptr(), B, HW, C, _stream()), "wg_nchw_to_tokens_bf16")
+    return y
+
+
+def dense_pe_tokens(gaussian, h, w):
+    """[h*w, 2F] fp32 positional encoding rows from the [2, F] fp32 gaussian matrix."""
+    _need_gpu(gaussian)
+    g = gaussian.float().contiguous()
+    F_ = g.shape[1]
+    pe = torch.empty(h * w, 2 * F_, device=g.device, dtype=torch.float32)
+    _lib.check(_lib.lib().wg_dense_pe_f32(g.data_ptr(), pe.data_ptr(), h, w, F_, _stream()), "wg_dense_pe_f32")
+    return pe
+
+
+def cast_bf16(x):
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty(x.shape, device=x.device, dtype=_BF16)
+    _lib.check(_lib.lib().wg_cast_f32_to_bf16(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "wg_cast_f32_to_bf16")
+    return y
+
+
+def hyper_mask_dot(up, hyper, T, h, w, first_mask, num_masks):
+    """up: pixel-shuffled upscaled embedding rows [T*h*w*4, 4*32]; hyper [T, nmask, 32] -> fp32 [T, num_masks, 4h, 4w]."""
+    _need_gpu(up, hyper)
+    assert up.is_contiguous() and hyper.is_contiguous() and up.shape == (T * h * w * 4, 128)
+    masks = torch.empty(T, num_masks, 4 * h, 4 * w, device=up.device, dtype=torch.float32)
+    rc = _lib.lib().wg_hyper_mask_dot(up.data_ptr(), hyper.data_ptr(), masks.data_ptr(), T, h, w, 32, hyper.shape[1],
+                                      first_mask, num_masks, _stream())
+    _lib.check(rc, "wg_hyper_mask_dot")
+    return masks
+
+
+def postprocess_masks(low_res, img_size, input_size, original_size):
+    """fp32 [N, C, lh, lw] -> fp32 [N, C, H0, W0] (Sam.postprocess_masks, both resamples + crop in one pass)."""
+    _need_gpu(low_res)
+    assert low_res.dtype == torch.float32 and low_res.is_contiguous() and low_res.dim() == 4
+    N, C, lh, lw = low_res.shape
+    out = torch.empty(N, C, int(original_size[0]), int(original_size[1]), device=low_res.device, dtype=torch.float32)
+    rc = _lib.lib().wg_postprocess_masks_f32(low_res.data_ptr(), out.data_ptr(), N * C, lh, lw, img_size,
+                                             int(input_size[0]), int(input_size[1]), int(original_size[0]),
+                                             int(original_size[1]), _stream())
+    _lib.check(rc, "wg_postprocess_masks_f32")
+    return out
+
+
+def mask_score(masks):
+    """fp32 [N, H, W] -> fp32 [N]."""
+    _need_gpu(masks)
+    assert masks.dtype == torch.float32 and masks.is_contiguous()
+    N = masks.shape[0]
+    score = torch.empty(N, device=masks.device, dtype=torch.float32)
+    _lib.check(_lib.lib().wg_mask_score_f32(masks.data_ptr(), score.data_ptr(), N, masks.numel() // N, _stream()), "wg_mask_score_f32")
+    return score
