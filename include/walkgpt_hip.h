@@ -1,0 +1,124 @@
+/* walkgpt_hip.h -- C ABI of libwalkgpt_hip.so: MI355X (gfx950) kernels for WalkGPT's grounded-segmentation forward path.
+ *
+ * The reference (rafiibnsultan/WalkGPT) has no FFI of its own: its hot path is a chain of stock torch.nn ops inside
+ * Python nn.Modules.  Each entry point below therefore names the reference *expression* it replaces (file:line relative
+ * to the reference repo); the Python modules in walkgpt_amd/ keep the reference's module/forward() surface and call
+ * these through ctypes (walkgpt_amd/_lib.py).  INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; device pointers unless stated; `stream` is a hipStream_t passed as void*
+ *   - bf16 = 16-bit brain float storage, all accumulation / statistics in fp32
+ *   - "ld*" = leading dimension in ELEMENTS (row stride); rows are contiguous in their last dimension
+ *   - return 0 on success, <0 on error (WG_ERR_*), never throw/abort; wg_last_error() gives the thread-local text
+ *   - no allocation, no host synchronisation, no global mutable state: callers own every buffer; re-entrant across
+ *     streams and threads; safe to capture into a hipGraph
+ */
+#ifndef WALKGPT_HIP_H
+#define WALKGPT_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WG_OK 0
+#define WG_ERR_BAD_ARG (-1)
+#define WG_ERR_UNSUPPORTED (-2)
+#define WG_ERR_LAUNCH (-3)
+
+/* activation codes of fused epilogues */
+#define WG_ACT_NONE 0
+#define WG_ACT_GELU_ERF 1   /* nn.GELU()            model/segment_anything/modeling/common.py:13-26, utils/utils_walkgpt.py:173 */
+#define WG_ACT_QUICK_GELU 2 /* x*sigmoid(1.702x)    HF CLIP MLP (custom_clip.py:50, third-party transformers) */
+#define WG_ACT_RELU 3       /* nn.ReLU()            model/segment_anything/modeling/transformer.py:23, mask_decoder.py:186 */
+
+int wg_version(void);               /* major*10000 + minor*100 + patch */
+const char* wg_last_error(void);    /* thread-local, valid until the next failing call on this thread */
+
+/* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ R[m % res_row_mod or m, :]).  bf16 in, bf16 or fp32 out.
+ * Replaces every nn.Linear / 1x1 conv / stride==kernel conv (after wg_patchify_bf16) / 3x3 conv (after
+ * wg_im2row3x3_bf16) / ConvTranspose2d(k2,s2) on the path:
+ *   image_encoder.py:238 (qkv) :257 (proj) :422-426 (patch embed, + pos_embed :111-113 via R/res_row_mod)
+ *   common.py:25 (MLP)   image_encoder.py:92-108 (neck)   transformer.py:222-224,240 (decoder projections)
+ *   mask_decoder.py:53-63 (upscaler) :169-191 (hyper / IoU MLPs)   utils_walkgpt.py:171-175,209-212,226,249,312-316
+ *   HF CLIPAttention / CLIPMLP linears (custom_clip.py:50-104 call site).
+ * MFMA path needs K%64==0, N%4==0, N>=16, lda/ldw %8==0, ldc/ldr %4==0, 16-byte aligned A/W/C; anything else takes a
+ * slower one-wave-per-row kernel.  tile_hint: 0 auto, 1 = 128x128 tiles, 2 = 256x256 tiles, 3 = force row-wave. */
+int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, const void* bias, const void* residual,
+                          long ldr, int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32,
+                          int tile_hint, void* stream);
+
+/* y = act(LayerNorm(x) * gamma + beta) per row, biased variance, eps inside the sqrt.
+ * nn.LayerNorm: image_encoder.py:177,191 (eps 1e-6), transformer.py:157-181, utils_walkgpt.py:166-167,207,311,315,
+ * HF CLIP layer norms; LayerNorm2d (common.py:31-43) on channels-last rows: neck (image_encoder.py:98,106),
+ * upscaler (mask_decoder.py:57, with the following GELU fused through `act`). */
+int wg_layernorm_rows(const void* x, long ldx, const void* gamma, const void* beta, void* y, long ldy, int M, int D,
+                      float eps, int act, void* stream);
+
+/* Multi-head attention softmax(scale * q k^T + key_bias) v, heads contiguous in the last dimension, batch b's rows
+ * start at b * rows_per_batch (0 = shared by every batch item).  MFMA flash kernel, head_dim in {32, 64, 128}.
+ * HF CLIPAttention with the additive key-padding mask of custom_clip.py:27-38 (key_bias = 0 / finfo.min, [B, Lk] fp32). */
+int wg_mha_bf16(const void* Q, long ldq, long q_rows_per_batch, const void* K, long ldk, const void* V, long ldv,
+                long k_rows_per_batch, void* O, long ldo, long o_rows_per_batch, const float* key_bias, int B,
+                int heads, int head_dim, int Lq, int Lk, float scale, void* stream);
+
+/* Same contract without key_bias, one wave per (batch, head, query); head_dim in {16, 32, 64, 128}.  For shapes with
+ * few queries or few keys: two-way decoder attention (transformer.py:220-242) and MSQP cross attention
+ * (nn.MultiheadAttention in utils_walkgpt.py:168,181). */
+int wg_mha_small_bf16(const void* Q, long ldq, long q_rows_per_batch, const void* K, long ldk, const void* V, long ldv,
+                      long k_rows_per_batch, void* O, long ldo, long o_rows_per_batch, int B, int heads, int head_dim,
+                      int Lq, int Lk, float scale, void* stream);
+
+/* SAM ViT attention on a packed qkv buffer [B*grid*grid, 3*heads*head_dim] -> out [B*grid*grid, heads*head_dim].
+ * window == grid: global attention; window < grid: image_encoder.py:263-318 window partition with zero padding (pad
+ * positions act as keys/values equal to qkv_bias, because the padding follows norm1), fused with
+ * Attention.forward :235-260 and add_decomposed_rel_pos :321-392 (unscaled q, index q-k+S-1).
+ * Compiled (head_dim, window): (64,14) (64,64) (64,32) (32,14) (32,28). */
+int wg_sam_attn_relpos_bf16(const void* qkv, const void* qkv_bias, const void* rel_pos_h, const void* rel_pos_w,
+                            void* out, int B, int grid, int window, int heads, int head_dim, float scale, void* stream);
+
+/* NCHW bf16 images -> rows [B*(H/P)*(W/P), Kpad], columns (c, ky, kx) zero padded to Kpad: the im2row of
+ * Conv2d(kernel=stride=P)  (image_encoder.py:422-426; CLIP patch_embedding). */
+int wg_patchify_bf16(const void* images, void* rows, int B, int C, int H, int W, int P, int Kpad, void* stream);
+
+/* channels-last [B,H,W,C] -> rows [B*H*W, 9*C], columns (ky, kx, c), zero padding 1 (neck 3x3 conv, image_encoder.py:99-106). */
+int wg_im2row3x3_bf16(const void* x, void* rows, int B, int H, int W, int C, void* stream);
+
+/* out[r,:] = a[r,:] + b[r % b_rows,:]  (q + query_pe, k + key_pe: transformer.py:159-176; src + dense: mask_decoder.py:138). */
+int wg_add_rows_bf16(const void* a, long lda, const void* b, long ldb, int b_rows, void* out, long ldo, long rows,
+                     int cols, void* stream);
+
+/* [B, HW, C] <-> [B, C, HW] (x.permute(0,3,1,2) image_encoder.py:118-124; flatten(2).permute(0,2,1) transformer.py:83-84). */
+int wg_tokens_to_nchw_bf16(const void* x, void* y, int B, int HW, int C, void* stream);
+int wg_nchw_to_tokens_bf16(const void* x, void* y, int B, int HW, int C, void* stream);
+
+/* PositionEmbeddingRandom.forward (prompt_encoder.py:216-229) as rows [h*w, 2*num_feats] fp32 from the fp32 [2, num_feats] matrix. */
+int wg_dense_pe_f32(const float* gaussian, float* pe_tokens, int h, int w, int num_feats, void* stream);
+int wg_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
+
+/* masks[t,k,Y,X] = sum_c hyper[t,first_mask+k,c] * up[t,c,Y,X] (mask_decoder.py:150-160); `up` is the pixel-shuffled
+ * GEMM output of the two transposed convs: rows (t, y, x, dy, dx), columns (dy2, dx2, c), channels == 32. */
+int wg_hyper_mask_dot(const void* up, const void* hyper, float* masks, int T, int h, int w, int channels, int nmask_total,
+                      int first_mask, int num_masks, void* stream);
+
+/* Sam.postprocess_masks (sam.py:137-172): bilinear to img_size^2, crop [:in_h,:in_w], bilinear to (out_h,out_w), one pass. */
+int wg_postprocess_masks_f32(const float* low_res, float* out, int N, int low_h, int low_w, int img_size, int in_h,
+                             int in_w, int out_h, int out_w, void* stream);
+
+/* mask score = sum(sigmoid(x)[x>0]) / (count[x>0] + 1e-6) per mask (model/walkgpt.py:540-542, :737). */
+int wg_mask_score_f32(const float* masks, float* score, int N, long hw, void* stream);
+
+/* MSQP pieces (utils/utils_walkgpt.py): _pool_grid_tokens :195-201, _global_token :256-257, SegAwareGate tail :213-217. */
+int wg_avgpool_tokens_bf16(const void* x, void* y, int B, int H, int W, int C, int s, void* stream);
+int wg_mean_tokens_bf16(const void* x, void* y, int B, int L, int C, void* stream);
+int wg_sigmoid_gate_bf16(const void* x, const float* logit, void* y, long rows, int C, void* stream);
+
+/* CTP tail (utils_walkgpt.py:321-327): normalize(LayerNorm(x) + text_type, dim=-1, eps 1e-12) * exp(log_temp). */
+int wg_ctp_tail_bf16(const void* x, long ldx, const void* gamma, const void* beta, const void* text_type,
+                     const void* log_temp, void* y, long ldy, int M, int C, float eps, void* stream);
+
+/* [n, p*p, C] -> bilinear(align_corners=False) -> [n, t*t, C] (llava_arch.py:252-259; clip_encoder.py:47-49). */
+int wg_resample_tokens_bf16(const void* x, void* y, int n, int p, int t, int C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WALKGPT_HIP_H */

@@ -147,7 +147,23 @@ def make_clip(name):
                         emb=states[0].numpy())
 
 
+def make_state_dict_shapes(_name):
+    """Key -> shape tables of the reference modules (data, not source): the de-facto checkpoint ABI."""
+    import json
+    sam_modeling, uw = _import_reference()
+    from model.segment_anything import build_sam_vit_b
+    with torch.device("meta"):
+        fix = {
+            "sam_vit_b": {k: list(v.shape) for k, v in build_sam_vit_b().state_dict().items()},
+            "msqp_4096": {k: list(v.shape) for k, v in uw.MultiScaleQFormerProjector(256, 4096, target_square_side=6).state_dict().items()},
+            "ctp_4096": {k: list(v.shape) for k, v in uw.CalibratedTextProjector(4096, 256).state_dict().items()},
+        }
+    with open(os.path.join(HERE, "state_dict_shapes.json"), "w") as f:
+        json.dump(fix, f, indent=0, sort_keys=True)
+
+
 ALL = {
+    "state_dict_shapes": (make_state_dict_shapes, {"all": None}),
     "sam_encoder": (make_sam_encoder, cases.SAM_ENCODERS),
     "decoder": (make_decoder, cases.DECODERS),
     "projectors": (make_projectors, cases.PROJECTORS),

@@ -1,0 +1,178 @@
+"""GPU parity of the HIP-backed modules (reference module surface) against the golden vectors the REFERENCE's own
+modules produced on the same synthetic weights (tests/golden/make_golden.py).  bf16 storage / fp32 accumulation
+on the GPU vs fp32 on the reference: tolerances are relative L2 error over the tapped tensor."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.golden import cases
+from walkgpt_amd import ops
+from walkgpt_amd.clip_encoder import CLIPVisionTower, patch_key_mask
+from walkgpt_amd.segment_anything import modeling as M
+from walkgpt_amd.utils_walkgpt import CalibratedTextProjector, MultiScaleQFormerProjector
+from walkgpt_amd.walkgpt import WalkGPTGrounding
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def load_into(module, weights, prefix, dev, strict=True):
+    sd = {k[len(prefix):]: v for k, v in weights.items() if k.startswith(prefix)}
+    res = module.load_state_dict(sd, strict=strict)
+    module.to(dev).bfloat16().eval()
+    return res
+
+
+def build_encoder(c, dev):
+    from functools import partial
+    enc = M.ImageEncoderViT(img_size=c["img"], patch_size=c["patch"], embed_dim=c["embed_dim"], depth=c["depth"],
+                            num_heads=c["heads"], mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+                            qkv_bias=True, use_rel_pos=True, global_attn_indexes=c["global_idx"], window_size=c["window"],
+                            out_chans=c["out"])
+    load_into(enc, cases.sam_encoder_weights(c), "image_encoder.", dev)
+    return enc
+
+
+@pytest.mark.parametrize("name,tol", [("tiny", 0.02), ("tiny_hd32", 0.02), ("vit_b", 0.03)])
+def test_sam_encoder_vs_reference_golden(dev, name, tol):
+    c = cases.SAM_ENCODERS[name]
+    gold = cases.load("sam_encoder_" + name)
+    enc = build_encoder(c, dev)
+    x = cases.sam_encoder_input(c).to(dev, torch.bfloat16)
+    with torch.no_grad():
+        out = enc(x)
+    assert out.shape == (c["batch"], c["out"], c["img"] // c["patch"], c["img"] // c["patch"])
+    e = rel_err(cases.tap_embedding(out.float().cpu()).numpy(), gold["out"])
+    assert e < tol, e
+    # block taps: run the same rows path block by block
+    with torch.no_grad():
+        p = enc._prep_get(enc._build_prepared)
+        g = c["img"] // c["patch"]
+        t = ops.linear(ops.patchify(x, c["patch"]), p["patch_w"], enc.patch_embed.proj.bias, residual=p["pos"], res_row_mod=g * g)
+        for i, blk in enumerate(enc.blocks):
+            t = blk.rows(t, c["batch"], g)
+            if "block%d" % i in gold:
+                tap = cases.tap_tokens(t.float().cpu().view(c["batch"], g, g, -1)).numpy()
+                assert rel_err(tap, gold["block%d" % i]) < tol, ("block", i)
+
+
+@pytest.mark.parametrize("name", ["g32", "g64"])
+def test_decoder_and_postprocess_vs_reference_golden(dev, name):
+    c = cases.DECODERS[name]
+    gold = cases.load("decoder_" + name)
+    g = c["grid"]
+    sam = M._build_sam(128, 1, 2, [0], image_size=g * 16)   # encoder unused here
+    w = cases.decoder_weights(c["seed"])
+    res = load_into(sam.prompt_encoder, w, "prompt_encoder.", dev, strict=False)
+    assert all(("point_embeddings" in k or "not_a_point" in k or "mask_downscaling" in k) for k in res.missing_keys)
+    load_into(sam.mask_decoder, w, "mask_decoder.", dev)
+    sam.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix.data = \
+        w["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].to(dev)  # keep the buffer fp32
+    sam.to(dev)
+    emb, text = cases.decoder_inputs(c)
+    emb, text = emb.to(dev, torch.bfloat16), text.to(dev, torch.bfloat16)
+    with torch.no_grad():
+        dpe = sam.prompt_encoder.get_dense_pe()
+        assert np.abs(dpe[0, ::8].float().cpu().numpy() - gold["dense_pe"]).max() < 2e-4
+        sparse, dense = sam.prompt_encoder(points=None, boxes=None, masks=None, text_embeds=text)
+        masks, iou = sam.mask_decoder(image_embeddings=emb, image_pe=dpe, sparse_prompt_embeddings=sparse,
+                                      dense_prompt_embeddings=dense, multimask_output=False)
+        post = sam.postprocess_masks(masks, input_size=c["input_size"], original_size=c["original_size"])
+    assert masks.shape == gold["masks"].shape and post.shape == gold["post"].shape
+    a, b = post.cpu().numpy() > 0, gold["post"] > 0
+    iou_px = (a & b).sum() / max(1, (a | b).sum())
+    print("decoder %s: rel_err masks %.4f iou %.4f post %.4f | pixel IoU vs reference %.4f" % (
+        name, rel_err(masks.cpu().numpy(), gold["masks"]), rel_err(iou.cpu().numpy(), gold["iou"]),
+        rel_err(post.cpu().numpy(), gold["post"]), iou_px))
+    assert rel_err(masks.cpu().numpy(), gold["masks"]) < 0.03
+    assert rel_err(iou.cpu().numpy(), gold["iou"]) < 0.03
+    assert rel_err(post.cpu().numpy(), gold["post"]) < 0.03
+    # thresholded masks: IoU with the reference's masks (the quantity WalkGPT reports)
+    assert iou_px > 0.98, iou_px
+
+
+def test_projectors_vs_reference_golden(dev):
+    c = cases.PROJECTORS["h64"]
+    gold = cases.load("projectors_h64")
+    wm, wt = cases.projector_weights(c)
+    msqp = MultiScaleQFormerProjector(256, c["llama_dim"], target_square_side=6)
+    ctp = CalibratedTextProjector(c["llama_dim"], 256)
+    load_into(msqp, {"x." + k: v for k, v in wm.items()}, "x.", dev)
+    load_into(ctp, {"x." + k: v for k, v in wt.items()}, "x.", dev)
+    toks, hid = cases.projector_inputs(c)
+    with torch.no_grad():
+        a = msqp(toks.to(dev, torch.bfloat16))
+        b = ctp(hid.to(dev, torch.bfloat16))
+    assert rel_err(a.float().cpu().numpy(), gold["msqp"]) < 0.03
+    assert rel_err(b.float().cpu().numpy(), gold["ctp"]) < 0.02
+
+
+def test_clip_tower_vs_standin_golden(dev):
+    from types import SimpleNamespace
+    c = cases.CLIPS["tiny"]
+    gold = cases.load("clip_tiny")
+    cfg = dict(hidden_size=c["dim"], intermediate_size=4 * c["dim"], num_hidden_layers=c["layers"],
+               num_attention_heads=c["heads"], image_size=c["img"], patch_size=14, layer_norm_eps=1e-5)
+    args = SimpleNamespace(mm_vision_select_layer=c["select_layer"], pad_train_clip_images=True,
+                           resize_vision_tower=True, resize_vision_tower_size=c["img"])
+    tower = CLIPVisionTower("synthetic", args, config=cfg)
+    load_into(tower.vision_tower, cases.clip_weights(c), "", dev)
+    x, key_mask = cases.clip_inputs(c)
+    xd = x.to(dev, torch.bfloat16)
+    assert torch.equal(patch_key_mask(xd, c["clip_resize_list"]).cpu(), key_mask)
+    with torch.no_grad():
+        sel, pre = tower(xd, attention_mask=key_mask.to(dev))
+        emb = tower.vision_tower.vision_model.hidden_states(xd, key_mask.to(dev), [0])[0]
+    assert rel_err(emb.float().cpu().numpy(), gold["emb"]) < 0.01
+    assert rel_err(sel.float().cpu().numpy(), gold["sel"]) < 0.03
+    assert rel_err(pre[0].float().cpu().numpy(), gold["pre"]) < 0.03
+
+
+def test_grounding_pipeline_end_to_end_vs_oracle(dev):
+    """Tiny SAM encoder -> CTP -> prompt encoder -> mask decoder -> postprocess, HIP vs the oracle on CPU."""
+    from oracle import projectors as oproj
+    from oracle import sam as osam
+    c = cases.SAM_ENCODERS["tiny"]
+    g = c["img"] // c["patch"]
+    model = WalkGPTGrounding(sam=dict(embed_dim=c["embed_dim"], depth=c["depth"], heads=c["heads"],
+                                      global_idx=c["global_idx"], img=c["img"]), llm_hidden=64, with_clip=False)
+    w_enc = cases.sam_encoder_weights(c)
+    w_dec = cases.decoder_weights(5)
+    pc = dict(cases.PROJECTORS["h64"])
+    wm, wt = cases.projector_weights(pc)
+    load_into(model.visual_model.image_encoder, w_enc, "image_encoder.", dev)
+    load_into(model.visual_model.prompt_encoder, w_dec, "prompt_encoder.", dev, strict=False)
+    load_into(model.visual_model.mask_decoder, w_dec, "mask_decoder.", dev)
+    load_into(model.out_mm_projector, {"x." + k: v for k, v in wm.items()}, "x.", dev)
+    load_into(model.text_hidden_fcs[0], {"x." + k: v for k, v in wt.items()}, "x.", dev)
+    model.visual_model.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix.data = \
+        w_dec["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].to(dev)
+    x = cases.sam_encoder_input(c)
+    hidden = [torch.randn(2, 64, generator=torch.Generator().manual_seed(3)), torch.randn(3, 64, generator=torch.Generator().manual_seed(4))]
+    resize, orig = [(512, 384), (400, 512)], [(200, 150), (75, 96)]
+    out = model(x.to(dev, torch.bfloat16), None, [h.to(dev, torch.bfloat16) for h in hidden], resize, orig)
+    # oracle
+    w_all = dict(w_enc)
+    w_all.update(w_dec)
+    with torch.no_grad():
+        emb = osam.image_encoder(w_all, x, dict(patch=c["patch"], depth=c["depth"], heads=c["heads"], global_idx=c["global_idx"], window=c["window"]))
+        dpe = osam.dense_pe(w_all, (g, g))
+        vis = oproj.msqp(wm, emb.flatten(2).transpose(1, 2))
+        assert rel_err(out["visual_tokens"].float().cpu().numpy(), vis.numpy()) < 0.04
+        for i in range(2):
+            pe = oproj.ctp(wt, hidden[i].to(torch.bfloat16).float())  # [T, 256]
+            sparse, dense = osam.prompt_encoder_text(w_all, pe.reshape(-1, 1, 256), (g, g))
+            masks, _ = osam.mask_decoder(w_all, emb[i:i + 1], dpe, sparse, dense)
+            ref = osam.postprocess_masks(masks, c["img"], resize[i], orig[i])[:, 0]
+            got = out["pred_masks"][i].cpu()
+            assert got.shape == ref.shape
+            assert rel_err(got.numpy(), ref.numpy()) < 0.05
+            a, b = got.numpy() > 0, ref.numpy() > 0
+            assert (a & b).sum() / max(1, (a | b).sum()) > 0.98
+            assert torch.allclose(out["mask_scores"][i].cpu(), osam.mask_score(ref), atol=0.02)

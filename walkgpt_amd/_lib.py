@@ -33,6 +33,12 @@ SIGNATURES = {
     "wg_hyper_mask_dot": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_postprocess_masks_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_mask_score_f32": [c_void_p, c_void_p, c_int, c_long, c_void_p],
+    "wg_avgpool_tokens_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "wg_mean_tokens_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "wg_sigmoid_gate_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
+    "wg_ctp_tail_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int,
+                         c_float, c_void_p],
+    "wg_resample_tokens_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
 }
 _SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, [])}
 
@@ -53,6 +59,10 @@ def lib():
         raise WalkgptHipError(
             "libwalkgpt_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `python walkgpt_amd/_build.py`. There is no CPU fallback." % LIB_PATH)
+    # torch must load its HIP runtime first: libwalkgpt_hip.so's libamdhip64 dependency then resolves to that same
+    # runtime instance (streams and device pointers are shared with torch).  Loaded the other way round the process
+    # ends up with two runtimes and launches fail with "no ROCm-capable device".
+    import torch  # noqa: F401
     h = ctypes.CDLL(LIB_PATH)
     for name, argtypes in SIGNATURES.items():
         fn = getattr(h, name)

@@ -22,4 +22,4 @@ int wg_check_launch(const char* what) {
 }
 
 extern "C" const char* wg_last_error(void) { return g_err; }
-extern "C" int wg_version(void) { return 100; }  // 0.1.0
+extern "C" int wg_version(void) { return 100; }  // 0.1.0 = major*10000 + minor*100 + patch

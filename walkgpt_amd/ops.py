@@ -33,6 +33,19 @@ def _rows(t):
     return t.numel() // t.shape[-1], t.shape[-1], t.shape[-1]
 
 
+GEMM_EVENT_HOOK = None  # bench.py: callable(M, N, K, tile) -> (start_event, end_event) recorded around the launch
+
+
+def gemm_tile_for(M, N, K, lda, ldw, ldc, ldr):
+    """Which kernel wg_gemm_bias_act_bf16 runs for this shape: 1 = 128x128 tiles, 2 = 256x256 tiles, 3 = row-wave
+    (mirrors the selection in csrc/gemm.hip; passed explicitly so host-side accounting and the library agree)."""
+    ok = K % 64 == 0 and N % 4 == 0 and N >= 16 and lda % 8 == 0 and ldw % 8 == 0 and ldc % 4 == 0 and ldr % 4 == 0
+    if not ok:
+        return 3
+    t256 = ((M + 255) // 256) * ((N + 255) // 256)
+    return 2 if (t256 >= 384 and N % 256 == 0) else 1
+
+
 def linear(x, weight, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out=None, out_f32=False, tile=0):
     """y = act(x @ weight.T + bias) (+ residual).  x [..., K] bf16, weight [N, K] bf16."""
     _need_gpu(x, weight, bias, residual, out)
@@ -51,9 +64,16 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out
         assert Nr == N
     if bias is not None:
         assert bias.dtype == _BF16 and bias.numel() == N
+    if tile == 0:
+        tile = gemm_tile_for(M, N, K, lda, weight.stride(0), ldc, ldr)
+    ev = GEMM_EVENT_HOOK(M, N, K, tile) if GEMM_EVENT_HOOK is not None else None
+    if ev is not None:
+        ev[0].record()
     rc = _lib.lib().wg_gemm_bias_act_bf16(x.data_ptr(), lda, weight.data_ptr(), weight.stride(0), _ptr(bias),
                                           _ptr(residual), ldr, res_row_mod, out.data_ptr(), ldc, M, N, K, act,
                                           1 if out.dtype == torch.float32 else 0, tile, _stream())
+    if ev is not None:
+        ev[1].record()
     _lib.check(rc, "wg_gemm_bias_act_bf16")
     return out
 
@@ -230,3 +250,59 @@ def mask_score(masks):
     score = torch.empty(N, device=masks.device, dtype=torch.float32)
     _lib.check(_lib.lib().wg_mask_score_f32(masks.data_ptr(), score.data_ptr(), N, masks.numel() // N, _stream()), "wg_mask_score_f32")
     return score
+
+
+def avgpool_tokens(x, B, H, W, s):
+    """channels-last [B,H,W,C] rows -> [B, (H/s)*(W/s), C]."""
+    _need_gpu(x)
+    C = x.shape[-1]
+    assert x.is_contiguous() and x.dtype == _BF16 and x.numel() == B * H * W * C
+    y = torch.empty(B, (H // s) * (W // s), C, device=x.device, dtype=_BF16)
+    _lib.check(_lib.lib().wg_avgpool_tokens_bf16(x.data_ptr(), y.data_ptr(), B, H, W, C, s, _stream()), "wg_avgpool_tokens_bf16")
+    return y
+
+
+def mean_tokens(x):
+    """[B, L, C] -> [B, 1, C]."""
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dtype == _BF16 and x.dim() == 3
+    B, L, C = x.shape
+    y = torch.empty(B, 1, C, device=x.device, dtype=_BF16)
+    _lib.check(_lib.lib().wg_mean_tokens_bf16(x.data_ptr(), y.data_ptr(), B, L, C, _stream()), "wg_mean_tokens_bf16")
+    return y
+
+
+def sigmoid_gate(x, logit):
+    """x [..., C] bf16 * sigmoid(logit [...]) fp32."""
+    _need_gpu(x, logit)
+    assert x.is_contiguous() and logit.is_contiguous() and logit.dtype == torch.float32
+    C = x.shape[-1]
+    rows = x.numel() // C
+    assert logit.numel() == rows
+    y = torch.empty(x.shape, device=x.device, dtype=_BF16)
+    _lib.check(_lib.lib().wg_sigmoid_gate_bf16(x.data_ptr(), logit.data_ptr(), y.data_ptr(), rows, C, _stream()), "wg_sigmoid_gate_bf16")
+    return y
+
+
+def ctp_tail(x, gamma, beta, text_type, log_temp, eps):
+    """normalize(LayerNorm(x) + text_type, dim=-1) * exp(log_temp)."""
+    _need_gpu(x, gamma, beta, text_type, log_temp)
+    M, C, ldx = _rows(x)
+    y = torch.empty(x.shape, device=x.device, dtype=_BF16)
+    _, _, ldy = _rows(y)
+    rc = _lib.lib().wg_ctp_tail_bf16(x.data_ptr(), ldx, gamma.data_ptr(), beta.data_ptr(), text_type.data_ptr(),
+                                     log_temp.data_ptr(), y.data_ptr(), ldy, M, C, float(eps), _stream())
+    _lib.check(rc, "wg_ctp_tail_bf16")
+    return y
+
+
+def resample_tokens(x, target=16):
+    """[n, p*p, C] -> bilinear (align_corners=False) -> [n, target*target, C]."""
+    _need_gpu(x)
+    assert x.is_contiguous() and x.dtype == _BF16 and x.dim() == 3
+    n, l, C = x.shape
+    p = int(round(l ** 0.5))
+    assert p * p == l, "Token count %d is not square." % l
+    y = torch.empty(n, target * target, C, device=x.device, dtype=_BF16)
+    _lib.check(_lib.lib().wg_resample_tokens_bf16(x.data_ptr(), y.data_ptr(), n, p, target, C, _stream()), "wg_resample_tokens_bf16")
+    return y

@@ -1,0 +1,514 @@
+"""MI355X-native SAM modules behind the reference's own module surface.
+
+Same class names, constructor arguments, attribute tree and state_dict keys as
+/root/reference/model/segment_anything/modeling/{image_encoder,prompt_encoder,transformer,mask_decoder,sam}.py, so a
+reference checkpoint loads with strict=True and callers (`model/walkgpt.py:241-258, 713-737`) are unchanged.  The
+nn.Linear / nn.Conv2d / nn.LayerNorm children are PARAMETER CONTAINERS ONLY: their forward is never called.  All
+arithmetic goes through walkgpt_amd.ops (the C-ABI of libwalkgpt_hip.so); tensors must be bf16 on the GPU and there is
+no CPU fallback.
+
+Internal layout is channels-last token rows [B*h*w, C]; NCHW appears only at the module boundary where the
+reference API returns / accepts it.
+"""
+import math
+from functools import partial
+from typing import Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+BF16 = torch.bfloat16
+
+
+class _Prepared:
+    """Derived (re-laid / concatenated / bf16) kernel operands, rebuilt after any parameter change."""
+
+    def _prep_get(self, build):
+        key = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in self.parameters(recurse=True))
+        if getattr(self, "_prep_key", None) != key:
+            object.__setattr__(self, "_prep_val", build())
+            object.__setattr__(self, "_prep_key", key)
+        return self._prep_val
+
+
+def _check_bf16_gpu(t, what):
+    if not t.is_cuda or t.dtype != BF16:
+        raise RuntimeError("%s must be a bf16 GPU tensor for the walkgpt_amd HIP path (got %s on %s); "
+                           "cast the model and inputs with .bfloat16().cuda() -- there is no CPU fallback"
+                           % (what, t.dtype, t.device))
+
+
+class LayerNorm2d(nn.Module):
+    """common.py:31-43 (parameter container; applied as a row LayerNorm on channels-last rows)."""
+
+    def __init__(self, num_channels: int, eps: float = 1e-6) -> None:
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(num_channels))
+        self.bias = nn.Parameter(torch.zeros(num_channels))
+        self.eps = eps
+
+
+class MLPBlock(nn.Module):
+    """common.py:13-26."""
+
+    def __init__(self, embedding_dim: int, mlp_dim: int, act=nn.GELU) -> None:
+        super().__init__()
+        self.lin1 = nn.Linear(embedding_dim, mlp_dim)
+        self.lin2 = nn.Linear(mlp_dim, embedding_dim)
+        self.act = act()
+        self._act_code = ops.ACT_RELU if isinstance(self.act, nn.ReLU) else ops.ACT_GELU
+
+    def rows(self, x, residual=None):
+        h = ops.linear(x, self.lin1.weight, self.lin1.bias, act=self._act_code)
+        return ops.linear(h, self.lin2.weight, self.lin2.bias, residual=residual)
+
+    def forward(self, x):
+        return self.rows(x)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# image encoder
+# ------------------------------------------------------------------------------------------------------------------
+class PatchEmbed(nn.Module):
+    def __init__(self, kernel_size=(16, 16), stride=(16, 16), padding=(0, 0), in_chans=3, embed_dim=768) -> None:
+        super().__init__()
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=kernel_size, stride=stride, padding=padding)
+
+
+class Attention(nn.Module):
+    """image_encoder.py:198-260 (container for qkv / proj / rel_pos_{h,w})."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=True, use_rel_pos=False, rel_pos_zero_init=True, input_size=None):
+        super().__init__()
+        self.num_heads = num_heads
+        head_dim = dim // num_heads
+        self.scale = head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.use_rel_pos = use_rel_pos
+        if self.use_rel_pos:
+            assert input_size is not None, "Input size must be provided if using relative positional encoding."
+            self.rel_pos_h = nn.Parameter(torch.zeros(2 * input_size[0] - 1, head_dim))
+            self.rel_pos_w = nn.Parameter(torch.zeros(2 * input_size[1] - 1, head_dim))
+
+
+class Block(nn.Module):
+    """image_encoder.py:130-193."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, norm_layer=nn.LayerNorm, act_layer=nn.GELU,
+                 use_rel_pos=False, rel_pos_zero_init=True, window_size=0, input_size=None):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, use_rel_pos=use_rel_pos,
+                              rel_pos_zero_init=rel_pos_zero_init,
+                              input_size=input_size if window_size == 0 else (window_size, window_size))
+        self.norm2 = norm_layer(dim)
+        self.mlp = MLPBlock(embedding_dim=dim, mlp_dim=int(dim * mlp_ratio), act=act_layer)
+        self.window_size = window_size
+
+    def rows(self, x, B, grid):
+        """x [B*grid*grid, D] -> same.  window partition / unpartition live inside the attention kernel."""
+        a = self.attn
+        if not a.use_rel_pos or a.qkv.bias is None:
+            raise NotImplementedError("the HIP SAM attention is built for use_rel_pos=True, qkv_bias=True (build_sam.py:56-108)")
+        y = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        qkv = ops.linear(y, a.qkv.weight, a.qkv.bias)
+        window = self.window_size if self.window_size > 0 else grid
+        o = ops.sam_attention(qkv, a.qkv.bias, a.rel_pos_h, a.rel_pos_w, B, grid, window, a.num_heads)
+        x = ops.linear(o, a.proj.weight, a.proj.bias, residual=x)
+        y = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return self.mlp.rows(y, residual=x)
+
+
+class ImageEncoderViT(nn.Module, _Prepared):
+    """image_encoder.py:17-125."""
+
+    def __init__(self, img_size=1024, patch_size=16, in_chans=3, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4.0,
+                 out_chans=256, qkv_bias=True, norm_layer=nn.LayerNorm, act_layer=nn.GELU, use_abs_pos=True,
+                 use_rel_pos=False, rel_pos_zero_init=True, window_size=0, global_attn_indexes=()):
+        super().__init__()
+        self.img_size = img_size
+        self.embed_dim = embed_dim
+        self.out_chans = out_chans
+        self.patch_size = patch_size
+        self.patch_embed = PatchEmbed(kernel_size=(patch_size, patch_size), stride=(patch_size, patch_size),
+                                      in_chans=in_chans, embed_dim=embed_dim)
+        self.pos_embed: Optional[nn.Parameter] = None
+        if use_abs_pos:
+            self.pos_embed = nn.Parameter(torch.zeros(1, img_size // patch_size, img_size // patch_size, embed_dim))
+        self.blocks = nn.ModuleList()
+        for i in range(depth):
+            self.blocks.append(Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                                     norm_layer=norm_layer, act_layer=act_layer, use_rel_pos=use_rel_pos,
+                                     rel_pos_zero_init=rel_pos_zero_init,
+                                     window_size=window_size if i not in global_attn_indexes else 0,
+                                     input_size=(img_size // patch_size, img_size // patch_size)))
+        self.neck = nn.Sequential(
+            nn.Conv2d(embed_dim, out_chans, kernel_size=1, bias=False),
+            LayerNorm2d(out_chans),
+            nn.Conv2d(out_chans, out_chans, kernel_size=3, padding=1, bias=False),
+            LayerNorm2d(out_chans),
+        )
+
+    def _build_prepared(self):
+        D = self.embed_dim
+        return {
+            "patch_w": self.patch_embed.proj.weight.reshape(D, -1),
+            "neck0_w": self.neck[0].weight.reshape(self.out_chans, D),
+            # [O, C, 3, 3] -> [O, (ky, kx, c)] to match wg_im2row3x3's column order
+            "neck2_w": self.neck[2].weight.permute(0, 2, 3, 1).reshape(self.out_chans, -1).contiguous(),
+            "pos": None if self.pos_embed is None else self.pos_embed.reshape(-1, D),
+        }
+
+    def forward_tokens(self, x: torch.Tensor) -> torch.Tensor:
+        """[B,3,S,S] bf16 -> channels-last embedding rows [B*g*g, out_chans]."""
+        _check_bf16_gpu(x, "images")
+        _check_bf16_gpu(self.patch_embed.proj.weight, "image encoder weights")
+        B = x.shape[0]
+        g = x.shape[-1] // self.patch_size
+        if x.shape[-2] != x.shape[-1] or g != self.img_size // self.patch_size:
+            raise RuntimeError("image encoder expects %dx%d inputs" % (self.img_size, self.img_size))
+        p = self._prep_get(self._build_prepared)
+        rows = ops.patchify(x.contiguous(), self.patch_size)
+        t = ops.linear(rows, p["patch_w"], self.patch_embed.proj.bias, residual=p["pos"], res_row_mod=g * g if p["pos"] is not None else 0)
+        for blk in self.blocks:
+            t = blk.rows(t, B, g)
+        t = ops.linear(t, p["neck0_w"])
+        t = ops.layernorm(t, self.neck[1].weight, self.neck[1].bias, self.neck[1].eps)
+        t = ops.linear(ops.im2row3x3(t, B, g, g), p["neck2_w"])
+        return ops.layernorm(t, self.neck[3].weight, self.neck[3].bias, self.neck[3].eps)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        t = self.forward_tokens(x)
+        B = x.shape[0]
+        g = self.img_size // self.patch_size
+        return ops.tokens_to_nchw(t, B, g * g, self.out_chans).view(B, self.out_chans, g, g)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# prompt encoder (text branch)
+# ------------------------------------------------------------------------------------------------------------------
+class PositionEmbeddingRandom(nn.Module):
+    def __init__(self, num_pos_feats: int = 64, scale: Optional[float] = None) -> None:
+        super().__init__()
+        if scale is None or scale <= 0.0:
+            scale = 1.0
+        self.register_buffer("positional_encoding_gaussian_matrix", scale * torch.randn((2, num_pos_feats)))
+
+    def tokens(self, size: Tuple[int, int]) -> torch.Tensor:
+        """[h*w, 2F] fp32 rows (prompt_encoder.py:203-229), computed by wg_dense_pe_f32."""
+        return ops.dense_pe_tokens(self.positional_encoding_gaussian_matrix, size[0], size[1])
+
+    def forward(self, size: Tuple[int, int]) -> torch.Tensor:
+        h, w = size
+        return self.tokens(size).t().reshape(-1, h, w)
+
+
+class PromptEncoder(nn.Module):
+    """prompt_encoder.py:16-186.  Only the text branch (`text_embeds`) is on WalkGPT's path; point / box / mask prompts
+    keep their parameters (checkpoint parity) but are out of scope."""
+
+    def __init__(self, embed_dim, image_embedding_size, input_image_size, mask_in_chans, activation=nn.GELU):
+        super().__init__()
+        self.embed_dim = embed_dim
+        self.input_image_size = input_image_size
+        self.image_embedding_size = image_embedding_size
+        self.pe_layer = PositionEmbeddingRandom(embed_dim // 2)
+        self.num_point_embeddings = 4
+        self.point_embeddings = nn.ModuleList([nn.Embedding(1, embed_dim) for _ in range(self.num_point_embeddings)])
+        self.not_a_point_embed = nn.Embedding(1, embed_dim)
+        self.mask_input_size = (4 * image_embedding_size[0], 4 * image_embedding_size[1])
+        self.mask_downscaling = nn.Sequential(
+            nn.Conv2d(1, mask_in_chans // 4, kernel_size=2, stride=2),
+            LayerNorm2d(mask_in_chans // 4),
+            activation(),
+            nn.Conv2d(mask_in_chans // 4, mask_in_chans, kernel_size=2, stride=2),
+            LayerNorm2d(mask_in_chans),
+            activation(),
+            nn.Conv2d(mask_in_chans, embed_dim, kernel_size=1),
+        )
+        self.no_mask_embed = nn.Embedding(1, embed_dim)
+        self._pe_cache = None
+
+    def dense_pe_tokens(self) -> torch.Tensor:
+        """bf16 [h*w, C] rows of get_dense_pe(); input independent, cached per (device, buffer version)."""
+        G = self.pe_layer.positional_encoding_gaussian_matrix
+        key = (G.data_ptr(), G._version, G.device)
+        if self._pe_cache is None or self._pe_cache[0] != key:
+            pe32 = self.pe_layer.tokens(self.image_embedding_size)
+            self._pe_cache = (key, pe32, ops.cast_bf16(pe32))
+        return self._pe_cache[2]
+
+    def get_dense_pe(self) -> torch.Tensor:
+        self.dense_pe_tokens()
+        h, w = self.image_embedding_size
+        return self._pe_cache[1].t().reshape(1, -1, h, w)
+
+    def forward(self, points, boxes, masks, text_embeds):
+        if points is not None or boxes is not None or masks is not None:
+            raise NotImplementedError("walkgpt_amd: only the text-embedding prompt branch is on the WalkGPT hot path")
+        if text_embeds is None:
+            raise ValueError("text_embeds is required")
+        bs = text_embeds.shape[0]
+        sparse = text_embeds  # prompt_encoder.py:175-176: concatenation with an empty tensor
+        dense = self.no_mask_embed.weight.reshape(1, -1, 1, 1).expand(bs, -1, self.image_embedding_size[0], self.image_embedding_size[1])
+        return sparse, dense
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# two-way transformer + mask decoder
+# ------------------------------------------------------------------------------------------------------------------
+class DecoderAttention(nn.Module):
+    """transformer.py:185-242 (named `Attention` there)."""
+
+    def __init__(self, embedding_dim: int, num_heads: int, downsample_rate: int = 1) -> None:
+        super().__init__()
+        self.embedding_dim = embedding_dim
+        self.internal_dim = embedding_dim // downsample_rate
+        self.num_heads = num_heads
+        assert self.internal_dim % num_heads == 0, "num_heads must divide embedding_dim."
+        self.q_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.k_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.v_proj = nn.Linear(embedding_dim, self.internal_dim)
+        self.out_proj = nn.Linear(self.internal_dim, embedding_dim)
+
+    def run(self, q, k, v, P, residual=None, res_row_mod=0):
+        """q [Pq, Nq, C], k/v [Pk, Nk, C] with Pq, Pk in {1, P}: a leading 1 means "shared by all P prompts" and is
+        projected once, then broadcast with a zero batch stride.  Returns [P, Nq, C] (+ residual)."""
+        qp = ops.linear(q, self.q_proj.weight, self.q_proj.bias)
+        kp = ops.linear(k, self.k_proj.weight, self.k_proj.bias)
+        vp = ops.linear(v, self.v_proj.weight, self.v_proj.bias)
+        ex = lambda t: t if t.shape[0] == P else t.expand(P, -1, -1)
+        c = self.internal_dim // self.num_heads
+        o = ops.mha(ex(qp), ex(kp), ex(vp), self.num_heads, 1.0 / math.sqrt(c), small=True)
+        return ops.linear(o, self.out_proj.weight, self.out_proj.bias, residual=residual, res_row_mod=res_row_mod)
+
+
+class TwoWayAttentionBlock(nn.Module):
+    def __init__(self, embedding_dim, num_heads, mlp_dim=2048, activation=nn.ReLU, attention_downsample_rate=2,
+                 skip_first_layer_pe=False):
+        super().__init__()
+        self.self_attn = DecoderAttention(embedding_dim, num_heads)
+        self.norm1 = nn.LayerNorm(embedding_dim)
+        self.cross_attn_token_to_image = DecoderAttention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.norm2 = nn.LayerNorm(embedding_dim)
+        self.mlp = MLPBlock(embedding_dim, mlp_dim, activation)
+        self.norm3 = nn.LayerNorm(embedding_dim)
+        self.norm4 = nn.LayerNorm(embedding_dim)
+        self.cross_attn_image_to_token = DecoderAttention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.skip_first_layer_pe = skip_first_layer_pe
+
+    def run(self, queries, keys, query_pe, key_pe, P):
+        """transformer.py:151-182.  queries/query_pe [P,N,C]; keys [1|P, hw, C]; key_pe [1, hw, C]."""
+        ln = lambda x, n: ops.layernorm(x, n.weight, n.bias, n.eps)
+        hw = keys.shape[1]
+        if self.skip_first_layer_pe:
+            queries = self.self_attn.run(queries, queries, queries, P)
+        else:
+            q = ops.add_rows(queries, query_pe)
+            queries = self.self_attn.run(q, q, queries, P, residual=queries)
+        queries = ln(queries, self.norm1)
+        q = ops.add_rows(queries, query_pe)
+        k = ops.add_rows(keys, key_pe)  # key_pe has hw rows: broadcast over prompts by row modulo
+        queries = self.cross_attn_token_to_image.run(q, k, keys, P, residual=queries)
+        queries = ln(queries, self.norm2)
+        queries = self.mlp.rows(queries, residual=queries)
+        queries = ln(queries, self.norm3)
+        q = ops.add_rows(queries, query_pe)
+        keys = self.cross_attn_image_to_token.run(k, q, queries, P, residual=keys,
+                                                  res_row_mod=hw if keys.shape[0] == 1 and P > 1 else 0)
+        keys = ln(keys, self.norm4)
+        return queries, keys
+
+
+class TwoWayTransformer(nn.Module):
+    """transformer.py:16-106."""
+
+    def __init__(self, depth, embedding_dim, num_heads, mlp_dim, activation=nn.ReLU, attention_downsample_rate=2):
+        super().__init__()
+        self.depth = depth
+        self.embedding_dim = embedding_dim
+        self.num_heads = num_heads
+        self.mlp_dim = mlp_dim
+        self.layers = nn.ModuleList()
+        for i in range(depth):
+            self.layers.append(TwoWayAttentionBlock(embedding_dim=embedding_dim, num_heads=num_heads, mlp_dim=mlp_dim,
+                                                    activation=activation,
+                                                    attention_downsample_rate=attention_downsample_rate,
+                                                    skip_first_layer_pe=(i == 0)))
+        self.final_attn_token_to_image = DecoderAttention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
+        self.norm_final_attn = nn.LayerNorm(embedding_dim)
+
+    def run(self, src_tokens, pe_tokens, point_embedding):
+        """src_tokens [1|P, hw, C] rows, pe_tokens [1, hw, C], point_embedding [P, N, C] -> (queries, keys [P, hw, C])."""
+        P = point_embedding.shape[0]
+        queries, keys = point_embedding, src_tokens
+        for layer in self.layers:
+            queries, keys = layer.run(queries, keys, point_embedding, pe_tokens, P)
+        q = ops.add_rows(queries, point_embedding)
+        k = ops.add_rows(keys, pe_tokens)
+        queries = self.final_attn_token_to_image.run(q, k, keys, P, residual=queries)
+        queries = ops.layernorm(queries, self.norm_final_attn.weight, self.norm_final_attn.bias, self.norm_final_attn.eps)
+        return queries, keys
+
+    def forward(self, image_embedding, image_pe, point_embedding):
+        bs, c, h, w = image_embedding.shape
+        src = ops.nchw_to_tokens(image_embedding.contiguous())
+        pe = ops.nchw_to_tokens(image_pe.to(BF16).contiguous())[:1]
+        return self.run(src, pe, point_embedding)
+
+
+class MLP(nn.Module):
+    """mask_decoder.py:169-191."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers, sigmoid_output=False):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+        self.sigmoid_output = sigmoid_output
+
+    def rows(self, x, out_f32=False):
+        for i, layer in enumerate(self.layers):
+            last = i == self.num_layers - 1
+            x = ops.linear(x, layer.weight, layer.bias, act=ops.ACT_NONE if last else ops.ACT_RELU, out_f32=out_f32 and last)
+        if self.sigmoid_output:
+            raise NotImplementedError("sigmoid_output is not used on the WalkGPT path")
+        return x
+
+
+class MaskDecoder(nn.Module, _Prepared):
+    """mask_decoder.py:16-164."""
+
+    def __init__(self, *, transformer_dim, transformer, num_multimask_outputs=3, activation=nn.GELU, iou_head_depth=3,
+                 iou_head_hidden_dim=256):
+        super().__init__()
+        self.transformer_dim = transformer_dim
+        self.transformer = transformer
+        self.num_multimask_outputs = num_multimask_outputs
+        self.iou_token = nn.Embedding(1, transformer_dim)
+        self.num_mask_tokens = num_multimask_outputs + 1
+        self.mask_tokens = nn.Embedding(self.num_mask_tokens, transformer_dim)
+        self.output_upscaling = nn.Sequential(
+            nn.ConvTranspose2d(transformer_dim, transformer_dim // 4, kernel_size=2, stride=2),
+            LayerNorm2d(transformer_dim // 4),
+            activation(),
+            nn.ConvTranspose2d(transformer_dim // 4, transformer_dim // 8, kernel_size=2, stride=2),
+            activation(),
+        )
+        self.output_hypernetworks_mlps = nn.ModuleList(
+            [MLP(transformer_dim, transformer_dim, transformer_dim // 8, 3) for _ in range(self.num_mask_tokens)])
+        self.iou_prediction_head = MLP(transformer_dim, iou_head_hidden_dim, self.num_mask_tokens, iou_head_depth)
+
+    def _build_prepared(self):
+        c1, c3 = self.output_upscaling[0], self.output_upscaling[3]
+        # ConvTranspose2d(k=2, s=2) == per-pixel GEMM whose output columns are (dy, dx, c_out): weight [Cin, Cout, 2, 2]
+        # -> [(dy, dx, Cout), Cin]; the bias repeats over the four sub-pixels.
+        return {
+            "up1_w": c1.weight.permute(2, 3, 1, 0).reshape(-1, c1.weight.shape[0]).contiguous(),
+            "up1_b": c1.bias.repeat(4).contiguous(),
+            "up2_w": c3.weight.permute(2, 3, 1, 0).reshape(-1, c3.weight.shape[0]).contiguous(),
+            "up2_b": c3.bias.repeat(4).contiguous(),
+            "out_tokens": torch.cat([self.iou_token.weight, self.mask_tokens.weight], 0).contiguous(),
+        }
+
+    def predict_masks_tokens(self, src_tokens, pe_tokens, sparse, h, w, mask_slice):
+        """src_tokens [1|P, hw, C] (image embedding + dense prompt, channels-last rows), pe_tokens [1, hw, C],
+        sparse [P, n, C] -> (masks fp32 [P, k, 4h, 4w], iou fp32 [P, k])."""
+        p = self._prep_get(self._build_prepared)
+        P = sparse.shape[0]
+        C = self.transformer_dim
+        tokens = torch.cat([p["out_tokens"].unsqueeze(0).expand(P, -1, -1), sparse.to(BF16)], dim=1).contiguous()
+        hs, keys = self.transformer.run(src_tokens, pe_tokens, tokens)
+        ln1 = self.output_upscaling[1]
+        u = ops.linear(keys.reshape(P * h * w, C), p["up1_w"], p["up1_b"])               # [P*hw, 4*C/4]
+        u = ops.layernorm(u.view(P * h * w * 4, C // 4), ln1.weight, ln1.bias, ln1.eps, act=ops.ACT_GELU)
+        u = ops.linear(u, p["up2_w"], p["up2_b"], act=ops.ACT_GELU)                       # [P*hw*4, 4*C/8]
+        hyper = torch.empty(P, self.num_mask_tokens, C // 8, device=u.device, dtype=BF16)
+        for i in range(self.num_mask_tokens):
+            hyper[:, i] = self.output_hypernetworks_mlps[i].rows(hs[:, 1 + i].contiguous())
+        k0, nk = mask_slice
+        masks = ops.hyper_mask_dot(u, hyper, P, h, w, k0, nk)
+        iou = self.iou_prediction_head.rows(hs[:, 0].contiguous(), out_f32=True)
+        return masks, iou[:, k0:k0 + nk]
+
+    def forward(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output):
+        """mask_decoder.py:75-114 signature.  image_embeddings [1,C,h,w]; dense [P,C,h,w] (normally the broadcast
+        no_mask_embed); returns (masks [P,1|3,4h,4w] fp32, iou [P,1|3] fp32)."""
+        _check_bf16_gpu(image_embeddings, "image_embeddings")
+        b, c, h, w = image_embeddings.shape
+        P = sparse_prompt_embeddings.shape[0]
+        emb = ops.nchw_to_tokens(image_embeddings.contiguous())                 # [b, hw, C]
+        d = dense_prompt_embeddings
+        if d.stride(0) == 0 and d.stride(2) == 0 and d.stride(3) == 0 and b == 1:
+            src = ops.add_rows(emb, d[0, :, 0, 0].to(BF16).reshape(1, c).contiguous())   # shared by all prompts
+        else:
+            src = ops.add_rows(emb.expand(P, -1, -1).contiguous() if b == 1 else emb,
+                               ops.nchw_to_tokens(d.to(BF16).contiguous()).reshape(-1, c))
+        pe = ops.nchw_to_tokens(image_pe.to(BF16).contiguous())[:1]
+        sl = (1, self.num_mask_tokens - 1) if multimask_output else (0, 1)
+        return self.predict_masks_tokens(src, pe, sparse_prompt_embeddings, h, w, sl)
+
+
+class Sam(nn.Module):
+    """sam.py:18-172 container + postprocess_masks (the only method WalkGPT calls on it)."""
+
+    mask_threshold: float = 0.0
+    image_format: str = "RGB"
+
+    def __init__(self, image_encoder, prompt_encoder, mask_decoder, pixel_mean=(123.675, 116.28, 103.53),
+                 pixel_std=(58.395, 57.12, 57.375)):
+        super().__init__()
+        self.image_encoder = image_encoder
+        self.prompt_encoder = prompt_encoder
+        self.mask_decoder = mask_decoder
+        self.register_buffer("pixel_mean", torch.Tensor(pixel_mean).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.Tensor(pixel_std).view(-1, 1, 1), False)
+
+    def postprocess_masks(self, masks, input_size, original_size):
+        """sam.py:137-172 (fp32 out), fused into one pass by wg_postprocess_masks_f32."""
+        return ops.postprocess_masks(masks.float().contiguous(), self.image_encoder.img_size, input_size, original_size)
+
+
+def _build_sam(encoder_embed_dim, encoder_depth, encoder_num_heads, encoder_global_attn_indexes, checkpoint=None,
+               image_size=1024):
+    """build_sam.py:56-108."""
+    prompt_embed_dim = 256
+    vit_patch_size = 16
+    image_embedding_size = image_size // vit_patch_size
+    sam = Sam(
+        image_encoder=ImageEncoderViT(depth=encoder_depth, embed_dim=encoder_embed_dim, img_size=image_size, mlp_ratio=4,
+                                      norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), num_heads=encoder_num_heads,
+                                      patch_size=vit_patch_size, qkv_bias=True, use_rel_pos=True,
+                                      global_attn_indexes=encoder_global_attn_indexes, window_size=14,
+                                      out_chans=prompt_embed_dim),
+        prompt_encoder=PromptEncoder(embed_dim=prompt_embed_dim, image_embedding_size=(image_embedding_size, image_embedding_size),
+                                     input_image_size=(image_size, image_size), mask_in_chans=16),
+        mask_decoder=MaskDecoder(num_multimask_outputs=3,
+                                 transformer=TwoWayTransformer(depth=2, embedding_dim=prompt_embed_dim, mlp_dim=2048, num_heads=8),
+                                 transformer_dim=prompt_embed_dim, iou_head_depth=3, iou_head_hidden_dim=256),
+    )
+    sam.eval()
+    if checkpoint is not None:
+        with open(checkpoint, "rb") as f:
+            state_dict = torch.load(f)
+        sam.load_state_dict(state_dict, strict=False)
+    return sam
+
+
+def build_sam_vit_h(checkpoint=None):
+    return _build_sam(1280, 32, 16, [7, 15, 23, 31], checkpoint)
+
+
+def build_sam_vit_l(checkpoint=None):
+    return _build_sam(1024, 24, 16, [5, 11, 17, 23], checkpoint)
+
+
+def build_sam_vit_b(checkpoint=None):
+    return _build_sam(768, 12, 12, [2, 5, 8, 11], checkpoint)
+
+
+build_sam = build_sam_vit_h
+sam_model_registry = {"default": build_sam_vit_h, "vit_h": build_sam_vit_h, "vit_l": build_sam_vit_l, "vit_b": build_sam_vit_b}

@@ -1,0 +1,114 @@
+"""Grounded-segmentation forward path of WalkGPT on the HIP modules.
+
+Mirrors the vision/grounding half of /root/reference/model/walkgpt.py:
+  * attribute names of walkgptMetaModel (`visual_model`, `out_mm_projector`, `text_hidden_fcs`, `vision_tower`) so
+    the `model.*` state_dict keys of SURVEY.md Appendix A line up;
+  * `get_visual_embs` (:241-258);
+  * the decode wiring of `evaluate()` (:713-737): image embedding i -> prompt encoder (text branch) -> mask decoder ->
+    Sam.postprocess_masks -> pred_mask[:, 0] and the mask score.  (The released `model_forward` feeds LLM tokens into
+    the mask decoder and raises; SURVEY.md fact 3.  The wiring here is the one that runs.)
+The language model between MSQP and CTP stays stock PyTorch and is not part of this module: callers hand over the
+LLM hidden states at the [SEG] positions (`decode_from_hidden`), or already-projected prompt embeddings (`decode`).
+"""
+from types import SimpleNamespace
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .clip_encoder import CLIPVisionTower, patch_key_mask
+from .segment_anything import modeling as sam_modeling
+from .utils_walkgpt import CalibratedTextProjector, MultiScaleQFormerProjector
+
+BF16 = torch.bfloat16
+
+
+class WalkGPTGrounding(nn.Module):
+    """Vision + grounding modules of walkgptMetaModel.initialize_walkgpt_modules (walkgpt.py:59-146).
+
+    sam: "vit_b" | "vit_l" | "vit_h" (the reference hard-codes vit_h, :128) or a dict of ImageEncoderViT geometry.
+    llm_hidden: H of the language model (4096 for 7B).  clip_config: None -> ViT-L/14.
+    """
+
+    def __init__(self, sam="vit_h", llm_hidden=4096, out_dim=256, clip_config=None, clip_image_size=448,
+                 select_layer=-2, with_clip=True, with_projectors=True):
+        super().__init__()
+        if isinstance(sam, str):
+            self.visual_model = sam_modeling.sam_model_registry[sam]()
+        else:
+            self.visual_model = sam_modeling._build_sam(sam["embed_dim"], sam["depth"], sam["heads"], list(sam["global_idx"]),
+                                                        image_size=sam.get("img", 1024))
+        if with_projectors:
+            self.out_mm_projector = MultiScaleQFormerProjector(256, llm_hidden, target_square_side=6)  # walkgpt.py:99-102
+            self.text_hidden_fcs = nn.ModuleList([CalibratedTextProjector(llm_hidden, out_dim)])        # :115-123
+        if with_clip:
+            args = SimpleNamespace(mm_vision_select_layer=select_layer, pad_train_clip_images=True,
+                                   resize_vision_tower=True, resize_vision_tower_size=clip_image_size)
+            self.vision_tower = CLIPVisionTower("openai/clip-vit-large-patch14-336", args, config=clip_config)
+        self.eval()
+
+    # -- walkgpt.py:241-258 -----------------------------------------------------------------------------------------
+    def get_visual_embs(self, pixel_values):
+        return self.visual_model.image_encoder(pixel_values)
+
+    def get_visual_emb_tokens(self, pixel_values):
+        """Channels-last form of get_visual_embs: [B, h*w, 256] rows (what MSQP and the mask decoder consume)."""
+        t = self.visual_model.image_encoder.forward_tokens(pixel_values)
+        return t.view(pixel_values.shape[0], -1, t.shape[-1])
+
+    # -- llava_arch.py:160-193 + clip_encoder.py:71-98 ---------------------------------------------------------------------
+    def encode_images_clip(self, images_clip, clip_resize_list=None):
+        mask = patch_key_mask(images_clip, clip_resize_list)
+        return self.vision_tower(images_clip, attention_mask=mask)
+
+    # -- walkgpt.py:316-318 / 364-378 (batched instead of one call per image) --------------------------------------------------
+    def project_visual_tokens(self, emb_tokens):
+        return self.out_mm_projector(emb_tokens)
+
+    # -- walkgpt.py:713-737 --------------------------------------------------------------------------------------------------------
+    def decode(self, emb_tokens, pred_embeddings: Sequence[torch.Tensor], resize_list, original_size_list,
+               multimask_output=False) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+        """emb_tokens [B, hw, 256]; pred_embeddings[i] [T_i, 256] -> (pred_masks[i] fp32 [T_i, H0, W0], mask_scores[i] [T_i])."""
+        vm = self.visual_model
+        h, w = vm.prompt_encoder.image_embedding_size
+        pe = vm.prompt_encoder.dense_pe_tokens().unsqueeze(0)
+        no_mask = vm.prompt_encoder.no_mask_embed.weight.reshape(1, -1)
+        sl = (1, vm.mask_decoder.num_mask_tokens - 1) if multimask_output else (0, 1)
+        pred_masks, mask_scores = [], []
+        for i, emb in enumerate(pred_embeddings):
+            if emb.shape[0] == 0:
+                H0, W0 = original_size_list[i]
+                pred_masks.append(torch.zeros(0, H0, W0, device=emb_tokens.device))
+                mask_scores.append(torch.zeros(0, device=emb_tokens.device))
+                continue
+            sparse, _ = vm.prompt_encoder(points=None, boxes=None, masks=None, text_embeds=emb.unsqueeze(1))
+            src = ops.add_rows(emb_tokens[i:i + 1], no_mask)             # image embedding + dense (no-mask) prompt
+            low_res, _iou = vm.mask_decoder.predict_masks_tokens(src, pe, sparse, h, w, sl)
+            full = vm.postprocess_masks(low_res, input_size=resize_list[i], original_size=original_size_list[i])
+            m = full[:, 0].contiguous()
+            pred_masks.append(m)
+            mask_scores.append(ops.mask_score(m))
+        return pred_masks, mask_scores
+
+    def decode_from_hidden(self, emb_tokens, seg_hidden: Sequence[torch.Tensor], resize_list, original_size_list):
+        """seg_hidden[i] [T_i, H_llm]: last-layer LLM states at the positions preceding each [SEG] (walkgpt.py:406-447;
+        CTP is per token, so projecting only the gathered rows equals projecting the sequence and gathering)."""
+        ctp = self.text_hidden_fcs[0]
+        return self.decode(emb_tokens, [ctp(hs) for hs in seg_hidden], resize_list, original_size_list)
+
+    @torch.no_grad()
+    def forward(self, images, images_clip, seg_hidden, resize_list, original_size_list, clip_resize_list=None):
+        """The fused vision + grounding step the bench times: CLIP tower, SAM encoder, MSQP, CTP, decode, postprocess.
+        Returns dict(pred_masks, mask_scores, clip_features, visual_tokens)."""
+        out = {}
+        if hasattr(self, "vision_tower"):
+            out["clip_features"], out["clip_pre_features"] = self.encode_images_clip(images_clip, clip_resize_list)
+        emb_tokens = self.get_visual_emb_tokens(images)
+        if hasattr(self, "out_mm_projector"):
+            out["visual_tokens"] = self.project_visual_tokens(emb_tokens)
+            pred = [self.text_hidden_fcs[0](hs) for hs in seg_hidden]
+        else:
+            pred = list(seg_hidden)  # already 256-d prompt embeddings
+        out["pred_masks"], out["mask_scores"] = self.decode(emb_tokens, pred, resize_list, original_size_list)
+        return out
