@@ -82,7 +82,7 @@ def cpu_baseline(args):
     from oracle import projectors as oproj
     from oracle import sam as osam
     from tests.golden import cases
-    threads = args.cpu_threads or len(os.sched_getaffinity(0))
+    threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))  # 16 = the CPU share of a one-GPU box
     torch.set_num_threads(threads)
     gen = torch.Generator().manual_seed(7)
 

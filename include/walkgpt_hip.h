@@ -103,8 +103,11 @@ int wg_hyper_mask_dot(const void* up, const void* hyper, float* masks, int T, in
 int wg_postprocess_masks_f32(const float* low_res, float* out, int N, int low_h, int low_w, int img_size, int in_h,
                              int in_w, int out_h, int out_w, void* stream);
 
-/* mask score = sum(sigmoid(x)[x>0]) / (count[x>0] + 1e-6) per mask (model/walkgpt.py:540-542, :737). */
-int wg_mask_score_f32(const float* masks, float* score, int N, long hw, void* stream);
+/* mask score = sum(sigmoid(x)[x>0]) / (count[x>0] + 1e-6) per mask (model/walkgpt.py:540-542, :737).  Two-pass,
+ * atomics-free reduction; the caller provides wg_mask_score_workspace_floats(N, hw) floats of scratch. */
+long wg_mask_score_workspace_floats(int N, long hw);
+int wg_mask_score_f32(const float* masks, float* score, float* workspace, long workspace_floats, int N, long hw,
+                      void* stream);
 
 /* MSQP pieces (utils/utils_walkgpt.py): _pool_grid_tokens :195-201, _global_token :256-257, SegAwareGate tail :213-217. */
 int wg_avgpool_tokens_bf16(const void* x, void* y, int B, int H, int W, int C, int s, void* stream);

@@ -32,7 +32,7 @@ SIGNATURES = {
     "wg_cast_f32_to_bf16": [c_void_p, c_void_p, c_long, c_void_p],
     "wg_hyper_mask_dot": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_postprocess_masks_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    "wg_mask_score_f32": [c_void_p, c_void_p, c_int, c_long, c_void_p],
+    "wg_mask_score_f32": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_void_p],
     "wg_avgpool_tokens_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_mean_tokens_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "wg_sigmoid_gate_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
@@ -40,7 +40,8 @@ SIGNATURES = {
                          c_float, c_void_p],
     "wg_resample_tokens_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
 }
-_SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, [])}
+_SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, []),
+            "wg_mask_score_workspace_floats": (c_long, [c_int, c_long])}
 
 
 class WalkgptHipError(RuntimeError):

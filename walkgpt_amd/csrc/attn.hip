@@ -243,50 +243,69 @@ __global__ __launch_bounds__(NW * 64) void wg_attn_kernel(AttnArgs a) {
             }
         }
 
-        // scores in the exp2 domain + bias + masking
+        // ---- softmax bookkeeping in the exp2 domain.  VALU-bound at head_dim 64 (2 MFMA per 4 exp), so every
+        // per-element instruction counts: s = fma(acc, scale*log2e, bias) only where a bias exists; the tile-uniform
+        // row term of the rel-pos bias and the running max are folded into one per-lane offset; keys beyond Lk are
+        // masked on the last tile only; O is rescaled only when some row's max grew by more than RESCALE_THR
+        // (p then stays below 2^RESCALE_THR, exactly representable scale in fp32 accumulators).
+        constexpr float RESCALE_THR = 6.0f;
         float rowh = 0.f;
         if constexpr (ROWTILE) rowh = relh_tab[t];
+        const bool last_tile = (t == nt - 1) && (Lk & 63) != 0;
+        const bool have_kb = !GRID && a.key_bias != nullptr;
         float mt = NEG_BIG;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
+            f32x4 kbv[4];
+            if (have_kb) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) kbv[g4] = *(const f32x4*)(tab + t * 64 + kb * 32 + 8 * g4 + 4 * hi);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kin = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // key index inside the tile
-                float v = st[kb][r] * sc2;
+                float v;
                 if constexpr (ROWTILE) {
-                    v += relw_reg[kb * 16 + r] + rowh;
+                    v = st[kb][r] * sc2 + relw_reg[kb * 16 + r];
                 } else if constexpr (GRID) {
                     int kl = t * 64 + kin;
                     kl = kl < SS ? kl : SS - 1;
-                    v += relh_tab[kl / S] + relw_tab[kl % S];
+                    v = st[kb][r] * sc2 + (relh_tab[kl / S] + relw_tab[kl % S]);
                 } else {
-                    if (a.key_bias) v += tab[t * 64 + kin];
+                    v = have_kb ? st[kb][r] * sc2 + kbv[r >> 2][r & 3] : st[kb][r];  // no bias: stay in raw units
                 }
-                if (t * 64 + kin >= Lk) v = NEG_BIG;
+                if (last_tile && t * 64 + kin >= Lk) v = NEG_BIG;
                 st[kb][r] = v;
                 mt = fmaxf(mt, v);
             }
         }
+        const bool raw = !GRID && !have_kb;          // scores still unscaled: p = exp2(s*sc2 - off)
+        if (raw) mt *= sc2;
+        mt += rowh;
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);
-        const float alpha = exp2f(m_run - m_new);
-        m_run = m_new;
+        if (__any(mt > m_run + RESCALE_THR)) {
+            const float m_new = fmaxf(m_run, mt);
+            const float alpha = exp2f(m_run - m_new);
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+        }
+        const float off = m_run - rowh;
         float ls = 0.f;
         bf16x8 pf[4];  // P^T fragments: k-step (kb, s2) uses registers 8*s2 .. 8*s2+7 of block kb
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(st[kb][r] - m_new);
+                const float p = raw ? exp2f(st[kb][r] * sc2 - off) : exp2f(st[kb][r] - off);
                 ls += p;
                 pf[kb * 2 + (r >> 3)][r & 7] = (bf16)p;
             }
         }
-        l_run = l_run * alpha + ls;
-#pragma unroll
-        for (int d = 0; d < DB; ++d)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+        l_run += ls;
 
         // O^T += V^T . P^T
         {
@@ -374,22 +393,24 @@ extern "C" int wg_mha_bf16(const void* Q, long ldq, long q_rows_per_batch, const
     a.key_bias = key_bias; a.B = B; a.heads = heads; a.Lq = Lq; a.Lk = Lk; a.scale = scale;
     hipStream_t st = (hipStream_t)stream;
     const int groups = B * heads;
-    if (Lq > 512) {
-        a.qchunks = (Lq + 255) / 256;
-        if (head_dim == 64) return launch_attn<64, 0, 8>(a, groups, st);
-        if (head_dim == 128) return launch_attn<128, 0, 8>(a, groups, st);
-        if (head_dim == 32) return launch_attn<32, 0, 8>(a, groups, st);
-    } else if (Lq > 32) {
-        a.qchunks = (Lq + 127) / 128;
-        if (head_dim == 64) return launch_attn<64, 0, 4>(a, groups, st);
-        if (head_dim == 128) return launch_attn<128, 0, 4>(a, groups, st);
-        if (head_dim == 32) return launch_attn<32, 0, 4>(a, groups, st);
-    } else {
-        a.qchunks = 1;
-        if (head_dim == 64) return launch_attn<64, 0, 1>(a, groups, st);
-        if (head_dim == 128) return launch_attn<128, 0, 1>(a, groups, st);
-        if (head_dim == 32) return launch_attn<32, 0, 1>(a, groups, st);
+    const int qblocks = (Lq + 31) / 32;
+    // waves per workgroup: the candidate that wastes the fewest 32-query slots (1025 CLIP tokens = 33 blocks = 11 x 3)
+    int nw = 1;
+    if (qblocks > 1) {
+        const int cand[3] = {8, 4, 3};
+        double best = -1.0;
+        for (int c : cand) {
+            if (head_dim != 64 && c == 3) continue;
+            const double util = (double)qblocks / (double)(((qblocks + c - 1) / c) * c);
+            if (util > best + 1e-9) { best = util; nw = c; }
+        }
     }
+    a.qchunks = (qblocks + nw - 1) / nw;
+#define WG_MHA_CASE(HD_, NW_) if (head_dim == HD_ && nw == NW_) return launch_attn<HD_, 0, NW_>(a, groups, st);
+    WG_MHA_CASE(64, 8) WG_MHA_CASE(64, 4) WG_MHA_CASE(64, 3) WG_MHA_CASE(64, 1)
+    WG_MHA_CASE(128, 8) WG_MHA_CASE(128, 4) WG_MHA_CASE(128, 1)
+    WG_MHA_CASE(32, 8) WG_MHA_CASE(32, 4) WG_MHA_CASE(32, 1)
+#undef WG_MHA_CASE
     wg_set_error("mha: head_dim %d not supported (32, 64, 128)", head_dim);
     return WG_ERR_UNSUPPORTED;
 }

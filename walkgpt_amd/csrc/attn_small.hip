@@ -103,6 +103,64 @@ __global__ __launch_bounds__(256) void wg_attn_small_kernel(SmallAttnArgs a) {
     }
 }
 
+// Few keys (the decoder's image -> token attention: 4096 queries x 6..20 keys, transformer.py:176-180): one THREAD per
+// (batch, head, query); the handful of K/V rows is shared by the whole block through L1.  q, o stay in registers.
+template <int HD>
+__global__ __launch_bounds__(256) void wg_attn_fewkeys_kernel(SmallAttnArgs a) {
+    const long total = (long)a.B * a.heads * a.Lq;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    // heads fastest so that consecutive threads write consecutive 2*HD-byte pieces of one output row
+    const int h = (int)(i % a.heads);
+    const int qi = (int)((i / a.heads) % a.Lq);
+    const int b = (int)(i / ((long)a.heads * a.Lq));
+    const int dcol = h * HD;
+    float q[HD], o[HD];
+    {
+        const bf16* qp = a.Q + ((long)b * a.q_bs + qi) * a.ldq + dcol;
+#pragma unroll
+        for (int c = 0; c < HD / 8; ++c) {
+            const bf16x8 t = *(const bf16x8*)(qp + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) q[8 * c + e] = (float)t[e] * a.scale * 1.4426950408889634f;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    float m = -1.0e30f, l = 0.f;
+    for (int j = 0; j < a.Lk; ++j) {
+        const long row = (long)b * a.k_bs + j;
+        const bf16* kp = a.K + row * a.ldk + dcol;
+        const bf16* vp = a.V + row * a.ldv + dcol;
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < HD / 8; ++c) {
+            const bf16x8 kk = *(const bf16x8*)(kp + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += q[8 * c + e] * (float)kk[e];
+        }
+        const float mn = fmaxf(m, s);
+        const float alpha = exp2f(m - mn), p = exp2f(s - mn);
+        m = mn;
+        l = l * alpha + p;
+#pragma unroll
+        for (int c = 0; c < HD / 8; ++c) {
+            const bf16x8 vv = *(const bf16x8*)(vp + 8 * c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[8 * c + e] = o[8 * c + e] * alpha + p * (float)vv[e];
+        }
+    }
+    const float inv = 1.0f / l;
+    bf16* op = a.O + ((long)b * a.o_bs + qi) * a.ldo + dcol;
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+        bf16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (bf16)(o[8 * c + e] * inv);
+        *(bf16x8*)(op + 8 * c) = t;
+    }
+}
+
 extern "C" int wg_mha_small_bf16(const void* Q, long ldq, long q_rows_per_batch, const void* K, long ldk, const void* V,
                                  long ldv, long k_rows_per_batch, void* O, long ldo, long o_rows_per_batch, int B,
                                  int heads, int head_dim, int Lq, int Lk, float scale, void* stream) {
@@ -115,6 +173,12 @@ extern "C" int wg_mha_small_bf16(const void* Q, long ldq, long q_rows_per_batch,
     const long waves = (long)B * heads * Lq;
     dim3 grid((unsigned)((waves + 3) / 4)), block(256);
     hipStream_t st = (hipStream_t)stream;
+    if (Lk <= 32 && Lq >= 256 && (head_dim == 16 || head_dim == 32)) {
+        dim3 g2((unsigned)((waves + 255) / 256));
+        if (head_dim == 16) hipLaunchKernelGGL(wg_attn_fewkeys_kernel<16>, g2, block, 0, st, a);
+        else hipLaunchKernelGGL(wg_attn_fewkeys_kernel<32>, g2, block, 0, st, a);
+        return wg_check_launch("wg_mha_small_bf16(fewkeys)");
+    }
     switch (head_dim) {
         case 16: hipLaunchKernelGGL(wg_attn_small_kernel<16>, grid, block, 0, st, a); break;
         case 32: hipLaunchKernelGGL(wg_attn_small_kernel<32>, grid, block, 0, st, a); break;

@@ -30,8 +30,9 @@ struct GemmArgs {
     int tiles_m, tiles_n;
 };
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool STAGED>
 __global__ __launch_bounds__(WM* WN * 64) void wg_gemm_kernel(GemmArgs g) {
+    static_assert((BM / WM) % 64 == 0, "the staged epilogue walks the wave tile 64 rows at a time");
     constexpr int NT = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int FI = WTM / 16, FJ = WTN / 16;
@@ -122,7 +123,80 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_gemm_kernel(GemmArgs g) {
         __syncthreads();
     }
 
-    // Epilogue. acc[i][j][e]: output row m = .. + i*16 + (lane&15), column n = .. + j*16 + (lane>>4)*4 + e.
+    // ---- epilogue -------------------------------------------------------------------------------------------------------
+    // acc[i][j][e]: output row m = .. + i*16 + (lane&15), column n = .. + j*16 + (lane>>4)*4 + e.
+    const int nbase = n0 + wn * WTN;
+    if (STAGED) {
+        // bf16 output: bias + activation in registers, then the wave's sub-tile goes through a private LDS slab
+        // (64 rows at a time, rows padded by 16 bytes) so that residual loads and output stores are whole 128-byte
+        // row segments, 16 bytes per lane, instead of 8-byte pieces of 16 different rows.
+        constexpr int SROW = WTN * 2 + 16;
+        constexpr int CH = WTN / 8;          // 16-byte chunks per row
+        constexpr int RPI = 64 / CH;         // rows per wave-instruction
+        char* stg = smem + wave * (64 * SROW);
+        float bv[FJ][4];
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            const int n = nbase + j * 16 + fq * 4;
+            if (g.bias && n < g.N) {
+                const bf16x4 b = *(const bf16x4*)(g.bias + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[j][e] = (float)b[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[j][e] = 0.f;
+            }
+        }
+#pragma unroll
+        for (int half = 0; half < WTM / 64; ++half) {
+            // residual rows of this 64-row slab: issued first, consumed after the LDS round trip
+            bf16x8 rres[64 / RPI];
+            if (g.R) {
+#pragma unroll
+                for (int it = 0; it < 64 / RPI; ++it) {
+                    const int m = m0 + wm * WTM + half * 64 + it * RPI + lane / CH;
+                    const int n = nbase + (lane % CH) * 8;
+                    if (m < g.M && n < g.N) {
+                        const long rrow = (long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr;
+                        rres[it] = *(const bf16x8*)(g.R + rrow + n);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[half * 4 + i][j][e] + bv[j][e];
+                        if (g.act != WG_ACT_NONE) v = wg_act(v, g.act);
+                        o[e] = (bf16)v;
+                    }
+                    *(bf16x4*)(stg + (i * 16 + fr) * SROW + (j * 16 + fq * 4) * 2) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 64 / RPI; ++it) {
+                const int r = it * RPI + lane / CH, ch = lane % CH;
+                const int m = m0 + wm * WTM + half * 64 + r;
+                const int n = nbase + ch * 8;
+                bf16x8 v = *(const bf16x8*)(stg + r * SROW + ch * 16);
+                if (m < g.M && n < g.N) {
+                    if (g.R) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rres[it][e]);
+                    }
+                    *(bf16x8*)((bf16*)g.C + (long)m * g.ldc + n) = v;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < FI; ++i) {
         const int m = m0 + wm * WTM + i * 16 + fr;
@@ -130,7 +204,7 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_gemm_kernel(GemmArgs g) {
         const long rrow = g.R ? (long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr : 0;
 #pragma unroll
         for (int j = 0; j < FJ; ++j) {
-            const int n = n0 + wn * WTN + j * 16 + fq * 4;
+            const int n = nbase + j * 16 + fq * 4;
             if (n >= g.N) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (g.bias) {
@@ -182,18 +256,25 @@ __global__ __launch_bounds__(256) void wg_gemm_rowwave_kernel(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-static int launch_tile(GemmArgs& g, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, bool STAGED>
+static int launch_tile_impl(GemmArgs& g, hipStream_t st) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
     constexpr int lds = 2 * (BM + BN) * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wg_gemm_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)wg_gemm_kernel<BM, BN, WM, WN, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wg_gemm_kernel<BM, BN, WM, WN>), dim3(g.tiles_m * g.tiles_n), dim3(WM * WN * 64), lds, st, g);
+    hipLaunchKernelGGL((wg_gemm_kernel<BM, BN, WM, WN, STAGED>), dim3(g.tiles_m * g.tiles_n), dim3(WM * WN * 64), lds, st, g);
     return wg_check_launch("wg_gemm_bias_act_bf16");
+}
+
+template <int BM, int BN, int WM, int WN>
+static int launch_tile(GemmArgs& g, hipStream_t st) {
+    // staged (LDS-transposed, 16-byte) epilogue for bf16 outputs whose rows are 16-byte addressable
+    const bool staged = !g.out_f32 && g.N % 8 == 0 && g.ldc % 8 == 0 && (!g.R || (g.ldr % 8 == 0 && ((uintptr_t)g.R & 15) == 0));
+    return staged ? launch_tile_impl<BM, BN, WM, WN, true>(g, st) : launch_tile_impl<BM, BN, WM, WN, false>(g, st);
 }
 
 extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, const void* bias,

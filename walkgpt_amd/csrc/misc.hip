@@ -313,25 +313,61 @@ extern "C" int wg_postprocess_masks_f32(const float* low_res, float* out, int N,
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Mask score (walkgpt.py:540-542, :737): sum(sigmoid(x) [x>0]) / (count[x>0] + 1e-6) per mask.  One block per mask.
+// Mask score (walkgpt.py:540-542, :737): sum(sigmoid(x) [x>0]) / (count[x>0] + 1e-6) per mask.
+// Two passes: `nblk` blocks per mask write (sum, count) partials into the caller's workspace [N*nblk*2] floats, then
+// one wave per mask folds them in a fixed order (bitwise reproducible; no atomics).  HBM-bound: reads N*hw*4 bytes.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void wg_mask_score_kernel(const float* masks, float* score, long hw) {
+template <bool VEC>
+__global__ __launch_bounds__(256) void wg_mask_score_partial_kernel(const float* masks, float* ws, long hw, int nblk) {
     __shared__ float ssum[4], scnt[4];
-    const float* m = masks + (long)blockIdx.x * hw;
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const float* m = masks + (long)n * hw;
     float s = 0.f, c = 0.f;
-    for (long i = threadIdx.x; i < hw; i += 256) {
-        const float x = m[i];
-        if (x > 0.f) { s += 1.0f / (1.0f + __expf(-x)); c += 1.f; }
+    if (VEC) {  // hw % 4 == 0 and 16-byte aligned base: 16-byte loads
+        for (long i = (long)blk * 256 + threadIdx.x; i < (hw >> 2); i += (long)nblk * 256) {
+            const f32x4 x = *(const f32x4*)(m + 4 * i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (x[e] > 0.f) { s += 1.0f / (1.0f + __expf(-x[e])); c += 1.f; }
+        }
+    } else {
+        for (long i = (long)blk * 256 + threadIdx.x; i < hw; i += (long)nblk * 256)
+            if (m[i] > 0.f) { s += 1.0f / (1.0f + __expf(-m[i])); c += 1.f; }
     }
     s = wg_wave_sum(s);
     c = wg_wave_sum(c);
     if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s; scnt[threadIdx.x >> 6] = c; }
     __syncthreads();
-    if (threadIdx.x == 0) score[blockIdx.x] = (ssum[0] + ssum[1] + ssum[2] + ssum[3]) / (scnt[0] + scnt[1] + scnt[2] + scnt[3] + 1e-6f);
+    if (threadIdx.x == 0) {
+        ws[((long)n * nblk + blk) * 2 + 0] = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+        ws[((long)n * nblk + blk) * 2 + 1] = scnt[0] + scnt[1] + scnt[2] + scnt[3];
+    }
 }
 
-extern "C" int wg_mask_score_f32(const float* masks, float* score, int N, long hw, void* stream) {
-    WG_REQUIRE(masks && score && N > 0 && hw > 0, "mask_score: bad arguments");
-    hipLaunchKernelGGL(wg_mask_score_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, masks, score, hw);
+__global__ __launch_bounds__(64) void wg_mask_score_final_kernel(const float* ws, float* score, int nblk) {
+    const int n = blockIdx.x;
+    float s = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < nblk; i += 64) { s += ws[((long)n * nblk + i) * 2]; c += ws[((long)n * nblk + i) * 2 + 1]; }
+    s = wg_wave_sum(s);
+    c = wg_wave_sum(c);
+    if (threadIdx.x == 0) score[n] = s / (c + 1e-6f);
+}
+
+static long wg_mask_score_blocks(long hw) {
+    long nblk = (hw + 4095) / 4096;
+    return nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
+}
+
+extern "C" long wg_mask_score_workspace_floats(int N, long hw) { return (long)N * wg_mask_score_blocks(hw) * 2; }
+
+extern "C" int wg_mask_score_f32(const float* masks, float* score, float* workspace, long workspace_floats, int N, long hw,
+                                 void* stream) {
+    WG_REQUIRE(masks && score && workspace && N > 0 && hw > 0, "mask_score: bad arguments");
+    const long nblk = wg_mask_score_blocks(hw);
+    WG_REQUIRE(workspace_floats >= (long)N * nblk * 2, "mask_score: workspace too small (need %ld floats)", (long)N * nblk * 2);
+    const bool vec = (((uintptr_t)masks & 15) == 0) && (hw & 3) == 0;
+    if (vec) hipLaunchKernelGGL(wg_mask_score_partial_kernel<true>, dim3((unsigned)nblk, N), dim3(256), 0, (hipStream_t)stream, masks, workspace, hw, (int)nblk);
+    else hipLaunchKernelGGL(wg_mask_score_partial_kernel<false>, dim3((unsigned)nblk, N), dim3(256), 0, (hipStream_t)stream, masks, workspace, hw, (int)nblk);
+    hipLaunchKernelGGL(wg_mask_score_final_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, workspace, score, (int)nblk);
     return wg_check_launch("wg_mask_score_f32");
 }

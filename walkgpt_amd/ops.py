@@ -247,8 +247,11 @@ def mask_score(masks):
     _need_gpu(masks)
     assert masks.dtype == torch.float32 and masks.is_contiguous()
     N = masks.shape[0]
+    hw = masks.numel() // N
     score = torch.empty(N, device=masks.device, dtype=torch.float32)
-    _lib.check(_lib.lib().wg_mask_score_f32(masks.data_ptr(), score.data_ptr(), N, masks.numel() // N, _stream()), "wg_mask_score_f32")
+    nws = _lib.lib().wg_mask_score_workspace_floats(N, hw)
+    ws = torch.empty(nws, device=masks.device, dtype=torch.float32)
+    _lib.check(_lib.lib().wg_mask_score_f32(masks.data_ptr(), score.data_ptr(), ws.data_ptr(), nws, N, hw, _stream()), "wg_mask_score_f32")
     return score
 
 

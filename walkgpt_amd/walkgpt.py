@@ -59,6 +59,11 @@ class WalkGPTGrounding(nn.Module):
 
     # -- llava_arch.py:160-193 + clip_encoder.py:71-98 ---------------------------------------------------------------------
     def encode_images_clip(self, images_clip, clip_resize_list=None):
+        h, w = images_clip.shape[-2:]
+        if clip_resize_list is None or all(tuple(s) == (h, w) for s in clip_resize_list):
+            # nothing is padded: the key mask is all ones and its additive bias all zeros, so it is not passed at all
+            # (decided from the python size list; no device sync)
+            return self.vision_tower(images_clip, attention_mask=None)
         mask = patch_key_mask(images_clip, clip_resize_list)
         return self.vision_tower(images_clip, attention_mask=mask)
 
@@ -69,33 +74,68 @@ class WalkGPTGrounding(nn.Module):
     # -- walkgpt.py:713-737 --------------------------------------------------------------------------------------------------------
     def decode(self, emb_tokens, pred_embeddings: Sequence[torch.Tensor], resize_list, original_size_list,
                multimask_output=False) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
-        """emb_tokens [B, hw, 256]; pred_embeddings[i] [T_i, 256] -> (pred_masks[i] fp32 [T_i, H0, W0], mask_scores[i] [T_i])."""
+        """emb_tokens [B, hw, 256]; pred_embeddings[i] [T_i, 256] -> (pred_masks[i] fp32 [T_i, H0, W0], mask_scores[i] [T_i]).
+
+        The reference decodes image by image (walkgpt.py:716-737); here every prompt of every image goes through the
+        prompt encoder / two-way decoder as ONE batch of P = sum(T_i) prompts (prompt p attends to the embedding of
+        its own image), and only the size-dependent postprocess runs per image.  Same arithmetic per prompt."""
         vm = self.visual_model
         h, w = vm.prompt_encoder.image_embedding_size
+        dev = emb_tokens.device
         pe = vm.prompt_encoder.dense_pe_tokens().unsqueeze(0)
         no_mask = vm.prompt_encoder.no_mask_embed.weight.reshape(1, -1)
         sl = (1, vm.mask_decoder.num_mask_tokens - 1) if multimask_output else (0, 1)
-        pred_masks, mask_scores = [], []
-        for i, emb in enumerate(pred_embeddings):
-            if emb.shape[0] == 0:
-                H0, W0 = original_size_list[i]
-                pred_masks.append(torch.zeros(0, H0, W0, device=emb_tokens.device))
-                mask_scores.append(torch.zeros(0, device=emb_tokens.device))
-                continue
-            sparse, _ = vm.prompt_encoder(points=None, boxes=None, masks=None, text_embeds=emb.unsqueeze(1))
-            src = ops.add_rows(emb_tokens[i:i + 1], no_mask)             # image embedding + dense (no-mask) prompt
+        counts = [int(e.shape[0]) for e in pred_embeddings]
+        P = sum(counts)
+        pred_masks = [None] * len(counts)
+        mask_scores = [None] * len(counts)
+        if P > 0:
+            text = torch.cat([e for e in pred_embeddings if e.shape[0] > 0], 0)
+            sparse, _ = vm.prompt_encoder(points=None, boxes=None, masks=None, text_embeds=text.unsqueeze(1))
+            if len(counts) == emb_tokens.shape[0] and all(c == 1 for c in counts):
+                src = ops.add_rows(emb_tokens, no_mask)                         # one prompt per image: no gather
+            elif len([c for c in counts if c > 0]) == 1:
+                i = next(k for k, c in enumerate(counts) if c > 0)
+                src = ops.add_rows(emb_tokens[i:i + 1], no_mask)                # one image: shared by its prompts
+            else:
+                idx = torch.tensor([i for i, c in enumerate(counts) for _ in range(c)], device=dev)
+                src = ops.add_rows(emb_tokens.index_select(0, idx), no_mask)
             low_res, _iou = vm.mask_decoder.predict_masks_tokens(src, pe, sparse, h, w, sl)
-            full = vm.postprocess_masks(low_res, input_size=resize_list[i], original_size=original_size_list[i])
-            m = full[:, 0].contiguous()
-            pred_masks.append(m)
-            mask_scores.append(ops.mask_score(m))
+            off = 0
+            same = len(set(zip(map(tuple, resize_list), map(tuple, original_size_list)))) == 1
+            if same and sl[1] == 1:
+                full = vm.postprocess_masks(low_res, input_size=resize_list[0], original_size=original_size_list[0])[:, 0]
+                scores = ops.mask_score(full)
+                for i, c in enumerate(counts):
+                    pred_masks[i], mask_scores[i] = full[off:off + c], scores[off:off + c]
+                    off += c
+            else:
+                for i, c in enumerate(counts):
+                    if c == 0:
+                        continue
+                    full = vm.postprocess_masks(low_res[off:off + c], input_size=resize_list[i], original_size=original_size_list[i])
+                    m = full[:, 0].contiguous()
+                    pred_masks[i], mask_scores[i] = m, ops.mask_score(m)
+                    off += c
+        for i, c in enumerate(counts):
+            if c == 0:
+                H0, W0 = original_size_list[i]
+                pred_masks[i] = torch.zeros(0, H0, W0, device=dev)
+                mask_scores[i] = torch.zeros(0, device=dev)
         return pred_masks, mask_scores
 
     def decode_from_hidden(self, emb_tokens, seg_hidden: Sequence[torch.Tensor], resize_list, original_size_list):
         """seg_hidden[i] [T_i, H_llm]: last-layer LLM states at the positions preceding each [SEG] (walkgpt.py:406-447;
         CTP is per token, so projecting only the gathered rows equals projecting the sequence and gathering)."""
-        ctp = self.text_hidden_fcs[0]
-        return self.decode(emb_tokens, [ctp(hs) for hs in seg_hidden], resize_list, original_size_list)
+        return self.decode(emb_tokens, self._project_seg_hidden(seg_hidden), resize_list, original_size_list)
+
+    def _project_seg_hidden(self, seg_hidden):
+        """CTP over all images' [SEG] rows in one call, split back per image."""
+        counts = [int(h.shape[0]) for h in seg_hidden]
+        if sum(counts) == 0:
+            return [h.new_zeros(0, 256) for h in seg_hidden]
+        pred = self.text_hidden_fcs[0](torch.cat(list(seg_hidden), 0))
+        return list(torch.split(pred, counts, 0))
 
     @torch.no_grad()
     def forward(self, images, images_clip, seg_hidden, resize_list, original_size_list, clip_resize_list=None):
@@ -107,7 +147,7 @@ class WalkGPTGrounding(nn.Module):
         emb_tokens = self.get_visual_emb_tokens(images)
         if hasattr(self, "out_mm_projector"):
             out["visual_tokens"] = self.project_visual_tokens(emb_tokens)
-            pred = [self.text_hidden_fcs[0](hs) for hs in seg_hidden]
+            pred = self._project_seg_hidden(seg_hidden)
         else:
             pred = list(seg_hidden)  # already 256-d prompt embeddings
         out["pred_masks"], out["mask_scores"] = self.decode(emb_tokens, pred, resize_list, original_size_list)
