@@ -193,7 +193,8 @@ def main():
                 e1.record()
                 decode_ev.append((e0, e1))
             if dist is not None:  # the path's one exchange step: mask logits only
-                dist.all_gather_into_tensor(gathered, torch.cat(masks, 0))
+                from walkgpt_amd.dist import all_gather_masks_uniform
+                all_gather_masks_uniform(torch.cat(masks, 0), out=gathered)
         return feats, masks, scores
 
     def fence():
@@ -224,7 +225,7 @@ def main():
     def hook(M, N, K, tile):
         e0 = torch.cuda.Event(enable_timing=True)
         e1 = torch.cuda.Event(enable_timing=True)
-        records.append((tile, 2.0 * M * N * K, e0, e1))
+        records.append((tile, 2.0 * M * N * K, e0, e1, 2.0 * (M * K + N * K + M * N)))
         return e0, e1
 
     ops.GEMM_EVENT_HOOK = hook
@@ -232,16 +233,17 @@ def main():
     torch.cuda.synchronize()
     ops.GEMM_EVENT_HOOK = None
     per_tile = {}
-    for tile, fl, e0, e1 in records:
-        d = per_tile.setdefault(tile, [0, 0.0, 0.0])
+    for tile, fl, e0, e1, nbytes in records:
+        d = per_tile.setdefault(tile, [0, 0.0, 0.0, 0.0])
         d[0] += 1
         d[1] += fl
         d[2] += e0.elapsed_time(e1) * 1e-3
+        d[3] += nbytes
     dom = max(per_tile, key=lambda k: per_tile[k][2])
-    n_l, fl, sec = per_tile[dom]
+    n_l, fl, sec, byt = per_tile[dom]
     achieved_tf = fl / sec / 1e12
     gf_step = B * (GF_CLIP_L_448 + GF_SAM_B + T * (GF_DECODE_PER_TOKEN + GF_CTP_PER_TOKEN))
-    roofline = {"bound": "mfma", "kernel": "wg_gemm_kernel<%s>" % {1: "128,128,2,2", 2: "256,256,2,4", 3: "rowwave"}[dom],
+    roofline = {"bound": "mfma", "kernel": "wg_gemm_kernel<%s>" % {1: "128,128,64,2,2,2", 2: "256,256,64,2,2,4", 8: "256,256,64,2,2,4,pipe", 3: "rowwave"}.get(dom, str(dom)),
                 "achieved": round(achieved_tf, 1), "peak": MFMA_BF16_DENSE_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / MFMA_BF16_DENSE_PEAK_TF, 4), "traffic": None,
                 "launches_per_step": n_l, "avg_launch_us": round(sec / n_l * 1e6, 1),
@@ -249,6 +251,17 @@ def main():
                 "e2e_algorithmic_gflop_per_step": round(gf_step, 1),
                 "e2e_achieved": round(gf_step / ms_per_step, 1),  # GFLOP/ms == TFLOP/s
                 "e2e_frac": round(gf_step / ms_per_step / MFMA_BF16_DENSE_PEAK_TF, 4)}
+
+    try:  # HBM traffic of the dominant kernel from the committed PMC passes of this same command (profiles/)
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)["kernels"]
+        key = [k for k in pmc if k.startswith("wg_gemm_kernel<%s" % ("256, 256" if dom in (2, 8) else "128, 128"))]
+        if key:
+            roofline["traffic"] = pmc[key[0]]["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
+    except (OSError, KeyError, ValueError):
+        pass
+    roofline["algorithmic_bytes_per_launch"] = round(byt / n_l)
 
     out = {"metric": "images/sec", "value": round(images_per_s, 2), "unit": "images/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,

@@ -41,7 +41,10 @@ const char* wg_last_error(void);    /* thread-local, valid until the next failin
  *   mask_decoder.py:53-63 (upscaler) :169-191 (hyper / IoU MLPs)   utils_walkgpt.py:171-175,209-212,226,249,312-316
  *   HF CLIPAttention / CLIPMLP linears (custom_clip.py:50-104 call site).
  * MFMA path needs K%64==0, N%4==0, N>=16, lda/ldw %8==0, ldc/ldr %4==0, 16-byte aligned A/W/C; anything else takes a
- * slower one-wave-per-row kernel.  tile_hint: 0 auto, 1 = 128x128 tiles, 2 = 256x256 tiles, 3 = force row-wave. */
+ * slower one-wave-per-row kernel.  tile_hint: 0 = auto (wg_gemm_pick_tile), 1 = 128x128 tiles (2 workgroups/CU),
+ * 2 = 256x256 tiles (1 workgroup/CU), 3 = force row-wave; 4..9 = experimental pipeline variants kept for A/B runs
+ * (tools/bench_gemm3.py). */
+int wg_gemm_pick_tile(int M, int N);
 int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, const void* bias, const void* residual,
                           long ldr, int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32,
                           int tile_hint, void* stream);

@@ -41,7 +41,8 @@ SIGNATURES = {
     "wg_resample_tokens_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
 }
 _SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, []),
-            "wg_mask_score_workspace_floats": (c_long, [c_int, c_long])}
+            "wg_mask_score_workspace_floats": (c_long, [c_int, c_long]),
+            "wg_gemm_pick_tile": (c_int, [c_int, c_int])}
 
 
 class WalkgptHipError(RuntimeError):

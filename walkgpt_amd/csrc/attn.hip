@@ -52,8 +52,12 @@ template <int HD> __device__ __forceinline__ int swzV(int row) {
     return 0;
 }
 
-template <int HD, int S, int NW>
-__global__ __launch_bounds__(NW * 64) void wg_attn_kernel(AttnArgs a) {
+// raw v_exp_f32: exp2f() adds a denormal-range fix-up (compare, select, ldexp) around it that triples the cost of the
+// one instruction softmax cannot avoid; arguments here are <= RESCALE_THR and results below 2^-126 may flush to zero.
+__device__ __forceinline__ float wg_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int HD, int S, int NW, bool KB>
+__global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     constexpr int CPR = HD / 8;            // 16-byte chunks per K/V row
     constexpr int ROWB = HD * 2;           // bytes per row
     constexpr int TILE = 64 * ROWB;        // bytes per K (or V) tile
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(NW * 64) void wg_attn_kernel(AttnArgs a) {
             }
         }
     } else {
-        if (a.key_bias) {
+        if (KB) {
             for (int k = tid; k < nt * 64; k += NW * 64) {
                 float v = k < Lk ? a.key_bias[(long)b * Lk + k] * LOG2E : NEG_BIG;
                 tab[k] = fmaxf(v, NEG_BIG);
@@ -249,43 +253,49 @@ __global__ __launch_bounds__(NW * 64) void wg_attn_kernel(AttnArgs a) {
         // masked on the last tile only; O is rescaled only when some row's max grew by more than RESCALE_THR
         // (p then stays below 2^RESCALE_THR, exactly representable scale in fp32 accumulators).
         constexpr float RESCALE_THR = 6.0f;
+        constexpr bool RAW = !GRID && !KB;           // no additive bias: scores stay unscaled, p = exp2(s*sc2 - off)
         float rowh = 0.f;
         if constexpr (ROWTILE) rowh = relh_tab[t];
-        const bool last_tile = (t == nt - 1) && (Lk & 63) != 0;
-        const bool have_kb = !GRID && a.key_bias != nullptr;
-        float mt = NEG_BIG;
+        if constexpr (!RAW) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-            f32x4 kbv[4];
-            if (have_kb) {
+            for (int kb = 0; kb < 2; ++kb) {
+                f32x4 kbv[4];
+                if constexpr (KB) {
 #pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) kbv[g4] = *(const f32x4*)(tab + t * 64 + kb * 32 + 8 * g4 + 4 * hi);
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kin = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // key index inside the tile
-                float v;
-                if constexpr (ROWTILE) {
-                    v = st[kb][r] * sc2 + relw_reg[kb * 16 + r];
-                } else if constexpr (GRID) {
-                    int kl = t * 64 + kin;
-                    kl = kl < SS ? kl : SS - 1;
-                    v = st[kb][r] * sc2 + (relh_tab[kl / S] + relw_tab[kl % S]);
-                } else {
-                    v = have_kb ? st[kb][r] * sc2 + kbv[r >> 2][r & 3] : st[kb][r];  // no bias: stay in raw units
+                    for (int g4 = 0; g4 < 4; ++g4) kbv[g4] = *(const f32x4*)(tab + t * 64 + kb * 32 + 8 * g4 + 4 * hi);
                 }
-                if (last_tile && t * 64 + kin >= Lk) v = NEG_BIG;
-                st[kb][r] = v;
-                mt = fmaxf(mt, v);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if constexpr (ROWTILE) {
+                        st[kb][r] = st[kb][r] * sc2 + relw_reg[kb * 16 + r];
+                    } else if constexpr (GRID) {
+                        int kl = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        kl = kl < SS ? kl : SS - 1;
+                        st[kb][r] = st[kb][r] * sc2 + (relh_tab[kl / S] + relw_tab[kl % S]);
+                    } else {
+                        st[kb][r] = st[kb][r] * sc2 + kbv[r >> 2][r & 3];
+                    }
+                }
             }
         }
-        const bool raw = !GRID && !have_kb;          // scores still unscaled: p = exp2(s*sc2 - off)
-        if (raw) mt *= sc2;
+        if (t == nt - 1 && (Lk & 63) != 0) {  // keys beyond Lk exist on the last tile only (wave-uniform branch)
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk) st[kb][r] = NEG_BIG;
+        }
+        float mt = NEG_BIG;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[kb][r]);
+        if constexpr (RAW) mt *= sc2;
         mt += rowh;
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         if (__any(mt > m_run + RESCALE_THR)) {
             const float m_new = fmaxf(m_run, mt);
-            const float alpha = exp2f(m_run - m_new);
+            const float alpha = wg_exp2(m_run - m_new);
             m_run = m_new;
             l_run *= alpha;
 #pragma unroll
@@ -300,7 +310,7 @@ __global__ __launch_bounds__(NW * 64) void wg_attn_kernel(AttnArgs a) {
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = raw ? exp2f(st[kb][r] * sc2 - off) : exp2f(st[kb][r] - off);
+                const float p = RAW ? wg_exp2(st[kb][r] * sc2 - off) : wg_exp2(st[kb][r] - off);
                 ls += p;
                 pf[kb * 2 + (r >> 3)][r & 7] = (bf16)p;
             }
@@ -357,8 +367,8 @@ __global__ __launch_bounds__(NW * 64) void wg_attn_kernel(AttnArgs a) {
     }
 }
 
-template <int HD, int S, int NW>
-static int launch_attn(const AttnArgs& a, int groups, hipStream_t st) {
+template <int HD, int S, int NW, bool KB>
+static int launch_attn_impl(const AttnArgs& a, int groups, hipStream_t st) {
     constexpr int TILE = 64 * HD * 2;
     constexpr bool ROWTILE = (S == 64);
     size_t lds = 4 * TILE;
@@ -370,11 +380,17 @@ static int launch_attn(const AttnArgs& a, int groups, hipStream_t st) {
     }
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wg_attn_kernel<HD, S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)wg_attn_kernel<HD, S, NW, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wg_attn_kernel<HD, S, NW>), dim3(groups * a.qchunks), dim3(NW * 64), lds, st, a);
+    hipLaunchKernelGGL((wg_attn_kernel<HD, S, NW, KB>), dim3(groups * a.qchunks), dim3(NW * 64), lds, st, a);
     return wg_check_launch("wg_attn");
+}
+
+template <int HD, int S, int NW>
+static int launch_attn(const AttnArgs& a, int groups, hipStream_t st) {
+    if (S == 0 && a.key_bias) return launch_attn_impl<HD, S, NW, (S == 0)>(a, groups, st);
+    return launch_attn_impl<HD, S, NW, false>(a, groups, st);
 }
 
 // Plain multi-head attention (optionally cross attention, optionally with an additive per-key bias).

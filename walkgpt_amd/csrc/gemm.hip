@@ -30,14 +30,27 @@ struct GemmArgs {
     int tiles_m, tiles_n;
 };
 
-template <int BM, int BN, int WM, int WN, bool STAGED>
-__global__ __launch_bounds__(WM* WN * 64) void wg_gemm_kernel(GemmArgs g) {
+template <int N_> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N_) : "memory"); }
+
+// swizzle of 16-byte chunk slots inside a K slab row (BK*2 bytes): spreads 16 rows x one chunk over all 16 slots of
+// the 256-byte LDS bank row for ds_read_b128.
+template <int BK> __device__ __forceinline__ int wg_swz(int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
+
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, bool PIPE>
+__global__ __launch_bounds__(WM* WN * 64, 2) void wg_gemm_kernel(GemmArgs g) {
+    static_assert(!PIPE || (BK == 64 && STAGES == 2), "the phase-offset pipeline is written for two 64-deep slabs");
     static_assert((BM / WM) % 64 == 0, "the staged epilogue walks the wave tile 64 rows at a time");
+    static_assert(BK == 32 || BK == 64, "K slab depth");
     constexpr int NT = WM * WN * 64;
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int FI = WTM / 16, FJ = WTN / 16;
-    constexpr int STAGE = (BM + BN) * 128;
-    constexpr int ROWS_PER_ROUND = NT / 8;
+    constexpr int ROWB = BK * 2;                  // bytes per LDS row
+    constexpr int CPR = BK / 8;                   // 16-byte chunks per row
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int RPI = 64 / CPR;                 // rows per LDS-DMA wave-instruction
+    constexpr int ROWS_PER_ROUND = (NT / 64) * RPI;
+    constexpr int G = (BM + BN) / ROWS_PER_ROUND; // LDS-DMA instructions per wave per stage
+    static_assert(BM % ROWS_PER_ROUND == 0 && BN % ROWS_PER_ROUND == 0, "tile rows must split evenly over the waves");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -56,30 +69,36 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_gemm_kernel(GemmArgs g) {
     const int tile_m = wgid / g.tiles_n, tile_n = wgid % g.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
+    // per-lane source pointers of this wave's LDS-DMA pieces (K offset 0); they advance by BK elements per stage
+    const bf16* srcA[BM / ROWS_PER_ROUND];
+    const bf16* srcW[BN / ROWS_PER_ROUND];
+#pragma unroll
+    for (int i = 0; i < BM / ROWS_PER_ROUND; ++i) {
+        const int r = i * ROWS_PER_ROUND + wave * RPI + lane / CPR;
+        const int c = (lane % CPR) ^ wg_swz<BK>(r);
+        int gr = m0 + r;
+        gr = gr < g.M ? gr : g.M - 1;
+        srcA[i] = g.A + (long)gr * g.lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < BN / ROWS_PER_ROUND; ++i) {
+        const int r = i * ROWS_PER_ROUND + wave * RPI + lane / CPR;
+        const int c = (lane % CPR) ^ wg_swz<BK>(r);
+        int gr = n0 + r;
+        gr = gr < g.N ? gr : g.N - 1;
+        srcW[i] = g.W + (long)gr * g.ldw + c * 8;
+    }
+
     auto stage = [&](int kt, int buf) {
         char* ldsA = smem + buf * STAGE;
-        char* ldsW = ldsA + BM * 128;
-        const int k0 = kt * 64;
+        char* ldsW = ldsA + BM * ROWB;
+        const int k0 = kt * BK;
 #pragma unroll
-        for (int i = 0; i < BM / ROWS_PER_ROUND; ++i) {
-            const int rbase = i * ROWS_PER_ROUND + wave * 8;
-            const int r = rbase + (lane >> 3);
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            int gr = m0 + r;
-            gr = gr < g.M ? gr : g.M - 1;
-            const bf16* src = g.A + (long)gr * g.lda + k0 + c * 8;
-            __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(src), WG_LDS_PTR(ldsA + rbase * 128), 16, 0, 0);
-        }
+        for (int i = 0; i < BM / ROWS_PER_ROUND; ++i)
+            __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcA[i] + k0), WG_LDS_PTR(ldsA + (i * ROWS_PER_ROUND + wave * RPI) * ROWB), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < BN / ROWS_PER_ROUND; ++i) {
-            const int rbase = i * ROWS_PER_ROUND + wave * 8;
-            const int r = rbase + (lane >> 3);
-            const int c = (lane & 7) ^ ((r >> 1) & 7);
-            int gr = n0 + r;
-            gr = gr < g.N ? gr : g.N - 1;
-            const bf16* src = g.W + (long)gr * g.ldw + k0 + c * 8;
-            __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(src), WG_LDS_PTR(ldsW + rbase * 128), 16, 0, 0);
-        }
+        for (int i = 0; i < BN / ROWS_PER_ROUND; ++i)
+            __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcW[i] + k0), WG_LDS_PTR(ldsW + (i * ROWS_PER_ROUND + wave * RPI) * ROWB), 16, 0, 0);
     };
 
     f32x4 acc[FI][FJ];
@@ -88,40 +107,202 @@ __global__ __launch_bounds__(WM* WN * 64) void wg_gemm_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = g.K / 64;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-
+    const int nk = g.K / BK;
     const int fr = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        const char* ldsA = smem + buf * STAGE;
-        const char* ldsW = ldsA + BM * 128;
+    if constexpr (PIPE) {
+        // Phase-offset software pipeline on 32x32x16 MFMA (4 k-steps of 16 per slab).  Fragments are double-buffered
+        // in registers: the ds_reads of step s+1 are issued before the MFMAs of step s, so LDS latency hides under the
+        // matrix pipe.  The slab hand-over sits between steps 2 and 3: wait for slab kt+1 (its LDS-DMA was issued a
+        // whole iteration earlier), barrier, issue the LDS-DMA of slab kt+2 into the buffer slab kt has just vacated,
+        // then step 3 already prefetches step 0 of slab kt+1.  Two LDS slabs, one barrier per slab, every DMA gets a
+        // full iteration to land.
+        constexpr int PI = WTM / 32, PJ = WTN / 32;
+        const int r32 = lane & 31, h32 = lane >> 5;
+        auto read_frags = [&](int buf, int step, bf16x8 (&af)[PI], bf16x8 (&wf)[PJ]) {
+            const char* ldsA = smem + buf * STAGE;
+            const char* ldsW = ldsA + BM * ROWB;
+            const int c = step * 2 + h32;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+            for (int j = 0; j < PJ; ++j) {
+                const int r = wn * WTN + j * 32 + r32;
+                wf[j] = *(const bf16x8*)(ldsW + r * ROWB + ((c ^ wg_swz<BK>(r)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < PI; ++i) {
+                const int r = wm * WTM + i * 32 + r32;
+                af[i] = *(const bf16x8*)(ldsA + r * ROWB + ((c ^ wg_swz<BK>(r)) << 4));
+            }
+        };
+        f32x16 pacc[PI][PJ];
+#pragma unroll
+        for (int i = 0; i < PI; ++i)
+#pragma unroll
+            for (int j = 0; j < PJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) pacc[i][j][e] = 0.f;
+        auto mma = [&](bf16x8 (&af)[PI], bf16x8 (&wf)[PJ]) {
+#pragma unroll
+            for (int i = 0; i < PI; ++i)
+#pragma unroll
+                for (int j = 0; j < PJ; ++j)
+                    pacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], pacc[i][j], 0, 0, 0);
+        };
+        bf16x8 a0[PI], w0[PJ], a1[PI], w1[PJ];
+        stage(0, 0);
+        wg_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (nk > 1) stage(1, 1);
+        read_frags(0, 0, a0, w0);
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            read_frags(buf, 1, a1, w1);
+            mma(a0, w0);
+            read_frags(buf, 2, a0, w0);
+            mma(a1, w1);
+            read_frags(buf, 3, a1, w1);
+            mma(a0, w0);
+            if (kt + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (kt + 2 < nk) stage(kt + 2, buf);
+                read_frags(buf ^ 1, 0, a0, w0);
+            }
+            mma(a1, w1);
+        }
+        __syncthreads();
+        // ---- epilogue (32x32 accumulator layout): lane holds output row m = i*32 + (lane&31), columns
+        //      n = j*32 + 8*g + 4*(lane>>5) + e for register 4*g + e.
+        const int nbase = n0 + wn * WTN;
+        constexpr int SROW = WTN * 2 + 16;
+        constexpr int CH = WTN / 8;
+        constexpr int RPI2 = 64 / CH;
+        char* stg = smem + wave * (64 * SROW);
+#pragma unroll
+        for (int half = 0; half < WTM / 64; ++half) {
+            bf16x8 rres[64 / RPI2];
+            if (STAGED && g.R) {
+#pragma unroll
+                for (int it = 0; it < 64 / RPI2; ++it) {
+                    const int m = m0 + wm * WTM + half * 64 + it * RPI2 + lane / CH;
+                    const int n = nbase + (lane % CH) * 8;
+                    if (m < g.M && n < g.N) {
+                        const long rrow = (long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr;
+                        rres[it] = *(const bf16x8*)(g.R + rrow + n);
+                    }
+                }
+            }
+#pragma unroll
+            for (int ii = 0; ii < 2; ++ii) {
+                const int i = half * 2 + ii;
+                const int m = m0 + wm * WTM + i * 32 + r32;
+#pragma unroll
+                for (int j = 0; j < PJ; ++j) {
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; ++g4) {
+                        const int nl = j * 32 + 8 * g4 + 4 * h32;
+                        const int n = nbase + nl;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = pacc[i][j][4 * g4 + e];
+                        if (g.bias && n < g.N) {
+                            const bf16x4 b = *(const bf16x4*)(g.bias + n);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
+                        }
+                        if (g.act != WG_ACT_NONE) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = wg_act(v[e], g.act);
+                        }
+                        if (STAGED) {
+                            bf16x4 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+                            *(bf16x4*)(stg + (ii * 32 + r32) * SROW + nl * 2) = o;
+                        } else if (m < g.M && n < g.N) {
+                            if (g.R) {
+                                const long rrow = (long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr;
+                                const bf16x4 rr = *(const bf16x4*)(g.R + rrow + n);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+                            }
+                            if (g.out_f32) {
+                                *(f32x4*)((float*)g.C + (long)m * g.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
+                            } else {
+                                bf16x4 o;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
+                                *(bf16x4*)((bf16*)g.C + (long)m * g.ldc + n) = o;
+                            }
+                        }
+                    }
+                }
+            }
+            if (STAGED) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int it = 0; it < 64 / RPI2; ++it) {
+                    const int r = it * RPI2 + lane / CH, ch = lane % CH;
+                    const int m = m0 + wm * WTM + half * 64 + r;
+                    const int n = nbase + ch * 8;
+                    bf16x8 v = *(const bf16x8*)(stg + r * SROW + ch * 16);
+                    if (m < g.M && n < g.N) {
+                        if (g.R) {
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rres[it][e]);
+                        }
+                        *(bf16x8*)((bf16*)g.C + (long)m * g.ldc + n) = v;
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        return;
+    } else {
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) stage(s, s);
+
+    int buf = 0, nbuf = STAGES - 1;
+    for (int kt = 0; kt < nk; ++kt) {
+        // tile kt must have landed; up to STAGES-2 younger stages may stay in flight across the barrier
+        // (counted vmcnt + raw s_barrier: a __syncthreads() here would drain the LDS-DMA queue, cdna_hip_programming.md §5)
+        const int younger = nk - 1 - kt;
+        if (STAGES >= 4 && younger >= 2) wg_wait_vmcnt<2 * G>();
+        else if (STAGES >= 3 && younger >= 1) wg_wait_vmcnt<G>();
+        else wg_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + STAGES - 1 < nk) stage(kt + STAGES - 1, nbuf);
+        const char* ldsA = smem + buf * STAGE;
+        const char* ldsW = ldsA + BM * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8 af[FI], wf[FJ];
             const int c = ks * 4 + fq;
 #pragma unroll
             for (int i = 0; i < FI; ++i) {
                 const int r = wm * WTM + i * 16 + fr;
-                af[i] = *(const bf16x8*)(ldsA + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+                af[i] = *(const bf16x8*)(ldsA + r * ROWB + ((c ^ wg_swz<BK>(r)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < FJ; ++j) {
                 const int r = wn * WTN + j * 16 + fr;
-                wf[j] = *(const bf16x8*)(ldsW + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+                wf[j] = *(const bf16x8*)(ldsW + r * ROWB + ((c ^ wg_swz<BK>(r)) << 4));
             }
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < FI; ++i)
 #pragma unroll
                 for (int j = 0; j < FJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        buf = buf + 1 == STAGES ? 0 : buf + 1;
+        nbuf = nbuf + 1 == STAGES ? 0 : nbuf + 1;
     }
+    }
+    __syncthreads();  // every wave is done with the last K slab before the staging slabs reuse the LDS
 
     // ---- epilogue -------------------------------------------------------------------------------------------------------
     // acc[i][j][e]: output row m = .. + i*16 + (lane&15), column n = .. + j*16 + (lane>>4)*4 + e.
@@ -256,25 +437,39 @@ __global__ __launch_bounds__(256) void wg_gemm_rowwave_kernel(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool STAGED>
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, bool PIPE>
 static int launch_tile_impl(GemmArgs& g, hipStream_t st) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
-    constexpr int lds = 2 * (BM + BN) * 128;
+    constexpr int lds_main = STAGES * (BM + BN) * BK * 2;
+    constexpr int lds_stg = WM * WN * 64 * ((BN / WN) * 2 + 16);
+    constexpr int lds = lds_main > lds_stg ? lds_main : lds_stg;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wg_gemm_kernel<BM, BN, WM, WN, STAGED>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)wg_gemm_kernel<BM, BN, BK, STAGES, WM, WN, STAGED, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wg_gemm_kernel<BM, BN, WM, WN, STAGED>), dim3(g.tiles_m * g.tiles_n), dim3(WM * WN * 64), lds, st, g);
+    hipLaunchKernelGGL((wg_gemm_kernel<BM, BN, BK, STAGES, WM, WN, STAGED, PIPE>), dim3(g.tiles_m * g.tiles_n), dim3(WM * WN * 64), lds, st, g);
     return wg_check_launch("wg_gemm_bias_act_bf16");
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool PIPE = false>
 static int launch_tile(GemmArgs& g, hipStream_t st) {
     // staged (LDS-transposed, 16-byte) epilogue for bf16 outputs whose rows are 16-byte addressable
     const bool staged = !g.out_f32 && g.N % 8 == 0 && g.ldc % 8 == 0 && (!g.R || (g.ldr % 8 == 0 && ((uintptr_t)g.R & 15) == 0));
-    return staged ? launch_tile_impl<BM, BN, WM, WN, true>(g, st) : launch_tile_impl<BM, BN, WM, WN, false>(g, st);
+    return staged ? launch_tile_impl<BM, BN, BK, STAGES, WM, WN, true, PIPE>(g, st)
+                  : launch_tile_impl<BM, BN, BK, STAGES, WM, WN, false, PIPE>(g, st);
+}
+
+// Tile choice = wave quantisation x measured kernel quality (tools/bench_gemm3.py on MI355X): the 256x256
+// kernel (1 workgroup / CU) runs ~15 % better per tile-slot than the 128x128 one (2 workgroups / CU), so it wins unless
+// its last round over the 256 CUs would be much emptier.
+extern "C" int wg_gemm_pick_tile(int M, int N) {
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+    const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
+    return (1.15 * e256 >= e128) ? 2 : 1;
 }
 
 extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, const void* bias,
@@ -300,11 +495,15 @@ extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, lon
         return wg_check_launch("wg_gemm_bias_act_bf16(rowwave)");
     }
     int tile = tile_hint;
-    if (tile <= 0) {
-        // 256x256 tiles once they fill the chip at least ~1.5 times, else 128x128 (2 blocks per CU).
-        const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
-        tile = (t256 >= 384 && N % 256 == 0) ? 2 : 1;
+    if (tile <= 0) tile = wg_gemm_pick_tile(M, N);
+    switch (tile) {
+        case 2: return launch_tile<256, 256, 64, 2, 2, 4>(g, st);   // 128 KiB LDS, 8 waves, 1 workgroup / CU
+        case 4: return launch_tile<256, 128, 32, 3, 2, 2>(g, st);   //  72 KiB LDS, 4 waves, 2 workgroups / CU, 2 slabs in flight
+        case 5: return launch_tile<256, 128, 64, 2, 2, 2>(g, st);   //  96 KiB LDS, 4 waves, 1 workgroup / CU
+        case 6: return launch_tile<128, 128, 32, 4, 2, 2>(g, st);   //  64 KiB LDS, 4 waves, 2 workgroups / CU, 3 slabs in flight
+        case 7: return launch_tile<256, 256, 32, 4, 2, 4>(g, st);   // 128 KiB LDS, 8 waves, 3 slabs in flight
+        case 8: return launch_tile<256, 256, 64, 2, 2, 4, true>(g, st);   // phase-offset pipeline, 8 waves
+        case 9: return launch_tile<128, 128, 64, 2, 2, 2, true>(g, st);   // phase-offset pipeline, 4 waves, 2 workgroups / CU
+        default: return launch_tile<128, 128, 64, 2, 2, 2>(g, st);  //  64 KiB LDS, 4 waves, 2 workgroups / CU
     }
-    if (tile == 2) return launch_tile<256, 256, 2, 4>(g, st);
-    return launch_tile<128, 128, 2, 2>(g, st);
 }

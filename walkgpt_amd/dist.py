@@ -1,0 +1,67 @@
+"""Data-parallel plumbing of the grounded-segmentation path: one process per GPU, images sharded by rank, ONE exchange
+step -- an all-gather of the mask logits (RCCL over xGMI through torch.distributed backend "nccl"; gloo on CPU in tests).
+
+The reference shards evaluation images with a DistributedSampler (evaluation_walkgpt.py:396-402) and exchanges only
+tiny IoU counters; the mask-logit all-gather is this build's addition (BASELINE.json north_star).  Masks are ragged
+(T_i [SEG] tokens per image, per-image original sizes), so ranks first exchange a small int64 header and then gather
+fixed-size flat payloads padded to the largest rank.
+"""
+from typing import List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous [start, end) slice of `n_items` for `rank`; the first n_items % world ranks get one extra item."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world %d/%d" % (rank, world))
+    base, extra = divmod(n_items, world)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def all_gather_masks(masks: Sequence[torch.Tensor], group=None) -> List[List[torch.Tensor]]:
+    """masks[i]: [T_i, H_i, W_i] float tensors of this rank's images.  Returns, on every rank, a list over ranks of
+    lists over that rank's images.  Collectives: one all_gather of the int64 header, one all_gather of the payload."""
+    world = dist.get_world_size(group)
+    dev = masks[0].device if len(masks) else torch.device("cpu")
+    dtype = masks[0].dtype if len(masks) else torch.float32
+    shapes = torch.tensor([list(m.shape) for m in masks], dtype=torch.int64, device=dev).reshape(-1, 3)
+    # header 1: images per rank and payload elements per rank
+    local = torch.tensor([shapes.shape[0], int(sum(m.numel() for m in masks))], dtype=torch.int64, device=dev)
+    counts = torch.empty(world * 2, dtype=torch.int64, device=dev)  # flat in/out: accepted by both RCCL and gloo
+    dist.all_gather_into_tensor(counts, local, group=group)
+    counts_h = counts.view(world, 2).cpu()
+    max_imgs, max_elems = int(counts_h[:, 0].max()), int(counts_h[:, 1].max())
+    # header 2: per-image shapes, padded to the largest image count
+    shp_pad = torch.zeros(max(max_imgs, 1), 3, dtype=torch.int64, device=dev)
+    shp_pad[: shapes.shape[0]] = shapes
+    all_shapes = torch.empty(world * shp_pad.numel(), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(all_shapes, shp_pad.reshape(-1), group=group)
+    all_shapes_h = all_shapes.view(world, -1, 3).cpu()
+    # payload
+    flat = torch.zeros(max(max_elems, 1), dtype=dtype, device=dev)
+    if len(masks):
+        torch.cat([m.reshape(-1) for m in masks], out=flat[: int(local[1])])
+    gathered = torch.empty(world * flat.numel(), dtype=dtype, device=dev)
+    dist.all_gather_into_tensor(gathered, flat, group=group)
+    gathered = gathered.view(world, -1)
+    out = []
+    for r in range(world):
+        off, per_rank = 0, []
+        for i in range(int(counts_h[r, 0])):
+            t, h, w = (int(v) for v in all_shapes_h[r, i])
+            per_rank.append(gathered[r, off: off + t * h * w].view(t, h, w))
+            off += t * h * w
+        out.append(per_rank)
+    return out
+
+
+def all_gather_masks_uniform(stacked: torch.Tensor, out: torch.Tensor = None, group=None) -> torch.Tensor:
+    """Fast path when every rank holds the same [N, H, W] block (bench config): a single collective, no header."""
+    world = dist.get_world_size(group)
+    if out is None:
+        out = torch.empty((world * stacked.shape[0],) + tuple(stacked.shape[1:]), dtype=stacked.dtype, device=stacked.device)
+    dist.all_gather_into_tensor(out.view(-1), stacked.contiguous().view(-1), group=group)
+    return out

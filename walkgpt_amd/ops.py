@@ -37,13 +37,12 @@ GEMM_EVENT_HOOK = None  # bench.py: callable(M, N, K, tile) -> (start_event, end
 
 
 def gemm_tile_for(M, N, K, lda, ldw, ldc, ldr):
-    """Which kernel wg_gemm_bias_act_bf16 runs for this shape: 1 = 128x128 tiles, 2 = 256x256 tiles, 3 = row-wave
-    (mirrors the selection in csrc/gemm.hip; passed explicitly so host-side accounting and the library agree)."""
+    """Which kernel wg_gemm_bias_act_bf16 runs for this shape: 1 = 128x128 tiles, 2 = 256x256 tiles,
+    3 = row-wave (asks the library's own selector, so host-side accounting and the library agree)."""
     ok = K % 64 == 0 and N % 4 == 0 and N >= 16 and lda % 8 == 0 and ldw % 8 == 0 and ldc % 4 == 0 and ldr % 4 == 0
     if not ok:
         return 3
-    t256 = ((M + 255) // 256) * ((N + 255) // 256)
-    return 2 if (t256 >= 384 and N % 256 == 0) else 1
+    return _lib.lib().wg_gemm_pick_tile(M, N)
 
 
 def linear(x, weight, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out=None, out_f32=False, tile=0):
