@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--sam", default="vit_b")
     ap.add_argument("--llm-hidden", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true", help="run the CLIP tower and the SAM branch back to back")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
 
@@ -180,9 +181,17 @@ def main():
 
     decode_ev = []
 
+    side = torch.cuda.Stream() if not args.single_stream else None
+
     def step(record_decode=False):
         with torch.no_grad():
-            feats, _pre = model.encode_images_clip(inp["images_clip"], inp["clip_resize_list"])
+            cur = torch.cuda.current_stream()
+            if side is not None:  # CLIP tower on a second HIP stream: fills the CUs the SAM branch leaves idle and vice versa
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    feats, _pre = model.encode_images_clip(inp["images_clip"], inp["clip_resize_list"])
+            else:
+                feats, _pre = model.encode_images_clip(inp["images_clip"], inp["clip_resize_list"])
             emb = model.get_visual_emb_tokens(inp["images"])
             if record_decode:
                 e0 = torch.cuda.Event(enable_timing=True)
@@ -192,6 +201,8 @@ def main():
             if record_decode:
                 e1.record()
                 decode_ev.append((e0, e1))
+            if side is not None:
+                cur.wait_stream(side)
             if dist is not None:  # the path's one exchange step: mask logits only
                 from walkgpt_amd.dist import all_gather_masks_uniform
                 all_gather_masks_uniform(torch.cat(masks, 0), out=gathered)

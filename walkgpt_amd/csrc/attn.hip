@@ -65,12 +65,18 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     constexpr int DB = HD / 32;
     constexpr bool GRID = (S > 0);
     constexpr int SS = GRID ? S * S : 0;
-    constexpr int SP = S + 1;              // padded table row (fp32 words)
-    constexpr bool ROWTILE = (S == 64);    // a 64-key tile is one grid row
-    constexpr int NTAB = GRID ? (ROWTILE ? 1 : 2) : 0;
+    // Grid mode key order: window rows padded to RP slots (16 / 32 / 64), RPT rows per 64-key tile.  A key slot's
+    // column (kw) then depends only on the accumulator register, its row (kh) only on (tile, register): the width term
+    // of the rel-pos bias is RP/2 registers per lane, the height term RPT LDS reads per tile, and padding slots are
+    // masked by -inf entries in those two tables instead of per-element tests.
+    constexpr int RP = S <= 16 ? 16 : (S <= 32 ? 32 : 64);
+    constexpr int RPT = 64 / RP;
+    constexpr int NTG = GRID ? (S + RPT - 1) / RPT : 0;   // key tiles per window
+    constexpr int SP = GRID ? NTG * RPT + 1 : 1;          // relh table row (fp32 words, odd => conflict-free)
+    constexpr int NRW = GRID ? RP / 2 : 1;                // width-bias registers per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* kv = smem;                                  // [2 buffers][K tile | V tile]
-    float* tab = (float*)(smem + 4 * TILE);           // grid: per-wave rel tables; plain: key bias row
+    float* tab = (float*)(smem + 4 * TILE);           // grid: per-wave rel table; plain: key bias row
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         b = bw;
     }
     const int Lq = GRID ? SS : a.Lq;
-    const int Lk = GRID ? SS : a.Lk;
+    const int Lk = GRID ? NTG * 64 : a.Lk;   // grid mode: every slot of every tile is either a key or masked by the tables
     const int hcol = head * HD;
 
     // ---- this lane's query ---------------------------------------------------------------------------------------
@@ -139,14 +145,14 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
             const bool isV = i >= NINST;
             const int ii = isV ? i - NINST : i;
             const int ci = ii * 64 + lane;
-            const int row = ci / CPR;
+            const int row = ci / CPR;       // key slot inside the tile
             const int cs = ci % CPR;
             const int c = cs ^ (isV ? swzV<HD>(row) : swzK<HD>(row));
-            int kl = t * 64 + row;
-            kl = kl < Lk ? kl : Lk - 1;
             const bf16* src;
             if (GRID) {
-                const int kh = kl / S, kw = kl % S;
+                int kh = t * RPT + row / RP, kw = row % RP;
+                kh = kh < S ? kh : S - 1;   // padding slots fetch a valid row; the bias tables mask them
+                kw = kw < S ? kw : S - 1;
                 const int gy = wy * S + kh, gx = wx * S + kw;
                 if (gy < a.Hg && gx < a.Hg) {
                     const long r = (long)b * a.Hg * a.Hg + gy * a.Hg + gx;
@@ -155,6 +161,8 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
                     src = (isV ? a.padV : a.padK) + hcol + c * 8;
                 }
             } else {
+                int kl = t * 64 + row;
+                kl = kl < Lk ? kl : Lk - 1;
                 const long r = (long)b * a.k_bs + kl;
                 src = (isV ? a.V + r * a.ldv : a.K + r * a.ldk) + hcol + c * 8;
             }
@@ -162,19 +170,19 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         }
     };
 
-    const int nt = (Lk + 63) / 64;
+    const int nt = GRID ? NTG : (Lk + 63) / 64;
     stage(0, 0);
 
     // ---- rel-pos tables (grid) / key bias row (plain) -----------------------------------------------------------
-    float relw_reg[ROWTILE ? 32 : 1];
-    float* mytab = tab + wave * 32 * SP * NTAB;
+    float relw_reg[NRW];
+    float* mytab = tab + wave * 32 * SP;
     if constexpr (GRID) {
         constexpr int NJB = (2 * S - 1 + 31) / 32;
-        // which == 0: width table (for S == 64 it is consumed into registers, then the slot is reused for height)
+        // pass 0: width table -> registers; pass 1: height table -> stays in LDS (same slot)
         for (int which = 0; which < 2; ++which) {
             const bf16* rel = which == 0 ? a.rel_w : a.rel_h;
-            float* dst = ROWTILE ? mytab : mytab + (which == 0 ? 32 * SP : 0);
             const int qpos = which == 0 ? qw : qh;
+            for (int k = S + hi; k < SP; k += 2) mytab[ql_lane * SP + k] = NEG_BIG;   // rows / columns beyond the window
 #pragma unroll
             for (int jb = 0; jb < NJB; ++jb) {
                 int j = jb * 32 + ql_lane;
@@ -191,15 +199,15 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) {
                     const int jj = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // table row held in acc[r]
                     const int kpos = qpos + S - 1 - jj;                        // key coordinate it belongs to
-                    if (jj < 2 * S - 1 && kpos >= 0 && kpos < S) dst[ql_lane * SP + kpos] = acc[r] * LOG2E;
+                    if (jj < 2 * S - 1 && kpos >= 0 && kpos < S) mytab[ql_lane * SP + kpos] = acc[r] * LOG2E;
                 }
             }
-            if (ROWTILE && which == 0) {
+            if (which == 0) {
                 __syncthreads();
 #pragma unroll
-                for (int r = 0; r < 32; ++r) {
-                    const int kw = (r & 3) + 8 * ((r & 15) >> 2) + 4 * hi + 32 * (r >> 4);
-                    relw_reg[r] = dst[ql_lane * SP + kw];
+                for (int j = 0; j < NRW; ++j) {
+                    const int kw = (j & 3) + 8 * (j >> 2) + 4 * hi;   // this lane's j-th column slot inside a padded row
+                    relw_reg[j] = kw < S ? mytab[ql_lane * SP + kw] : NEG_BIG;
                 }
                 __syncthreads();
             }
@@ -213,7 +221,6 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         }
     }
     const float* relh_tab = mytab + ql_lane * SP;
-    const float* relw_tab = mytab + 32 * SP + ql_lane * SP;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -248,37 +255,43 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         }
 
         // ---- softmax bookkeeping in the exp2 domain.  VALU-bound at head_dim 64 (2 MFMA per 4 exp), so every
-        // per-element instruction counts: s = fma(acc, scale*log2e, bias) only where a bias exists; the tile-uniform
-        // row term of the rel-pos bias and the running max are folded into one per-lane offset; keys beyond Lk are
-        // masked on the last tile only; O is rescaled only when some row's max grew by more than RESCALE_THR
-        // (p then stays below 2^RESCALE_THR, exactly representable scale in fp32 accumulators).
+        // per-element instruction counts: s = fma(acc, scale*log2e, bias) only where a bias exists; with one window row
+        // per tile the row term of the rel-pos bias and the running max fold into one per-lane offset; keys beyond Lk
+        // are masked on the last tile only (plain mode) or by the bias tables (grid mode); O is rescaled only when some
+        // row's max grew by more than RESCALE_THR (p then stays below 2^RESCALE_THR).
         constexpr float RESCALE_THR = 6.0f;
         constexpr bool RAW = !GRID && !KB;           // no additive bias: scores stay unscaled, p = exp2(s*sc2 - off)
         float rowh = 0.f;
-        if constexpr (ROWTILE) rowh = relh_tab[t];
-        if constexpr (!RAW) {
+        if constexpr (GRID) {
+            float rh[RPT];
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) rh[i] = relh_tab[t * RPT + i];
+            if constexpr (RPT == 1) rowh = rh[0];
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    constexpr int dummy = 0;
+                    const int sl0 = 32 * kb + (r & 3) + 8 * (r >> 2);        // slot in tile without the lane-half bit
+                    const int slr = sl0 % RP;                                  // slot in its padded row
+                    const int j = (slr & 3) + 4 * (slr >> 3);                  // which of this lane's column registers
+                    const int rt = sl0 / RP;                                   // row inside the tile
+                    float v = st[kb][r] * sc2 + relw_reg[j];
+                    if constexpr (RPT > 1) v += rh[rt];
+                    st[kb][r] = v;
+                    (void)dummy;
+                }
+        } else if constexpr (KB) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb) {
                 f32x4 kbv[4];
-                if constexpr (KB) {
 #pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) kbv[g4] = *(const f32x4*)(tab + t * 64 + kb * 32 + 8 * g4 + 4 * hi);
-                }
+                for (int g4 = 0; g4 < 4; ++g4) kbv[g4] = *(const f32x4*)(tab + t * 64 + kb * 32 + 8 * g4 + 4 * hi);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if constexpr (ROWTILE) {
-                        st[kb][r] = st[kb][r] * sc2 + relw_reg[kb * 16 + r];
-                    } else if constexpr (GRID) {
-                        int kl = t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        kl = kl < SS ? kl : SS - 1;
-                        st[kb][r] = st[kb][r] * sc2 + (relh_tab[kl / S] + relw_tab[kl % S]);
-                    } else {
-                        st[kb][r] = st[kb][r] * sc2 + kbv[r >> 2][r & 3];
-                    }
-                }
+                for (int r = 0; r < 16; ++r) st[kb][r] = st[kb][r] * sc2 + kbv[r >> 2][r & 3];
             }
         }
-        if (t == nt - 1 && (Lk & 63) != 0) {  // keys beyond Lk exist on the last tile only (wave-uniform branch)
+        if (!GRID && t == nt - 1 && (Lk & 63) != 0) {  // plain mode: keys beyond Lk exist on the last tile only
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -370,9 +383,11 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
 template <int HD, int S, int NW, bool KB>
 static int launch_attn_impl(const AttnArgs& a, int groups, hipStream_t st) {
     constexpr int TILE = 64 * HD * 2;
-    constexpr bool ROWTILE = (S == 64);
+    constexpr int RP = S <= 16 ? 16 : (S <= 32 ? 32 : 64);
+    constexpr int RPT = 64 / RP;
+    constexpr int SP = S > 0 ? ((S + RPT - 1) / RPT) * RPT + 1 : 1;
     size_t lds = 4 * TILE;
-    if (S > 0) lds += (size_t)NW * 32 * (S + 1) * 4 * (ROWTILE ? 1 : 2);
+    if (S > 0) lds += (size_t)NW * 32 * SP * 4;
     else lds += (size_t)((a.Lk + 63) / 64) * 64 * 4;
     if (lds > 160 * 1024) {
         wg_set_error("attention: LDS request %zu exceeds 160 KiB", lds);

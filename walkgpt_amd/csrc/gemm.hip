@@ -465,6 +465,7 @@ static int launch_tile(GemmArgs& g, hipStream_t st) {
 // kernel (1 workgroup / CU) runs ~15 % better per tile-slot than the 128x128 one (2 workgroups / CU), so it wins unless
 // its last round over the 256 CUs would be much emptier.
 extern "C" int wg_gemm_pick_tile(int M, int N) {
+    if (M <= 128) return 1;  // the mask decoder's token-side linears: one or two small workgroups
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);

@@ -138,12 +138,26 @@ class WalkGPTGrounding(nn.Module):
         return list(torch.split(pred, counts, 0))
 
     @torch.no_grad()
-    def forward(self, images, images_clip, seg_hidden, resize_list, original_size_list, clip_resize_list=None):
+    def forward(self, images, images_clip, seg_hidden, resize_list, original_size_list, clip_resize_list=None,
+                overlap_streams=True):
         """The fused vision + grounding step the bench times: CLIP tower, SAM encoder, MSQP, CTP, decode, postprocess.
-        Returns dict(pred_masks, mask_scores, clip_features, visual_tokens)."""
+        Returns dict(pred_masks, mask_scores, clip_features, visual_tokens).
+
+        The CLIP tower and the SAM branch are independent until the LLM; with overlap_streams they run on two HIP
+        streams so each one's partially filled launches (M = B*1025 rows never tile evenly) use the other's idle CUs."""
         out = {}
-        if hasattr(self, "vision_tower"):
-            out["clip_features"], out["clip_pre_features"] = self.encode_images_clip(images_clip, clip_resize_list)
+        side = None
+        if hasattr(self, "vision_tower") and images_clip is not None:
+            cur = torch.cuda.current_stream()
+            if overlap_streams:
+                if getattr(self, "_side_stream", None) is None:
+                    self._side_stream = torch.cuda.Stream()
+                side = self._side_stream
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    out["clip_features"], out["clip_pre_features"] = self.encode_images_clip(images_clip, clip_resize_list)
+            else:
+                out["clip_features"], out["clip_pre_features"] = self.encode_images_clip(images_clip, clip_resize_list)
         emb_tokens = self.get_visual_emb_tokens(images)
         if hasattr(self, "out_mm_projector"):
             out["visual_tokens"] = self.project_visual_tokens(emb_tokens)
@@ -151,4 +165,9 @@ class WalkGPTGrounding(nn.Module):
         else:
             pred = list(seg_hidden)  # already 256-d prompt embeddings
         out["pred_masks"], out["mask_scores"] = self.decode(emb_tokens, pred, resize_list, original_size_list)
+        if side is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_stream(side)
+            for t in [out["clip_features"]] + list(out["clip_pre_features"]):
+                t.record_stream(cur)
         return out
