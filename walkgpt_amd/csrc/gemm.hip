@@ -414,6 +414,213 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wg_gemm_kernel(GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent-tile variant (bf16 output, staged epilogue).  One workgroup per CU walks tiles v, v+grid, v+2*grid ...
+// (same XCD for all of them, consecutive tiles of an XCD stay neighbours).  Per tile the fixed costs of the plain
+// kernel -- first-slab latency (~2.5 us) and the store-issue-bound epilogue (~5 us of a ~30 us tile at K = 768) --
+// are taken off the matrix pipe's critical path:
+//   * bias for the tile is loaded before its main loop, the residual rows of the first 64-row slab during the last K
+//     slab, so the epilogue starts without a memory wait;
+//   * after the last slab's barrier the NEXT tile's first slab is sent by LDS-DMA into buffer 0 while the epilogue
+//     stages through buffer 1's region (+ one 9 KiB extension for wave 7);
+//   * the next main loop starts behind `s_waitcnt vmcnt(#stores)`: memory operations retire in issue order, so this
+//     waits for the slab (older) and leaves the epilogue's 16-byte output stores (younger) draining in the background.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64, 2) void wg_gemm_persist_kernel(GemmArgs g) {
+    constexpr int BK = 64;
+    constexpr int NT = WM * WN * 64;
+    constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int FI = WTM / 16, FJ = WTN / 16;
+    constexpr int ROWB = BK * 2;
+    constexpr int CPR = BK / 8;
+    constexpr int STAGE = (BM + BN) * ROWB;
+    constexpr int RPI = 64 / CPR;
+    constexpr int ROWS_PER_ROUND = (NT / 64) * RPI;
+    constexpr int SROW = WTN * 2 + 16;
+    constexpr int CH = WTN / 8;
+    constexpr int RPS = 64 / CH;                         // rows per store instruction
+    constexpr int NSTORE = (WTM / 64) * (64 / RPS);      // output store instructions per wave per tile
+    constexpr int SLAB = 64 * SROW;                      // per-wave staging bytes
+    constexpr int FIT = STAGE / SLAB;                    // waves whose staging slab fits inside buffer 1's region
+    static_assert(WTM % 64 == 0, "staged epilogue walks 64 rows at a time");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    char* stg = wave < FIT ? smem + STAGE + wave * SLAB : smem + 2 * STAGE + (wave - FIT) * SLAB;
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int nk = g.K / BK;
+    auto tile_of = [&](int v, int& m0, int& n0) {
+        const int q = nwg >> 3, r = nwg & 7, xcd = v & 7;
+        const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        m0 = (wgid / g.tiles_n) * BM;
+        n0 = (wgid % g.tiles_n) * BN;
+    };
+
+    // element offsets (32-bit: operands are < 2^31 elements, checked by the launcher) of this wave's LDS-DMA pieces
+    unsigned offA[BM / ROWS_PER_ROUND], offW[BN / ROWS_PER_ROUND];
+    auto set_sources = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < BM / ROWS_PER_ROUND; ++i) {
+            const int r = i * ROWS_PER_ROUND + wave * RPI + lane / CPR;
+            const int c = (lane % CPR) ^ wg_swz<BK>(r);
+            int gr = m0 + r;
+            gr = gr < g.M ? gr : g.M - 1;
+            offA[i] = (unsigned)((long)gr * g.lda + c * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < BN / ROWS_PER_ROUND; ++i) {
+            const int r = i * ROWS_PER_ROUND + wave * RPI + lane / CPR;
+            const int c = (lane % CPR) ^ wg_swz<BK>(r);
+            int gr = n0 + r;
+            gr = gr < g.N ? gr : g.N - 1;
+            offW[i] = (unsigned)((long)gr * g.ldw + c * 8);
+        }
+    };
+    auto stage = [&](int kt, int buf) {
+        char* ldsA = smem + buf * STAGE;
+        char* ldsW = ldsA + BM * ROWB;
+        const bf16* baseA = g.A + kt * BK;
+        const bf16* baseW = g.W + kt * BK;
+#pragma unroll
+        for (int i = 0; i < BM / ROWS_PER_ROUND; ++i)
+            __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(baseA + offA[i]), WG_LDS_PTR(ldsA + (i * ROWS_PER_ROUND + wave * RPI) * ROWB), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BN / ROWS_PER_ROUND; ++i)
+            __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(baseW + offW[i]), WG_LDS_PTR(ldsW + (i * ROWS_PER_ROUND + wave * RPI) * ROWB), 16, 0, 0);
+    };
+
+    int v = blockIdx.x;
+    int m0, n0;
+    tile_of(v, m0, n0);
+    set_sources(m0, n0);
+    stage(0, 0);
+    bool stores_in_flight = false;
+
+    while (true) {
+        const int nbase = n0 + wn * WTN;
+        // bias of this tile, kept packed; loaded while the wave has to wait for its first slab anyway
+        bf16x4 bvp[FJ];
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            const int n = nbase + j * 16 + fq * 4;
+            if (g.bias && n < g.N) bvp[j] = *(const bf16x4*)(g.bias + n);
+            else bvp[j] = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+        }
+        f32x4 acc[FI][FJ];
+#pragma unroll
+        for (int i = 0; i < FI; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt == 0 && stores_in_flight) wg_wait_vmcnt<NSTORE>();   // slab 0 landed; the previous tile's stores may still drain
+            else wg_wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+            const char* ldsA = smem + (kt & 1) * STAGE;
+            const char* ldsW = ldsA + BM * ROWB;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[FI], wf[FJ];
+                const int c = ks * 4 + fq;
+#pragma unroll
+                for (int i = 0; i < FI; ++i) {
+                    const int r = wm * WTM + i * 16 + fr;
+                    af[i] = *(const bf16x8*)(ldsA + r * ROWB + ((c ^ wg_swz<BK>(r)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    const int r = wn * WTN + j * 16 + fr;
+                    wf[j] = *(const bf16x8*)(ldsW + r * ROWB + ((c ^ wg_swz<BK>(r)) << 4));
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < FI; ++i)
+#pragma unroll
+                    for (int j = 0; j < FJ; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // every LDS read of the last slab is done
+        __builtin_amdgcn_s_barrier();
+
+        // next tile: coordinates, sources, first slab on its way before the epilogue touches memory
+        const int vn = v + gridDim.x;
+        const bool has_next = vn < nwg;
+        const int cm0 = m0;
+        const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
+        // opaque copies of the lane coordinates: keeps hipcc from hoisting the epilogue's (tile-invariant) address
+        // arithmetic out of the tile loop, where it would stay live across the main loop and push it into spills
+        int el = lane, efr = fr, efq = fq;
+        asm volatile("" : "+v"(el), "+v"(efr), "+v"(efq));
+        if (has_next) {
+            tile_of(vn, m0, n0);
+            set_sources(m0, n0);
+            stage(0, 0);
+        }
+
+#pragma unroll
+        for (int half = 0; half < WTM / 64; ++half) {
+            bf16x8 rres[64 / RPS];
+            if (g.R) {   // (ordinary loads: hipcc waits for the slab in flight too before their first use)
+#pragma unroll
+                for (int it = 0; it < 64 / RPS; ++it) {
+                    const int m = cm0 + wm * WTM + half * 64 + it * RPS + el / CH;
+                    const int n = nbase + (el % CH) * 8;
+                    if (m < g.M && n < g.N) {
+                        const long rrow = (long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr;
+                        rres[it] = *(const bf16x8*)(g.R + rrow + n);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) {
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float x = acc[half * 4 + i][j][e] + (float)bvp[j][e];
+                        if (g.act != WG_ACT_NONE) x = wg_act(x, g.act);
+                        o[e] = (bf16)x;
+                    }
+                    *(bf16x4*)(stg + (i * 16 + efr) * SROW + (j * 16 + efq * 4) * 2) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < 64 / RPS; ++it) {
+                const int r = it * RPS + el / CH, ch = el % CH;
+                const int m = cm0 + wm * WTM + half * 64 + r;
+                const int n = nbase + ch * 8;
+                bf16x8 o = *(const bf16x8*)(stg + r * SROW + ch * 16);
+                if (m < g.M && n < g.N) {
+                    if (g.R) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] + (float)rres[it][e]);
+                    }
+                    *(bf16x8*)((bf16*)g.C + (long)m * g.ldc + n) = o;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!has_next) break;
+        v = vn;
+        // the counted wait is exact only when every lane issued every store and nothing younger than the slab but
+        // older than the stores is pending: full tiles, no residual loads in the epilogue
+        stores_in_flight = full && !g.R;
+    }
+}
+
 // Small / ragged shapes (N of 1, 4, 32 ..., K not a multiple of 64): one wave per output row, lanes split K.
 // Used by the gate's 128->1 linear, the IoU head, the hyper-network output layers; never on the FLOP-heavy path.
 __global__ __launch_bounds__(256) void wg_gemm_rowwave_kernel(GemmArgs g) {
@@ -453,6 +660,28 @@ static int launch_tile_impl(GemmArgs& g, hipStream_t st) {
     return wg_check_launch("wg_gemm_bias_act_bf16");
 }
 
+template <int BM, int BN, int WM, int WN>
+static int launch_persist(GemmArgs& g, hipStream_t st) {
+    g.tiles_m = (g.M + BM - 1) / BM;
+    g.tiles_n = (g.N + BN - 1) / BN;
+    constexpr int stage = (BM + BN) * 128;
+    constexpr int slab = 64 * ((BN / WN) * 2 + 16);
+    constexpr int fit = stage / slab;
+    constexpr int extra = (WM * WN > fit) ? (WM * WN - fit) * slab : 0;
+    constexpr int lds = 2 * stage + extra;
+    constexpr int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)wg_gemm_persist_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    const int nwg = g.tiles_m * g.tiles_n;
+    int grid = 256 * per_cu;           // one (or two) resident workgroups per CU; a multiple of 8 keeps a workgroup on one XCD
+    if (grid > nwg) grid = nwg;
+    hipLaunchKernelGGL((wg_gemm_persist_kernel<BM, BN, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, st, g);
+    return wg_check_launch("wg_gemm_bias_act_bf16(persistent)");
+}
+
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool PIPE = false>
 static int launch_tile(GemmArgs& g, hipStream_t st) {
     // staged (LDS-transposed, 16-byte) epilogue for bf16 outputs whose rows are 16-byte addressable
@@ -461,16 +690,17 @@ static int launch_tile(GemmArgs& g, hipStream_t st) {
                   : launch_tile_impl<BM, BN, BK, STAGES, WM, WN, false, PIPE>(g, st);
 }
 
-// Tile choice = wave quantisation x measured kernel quality (tools/bench_gemm3.py on MI355X): the 256x256
-// kernel (1 workgroup / CU) runs ~15 % better per tile-slot than the 128x128 one (2 workgroups / CU), so it wins unless
-// its last round over the 256 CUs would be much emptier.
+// Tile choice (measured, tools/bench_gemm3.py and bench.py with WG_GEMM_TILE=n on MI355X): the 256x256 kernel
+// (8 waves, 1 workgroup / CU) is ~15 % better per tile-slot than the 128x128 one, and with the CLIP tower and the SAM
+// branch on two streams a partially filled last round is back-filled by the other stream -- so wave quantisation
+// decides only for shapes that cannot fill even one round of big tiles.
 extern "C" int wg_gemm_pick_tile(int M, int N) {
-    if (M <= 128) return 1;  // the mask decoder's token-side linears: one or two small workgroups
+    if (M <= 128) return 1;             // decoder token-side linears: one or two workgroups
+    if (N < 256) return 11;             // the 64->128 transposed conv (131k rows): persistent 128x128 tiles
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-    const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
-    const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
-    return (1.15 * e256 >= e128) ? 2 : 1;
+    if (t256 < 64 && t128 > t256) return 11;  // too few big tiles to matter: spread over more CUs
+    return 2;
 }
 
 extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, const void* bias,
@@ -497,7 +727,12 @@ extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, lon
     }
     int tile = tile_hint;
     if (tile <= 0) tile = wg_gemm_pick_tile(M, N);
+    const bool can_stage = !out_f32 && N % 8 == 0 && ldc % 8 == 0 && (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0));
+    const bool small_ops = (long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31);
+    if ((tile == 10 || tile == 11) && !(can_stage && small_ops)) tile = tile == 10 ? 2 : 1;
     switch (tile) {
+        case 10: return launch_persist<256, 256, 2, 4>(g, st);      // persistent tiles, 137 KiB LDS, 8 waves, 1 workgroup / CU
+        case 11: return launch_persist<128, 128, 2, 2>(g, st);      // persistent tiles, 64 KiB LDS, 4 waves, 2 workgroups / CU
         case 2: return launch_tile<256, 256, 64, 2, 2, 4>(g, st);   // 128 KiB LDS, 8 waves, 1 workgroup / CU
         case 4: return launch_tile<256, 128, 32, 3, 2, 2>(g, st);   //  72 KiB LDS, 4 waves, 2 workgroups / CU, 2 slabs in flight
         case 5: return launch_tile<256, 128, 64, 2, 2, 2>(g, st);   //  96 KiB LDS, 4 waves, 1 workgroup / CU

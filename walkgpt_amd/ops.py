@@ -33,6 +33,9 @@ def _rows(t):
     return t.numel() // t.shape[-1], t.shape[-1], t.shape[-1]
 
 
+import os as _os
+
+_FORCE_TILE = int(_os.environ.get("WG_GEMM_TILE", "0"))  # experiments only: force one GEMM tile variant
 GEMM_EVENT_HOOK = None  # bench.py: callable(M, N, K, tile) -> (start_event, end_event) recorded around the launch
 
 
@@ -42,6 +45,8 @@ def gemm_tile_for(M, N, K, lda, ldw, ldc, ldr):
     ok = K % 64 == 0 and N % 4 == 0 and N >= 16 and lda % 8 == 0 and ldw % 8 == 0 and ldc % 4 == 0 and ldr % 4 == 0
     if not ok:
         return 3
+    if _FORCE_TILE:
+        return _FORCE_TILE
     return _lib.lib().wg_gemm_pick_tile(M, N)
 
 
