@@ -56,6 +56,16 @@ template <int HD> __device__ __forceinline__ int swzV(int row) {
 // one instruction softmax cannot avoid; arguments here are <= RESCALE_THR and results below 2^-126 may flush to zero.
 __device__ __forceinline__ float wg_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// ds_read_b64_tr_b16 through inline asm.  The builtin form makes hipcc park an `s_waitcnt vmcnt(0)` in front of the
+// first transposed read (it cannot tell the V tile being read from the LDS-DMA still writing the NEXT tile), which
+// drains the prefetch in the middle of every tile.  The asm form is invisible to that pass; the matching wait is
+// wg_tr_wait() below (cdna_hip_programming.md §5.7: own wait + sched_barrier before the consumers).
+template <int OFF> __device__ __forceinline__ u32x2 wg_ds_read_tr(unsigned lds_addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "i"(OFF));
+    return v;
+}
+
 template <int HD, int S, int NW, bool KB>
 __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     constexpr int CPR = HD / 8;            // 16-byte chunks per K/V row
@@ -254,6 +264,33 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
             }
         }
 
+        // V^T fragments of this tile: 4 k-steps x DB d-blocks x 2 transposed reads, issued now so that their LDS
+        // latency hides under the softmax below.  Lane (g = lane>>4, i16 = lane&15) supplies the address of key row
+        // 16*ks + 4*hi + (i16>>2) (+8 for the second read), d columns 32*d + 16*(g&1) + 4*(i16&3) .. +3; the swizzle
+        // bit(s) depend only on i16>>2, so each d block needs one lane-dependent base and compile-time offsets.
+        u32x2 vt[4][DB][2];
+        {
+            const int g = lane >> 4, i16 = lane & 15;
+            const int rq = i16 >> 2, cp = i16 & 3;
+            const unsigned vbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem) +
+                                   (unsigned)(buf * 2 * TILE + TILE);
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+                const int col = 32 * d + 16 * (g & 1) + 4 * cp;
+                const int chunk = col >> 3;
+                const unsigned ad = vbase + (4 * hi + rq) * ROWB + ((chunk ^ swzV<HD>(4 * hi + rq)) << 4) + (col & 7) * 2;
+                // swzV depends on the key only through its low bits, which 16*ks and +8 leave untouched
+                vt[0][d][0] = wg_ds_read_tr<0 * 16 * ROWB>(ad);
+                vt[0][d][1] = wg_ds_read_tr<0 * 16 * ROWB + 8 * ROWB>(ad);
+                vt[1][d][0] = wg_ds_read_tr<1 * 16 * ROWB>(ad);
+                vt[1][d][1] = wg_ds_read_tr<1 * 16 * ROWB + 8 * ROWB>(ad);
+                vt[2][d][0] = wg_ds_read_tr<2 * 16 * ROWB>(ad);
+                vt[2][d][1] = wg_ds_read_tr<2 * 16 * ROWB + 8 * ROWB>(ad);
+                vt[3][d][0] = wg_ds_read_tr<3 * 16 * ROWB>(ad);
+                vt[3][d][1] = wg_ds_read_tr<3 * 16 * ROWB + 8 * ROWB>(ad);
+            }
+        }
+
         // ---- softmax bookkeeping in the exp2 domain.  VALU-bound at head_dim 64 (2 MFMA per 4 exp), so every
         // per-element instruction counts: s = fma(acc, scale*log2e, bias) only where a bias exists; with one window row
         // per tile the row term of the rel-pos bias and the running max fold into one per-lane offset; keys beyond Lk
@@ -330,29 +367,16 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         }
         l_run += ls;
 
-        // O^T += V^T . P^T
-        {
-            const int g = lane >> 4;           // 16-lane group
-            const int i16 = lane & 15;
-            const int rq = i16 >> 2, cp = i16 & 3;
+        // O^T += V^T . P^T  (operands of the asm reads above: wait for them here, fenced from the MFMAs)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {   // 16 keys per step: keys 16*ks + {4hi..4hi+3, 8+4hi..8+4hi+3}
+        for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-                for (int d = 0; d < DB; ++d) {
-                    const int col = 32 * d + 16 * (g & 1) + 4 * cp;  // first of this lane's 4 d-columns
-                    const int chunk = col >> 3;
-                    const int within = (col & 7) * 2;
-                    const int key0 = 16 * ks + 4 * hi + rq;
-                    const int key1 = key0 + 8;
-                    const char* p0 = vbuf + key0 * ROWB + ((chunk ^ swzV<HD>(key0)) << 4) + within;
-                    const char* p1 = vbuf + key1 * ROWB + ((chunk ^ swzV<HD>(key1)) << 4) + within;
-                    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p0);
-                    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p1);
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
-                    s16x8 vv = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                    bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
-                    ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], ot[d], 0, 0, 0);
-                }
+            for (int d = 0; d < DB; ++d) {
+                u32x4 vv = {vt[ks][d][0][0], vt[ks][d][0][1], vt[ks][d][1][0], vt[ks][d][1][1]};
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+                ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], ot[d], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
