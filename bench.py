@@ -34,6 +34,8 @@ GF_CLIP_L_448 = 723.6
 GF_SAM_B = 972.1
 GF_DECODE_PER_TOKEN = 3.61
 GF_CTP_PER_TOKEN = 0.00446
+GF_MSQP = 50.8
+GF_SAM = {"vit_b": 972.1, "vit_l": 2985.7, "vit_h": 5961.1}
 MFMA_BF16_DENSE_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
 
 
@@ -47,6 +49,7 @@ def parse():
     ap.add_argument("--sam", default="vit_b")
     ap.add_argument("--llm-hidden", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-msqp", action="store_true", help="also run the Multi-Scale Query Projector on the SAM tokens (config C3's projector)")
     ap.add_argument("--single-stream", action="store_true", help="run the CLIP tower and the SAM branch back to back")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
@@ -56,7 +59,8 @@ def build_model(args, dev):
     from walkgpt_amd.walkgpt import WalkGPTGrounding
     torch.manual_seed(1234)
     model = WalkGPTGrounding(sam=args.sam, llm_hidden=args.llm_hidden, with_clip=True, with_projectors=True)
-    del model.out_mm_projector  # MSQP feeds the LLM, which is not part of config C2
+    if not args.with_msqp:
+        del model.out_mm_projector  # MSQP feeds the LLM, which is not part of config C2
     with torch.no_grad():
         for n, p in model.named_parameters():
             if "rel_pos" in n or n.endswith("pos_embed"):
@@ -193,6 +197,8 @@ def main():
             else:
                 feats, _pre = model.encode_images_clip(inp["images_clip"], inp["clip_resize_list"])
             emb = model.get_visual_emb_tokens(inp["images"])
+            if args.with_msqp:
+                model.project_visual_tokens(emb)
             if record_decode:
                 e0 = torch.cuda.Event(enable_timing=True)
                 e1 = torch.cuda.Event(enable_timing=True)
@@ -253,7 +259,7 @@ def main():
     dom = max(per_tile, key=lambda k: per_tile[k][2])
     n_l, fl, sec, byt = per_tile[dom]
     achieved_tf = fl / sec / 1e12
-    gf_step = B * (GF_CLIP_L_448 + GF_SAM_B + T * (GF_DECODE_PER_TOKEN + GF_CTP_PER_TOKEN))
+    gf_step = B * (GF_CLIP_L_448 + GF_SAM[args.sam] + (GF_MSQP if args.with_msqp else 0.0) + T * (GF_DECODE_PER_TOKEN + GF_CTP_PER_TOKEN))
     roofline = {"bound": "mfma", "kernel": "wg_gemm_kernel<%s>" % {1: "128,128,64,2,2,2", 2: "256,256,64,2,2,4", 8: "256,256,64,2,2,4,pipe", 11: "persist 128,128,2,2", 10: "persist 256,256,2,4", 3: "rowwave"}.get(dom, str(dom)),
                 "achieved": round(achieved_tf, 1), "peak": MFMA_BF16_DENSE_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / MFMA_BF16_DENSE_PEAK_TF, 4), "traffic": None,
@@ -279,8 +285,8 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "mask_decode_ms": round(decode_ms, 3),
            "config": {"workload": "C2: bs=%d/GPU 448x448 source images (CLIP input 448^2, SAM input 1024^2), CLIP ViT-L/14 + SAM %s "
-                                  "encoder + CTP + prompt encoder + mask decoder + postprocess, T=%d [SEG]/image, random-init weights"
-                                  % (B, args.sam, T),
+                                  "encoder%s + CTP + prompt encoder + mask decoder + postprocess, T=%d [SEG]/image, random-init weights"
+                                  % (B, args.sam, " + MSQP" if args.with_msqp else "", T),
                       "global_batch": world * B, "batch_per_gpu": B, "seg_tokens_per_image": T,
                       "parallelism": "dp%d (images sharded, RCCL all-gather of mask logits)" % world if world > 1 else "single GPU"},
            "roofline": roofline}

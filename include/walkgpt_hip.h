@@ -74,7 +74,7 @@ int wg_mha_small_bf16(const void* Q, long ldq, long q_rows_per_batch, const void
  * window == grid: global attention; window < grid: image_encoder.py:263-318 window partition with zero padding (pad
  * positions act as keys/values equal to qkv_bias, because the padding follows norm1), fused with
  * Attention.forward :235-260 and add_decomposed_rel_pos :321-392 (unscaled q, index q-k+S-1).
- * Compiled (head_dim, window): (64,14) (64,64) (64,32) (32,14) (32,28). */
+ * Compiled (head_dim, window): (64,14) (64,64) (64,32) (32,14) (32,28) (80,14) (80,64) -- 80 = SAM ViT-H. */
 int wg_sam_attn_relpos_bf16(const void* qkv, const void* qkv_bias, const void* rel_pos_h, const void* rel_pos_w,
                             void* out, int B, int grid, int window, int heads, int head_dim, float scale, void* stream);
 

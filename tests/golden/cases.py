@@ -17,6 +17,9 @@ SAM_ENCODERS = {
                  batch=2, seed=11, tap_blocks=(0, 1, 3)),
     "tiny_hd32": dict(img=448, patch=16, embed_dim=64, depth=2, heads=2, global_idx=(1,), window=14, out=256,
                       batch=1, seed=12, tap_blocks=(0, 1)),
+    # head_dim 80 (SAM ViT-H's) on the real 64x64 grid: one windowed (64 -> 70 padding) and one global block
+    "hd80": dict(img=1024, patch=16, embed_dim=160, depth=2, heads=2, global_idx=(1,), window=14, out=256,
+                 batch=1, seed=14, tap_blocks=(0, 1)),
     "vit_b": dict(img=1024, patch=16, embed_dim=768, depth=12, heads=12, global_idx=(2, 5, 8, 11), window=14,
                   out=256, batch=1, seed=13, tap_blocks=(0, 2, 11)),
 }

@@ -54,6 +54,8 @@ def _ref_sam_attention(qkv, bias, rel_h, rel_w, B, grid, window, heads):
     (2, 32, 32, 2, 64),
     (1, 28, 14, 2, 32),   # hd 32, no padding
     (1, 28, 28, 2, 32),
+    (1, 64, 14, 2, 80),   # SAM ViT-H head_dim (padded to 96 inside LDS)
+    (1, 64, 64, 2, 80),
 ])
 def test_sam_attention_relpos(dev, B, grid, window, heads, hd):
     D = heads * hd

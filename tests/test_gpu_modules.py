@@ -39,7 +39,7 @@ def build_encoder(c, dev):
     return enc
 
 
-@pytest.mark.parametrize("name,tol", [("tiny", 0.02), ("tiny_hd32", 0.02), ("vit_b", 0.03)])
+@pytest.mark.parametrize("name,tol", [("tiny", 0.02), ("tiny_hd32", 0.02), ("hd80", 0.02), ("vit_b", 0.03)])
 def test_sam_encoder_vs_reference_golden(dev, name, tol):
     c = cases.SAM_ENCODERS[name]
     gold = cases.load("sam_encoder_" + name)
@@ -111,6 +111,28 @@ def test_projectors_vs_reference_golden(dev):
         b = ctp(hid.to(dev, torch.bfloat16))
     assert rel_err(a.float().cpu().numpy(), gold["msqp"]) < 0.03
     assert rel_err(b.float().cpu().numpy(), gold["ctp"]) < 0.02
+
+
+def test_msqp_full_width_vs_oracle(dev):
+    """MSQP at the deployed width (H_llm = 4096, 64x64 SAM tokens) against the oracle on the same synthetic weights."""
+    from oracle import projectors as oproj
+    c = dict(llama_dim=4096, grid=64, batch=2, seed=33, ctp_shape=(4, 3))
+    wm, wt = cases.projector_weights(c)
+    msqp = MultiScaleQFormerProjector(256, 4096, target_square_side=6)
+    ctp = CalibratedTextProjector(4096, 256)
+    load_into(msqp, {"x." + k: v for k, v in wm.items()}, "x.", dev)
+    load_into(ctp, {"x." + k: v for k, v in wt.items()}, "x.", dev)
+    toks, hid = cases.projector_inputs(c)
+    with torch.no_grad():
+        a = msqp(toks.to(dev, torch.bfloat16))
+        b = ctp(hid.to(dev, torch.bfloat16))
+        ra = oproj.msqp(wm, toks.to(torch.bfloat16).float())
+        rb = oproj.ctp(wt, hid.to(torch.bfloat16).float())
+    assert a.shape == (2, 36, 4096)
+    assert rel_err(a.float().cpu().numpy(), ra.numpy()) < 0.03
+    assert rel_err(b.float().cpu().numpy(), rb.numpy()) < 0.02
+    r = ops.resample_tokens(a)   # llava_arch.py:252-259
+    assert rel_err(r.float().cpu().numpy(), oproj.resample_tokens(a.float().cpu()).numpy()) < 0.01
 
 
 def test_clip_tower_vs_standin_golden(dev):

@@ -42,11 +42,13 @@ struct AttnArgs {
 };
 
 template <int HD> __device__ __forceinline__ int swzK(int row) {
+    if (HD == 80) return 0;   // 192-byte padded rows (SAM ViT-H): unswizzled for now (4-way conflicts on the K reads)
     if (HD == 128) return row & 15;
     if (HD == 64) return (row >> 1) & 7;
     return (row >> 2) & 3;  // HD == 32
 }
 template <int HD> __device__ __forceinline__ int swzV(int row) {
+    if (HD == 80) return 0;
     if (HD == 128) return (row & 3) << 2;
     if (HD == 64) return ((row >> 1) & 1) << 2;
     return 0;
@@ -68,11 +70,12 @@ template <int OFF> __device__ __forceinline__ u32x2 wg_ds_read_tr(unsigned lds_a
 
 template <int HD, int S, int NW, bool KB>
 __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
-    constexpr int CPR = HD / 8;            // 16-byte chunks per K/V row
-    constexpr int ROWB = HD * 2;           // bytes per row
+    constexpr int HDP = (HD == 80) ? 96 : HD;  // head dim padded to a multiple of 32 inside LDS (SAM ViT-H: 80 -> 96)
+    constexpr int CPR = HDP / 8;           // 16-byte chunks per K/V row
+    constexpr int ROWB = HDP * 2;          // bytes per row
     constexpr int TILE = 64 * ROWB;        // bytes per K (or V) tile
-    constexpr int KSTEPS = HD / 16;
-    constexpr int DB = HD / 32;
+    constexpr int KSTEPS = HD / 16;        // QK^T runs over the real head dim only
+    constexpr int DB = HDP / 32;           // PV d-blocks; columns >= HD hold don't-care data and are never stored
     constexpr bool GRID = (S > 0);
     constexpr int SS = GRID ? S * S : 0;
     // Grid mode key order: window rows padded to RP slots (16 / 32 / 64), RPT rows per 64-key tile.  A key slot's
@@ -157,7 +160,8 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
             const int ci = ii * 64 + lane;
             const int row = ci / CPR;       // key slot inside the tile
             const int cs = ci % CPR;
-            const int c = cs ^ (isV ? swzV<HD>(row) : swzK<HD>(row));
+            int c = cs ^ (isV ? swzV<HD>(row) : swzK<HD>(row));
+            if (HDP != HD && c * 8 >= HD) c = HD / 8 - 1;   // pad columns: any readable bytes will do
             const bf16* src;
             if (GRID) {
                 int kh = t * RPT + row / RP, kw = row % RP;
@@ -395,6 +399,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         for (int d = 0; d < DB; ++d) {
 #pragma unroll
             for (int g4 = 0; g4 < 4; ++g4) {
+                if (HDP != HD && 32 * d + 8 * g4 + 4 * hi >= HD) continue;
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (bf16)(ot[d][g4 * 4 + e] * inv);
@@ -406,7 +411,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
 
 template <int HD, int S, int NW, bool KB>
 static int launch_attn_impl(const AttnArgs& a, int groups, hipStream_t st) {
-    constexpr int TILE = 64 * HD * 2;
+    constexpr int TILE = 64 * ((HD == 80) ? 96 : HD) * 2;
     constexpr int RP = S <= 16 ? 16 : (S <= 32 ? 32 : 64);
     constexpr int RPT = 64 / RP;
     constexpr int SP = S > 0 ? ((S + RPT - 1) / RPT) * RPT + 1 : 1;
@@ -501,6 +506,8 @@ extern "C" int wg_sam_attn_relpos_bf16(const void* qkv, const void* qkv_bias, co
     WG_SAM_CASE(64, 32, 8)
     WG_SAM_CASE(32, 14, 7)
     WG_SAM_CASE(32, 28, 5)
+    WG_SAM_CASE(80, 14, 7)
+    WG_SAM_CASE(80, 64, 8)
 #undef WG_SAM_CASE
     wg_set_error("sam_attn: (head_dim %d, window %d) has no compiled kernel", head_dim, window);
     return WG_ERR_UNSUPPORTED;
