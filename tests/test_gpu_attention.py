@@ -90,6 +90,23 @@ def test_mha_plain_and_keymask(dev, B, Lq, Lk, heads, hd, masked):
     assert err < 0.03, err
 
 
+@pytest.mark.parametrize("B,Lq,Lk,heads,hd", [(5, 7, 4096, 8, 16), (3, 6, 1000, 8, 16), (2, 12, 4096, 8, 128), (2, 8, 1024, 8, 128),
+                                             (2, 20, 300, 4, 32), (2, 9, 257, 2, 64)])
+def test_mha_few_queries_many_keys_auto_routing(dev, B, Lq, Lk, heads, hd):
+    """Decoder token->image and MSQP shapes through the default routing (MFMA flash kernel, one wave per (batch, head))."""
+    D = heads * hd
+    q, k, v = _rand((B, Lq, D), 20), _rand((B, Lk, D), 21), _rand((B, Lk, D), 22)
+    scale = 1.0 / math.sqrt(hd)
+    ref = _ref_mha(q, k, v, heads, scale)
+    out = ops.mha(q.to(dev), k.to(dev), v.to(dev), heads, scale)
+    assert (out.float().cpu() - ref).abs().max().item() < 0.03
+    # shared (zero batch stride) keys, as the decoder's first layer uses them
+    k1, v1 = k[:1].to(dev), v[:1].to(dev)
+    out1 = ops.mha(q.to(dev), k1.expand(B, -1, -1), v1.expand(B, -1, -1), heads, scale)
+    ref1 = _ref_mha(q, k[:1].expand(B, -1, -1), v[:1].expand(B, -1, -1), heads, scale)
+    assert (out1.float().cpu() - ref1).abs().max().item() < 0.03
+
+
 def test_mha_packed_qkv_views(dev):
     # q/k/v as column slices of one packed [B, L, 3D] buffer (CLIP layout)
     B, L, heads, hd = 2, 130, 2, 64

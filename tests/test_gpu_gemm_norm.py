@@ -75,7 +75,7 @@ def test_gemm_rowwave_fallback(dev, M, N, K):
 
 
 @pytest.mark.parametrize("M,D,eps", [(4100, 768, 1e-6), (1025, 1024, 1e-5), (37, 256, 1e-6), (9, 4096, 1e-5),
-                                     (3, 5120, 1e-5), (50, 64, 1e-6)])
+                                     (3, 5120, 1e-5), (50, 64, 1e-6), (100003, 64, 1e-6), (77, 32, 1e-5), (1001, 128, 1e-5)])
 def test_layernorm_rows(dev, M, D, eps):
     g = torch.Generator().manual_seed(D)
     x = (torch.randn(M, D, generator=g) * 3 + 1).to(torch.bfloat16)

@@ -42,6 +42,7 @@ struct AttnArgs {
 };
 
 template <int HD> __device__ __forceinline__ int swzK(int row) {
+    if (HD == 16) return (row >> 2) & 3;   // stored as 64-byte rows like head_dim 32
     if (HD == 80) return 0;   // 192-byte padded rows (SAM ViT-H): unswizzled for now (4-way conflicts on the K reads)
     if (HD == 128) return row & 15;
     if (HD == 64) return (row >> 1) & 7;
@@ -70,7 +71,7 @@ template <int OFF> __device__ __forceinline__ u32x2 wg_ds_read_tr(unsigned lds_a
 
 template <int HD, int S, int NW, bool KB>
 __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
-    constexpr int HDP = (HD == 80) ? 96 : HD;  // head dim padded to a multiple of 32 inside LDS (SAM ViT-H: 80 -> 96)
+    constexpr int HDP = (HD == 80) ? 96 : (HD == 16 ? 32 : HD);  // head dim padded to a multiple of 32 inside LDS
     constexpr int CPR = HDP / 8;           // 16-byte chunks per K/V row
     constexpr int ROWB = HDP * 2;          // bytes per row
     constexpr int TILE = 64 * ROWB;        // bytes per K (or V) tile
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
 
 template <int HD, int S, int NW, bool KB>
 static int launch_attn_impl(const AttnArgs& a, int groups, hipStream_t st) {
-    constexpr int TILE = 64 * ((HD == 80) ? 96 : HD) * 2;
+    constexpr int TILE = 64 * ((HD == 80) ? 96 : (HD == 16 ? 32 : HD)) * 2;
     constexpr int RP = S <= 16 ? 16 : (S <= 32 ? 32 : 64);
     constexpr int RPT = 64 / RP;
     constexpr int SP = S > 0 ? ((S + RPT - 1) / RPT) * RPT + 1 : 1;
@@ -470,8 +471,9 @@ extern "C" int wg_mha_bf16(const void* Q, long ldq, long q_rows_per_batch, const
     WG_MHA_CASE(64, 8) WG_MHA_CASE(64, 4) WG_MHA_CASE(64, 3) WG_MHA_CASE(64, 1)
     WG_MHA_CASE(128, 8) WG_MHA_CASE(128, 4) WG_MHA_CASE(128, 1)
     WG_MHA_CASE(32, 8) WG_MHA_CASE(32, 4) WG_MHA_CASE(32, 1)
+    WG_MHA_CASE(16, 1)
 #undef WG_MHA_CASE
-    wg_set_error("mha: head_dim %d not supported (32, 64, 128)", head_dim);
+    wg_set_error("mha: head_dim %d with %d query blocks not supported (32, 64, 128; 16 for <= 32 queries)", head_dim, qblocks);
     return WG_ERR_UNSUPPORTED;
 }
 

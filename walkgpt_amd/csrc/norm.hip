@@ -68,6 +68,49 @@ __global__ __launch_bounds__(256) void wg_layernorm_kernel(LnArgs a) {
     }
 }
 
+// D <= 128 (the mask decoder's LayerNorm2d over 64 channels runs on P*16384 rows): D/8 lanes per row, 512/D rows per
+// wave, so every lane moves 16 bytes; statistics by xor-shuffles inside the lane group.
+template <int D>
+__global__ __launch_bounds__(256) void wg_layernorm_small_kernel(LnArgs a) {
+    constexpr int LPR = D / 8;          // lanes per row
+    constexpr int RPW = 64 / LPR;       // rows per wave
+    const int lane = threadIdx.x & 63;
+    const long m = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const int d = (lane % LPR) * 8;
+    const bool on = m < a.M;
+    float v[8];
+    float s = 0.f;
+    if (on) {
+        const bf16x8 t = *(const bf16x8*)(a.x + m * a.ldx + d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] = (float)t[e]; s += v[e]; }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float t = v[e] - mean; q += t * t; }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)D + a.eps);
+    if (on) {
+        const bf16x8 gm = *(const bf16x8*)(a.gamma + d);
+        const bf16x8 bt = *(const bf16x8*)(a.beta + d);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float t = (v[e] - mean) * rstd * (float)gm[e] + (float)bt[e];
+            if (a.act != WG_ACT_NONE) t = wg_act(t, a.act);
+            o[e] = (bf16)t;
+        }
+        *(bf16x8*)(a.y + m * a.ldy + d) = o;
+    }
+}
+
 extern "C" int wg_layernorm_rows(const void* x, long ldx, const void* gamma, const void* beta, void* y, long ldy,
                                  int M, int D, float eps, int act, void* stream) {
     WG_REQUIRE(x && gamma && beta && y, "layernorm: null operand");
@@ -77,6 +120,14 @@ extern "C" int wg_layernorm_rows(const void* x, long ldx, const void* gamma, con
     LnArgs a{(const bf16*)x, ldx, (const bf16*)gamma, (const bf16*)beta, (bf16*)y, ldy, M, D, eps, act};
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((M + 3) / 4), block(256);
+    if (D == 32 || D == 64 || D == 128) {
+        const int rpw = 512 / D;
+        dim3 g2((unsigned)((M + 4 * rpw - 1) / (4 * rpw)));
+        if (D == 32) hipLaunchKernelGGL(wg_layernorm_small_kernel<32>, g2, block, 0, st, a);
+        else if (D == 64) hipLaunchKernelGGL(wg_layernorm_small_kernel<64>, g2, block, 0, st, a);
+        else hipLaunchKernelGGL(wg_layernorm_small_kernel<128>, g2, block, 0, st, a);
+        return wg_check_launch("wg_layernorm_rows(small)");
+    }
     if (D <= 1024) hipLaunchKernelGGL(wg_layernorm_kernel<2>, grid, block, 0, st, a);
     else if (D <= 2048) hipLaunchKernelGGL(wg_layernorm_kernel<4>, grid, block, 0, st, a);
     else if (D <= 4096) hipLaunchKernelGGL(wg_layernorm_kernel<8>, grid, block, 0, st, a);

@@ -119,6 +119,8 @@ def mha(q, k, v, heads, scale, key_bias=None, out=None, small=None):
     _, _, ldo, obs = _rows_per_batch(out)
     if small is None:
         small = hd < 32 or Lq <= 32 or Lk <= 32
+    if small and key_bias is None and Lq <= 32 and Lk >= 256 and hd in (16, 32, 64, 128):
+        small = False  # few queries, many keys: one MFMA wave per (batch, head) reads K/V once for all queries
     if small:
         assert key_bias is None
         rc = _lib.lib().wg_mha_small_bf16(q.data_ptr(), ldq, qbs, k.data_ptr(), ldk, v.data_ptr(), ldv, kbs,

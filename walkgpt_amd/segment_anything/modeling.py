@@ -282,7 +282,7 @@ class DecoderAttention(nn.Module):
         vp = ops.linear(v, self.v_proj.weight, self.v_proj.bias)
         ex = lambda t: t if t.shape[0] == P else t.expand(P, -1, -1)
         c = self.internal_dim // self.num_heads
-        o = ops.mha(ex(qp), ex(kp), ex(vp), self.num_heads, 1.0 / math.sqrt(c), small=True)
+        o = ops.mha(ex(qp), ex(kp), ex(vp), self.num_heads, 1.0 / math.sqrt(c))
         return ops.linear(o, self.out_proj.weight, self.out_proj.bias, residual=residual, res_row_mod=res_row_mod)
 
 

@@ -49,7 +49,7 @@ class CrossAttnBlock(nn.Module):
         a = self.attn
         q = ops.linear(_ln(queries, self.q_norm), a.in_proj_weight[:D], a.in_proj_bias[:D])
         kvp = self.project_kv(kv)
-        o = ops.mha(q, kvp[..., :D], kvp[..., D:], self.nhead, 1.0 / math.sqrt(D // self.nhead), small=True)
+        o = ops.mha(q, kvp[..., :D], kvp[..., D:], self.nhead, 1.0 / math.sqrt(D // self.nhead))
         out = ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=queries)
         h = ops.linear(_ln(out, self.ffn[0]), self.ffn[1].weight, self.ffn[1].bias, act=ops.ACT_GELU)
         return ops.linear(h, self.ffn[3].weight, self.ffn[3].bias, residual=out)
