@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--llm-hidden", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-msqp", action="store_true", help="also run the Multi-Scale Query Projector on the SAM tokens (config C3's projector)")
+    ap.add_argument("--side-priority", type=int, default=0, help="HIP priority of the CLIP stream (-1 = high)")
     ap.add_argument("--single-stream", action="store_true", help="run the CLIP tower and the SAM branch back to back")
     ap.add_argument("--cpu-threads", type=int, default=0)
     return ap.parse_args()
@@ -176,6 +177,7 @@ def main():
     if dist is not None:
         dist.barrier()
     from walkgpt_amd import ops
+    ops.ALLOW_TAIL_TILES = bool(args.single_stream)
     model = build_model(args, dev)
     inp = make_inputs(args, dev, rank)
     B, T = args.batch, args.seg_tokens
@@ -185,7 +187,7 @@ def main():
 
     decode_ev = []
 
-    side = torch.cuda.Stream() if not args.single_stream else None
+    side = torch.cuda.Stream(priority=args.side_priority) if not args.single_stream else None
 
     def step(record_decode=False):
         with torch.no_grad():
@@ -260,7 +262,7 @@ def main():
     n_l, fl, sec, byt = per_tile[dom]
     achieved_tf = fl / sec / 1e12
     gf_step = B * (GF_CLIP_L_448 + GF_SAM[args.sam] + (GF_MSQP if args.with_msqp else 0.0) + T * (GF_DECODE_PER_TOKEN + GF_CTP_PER_TOKEN))
-    roofline = {"bound": "mfma", "kernel": "wg_gemm_kernel<%s>" % {1: "128,128,64,2,2,2", 2: "256,256,64,2,2,4", 8: "256,256,64,2,2,4,pipe", 11: "persist 128,128,2,2", 10: "persist 256,256,2,4", 3: "rowwave"}.get(dom, str(dom)),
+    roofline = {"bound": "mfma", "kernel": "wg_gemm_kernel<%s>" % {1: "128,128,64,2,2,2", 2: "256,256,64,2,2,4", 8: "256,256,64,2,2,4,pipe", 11: "persist 128,128,2,2", 12: "tail 128,128 (+16 rows)", 10: "persist 256,256,2,4", 3: "rowwave"}.get(dom, str(dom)),
                 "achieved": round(achieved_tf, 1), "peak": MFMA_BF16_DENSE_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / MFMA_BF16_DENSE_PEAK_TF, 4), "traffic": None,
                 "launches_per_step": n_l, "avg_launch_us": round(sec / n_l * 1e6, 1),

@@ -50,6 +50,29 @@ def test_gemm_epilogues(dev, M, N, K, tile, act):
     assert err32 <= 2e-3, err32
 
 
+@pytest.mark.parametrize("M,N,K", [(8200, 1024, 1024), (129, 128, 64), (144, 256, 128), (263, 384, 192), (8200, 3072, 1024)])
+@pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_QUICK_GELU])
+def test_gemm_tail_absorbing_tiles(dev, M, N, K, act):
+    """tile 12: the last 128-row tile also computes the M % 128 <= 16 leftover rows (CLIP's 8*1025 token rows)."""
+    g = torch.Generator().manual_seed(M + N)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16)
+    r = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    ref = _ref_act(a.float() @ w.float().t() + b.float(), act) + r.float()
+    out = ops.linear(a.to(dev), w.to(dev), b.to(dev), act=act, residual=r.to(dev), tile=12)
+    err = (out.float().cpu() - ref).abs()
+    assert err.max().item() <= 0.02 * max(1.0, ref.abs().max().item())
+    assert err[-16:].max().item() <= 0.02 * max(1.0, ref.abs().max().item())   # the absorbed rows
+    # exact small-integer check of the absorbed rows' fragment mapping
+    ai = torch.randint(-3, 4, (M, K), generator=g).float()
+    wi = torch.randint(-3, 4, (N, K), generator=g).float()
+    wi[:, 0] += torch.arange(N).float() % 5
+    oi = ops.linear(ai.to(dev, torch.bfloat16), wi.to(dev, torch.bfloat16), tile=12)
+    refi = (ai @ wi.t())
+    assert torch.equal(oi.float().cpu(), refi.to(torch.bfloat16).float())
+
+
 def test_gemm_residual_row_modulo_and_strided(dev):
     g = torch.Generator().manual_seed(5)
     M, N, K = 512, 128, 192

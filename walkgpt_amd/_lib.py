@@ -42,7 +42,8 @@ SIGNATURES = {
 }
 _SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, []),
             "wg_mask_score_workspace_floats": (c_long, [c_int, c_long]),
-            "wg_gemm_pick_tile": (c_int, [c_int, c_int])}
+            "wg_gemm_pick_tile": (c_int, [c_int, c_int]),
+            "wg_gemm_pick_tile_ex": (c_int, [c_int, c_int, c_int])}
 
 
 class WalkgptHipError(RuntimeError):

@@ -621,6 +621,210 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wg_gemm_persist_kernel(GemmArg
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 128x128 tiles whose LAST row tile absorbs up to 16 extra rows (bf16 output, staged epilogue).
+// CLIP's token matrices have M = B*1025 = 64*128 + 8 rows at B = 8: with plain tiling every GEMM of the tower pays a
+// 65th, almost empty row of tiles -- a whole extra round over the CUs (520 workgroups on 512 slots for N = 1024).  Here
+// the 64th row tile carries 136 rows: one more 16-row MFMA fragment for the waves that own the bottom half, fetched by two
+// extra LDS-DMA pieces per slab.  M = 8200 then tiles as 64 x N/128 workgroups = whole rounds at two workgroups per CU.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void wg_gemm_tail_kernel(GemmArgs g) {
+    constexpr int BM = 128, BN = 128, BK = 64, WM = 2, WN = 2, XR = 16;
+    constexpr int WTM = 64, WTN = 64, FI = 4, FJ = 4;
+    constexpr int ROWB = 128, STAGE = (BM + XR + BN) * ROWB;
+    constexpr int ROWS_PER_ROUND = 32;
+    constexpr int SROW = WTN * 2 + 16, CH = 8, RPS = 8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    int wgid;
+    {
+        const int orig = blockIdx.x;
+        const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+        wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int tile_m = wgid / g.tiles_n, tile_n = wgid % g.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bool tail = (tile_m == g.tiles_m - 1) && (m0 + BM < g.M);   // this tile also owns rows m0+128 .. M-1 (<= 16)
+
+    const bf16* srcA[BM / ROWS_PER_ROUND];
+    const bf16* srcW[BN / ROWS_PER_ROUND];
+    const bf16* srcX;
+#pragma unroll
+    for (int i = 0; i < BM / ROWS_PER_ROUND; ++i) {
+        const int r = i * ROWS_PER_ROUND + wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ wg_swz<BK>(r);
+        int gr = m0 + r;
+        gr = gr < g.M ? gr : g.M - 1;
+        srcA[i] = g.A + (long)gr * g.lda + c * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < BN / ROWS_PER_ROUND; ++i) {
+        const int r = i * ROWS_PER_ROUND + wave * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ wg_swz<BK>(r);
+        int gr = n0 + r;
+        gr = gr < g.N ? gr : g.N - 1;
+        srcW[i] = g.W + (long)gr * g.ldw + c * 8;
+    }
+    {   // the 16 extra rows: waves 0 and 1 fetch 8 rows each
+        const int r = BM + (wave & 1) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ wg_swz<BK>(r);
+        int gr = m0 + r;
+        gr = gr < g.M ? gr : g.M - 1;
+        srcX = g.A + (long)gr * g.lda + c * 8;
+    }
+    auto stage = [&](int kt, int buf) {
+        char* ldsA = smem + buf * STAGE;
+        char* ldsW = ldsA + (BM + XR) * ROWB;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int i = 0; i < BM / ROWS_PER_ROUND; ++i)
+            __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcA[i] + k0), WG_LDS_PTR(ldsA + (i * ROWS_PER_ROUND + wave * 8) * ROWB), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < BN / ROWS_PER_ROUND; ++i)
+            __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcW[i] + k0), WG_LDS_PTR(ldsW + (i * ROWS_PER_ROUND + wave * 8) * ROWB), 16, 0, 0);
+        if (tail && wave < 2)
+            __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcX + k0), WG_LDS_PTR(ldsA + (BM + wave * 8) * ROWB), 16, 0, 0);
+    };
+
+    f32x4 acc[FI][FJ], accx[FJ];
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+        accx[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < FI; ++i) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool own_tail = tail && wm == WM - 1;   // the bottom-half waves run the extra fragment row (wave-uniform)
+
+    const int nk = g.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        wg_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < nk) stage(kt + 1, (kt + 1) & 1);
+        const char* ldsA = smem + (kt & 1) * STAGE;
+        const char* ldsW = ldsA + (BM + XR) * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[FI], wf[FJ], xf;
+            const int c = ks * 4 + fq;
+#pragma unroll
+            for (int i = 0; i < FI; ++i) {
+                const int r = wm * WTM + i * 16 + fr;
+                af[i] = *(const bf16x8*)(ldsA + r * ROWB + ((c ^ wg_swz<BK>(r)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) {
+                const int r = wn * WTN + j * 16 + fr;
+                wf[j] = *(const bf16x8*)(ldsW + r * ROWB + ((c ^ wg_swz<BK>(r)) << 4));
+            }
+            if (own_tail) {
+                const int r = BM + fr;
+                xf = *(const bf16x8*)(ldsA + r * ROWB + ((c ^ wg_swz<BK>(r)) << 4));
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < FI; ++i)
+#pragma unroll
+                for (int j = 0; j < FJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+            if (own_tail) {
+#pragma unroll
+                for (int j = 0; j < FJ; ++j) accx[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf, accx[j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+    __syncthreads();
+
+    // ---- staged epilogue: 64 rows of the wave tile, then (bottom waves of the last row tile) the 16 extra rows ------
+    const int nbase = n0 + wn * WTN;
+    char* stg = smem + wave * (64 * SROW);
+    float bv[FJ][4];
+#pragma unroll
+    for (int j = 0; j < FJ; ++j) {
+        const int n = nbase + j * 16 + fq * 4;
+        if (g.bias && n < g.N) {
+            const bf16x4 b = *(const bf16x4*)(g.bias + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[j][e] = (float)b[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[j][e] = 0.f;
+        }
+    }
+    auto flush = [&](int row0, int nrows) {   // staging rows [0, nrows) hold output rows row0 .. ; 16 bytes per lane out
+        for (int it = 0; it * RPS < nrows; ++it) {
+            const int r = it * RPS + lane / CH, ch = lane % CH;
+            const int m = row0 + r;
+            const int n = nbase + ch * 8;
+            bf16x8 o = *(const bf16x8*)(stg + r * SROW + ch * 16);
+            if (m < g.M && n < g.N) {
+                if (g.R) {
+                    const long rrow = (long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr;
+                    const bf16x8 rr = *(const bf16x8*)(g.R + rrow + n);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] + (float)rr[e]);
+                }
+                *(bf16x8*)((bf16*)g.C + (long)m * g.ldc + n) = o;
+            }
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < FI; ++i)
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = acc[i][j][e] + bv[j][e];
+                if (g.act != WG_ACT_NONE) x = wg_act(x, g.act);
+                o[e] = (bf16)x;
+            }
+            *(bf16x4*)(stg + (i * 16 + fr) * SROW + (j * 16 + fq * 4) * 2) = o;
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    flush(m0 + wm * WTM, 64);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (own_tail) {
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = accx[j][e] + bv[j][e];
+                if (g.act != WG_ACT_NONE) x = wg_act(x, g.act);
+                o[e] = (bf16)x;
+            }
+            *(bf16x4*)(stg + fr * SROW + (j * 16 + fq * 4) * 2) = o;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        flush(m0 + BM, 16);
+    }
+}
+
+static int launch_tail(GemmArgs& g, hipStream_t st) {
+    g.tiles_m = g.M / 128;             // the last row tile takes the M % 128 (<= 16) leftover rows
+    g.tiles_n = (g.N + 127) / 128;
+    constexpr int lds = 2 * (128 + 16 + 128) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)wg_gemm_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(wg_gemm_tail_kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, st, g);
+    return wg_check_launch("wg_gemm_bias_act_bf16(tail)");
+}
+
 // Small / ragged shapes (N of 1, 4, 32 ..., K not a multiple of 64): one wave per output row, lanes split K.
 // Used by the gate's 128->1 linear, the IoU head, the hyper-network output layers; never on the FLOP-heavy path.
 __global__ __launch_bounds__(256) void wg_gemm_rowwave_kernel(GemmArgs g) {
@@ -694,14 +898,30 @@ static int launch_tile(GemmArgs& g, hipStream_t st) {
 // (8 waves, 1 workgroup / CU) is ~15 % better per tile-slot than the 128x128 one, and with the CLIP tower and the SAM
 // branch on two streams a partially filled last round is back-filled by the other stream -- so wave quantisation
 // decides only for shapes that cannot fill even one round of big tiles.
-extern "C" int wg_gemm_pick_tile(int M, int N) {
+//
+// allow_tail: also consider the tail-absorbing 128x128 kernel (tile 12).  It wins by 15-40 % per GEMM on M = B*1025
+// shapes when the GEMMs run back to back on one stream (+3 % end to end), but its 68 KiB workgroups cannot share a CU
+// with the other stream's 128 KiB ones, and with the two-stream overlap it measured 3-4 % SLOWER end to end -- so the
+// host only asks for it in single-stream runs.
+extern "C" int wg_gemm_pick_tile_ex(int M, int N, int allow_tail) {
     if (M <= 128) return 1;             // decoder token-side linears: one or two workgroups
+    if (allow_tail && M % 128 >= 1 && M % 128 <= 16 && N % 8 == 0) {
+        // ragged M just above a multiple of 128 (CLIP: 8 * 1025): fold the leftover rows into the last row tile when that
+        // removes a nearly empty round of 128x128 tiles and the big tiles would not fill the chip well either
+        const long t = (long)(M / 128) * ((N + 127) / 128);
+        const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+        const double e128 = (double)t / (double)(((t + 511) / 512) * 512);
+        const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+        if (e128 >= 0.9 && e128 > e256) return 12;
+    }
     if (N < 256) return 11;             // the 64->128 transposed conv (131k rows): persistent 128x128 tiles
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (t256 < 64 && t128 > t256) return 11;  // too few big tiles to matter: spread over more CUs
     return 2;
 }
+
+extern "C" int wg_gemm_pick_tile(int M, int N) { return wg_gemm_pick_tile_ex(M, N, 0); }
 
 extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, const void* bias,
                                      const void* residual, long ldr, int res_row_mod, void* C, long ldc, int M, int N,
@@ -730,7 +950,9 @@ extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, lon
     const bool can_stage = !out_f32 && N % 8 == 0 && ldc % 8 == 0 && (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0));
     const bool small_ops = (long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31);
     if ((tile == 10 || tile == 11) && !(can_stage && small_ops)) tile = tile == 10 ? 2 : 1;
+    if (tile == 12 && !(can_stage && M >= 128 && M % 128 >= 1 && M % 128 <= 16)) tile = 1;
     switch (tile) {
+        case 12: return launch_tail(g, st);                         // 128x128 tiles, last row tile absorbs M % 128 <= 16 rows
         case 10: return launch_persist<256, 256, 2, 4>(g, st);      // persistent tiles, 137 KiB LDS, 8 waves, 1 workgroup / CU
         case 11: return launch_persist<128, 128, 2, 2>(g, st);      // persistent tiles, 64 KiB LDS, 4 waves, 2 workgroups / CU
         case 2: return launch_tile<256, 256, 64, 2, 2, 4>(g, st);   // 128 KiB LDS, 8 waves, 1 workgroup / CU

@@ -36,6 +36,7 @@ def _rows(t):
 import os as _os
 
 _FORCE_TILE = int(_os.environ.get("WG_GEMM_TILE", "0"))  # experiments only: force one GEMM tile variant
+ALLOW_TAIL_TILES = False  # single-stream callers set this: see wg_gemm_pick_tile_ex in csrc/gemm.hip
 GEMM_EVENT_HOOK = None  # bench.py: callable(M, N, K, tile) -> (start_event, end_event) recorded around the launch
 
 
@@ -47,7 +48,7 @@ def gemm_tile_for(M, N, K, lda, ldw, ldc, ldr):
         return 3
     if _FORCE_TILE:
         return _FORCE_TILE
-    return _lib.lib().wg_gemm_pick_tile(M, N)
+    return _lib.lib().wg_gemm_pick_tile_ex(M, N, 1 if ALLOW_TAIL_TILES else 0)
 
 
 def linear(x, weight, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out=None, out_f32=False, tile=0):

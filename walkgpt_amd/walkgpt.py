@@ -147,6 +147,7 @@ class WalkGPTGrounding(nn.Module):
         streams so each one's partially filled launches (M = B*1025 rows never tile evenly) use the other's idle CUs."""
         out = {}
         side = None
+        ops.ALLOW_TAIL_TILES = not overlap_streams
         if hasattr(self, "vision_tower") and images_clip is not None:
             cur = torch.cuda.current_stream()
             if overlap_streams:
