@@ -188,11 +188,16 @@ def main():
     decode_ev = []
 
     side = torch.cuda.Stream(priority=args.side_priority) if not args.single_stream else None
+    dec = torch.cuda.Stream() if not args.single_stream else None
 
     def step(record_decode=False):
+        """One pass over one batch.  Three HIP streams in steady state: the CLIP tower (side), the SAM encoder (main) and
+        the prompt-encoder / mask-decoder / postprocess chain (dec).  The decode chain is ~75 small latency-bound
+        launches at low occupancy; on its own stream it runs under the NEXT step's encoders instead of in front of them.
+        All work of every step is inside the timed region (the closing fence synchronises the device)."""
         with torch.no_grad():
             cur = torch.cuda.current_stream()
-            if side is not None:  # CLIP tower on a second HIP stream: fills the CUs the SAM branch leaves idle and vice versa
+            if side is not None:
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     feats, _pre = model.encode_images_clip(inp["images_clip"], inp["clip_resize_list"])
@@ -201,19 +206,29 @@ def main():
             emb = model.get_visual_emb_tokens(inp["images"])
             if args.with_msqp:
                 model.project_visual_tokens(emb)
-            if record_decode:
-                e0 = torch.cuda.Event(enable_timing=True)
-                e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-            masks, scores = model.decode_from_hidden(emb, inp["seg_hidden"], inp["resize_list"], inp["original_size_list"])
-            if record_decode:
-                e1.record()
-                decode_ev.append((e0, e1))
-            if side is not None:
-                cur.wait_stream(side)
-            if dist is not None:  # the path's one exchange step: mask logits only
-                from walkgpt_amd.dist import all_gather_masks_uniform
-                all_gather_masks_uniform(torch.cat(masks, 0), out=gathered)
+
+            def decode_part():
+                if record_decode:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                masks, scores = model.decode_from_hidden(emb, inp["seg_hidden"], inp["resize_list"], inp["original_size_list"])
+                if record_decode:
+                    e1.record()
+                    decode_ev.append((e0, e1))
+                if dist is not None:  # the path's one exchange step: mask logits only
+                    from walkgpt_amd.dist import all_gather_masks_uniform
+                    all_gather_masks_uniform(torch.cat(masks, 0), out=gathered)
+                return masks, scores
+
+            if dec is not None:
+                dec.wait_stream(cur)          # the embedding is ready once the main stream reaches this point
+                emb.record_stream(dec)
+                with torch.cuda.stream(dec):
+                    masks, scores = decode_part()
+                cur.wait_stream(side)         # keep at most one CLIP pass in flight per step
+            else:
+                masks, scores = decode_part()
         return feats, masks, scores
 
     def fence():

@@ -37,7 +37,7 @@ template <int N_> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile
 template <int BK> __device__ __forceinline__ int wg_swz(int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, bool PIPE>
-__global__ __launch_bounds__(WM* WN * 64, 2) void wg_gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 : 2)) void wg_gemm_kernel(GemmArgs g) {
     static_assert(!PIPE || (BK == 64 && STAGES == 2), "the phase-offset pipeline is written for two 64-deep slabs");
     static_assert((BM / WM) % 64 == 0, "the staged epilogue walks the wave tile 64 rows at a time");
     static_assert(BK == 32 || BK == 64, "K slab depth");
@@ -955,6 +955,7 @@ extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, lon
         case 12: return launch_tail(g, st);                         // 128x128 tiles, last row tile absorbs M % 128 <= 16 rows
         case 10: return launch_persist<256, 256, 2, 4>(g, st);      // persistent tiles, 137 KiB LDS, 8 waves, 1 workgroup / CU
         case 11: return launch_persist<128, 128, 2, 2>(g, st);      // persistent tiles, 64 KiB LDS, 4 waves, 2 workgroups / CU
+        case 13: return launch_tile<256, 256, 64, 2, 2, 2>(g, st);  // 128 KiB LDS, 4 waves x (128x128), accumulators in AGPRs
         case 2: return launch_tile<256, 256, 64, 2, 2, 4>(g, st);   // 128 KiB LDS, 8 waves, 1 workgroup / CU
         case 4: return launch_tile<256, 128, 32, 3, 2, 2>(g, st);   //  72 KiB LDS, 4 waves, 2 workgroups / CU, 2 slabs in flight
         case 5: return launch_tile<256, 128, 64, 2, 2, 2>(g, st);   //  96 KiB LDS, 4 waves, 1 workgroup / CU
