@@ -13,8 +13,9 @@ The language model between MSQP and CTP is not part of config C2 and is not run.
 
 Prints ONE JSON line (rank 0).  Extra objects:
   roofline      the dominant kernel (the 256x256-tile bf16 MFMA GEMM): algorithmic FLOPs of all its launches in one step
-                / the sum of their durations, timed with HIP events on the launch stream in an instrumented step that
-                runs right after the timed region (same process, same buffers).
+                / the sum of their durations, timed with HIP events on the launch stream in an instrumented, serialised
+                (single-stream) step that runs right after the timed region (same process, same buffers);
+                rocprofv3's average for the same kernel: profiles/r01_single_stream_summary.md.  e2e_* = whole step.
   cpu_baseline  the CPU oracle (oracle/, fp32 PyTorch restatement pinned to the reference) timed on the host cores on
                 a bounded sample (one image of the batch), rank 0 at N=1 only.
 """
@@ -50,6 +51,8 @@ def parse():
     ap.add_argument("--llm-hidden", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--with-msqp", action="store_true", help="also run the Multi-Scale Query Projector on the SAM tokens (config C3's projector)")
+    ap.add_argument("--tail-tiles", action="store_true", help="allow the tail-absorbing 128x128 GEMM tiles (wins with --single-stream)")
+    ap.add_argument("--sam-split", type=int, default=1, help="experiment: run the SAM encoder in this many batch chunks on separate streams")
     ap.add_argument("--side-priority", type=int, default=0, help="HIP priority of the CLIP stream (-1 = high)")
     ap.add_argument("--single-stream", action="store_true", help="run the CLIP tower and the SAM branch back to back")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -177,7 +180,7 @@ def main():
     if dist is not None:
         dist.barrier()
     from walkgpt_amd import ops
-    ops.ALLOW_TAIL_TILES = bool(args.single_stream)
+    ops.ALLOW_TAIL_TILES = bool(args.tail_tiles)
     model = build_model(args, dev)
     inp = make_inputs(args, dev, rank)
     B, T = args.batch, args.seg_tokens
@@ -189,21 +192,38 @@ def main():
 
     side = torch.cuda.Stream(priority=args.side_priority) if not args.single_stream else None
     dec = torch.cuda.Stream() if not args.single_stream else None
+    sam_streams = [torch.cuda.Stream() for _ in range(args.sam_split)] if args.sam_split > 1 else []
 
-    def step(record_decode=False):
+    def step(record_decode=False, serial=False):
         """One pass over one batch.  Three HIP streams in steady state: the CLIP tower (side), the SAM encoder (main) and
         the prompt-encoder / mask-decoder / postprocess chain (dec).  The decode chain is ~75 small latency-bound
         launches at low occupancy; on its own stream it runs under the NEXT step's encoders instead of in front of them.
         All work of every step is inside the timed region (the closing fence synchronises the device)."""
         with torch.no_grad():
             cur = torch.cuda.current_stream()
-            if side is not None:
+            use_side = side is not None and not serial
+            if use_side:
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     feats, _pre = model.encode_images_clip(inp["images_clip"], inp["clip_resize_list"])
             else:
                 feats, _pre = model.encode_images_clip(inp["images_clip"], inp["clip_resize_list"])
-            emb = model.get_visual_emb_tokens(inp["images"])
+            if args.sam_split > 1 and use_side:
+                # experiment: the SAM batch in `sam_split` chunks on separate streams (MFMA-bound GEMMs of one chunk
+                # next to the VALU-bound attention of another)
+                chunks = list(torch.chunk(inp["images"], args.sam_split, 0))
+                parts = [None] * len(chunks)
+                for i, ch in enumerate(chunks):
+                    st = sam_streams[i]
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        parts[i] = model.get_visual_emb_tokens(ch.contiguous())
+                for i, st in enumerate(sam_streams[:len(chunks)]):
+                    cur.wait_stream(st)
+                    parts[i].record_stream(cur)
+                emb = torch.cat(parts, 0)
+            else:
+                emb = model.get_visual_emb_tokens(inp["images"])
             if args.with_msqp:
                 model.project_visual_tokens(emb)
 
@@ -221,7 +241,7 @@ def main():
                     all_gather_masks_uniform(torch.cat(masks, 0), out=gathered)
                 return masks, scores
 
-            if dec is not None:
+            if dec is not None and not serial:
                 dec.wait_stream(cur)          # the embedding is ready once the main stream reaches this point
                 emb.record_stream(dec)
                 with torch.cuda.stream(dec):
@@ -262,8 +282,11 @@ def main():
         records.append((tile, 2.0 * M * N * K, e0, e1, 2.0 * (M * K + N * K + M * N)))
         return e0, e1
 
+    # serialised (one stream): the events then bracket each launch running alone on the chip, which is what a kernel
+    # roofline describes; in the timed region above the streams overlap and per-launch times are not separable
+    torch.cuda.synchronize()
     ops.GEMM_EVENT_HOOK = hook
-    step()
+    step(serial=True)
     torch.cuda.synchronize()
     ops.GEMM_EVENT_HOOK = None
     per_tile = {}
@@ -281,7 +304,8 @@ def main():
                 "achieved": round(achieved_tf, 1), "peak": MFMA_BF16_DENSE_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / MFMA_BF16_DENSE_PEAK_TF, 4), "traffic": None,
                 "launches_per_step": n_l, "avg_launch_us": round(sec / n_l * 1e6, 1),
-                "gemm_share_of_step": round(sum(v[2] for v in per_tile.values()) * 1e3 / ms_per_step, 3),
+                "measured": "HIP events around every launch of this kernel in one serialised (single-stream) step run right after the timed region",
+                "all_gemm_ms_serial": round(sum(v[2] for v in per_tile.values()) * 1e3, 3),
                 "e2e_algorithmic_gflop_per_step": round(gf_step, 1),
                 "e2e_achieved": round(gf_step / ms_per_step, 1),  # GFLOP/ms == TFLOP/s
                 "e2e_frac": round(gf_step / ms_per_step / MFMA_BF16_DENSE_PEAK_TF, 4)}

@@ -29,6 +29,7 @@ def short(name):
 
 def main():
     tag, stats_dir, fetch_dir, write_dir = sys.argv[1:5]
+    cmd = sys.argv[5] if len(sys.argv) > 5 else "python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline"
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
     rows = list(csv.DictReader(open(one(os.path.join(stats_dir, "*", "*_kernel_stats.csv")))))
@@ -59,7 +60,7 @@ def main():
                            "bytes = KB * 1024, FETCH_SIZE x2 (MI355X_MICROARCH.md: gfx950 counts 128-B requests at 64 B)",
                    "kernels": traffic}, f, indent=1, sort_keys=True)
     with open(os.path.join(out, tag + "_summary.md"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats of `python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline` (%s)\n\n" % tag)
+        f.write("# rocprofv3 --kernel-trace --stats of `%s` (%s)\n\n" % (cmd, tag))
         f.write("Total kernel time %.1f ms over 6 steps (2 warm-up, 3 timed, 1 instrumented) = %.2f ms / step.\n\n" % (total / 1e6, total / 6e6))
         f.write("| kernel | calls | total ms | avg us | % | HBM bytes / launch (PMC) |\n|---|---|---|---|---|---|\n")
         for r in rows[:18]:
