@@ -36,9 +36,9 @@ template <int N_> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile
 // the 256-byte LDS bank row for ds_read_b128.
 template <int BK> __device__ __forceinline__ int wg_swz(int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
 
-template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, bool PIPE>
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, int PIPE>
 __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 : 2)) void wg_gemm_kernel(GemmArgs g) {
-    static_assert(!PIPE || (BK == 64 && STAGES == 2), "the phase-offset pipeline is written for two 64-deep slabs");
+    static_assert(PIPE == 0 || (BK == 64 && STAGES == 2), "the pipelined variants are written for two 64-deep slabs");
     static_assert((BM / WM) % 64 == 0, "the staged epilogue walks the wave tile 64 rows at a time");
     static_assert(BK == 32 || BK == 64, "K slab depth");
     constexpr int NT = WM * WN * 64;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
 
     const int nk = g.K / BK;
     const int fr = lane & 15, fq = lane >> 4;
-    if constexpr (PIPE) {
+    if constexpr (PIPE == 1) {
         // Phase-offset software pipeline on 32x32x16 MFMA (4 k-steps of 16 per slab).  Fragments are double-buffered
         // in registers: the ds_reads of step s+1 are issued before the MFMAs of step s, so LDS latency hides under the
         // matrix pipe.  The slab hand-over sits between steps 2 and 3: wait for slab kt+1 (its LDS-DMA was issued a
@@ -259,6 +259,97 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
             }
         }
         return;
+    } else if constexpr (PIPE == 2) {
+        // ---- ping-pong between the two waves of every SIMD (waves w and w+4 = the two M halves of the tile) -------------
+        // A slab's 64 MFMAs per wave are cut into four clusters of 16 (64 rows x 32 columns x K 64).  Every cluster is two
+        // half-phases separated by s_barrier:  M = issue this cluster's ds_reads (+ the next slab's LDS-DMA in the
+        // first cluster), wait for them;  C = the 16 MFMAs.  The bottom-half waves run one half-phase behind the top-half
+        // ones (one extra barrier up front, one at the end for the others), so on each SIMD one wave is always in C while
+        // its partner is in M: the matrix pipe sees back-to-back clusters and LDS / DMA latency sits under them.
+        // Hazards: reads are retired (lgkmcnt(0)) inside their own M half-phase, so a buffer is re-staged at the earliest
+        // one barrier after its last read was complete; a slab's DMA is issued in the first cluster of the previous slab
+        // and waited (vmcnt(0)) in that slab's last M, i.e. before the barrier that precedes its first read.
+        static_assert(FI == 8 && FJ == 4, "written for 128x64 wave tiles");
+        const int grp = wm;   // 0: top half (leads), 1: bottom half (lags by one half-phase)
+        bf16x8 af[4][2], wf[2][2];
+        auto read_a = [&](const char* ldsA, int ci) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int r = wm * WTM + (4 * ci + i) * 16 + fr;
+                    af[i][ks] = *(const bf16x8*)(ldsA + r * ROWB + (((ks * 4 + fq) ^ wg_swz<BK>(r)) << 4));
+                }
+        };
+        auto read_w = [&](const char* ldsW, int cj) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int r = wn * WTN + (2 * cj + j) * 16 + fr;
+                    wf[j][ks] = *(const bf16x8*)(ldsW + r * ROWB + (((ks * 4 + fq) ^ wg_swz<BK>(r)) << 4));
+                }
+        };
+        // The next slab's 8 LDS-DMA pieces per wave are spread over the four M half-phases (2 each; a piece costs ~60+ issue
+        // cycles, so all eight in one half-phase would outlast the partner's 256-cycle MFMA cluster).  Issue order
+        // W rows 0-127, W rows 128-255, A rows {0-63, 128-191}, A rows {64-127, 192-255}: the first cluster of the next slab
+        // needs all of W and the first 64 rows of each A half, its third cluster the rest -- so the pieces issued last are
+        // the ones read last, and the waits are counted (memory operations retire in issue order).
+        auto piece = [&](int kt, int which) {   // which: 0,1 = W round pairs; 2 = A rounds 0,2; 3 = A rounds 1,3
+            char* ldsA = smem + (kt & 1) * STAGE;
+            char* ldsW = ldsA + BM * ROWB;
+            const int k0 = kt * BK;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if (which < 2) {
+                    const int i = which * 2 + u;
+                    __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcW[i] + k0), WG_LDS_PTR(ldsW + (i * ROWS_PER_ROUND + wave * RPI) * ROWB), 16, 0, 0);
+                } else {
+                    const int i = (which - 2) + 2 * u;
+                    __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcA[i] + k0), WG_LDS_PTR(ldsA + (i * ROWS_PER_ROUND + wave * RPI) * ROWB), 16, 0, 0);
+                }
+            }
+        };
+        static_assert(BM / ROWS_PER_ROUND == 4 && BN / ROWS_PER_ROUND == 4, "piece schedule assumes four 64-row rounds per operand");
+        stage(0, 0);
+        wg_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();   // half-phase 0: only the leading group works
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* ldsA = smem + (kt & 1) * STAGE;
+            const char* ldsW = ldsA + BM * ROWB;
+            const bool more = kt + 1 < nk;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ci = c >> 1, cj = (c == 1 || c == 2) ? 1 : 0;   // (0,0) (0,1) (1,1) (1,0)
+                // ---- M half-phase ----
+                if (c == 0 || c == 2) read_a(ldsA, ci);
+                read_w(ldsW, cj);
+                if (more) piece(kt + 1, c);
+                // in flight at this point (oldest first): [A-late pieces of THIS slab, issued in the previous slab's c=3]
+                // then this slab's pieces for kt+1.  c=1: the A-late pieces must be in before cluster 2 reads them (all but
+                // the 4 youngest); c=3: everything for kt+1 except the 2 just issued must be in before its cluster 0.
+                if (c == 1) { if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+                else if (c == 3) { if (more) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                // ---- C half-phase ----
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[4 * ci + i][2 * cj + j] =
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[i][ks], acc[4 * ci + i][2 * cj + j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();   // last half-phase: only the lagging group works
     } else {
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
@@ -848,7 +939,7 @@ __global__ __launch_bounds__(256) void wg_gemm_rowwave_kernel(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, bool PIPE>
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, int PIPE>
 static int launch_tile_impl(GemmArgs& g, hipStream_t st) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
@@ -886,7 +977,7 @@ static int launch_persist(GemmArgs& g, hipStream_t st) {
     return wg_check_launch("wg_gemm_bias_act_bf16(persistent)");
 }
 
-template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool PIPE = false>
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, int PIPE = 0>
 static int launch_tile(GemmArgs& g, hipStream_t st) {
     // staged (LDS-transposed, 16-byte) epilogue for bf16 outputs whose rows are 16-byte addressable
     const bool staged = !g.out_f32 && g.N % 8 == 0 && g.ldc % 8 == 0 && (!g.R || (g.ldr % 8 == 0 && ((uintptr_t)g.R & 15) == 0));
@@ -918,7 +1009,7 @@ extern "C" int wg_gemm_pick_tile_ex(int M, int N, int allow_tail) {
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (t256 < 64 && t128 > t256) return 11;  // too few big tiles to matter: spread over more CUs
-    return 2;
+    return 14;                                // 256x256 tiles, ping-pong schedule (+3..16 % over the plain loop at K <= 4096)
 }
 
 extern "C" int wg_gemm_pick_tile(int M, int N) { return wg_gemm_pick_tile_ex(M, N, 0); }
@@ -961,8 +1052,9 @@ extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, lon
         case 5: return launch_tile<256, 128, 64, 2, 2, 2>(g, st);   //  96 KiB LDS, 4 waves, 1 workgroup / CU
         case 6: return launch_tile<128, 128, 32, 4, 2, 2>(g, st);   //  64 KiB LDS, 4 waves, 2 workgroups / CU, 3 slabs in flight
         case 7: return launch_tile<256, 256, 32, 4, 2, 4>(g, st);   // 128 KiB LDS, 8 waves, 3 slabs in flight
-        case 8: return launch_tile<256, 256, 64, 2, 2, 4, true>(g, st);   // phase-offset pipeline, 8 waves
-        case 9: return launch_tile<128, 128, 64, 2, 2, 2, true>(g, st);   // phase-offset pipeline, 4 waves, 2 workgroups / CU
+        case 8: return launch_tile<256, 256, 64, 2, 2, 4, 1>(g, st);   // phase-offset pipeline, 8 waves
+        case 9: return launch_tile<128, 128, 64, 2, 2, 2, 1>(g, st);   // phase-offset pipeline, 4 waves, 2 workgroups / CU
+        case 14: return launch_tile<256, 256, 64, 2, 2, 4, 2>(g, st);  // ping-pong between the two waves of each SIMD
         default: return launch_tile<128, 128, 64, 2, 2, 2>(g, st);  //  64 KiB LDS, 4 waves, 2 workgroups / CU
     }
 }
