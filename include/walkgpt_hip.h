@@ -42,8 +42,8 @@ const char* wg_last_error(void);    /* thread-local, valid until the next failin
  *   HF CLIPAttention / CLIPMLP linears (custom_clip.py:50-104 call site).
  * MFMA path needs K%64==0, N%4==0, N>=16, lda/ldw %8==0, ldc/ldr %4==0, 16-byte aligned A/W/C; anything else takes a
  * slower one-wave-per-row kernel.  tile_hint: 0 = auto (wg_gemm_pick_tile), 1 = 128x128 tiles (2 workgroups/CU),
- * 2 = 256x256 tiles (1 workgroup/CU), 3 = force row-wave; 4..9 = experimental pipeline variants kept for A/B runs
- * (tools/bench_gemm3.py). */
+ * 11 = persistent 128x128 tiles, 12 = 128x128 tiles whose last row tile absorbs M % 128 <= 16 rows, 2 = 256x256 tiles
+ * (8 waves, 1 workgroup/CU), 14 = 256x256 tiles with the ping-pong schedule, 3 = force row-wave. */
 int wg_gemm_pick_tile(int M, int N);
 /* same, optionally allowing tile 12 = 128x128 tiles whose last row tile absorbs M % 128 <= 16 leftover rows (CLIP's
  * M = B*1025): faster when GEMMs run back to back on one stream, slower when two streams share the chip. */

@@ -34,11 +34,16 @@ template <int N_> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile
 
 // swizzle of 16-byte chunk slots inside a K slab row (BK*2 bytes): spreads 16 rows x one chunk over all 16 slots of
 // the 256-byte LDS bank row for ds_read_b128.
-template <int BK> __device__ __forceinline__ int wg_swz(int row) { return BK == 64 ? (row >> 1) & 7 : (row >> 2) & 3; }
+// BK = 32 (64-byte rows, four rows per bank row): the 16x16x32 fragment read touches rows {R..R+3, R+12..R+15} at chunk c and
+// rows {R+4..R+11} at chunk c+1 inside one 16-lane group; the permutation {0,2,3,1} of (row>>2)&3 sends those to 16
+// distinct slots (the identity map would fold rows R and R+4 onto the same banks).
+template <int BK> __device__ __forceinline__ int wg_swz(int row) {
+    return BK == 64 ? (row >> 1) & 7 : (0x78 >> (2 * ((row >> 2) & 3))) & 3;
+}
 
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, int PIPE>
 __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 : 2)) void wg_gemm_kernel(GemmArgs g) {
-    static_assert(PIPE == 0 || (BK == 64 && STAGES == 2), "the pipelined variants are written for two 64-deep slabs");
+    static_assert(PIPE == 0 || (PIPE == 2 && BK == 64 && STAGES == 2), "the ping-pong schedule is written for two 64-deep slabs");
     static_assert((BM / WM) % 64 == 0, "the staged epilogue walks the wave tile 64 rows at a time");
     static_assert(BK == 32 || BK == 64, "K slab depth");
     constexpr int NT = WM * WN * 64;
@@ -109,157 +114,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
 
     const int nk = g.K / BK;
     const int fr = lane & 15, fq = lane >> 4;
-    if constexpr (PIPE == 1) {
-        // Phase-offset software pipeline on 32x32x16 MFMA (4 k-steps of 16 per slab).  Fragments are double-buffered
-        // in registers: the ds_reads of step s+1 are issued before the MFMAs of step s, so LDS latency hides under the
-        // matrix pipe.  The slab hand-over sits between steps 2 and 3: wait for slab kt+1 (its LDS-DMA was issued a
-        // whole iteration earlier), barrier, issue the LDS-DMA of slab kt+2 into the buffer slab kt has just vacated,
-        // then step 3 already prefetches step 0 of slab kt+1.  Two LDS slabs, one barrier per slab, every DMA gets a
-        // full iteration to land.
-        constexpr int PI = WTM / 32, PJ = WTN / 32;
-        const int r32 = lane & 31, h32 = lane >> 5;
-        auto read_frags = [&](int buf, int step, bf16x8 (&af)[PI], bf16x8 (&wf)[PJ]) {
-            const char* ldsA = smem + buf * STAGE;
-            const char* ldsW = ldsA + BM * ROWB;
-            const int c = step * 2 + h32;
-#pragma unroll
-            for (int j = 0; j < PJ; ++j) {
-                const int r = wn * WTN + j * 32 + r32;
-                wf[j] = *(const bf16x8*)(ldsW + r * ROWB + ((c ^ wg_swz<BK>(r)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < PI; ++i) {
-                const int r = wm * WTM + i * 32 + r32;
-                af[i] = *(const bf16x8*)(ldsA + r * ROWB + ((c ^ wg_swz<BK>(r)) << 4));
-            }
-        };
-        f32x16 pacc[PI][PJ];
-#pragma unroll
-        for (int i = 0; i < PI; ++i)
-#pragma unroll
-            for (int j = 0; j < PJ; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) pacc[i][j][e] = 0.f;
-        auto mma = [&](bf16x8 (&af)[PI], bf16x8 (&wf)[PJ]) {
-#pragma unroll
-            for (int i = 0; i < PI; ++i)
-#pragma unroll
-                for (int j = 0; j < PJ; ++j)
-                    pacc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], pacc[i][j], 0, 0, 0);
-        };
-        bf16x8 a0[PI], w0[PJ], a1[PI], w1[PJ];
-        stage(0, 0);
-        wg_wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (nk > 1) stage(1, 1);
-        read_frags(0, 0, a0, w0);
-        for (int kt = 0; kt < nk; ++kt) {
-            const int buf = kt & 1;
-            read_frags(buf, 1, a1, w1);
-            mma(a0, w0);
-            read_frags(buf, 2, a0, w0);
-            mma(a1, w1);
-            read_frags(buf, 3, a1, w1);
-            mma(a0, w0);
-            if (kt + 1 < nk) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (kt + 2 < nk) stage(kt + 2, buf);
-                read_frags(buf ^ 1, 0, a0, w0);
-            }
-            mma(a1, w1);
-        }
-        __syncthreads();
-        // ---- epilogue (32x32 accumulator layout): lane holds output row m = i*32 + (lane&31), columns
-        //      n = j*32 + 8*g + 4*(lane>>5) + e for register 4*g + e.
-        const int nbase = n0 + wn * WTN;
-        constexpr int SROW = WTN * 2 + 16;
-        constexpr int CH = WTN / 8;
-        constexpr int RPI2 = 64 / CH;
-        char* stg = smem + wave * (64 * SROW);
-#pragma unroll
-        for (int half = 0; half < WTM / 64; ++half) {
-            bf16x8 rres[64 / RPI2];
-            if (STAGED && g.R) {
-#pragma unroll
-                for (int it = 0; it < 64 / RPI2; ++it) {
-                    const int m = m0 + wm * WTM + half * 64 + it * RPI2 + lane / CH;
-                    const int n = nbase + (lane % CH) * 8;
-                    if (m < g.M && n < g.N) {
-                        const long rrow = (long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr;
-                        rres[it] = *(const bf16x8*)(g.R + rrow + n);
-                    }
-                }
-            }
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int i = half * 2 + ii;
-                const int m = m0 + wm * WTM + i * 32 + r32;
-#pragma unroll
-                for (int j = 0; j < PJ; ++j) {
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; ++g4) {
-                        const int nl = j * 32 + 8 * g4 + 4 * h32;
-                        const int n = nbase + nl;
-                        float v[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = pacc[i][j][4 * g4 + e];
-                        if (g.bias && n < g.N) {
-                            const bf16x4 b = *(const bf16x4*)(g.bias + n);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] += (float)b[e];
-                        }
-                        if (g.act != WG_ACT_NONE) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = wg_act(v[e], g.act);
-                        }
-                        if (STAGED) {
-                            bf16x4 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-                            *(bf16x4*)(stg + (ii * 32 + r32) * SROW + nl * 2) = o;
-                        } else if (m < g.M && n < g.N) {
-                            if (g.R) {
-                                const long rrow = (long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr;
-                                const bf16x4 rr = *(const bf16x4*)(g.R + rrow + n);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
-                            }
-                            if (g.out_f32) {
-                                *(f32x4*)((float*)g.C + (long)m * g.ldc + n) = (f32x4){v[0], v[1], v[2], v[3]};
-                            } else {
-                                bf16x4 o;
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) o[e] = (bf16)v[e];
-                                *(bf16x4*)((bf16*)g.C + (long)m * g.ldc + n) = o;
-                            }
-                        }
-                    }
-                }
-            }
-            if (STAGED) {
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int it = 0; it < 64 / RPI2; ++it) {
-                    const int r = it * RPI2 + lane / CH, ch = lane % CH;
-                    const int m = m0 + wm * WTM + half * 64 + r;
-                    const int n = nbase + ch * 8;
-                    bf16x8 v = *(const bf16x8*)(stg + r * SROW + ch * 16);
-                    if (m < g.M && n < g.N) {
-                        if (g.R) {
-#pragma unroll
-                            for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rres[it][e]);
-                        }
-                        *(bf16x8*)((bf16*)g.C + (long)m * g.ldc + n) = v;
-                    }
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        return;
-    } else if constexpr (PIPE == 2) {
+    if constexpr (PIPE == 2) {
         // ---- ping-pong between the two waves of every SIMD (waves w and w+4 = the two M halves of the tile) -------------
         // A slab's 64 MFMAs per wave are cut into four clusters of 16 (64 rows x 32 columns x K 64).  Every cluster is two
         // half-phases separated by s_barrier:  M = issue this cluster's ds_reads (+ the next slab's LDS-DMA in the
@@ -271,7 +126,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
         // and waited (vmcnt(0)) in that slab's last M, i.e. before the barrier that precedes its first read.
         static_assert(FI == 8 && FJ == 4, "written for 128x64 wave tiles");
         const int grp = wm;   // 0: top half (leads), 1: bottom half (lags by one half-phase)
-        bf16x8 af[4][2], wf[2][2];
+        bf16x8 af[4][2], wf2[2][2][2];   // A fragments of the current 64-row half; W fragments of BOTH 32-column halves stay resident
         auto read_a = [&](const char* ldsA, int ci) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -287,7 +142,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const int r = wn * WTN + (2 * cj + j) * 16 + fr;
-                    wf[j][ks] = *(const bf16x8*)(ldsW + r * ROWB + (((ks * 4 + fq) ^ wg_swz<BK>(r)) << 4));
+                    wf2[cj][j][ks] = *(const bf16x8*)(ldsW + r * ROWB + (((ks * 4 + fq) ^ wg_swz<BK>(r)) << 4));
                 }
         };
         // The next slab's 8 LDS-DMA pieces per wave are spread over the four M half-phases (2 each; a piece costs ~60+ issue
@@ -323,8 +178,9 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
             for (int c = 0; c < 4; ++c) {
                 const int ci = c >> 1, cj = (c == 1 || c == 2) ? 1 : 0;   // (0,0) (0,1) (1,1) (1,0)
                 // ---- M half-phase ----
+                // LDS reads per slab: 12 + 4 + 8 + 0 (each W half is read once and reused by the second A half)
                 if (c == 0 || c == 2) read_a(ldsA, ci);
-                read_w(ldsW, cj);
+                if (c < 2) read_w(ldsW, cj);
                 if (more) piece(kt + 1, c);
                 // in flight at this point (oldest first): [A-late pieces of THIS slab, issued in the previous slab's c=3]
                 // then this slab's pieces for kt+1.  c=1: the A-late pieces must be in before cluster 2 reads them (all but
@@ -343,7 +199,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
 #pragma unroll
                         for (int j = 0; j < 2; ++j)
                             acc[4 * ci + i][2 * cj + j] =
-                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j][ks], af[i][ks], acc[4 * ci + i][2 * cj + j], 0, 0, 0);
+                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[cj][j][ks], af[i][ks], acc[4 * ci + i][2 * cj + j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -1040,21 +896,14 @@ extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, lon
     if (tile <= 0) tile = wg_gemm_pick_tile(M, N);
     const bool can_stage = !out_f32 && N % 8 == 0 && ldc % 8 == 0 && (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0));
     const bool small_ops = (long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31);
-    if ((tile == 10 || tile == 11) && !(can_stage && small_ops)) tile = tile == 10 ? 2 : 1;
+    if (tile == 11 && !(can_stage && small_ops)) tile = 1;
+    if (tile != 1 && tile != 2 && tile != 11 && tile != 12 && tile != 14) tile = 1;
     if (tile == 12 && !(can_stage && M >= 128 && M % 128 >= 1 && M % 128 <= 16)) tile = 1;
     switch (tile) {
-        case 12: return launch_tail(g, st);                         // 128x128 tiles, last row tile absorbs M % 128 <= 16 rows
-        case 10: return launch_persist<256, 256, 2, 4>(g, st);      // persistent tiles, 137 KiB LDS, 8 waves, 1 workgroup / CU
-        case 11: return launch_persist<128, 128, 2, 2>(g, st);      // persistent tiles, 64 KiB LDS, 4 waves, 2 workgroups / CU
-        case 13: return launch_tile<256, 256, 64, 2, 2, 2>(g, st);  // 128 KiB LDS, 4 waves x (128x128), accumulators in AGPRs
-        case 2: return launch_tile<256, 256, 64, 2, 2, 4>(g, st);   // 128 KiB LDS, 8 waves, 1 workgroup / CU
-        case 4: return launch_tile<256, 128, 32, 3, 2, 2>(g, st);   //  72 KiB LDS, 4 waves, 2 workgroups / CU, 2 slabs in flight
-        case 5: return launch_tile<256, 128, 64, 2, 2, 2>(g, st);   //  96 KiB LDS, 4 waves, 1 workgroup / CU
-        case 6: return launch_tile<128, 128, 32, 4, 2, 2>(g, st);   //  64 KiB LDS, 4 waves, 2 workgroups / CU, 3 slabs in flight
-        case 7: return launch_tile<256, 256, 32, 4, 2, 4>(g, st);   // 128 KiB LDS, 8 waves, 3 slabs in flight
-        case 8: return launch_tile<256, 256, 64, 2, 2, 4, 1>(g, st);   // phase-offset pipeline, 8 waves
-        case 9: return launch_tile<128, 128, 64, 2, 2, 2, 1>(g, st);   // phase-offset pipeline, 4 waves, 2 workgroups / CU
-        case 14: return launch_tile<256, 256, 64, 2, 2, 4, 2>(g, st);  // ping-pong between the two waves of each SIMD
+        case 12: return launch_tail(g, st);                            // 128x128 tiles, last row tile absorbs M % 128 <= 16 rows
+        case 11: return launch_persist<128, 128, 2, 2>(g, st);         // persistent 128x128 tiles, 2 workgroups / CU
+        case 2: return launch_tile<256, 256, 64, 2, 2, 4>(g, st);      // 256x256, plain two-slab loop (best at K >= 8192)
+        case 14: return launch_tile<256, 256, 64, 2, 2, 4, 2>(g, st);  // 256x256, ping-pong between the two waves of each SIMD
         default: return launch_tile<128, 128, 64, 2, 2, 2>(g, st);  //  64 KiB LDS, 4 waves, 2 workgroups / CU
     }
 }
