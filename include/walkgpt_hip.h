@@ -115,6 +115,17 @@ long wg_mask_score_workspace_floats(int N, long hw);
 int wg_mask_score_f32(const float* masks, float* score, float* workspace, long workspace_floats, int N, long hw,
                       void* stream);
 
+/* SURVEY.md 8(f) rows 1-2.  Per-mask one-pass statistics of fp32 logits [N, hw] against fp32 ground truth [N, hw]; scratch =
+ * wg_mask_stats_workspace_floats(N, hw) floats.
+ * wg_mask_iou_f32: intersectionAndUnionGPU(pred > 0, gt, K = 2, ignore) (utils/utils.py:192-204) with the threshold fused;
+ *   out6[n] = {inter0, inter1, union0, union1, target0, target1}.
+ * wg_mask_losses_f32: out2[n] = {mean BCE-with-logits, dice loss} of mask n (utils/utils_walkgpt.py:76-120). */
+long wg_mask_stats_workspace_floats(int N, long hw);
+int wg_mask_iou_f32(const float* pred_logits, const float* gt, float* out6, float* workspace, long workspace_floats, int N,
+                    long hw, float ignore_value, void* stream);
+int wg_mask_losses_f32(const float* pred_logits, const float* targets, float* out2, float* workspace, long workspace_floats,
+                       int N, long hw, float dice_scale, float dice_eps, void* stream);
+
 /* MSQP pieces (utils/utils_walkgpt.py): _pool_grid_tokens :195-201, _global_token :256-257, SegAwareGate tail :213-217. */
 int wg_avgpool_tokens_bf16(const void* x, void* y, int B, int H, int W, int C, int s, void* stream);
 int wg_mean_tokens_bf16(const void* x, void* y, int B, int L, int C, void* stream);

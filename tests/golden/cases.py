@@ -207,5 +207,19 @@ def clip_inputs(c):
     return x, patch_key_mask(c["batch"], (c["img"], c["img"]), c["clip_resize_list"])
 
 
+# --- eval metric + mask losses ---------------------------------------------------------------
+METRICS = {"m1": dict(n=5, h=61, w=83, seed=51)}
+
+
+def metric_inputs(c):
+    """pred logits [n,h,w] fp32; gt [n,h,w] fp32 in {0,1} with a band of 255 (ignore) pixels."""
+    pred = torch.from_numpy(synth.normal(c["seed"], "input.pred_logits", (c["n"], c["h"], c["w"]), 3.0))
+    u = torch.from_numpy(synth.uniform01(c["seed"], "input.gt", c["n"] * c["h"] * c["w"]).astype(np.float32)).reshape(c["n"], c["h"], c["w"])
+    gt = (u > 0.6).float()
+    gt[:, :3, :] = 255.0
+    gt[0] = 0.0            # an empty ground truth (union only from the prediction)
+    return pred, gt
+
+
 def load(name):
     return dict(np.load(os.path.join(HERE, name + ".npz")))

@@ -147,6 +147,24 @@ def make_clip(name):
                         emb=states[0].numpy())
 
 
+def make_metrics(name):
+    """intersectionAndUnionGPU (utils/utils.py:192-204) and the mask losses (utils/utils_walkgpt.py:76-120)."""
+    _, uw = _import_reference()
+    from utils.utils import intersectionAndUnionGPU
+    c = cases.METRICS[name]
+    pred, gt = cases.metric_inputs(c)
+    inter, union, tgt = [], [], []
+    for i in range(c["n"]):
+        # float carriers of the integral class ids: torch.histc has no CPU kernel for int tensors (the reference calls this on
+        # the GPU only); the function's comparisons and histograms are dtype-agnostic
+        a, b, t = intersectionAndUnionGPU((pred[i] > 0).float().contiguous().clone(), gt[i].contiguous().clone(), 2, ignore_index=255)
+        inter.append(a); union.append(b); tgt.append(t)
+    tg = (gt == 1).float()
+    np.savez_compressed(os.path.join(HERE, "metrics_%s.npz" % name), inter=torch.stack(inter).numpy(), union=torch.stack(union).numpy(),
+                        target=torch.stack(tgt).numpy(), bce=uw.sigmoid_ce_loss(pred, tg, num_masks=c["n"]).numpy(),
+                        dice=uw.dice_loss(pred, tg, num_masks=c["n"]).numpy())
+
+
 def make_state_dict_shapes(_name):
     """Key -> shape tables of the reference modules (data, not source): the de-facto checkpoint ABI."""
     import json
@@ -164,6 +182,7 @@ def make_state_dict_shapes(_name):
 
 ALL = {
     "state_dict_shapes": (make_state_dict_shapes, {"all": None}),
+    "metrics": (make_metrics, cases.METRICS),
     "sam_encoder": (make_sam_encoder, cases.SAM_ENCODERS),
     "decoder": (make_decoder, cases.DECODERS),
     "projectors": (make_projectors, cases.PROJECTORS),

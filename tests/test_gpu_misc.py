@@ -93,3 +93,24 @@ def test_postprocess_and_score(dev, lh, img, inp, orig):
     assert (out.cpu() - ref).abs().max().item() < 1e-4 * ref.abs().max().item() + 1e-5
     sc = ops.mask_score(out[:, 0].contiguous()).cpu()
     assert torch.allclose(sc, osam.mask_score(ref[:, 0]), atol=1e-5)
+
+
+def test_mask_iou_and_losses_vs_reference_golden(dev):
+    """SURVEY.md 8f rows 1-2 through the C-ABI against values the reference's own functions produced."""
+    from tests.golden import cases
+    c = cases.METRICS["m1"]
+    gold = cases.load("metrics_m1")
+    pred, gt = cases.metric_inputs(c)
+    inter, union, tgt = ops.mask_iou(pred.to(dev), gt.to(dev), ignore_index=255)
+    assert torch.equal(inter.cpu(), torch.from_numpy(gold["inter"]))        # integer counts: exact
+    assert torch.equal(union.cpu(), torch.from_numpy(gold["union"]))
+    assert torch.equal(tgt.cpu(), torch.from_numpy(gold["target"]))
+    tg = (gt == 1).float()
+    bce, dice = ops.mask_losses(pred.to(dev), tg.to(dev), num_masks=c["n"])
+    assert abs(bce.item() - float(gold["bce"])) < 2e-5 * max(1.0, abs(float(gold["bce"])))
+    assert abs(dice.item() - float(gold["dice"])) < 2e-5 * max(1.0, abs(float(gold["dice"])))
+    # full-size property check: a mask compared with itself has union == intersection and dice -> ~0
+    big = torch.randn(2, 1024, 1024, generator=torch.Generator().manual_seed(1)).to(dev)
+    g = (big > 0).float()
+    i2, u2, _ = ops.mask_iou(big, g)
+    assert torch.equal(i2, u2) and float(i2.sum()) == 2 * 1024 * 1024

@@ -117,3 +117,17 @@ def test_resample_tokens_matches_torch():
     assert y.shape == (2, 256, 8)
     # corners are preserved by align_corners=False bilinear at the 4 extreme cells (clamped)
     assert torch.allclose(y[:, 0], x[:, 0]) and torch.allclose(y[:, -1], x[:, -1])
+
+
+def test_metrics_and_losses_match_reference():
+    from oracle import metrics as om
+    c = cases.METRICS["m1"]
+    gold = cases.load("metrics_m1")
+    pred, gt = cases.metric_inputs(c)
+    for i in range(c["n"]):
+        a, b, t = om.intersection_and_union((pred[i] > 0).int(), gt[i].int())
+        assert np.array_equal(a.numpy(), gold["inter"][i]) and np.array_equal(b.numpy(), gold["union"][i])
+        assert np.array_equal(t.numpy(), gold["target"][i])
+    tg = (gt == 1).float()
+    assert abs(om.sigmoid_ce_loss(pred, tg, c["n"]).item() - float(gold["bce"])) < 1e-6
+    assert abs(om.dice_loss(pred, tg, c["n"]).item() - float(gold["dice"])) < 1e-6

@@ -33,6 +33,8 @@ SIGNATURES = {
     "wg_hyper_mask_dot": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_postprocess_masks_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_mask_score_f32": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_void_p],
+    "wg_mask_iou_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_void_p],
+    "wg_mask_losses_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_float, c_void_p],
     "wg_avgpool_tokens_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_mean_tokens_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "wg_sigmoid_gate_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
@@ -42,6 +44,7 @@ SIGNATURES = {
 }
 _SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, []),
             "wg_mask_score_workspace_floats": (c_long, [c_int, c_long]),
+            "wg_mask_stats_workspace_floats": (c_long, [c_int, c_long]),
             "wg_gemm_pick_tile": (c_int, [c_int, c_int]),
             "wg_gemm_pick_tile_ex": (c_int, [c_int, c_int, c_int])}
 

@@ -371,3 +371,97 @@ extern "C" int wg_mask_score_f32(const float* masks, float* score, float* worksp
     hipLaunchKernelGGL(wg_mask_score_final_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, workspace, score, (int)nblk);
     return wg_check_launch("wg_mask_score_f32");
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// per-mask statistics of the predicted logits against the ground truth, one pass over HBM.
+//   MODE 0  eval metric   intersectionAndUnionGPU(pred > 0, gt, K = 2, ignore_index)  (utils/utils.py:192-204, called
+//           evaluation_walkgpt.py:936-944): joint counts n[o][t] over pixels whose gt is not `ignore`; the thresholding
+//           happens here, so logits never leave the GPU un-thresholded.
+//   MODE 1  loss forward  sigmoid_ce_loss / dice_loss (utils/utils_walkgpt.py:76-120): sums of bce, sigmoid*t, sigmoid, t.
+// Same two-pass, atomics-free reduction as the mask score: nblk blocks per mask -> partials [N, nblk, 4] -> fold.
+// ------------------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void wg_mask_stats_partial_kernel(const float* pred, const float* gt, float* ws, long hw, int nblk,
+                                                                    float ignore) {
+    __shared__ float red[4][4];
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const float* p = pred + (long)n * hw;
+    const float* t = gt + (long)n * hw;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long i = (long)blk * 256 + threadIdx.x; i < hw; i += (long)nblk * 256) {
+        const float x = p[i], y = t[i];
+        if (MODE == 0) {
+            if (y != ignore) {
+                const int o = x > 0.f ? 1 : 0, g = (int)y;
+                a[0] += (o == 0 && g == 0) ? 1.f : 0.f;
+                a[1] += (o == 0 && g == 1) ? 1.f : 0.f;
+                a[2] += (o == 1 && g == 0) ? 1.f : 0.f;
+                a[3] += (o == 1 && g == 1) ? 1.f : 0.f;
+            }
+        } else {
+            const float s = 1.0f / (1.0f + __expf(-x));
+            a[0] += fmaxf(x, 0.f) - x * y + log1pf(__expf(-fabsf(x)));   // binary_cross_entropy_with_logits, stable form
+            a[1] += s * y;
+            a[2] += s;
+            a[3] += y;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = wg_wave_sum(a[k]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) red[threadIdx.x >> 6][k] = a[k];
+    __syncthreads();
+    if (threadIdx.x < 4)
+        ws[((long)n * nblk + blk) * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void wg_mask_stats_final_kernel(const float* ws, float* out, int nblk, long hw, float scale, float eps) {
+    const int n = blockIdx.x;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = threadIdx.x; i < nblk; i += 64)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] += ws[((long)n * nblk + i) * 4 + k];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) a[k] = wg_wave_sum(a[k]);
+    if (threadIdx.x == 0) {
+        if (MODE == 0) {   // [inter0, inter1, union0, union1, target0, target1]
+            const float i0 = a[0], i1 = a[3], o0 = a[0] + a[1], o1 = a[2] + a[3], t0 = a[0] + a[2], t1 = a[1] + a[3];
+            float* o = out + (long)n * 6;
+            o[0] = i0; o[1] = i1; o[2] = o0 + t0 - i0; o[3] = o1 + t1 - i1; o[4] = t0; o[5] = t1;
+        } else {           // [mean bce, dice loss] of this mask
+            out[(long)n * 2 + 0] = a[0] / (float)hw;
+            out[(long)n * 2 + 1] = 1.0f - (2.0f * a[1] / scale + eps) / (a[2] / scale + a[3] / scale + eps);
+        }
+    }
+}
+
+static long wg_mask_stats_blocks(long hw) {
+    long nblk = (hw + 8191) / 8192;
+    return nblk < 1 ? 1 : (nblk > 64 ? 64 : nblk);
+}
+extern "C" long wg_mask_stats_workspace_floats(int N, long hw) { return (long)N * wg_mask_stats_blocks(hw) * 4; }
+
+extern "C" int wg_mask_iou_f32(const float* pred_logits, const float* gt, float* out6, float* workspace, long workspace_floats,
+                               int N, long hw, float ignore_value, void* stream) {
+    WG_REQUIRE(pred_logits && gt && out6 && workspace && N > 0 && hw > 0, "mask_iou: bad arguments");
+    const long nblk = wg_mask_stats_blocks(hw);
+    WG_REQUIRE(workspace_floats >= (long)N * nblk * 4, "mask_iou: workspace too small (need %ld floats)", (long)N * nblk * 4);
+    hipLaunchKernelGGL(wg_mask_stats_partial_kernel<0>, dim3((unsigned)nblk, N), dim3(256), 0, (hipStream_t)stream, pred_logits, gt,
+                       workspace, hw, (int)nblk, ignore_value);
+    hipLaunchKernelGGL(wg_mask_stats_final_kernel<0>, dim3(N), dim3(64), 0, (hipStream_t)stream, workspace, out6, (int)nblk, hw, 1.f, 0.f);
+    return wg_check_launch("wg_mask_iou_f32");
+}
+
+extern "C" int wg_mask_losses_f32(const float* pred_logits, const float* targets, float* out2, float* workspace,
+                                  long workspace_floats, int N, long hw, float dice_scale, float dice_eps, void* stream) {
+    WG_REQUIRE(pred_logits && targets && out2 && workspace && N > 0 && hw > 0, "mask_losses: bad arguments");
+    const long nblk = wg_mask_stats_blocks(hw);
+    WG_REQUIRE(workspace_floats >= (long)N * nblk * 4, "mask_losses: workspace too small (need %ld floats)", (long)N * nblk * 4);
+    hipLaunchKernelGGL(wg_mask_stats_partial_kernel<1>, dim3((unsigned)nblk, N), dim3(256), 0, (hipStream_t)stream, pred_logits, targets,
+                       workspace, hw, (int)nblk, 0.f);
+    hipLaunchKernelGGL(wg_mask_stats_final_kernel<1>, dim3(N), dim3(64), 0, (hipStream_t)stream, workspace, out2, (int)nblk, hw,
+                       dice_scale, dice_eps);
+    return wg_check_launch("wg_mask_losses_f32");
+}

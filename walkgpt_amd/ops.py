@@ -316,3 +316,36 @@ def resample_tokens(x, target=16):
     y = torch.empty(n, target * target, C, device=x.device, dtype=_BF16)
     _lib.check(_lib.lib().wg_resample_tokens_bf16(x.data_ptr(), y.data_ptr(), n, p, target, C, _stream()), "wg_resample_tokens_bf16")
     return y
+
+
+def mask_iou(pred_logits, gt, ignore_index=255):
+    """intersectionAndUnionGPU(pred > 0, gt, K=2, ignore_index) per mask, thresholding fused.  pred_logits, gt fp32 [N,H,W]
+    (gt values 0 / 1 / ignore_index) -> (intersection [N,2], union [N,2], target_area [N,2]) fp32."""
+    _need_gpu(pred_logits, gt)
+    assert pred_logits.dtype == torch.float32 and gt.dtype == torch.float32 and pred_logits.shape == gt.shape
+    assert pred_logits.is_contiguous() and gt.is_contiguous()
+    N = pred_logits.shape[0]
+    hw = pred_logits.numel() // N
+    out = torch.empty(N, 6, device=pred_logits.device, dtype=torch.float32)
+    nws = _lib.lib().wg_mask_stats_workspace_floats(N, hw)
+    ws = torch.empty(nws, device=pred_logits.device, dtype=torch.float32)
+    _lib.check(_lib.lib().wg_mask_iou_f32(pred_logits.data_ptr(), gt.data_ptr(), out.data_ptr(), ws.data_ptr(), nws, N, hw,
+                                          float(ignore_index), _stream()), "wg_mask_iou_f32")
+    return out[:, 0:2], out[:, 2:4], out[:, 4:6]
+
+
+def mask_losses(pred_logits, targets, num_masks, dice_scale=1000.0, dice_eps=1e-6):
+    """(sigmoid_ce_loss, dice_loss) forward of utils_walkgpt.py:76-120: per-mask reductions on the GPU, the final
+    sum / (num_masks + 1e-8) over N scalars on the host side of the stream (torch, N values)."""
+    _need_gpu(pred_logits, targets)
+    assert pred_logits.dtype == torch.float32 and targets.dtype == torch.float32 and pred_logits.shape == targets.shape
+    assert pred_logits.is_contiguous() and targets.is_contiguous()
+    N = pred_logits.shape[0]
+    hw = pred_logits.numel() // N
+    out = torch.empty(N, 2, device=pred_logits.device, dtype=torch.float32)
+    nws = _lib.lib().wg_mask_stats_workspace_floats(N, hw)
+    ws = torch.empty(nws, device=pred_logits.device, dtype=torch.float32)
+    _lib.check(_lib.lib().wg_mask_losses_f32(pred_logits.data_ptr(), targets.data_ptr(), out.data_ptr(), ws.data_ptr(), nws, N, hw,
+                                             float(dice_scale), float(dice_eps), _stream()), "wg_mask_losses_f32")
+    per = out.sum(0) / (num_masks + 1e-8)
+    return per[0], per[1]
