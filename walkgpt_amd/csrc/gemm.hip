@@ -861,7 +861,8 @@ extern "C" int wg_gemm_pick_tile_ex(int M, int N, int allow_tail) {
         const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
         if (e128 >= 0.9 && e128 > e256) return 12;
     }
-    if (N < 256) return 11;             // the 64->128 transposed conv (131k rows): persistent 128x128 tiles
+    if (N < 256 || (N < 512 && N % 256 != 0 && N % 128 == 0))
+        return 11;                      // N = 128 / 384 (decoder image-side projections, 64->128 transposed conv): 128x128 tiles
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (t256 < 64 && t128 > t256) return 11;  // too few big tiles to matter: spread over more CUs

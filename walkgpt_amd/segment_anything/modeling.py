@@ -280,10 +280,29 @@ class DecoderAttention(nn.Module):
         qp = ops.linear(q, self.q_proj.weight, self.q_proj.bias)
         kp = ops.linear(k, self.k_proj.weight, self.k_proj.bias)
         vp = ops.linear(v, self.v_proj.weight, self.v_proj.bias)
+        return self.run_projected(qp, kp, vp, P, residual, res_row_mod)
+
+    def run_projected(self, qp, kp, vp, P, residual=None, res_row_mod=0):
+        """Attention + out_proj on already projected q/k/v (possibly column slices of a fused projection buffer)."""
         ex = lambda t: t if t.shape[0] == P else t.expand(P, -1, -1)
         c = self.internal_dim // self.num_heads
         o = ops.mha(ex(qp), ex(kp), ex(vp), self.num_heads, 1.0 / math.sqrt(c))
         return ops.linear(o, self.out_proj.weight, self.out_proj.bias, residual=residual, res_row_mod=res_row_mod)
+
+
+def _pe_folded_projection(pe_rows, parts):
+    """Fused image-side projection operands.  (x + pe) W^T + b == x W^T + (pe W^T + b), and pe is input independent, so
+    every projection that reads the image tokens `x` of one layer becomes a column block of ONE GEMM `x @ Wcat^T + R[row %
+    hw]`.  parts: [(Linear, adds_pe)]; returns (Wcat [sum N, C], R [hw, sum N]) in bf16."""
+    ws, rs = [], []
+    hw = pe_rows.shape[0]
+    for lin, adds_pe in parts:
+        ws.append(lin.weight)
+        if adds_pe:
+            rs.append(ops.linear(pe_rows, lin.weight, lin.bias))
+        else:
+            rs.append(lin.bias.unsqueeze(0).expand(hw, -1))
+    return torch.cat(ws, 0).contiguous(), torch.cat(rs, 1).contiguous()
 
 
 class TwoWayAttentionBlock(nn.Module):
@@ -300,25 +319,46 @@ class TwoWayAttentionBlock(nn.Module):
         self.cross_attn_image_to_token = DecoderAttention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
         self.skip_first_layer_pe = skip_first_layer_pe
 
+    def _image_side(self, key_pe):
+        """[K_t2i | V_t2i | Q_i2t] of the image tokens as one GEMM (cached per positional-encoding tensor / weights)."""
+        t2i, i2t = self.cross_attn_token_to_image, self.cross_attn_image_to_token
+        key = (key_pe.data_ptr(), key_pe._version) + tuple((p.data_ptr(), p._version) for p in
+                                                           (t2i.k_proj.weight, t2i.v_proj.weight, i2t.q_proj.weight,
+                                                            t2i.k_proj.bias, t2i.v_proj.bias, i2t.q_proj.bias))
+        if getattr(self, "_img_key", None) != key:
+            self._img_val = _pe_folded_projection(key_pe.reshape(-1, key_pe.shape[-1]),
+                                                  [(t2i.k_proj, True), (t2i.v_proj, False), (i2t.q_proj, True)])
+            self._img_key = key
+        return self._img_val
+
     def run(self, queries, keys, query_pe, key_pe, P):
-        """transformer.py:151-182.  queries/query_pe [P,N,C]; keys [1|P, hw, C]; key_pe [1, hw, C]."""
+        """transformer.py:151-182.  queries/query_pe [P,N,C]; keys [1|P, hw, C]; key_pe [1, hw, C].
+        The three projections that read `keys` in this layer (k and v of token->image, q of image->token: the reference
+        recomputes keys + key_pe for two of them) are one fused GEMM with the positional term folded into an additive
+        table; `keys + key_pe` is never materialised."""
         ln = lambda x, n: ops.layernorm(x, n.weight, n.bias, n.eps)
         hw = keys.shape[1]
+        t2i, i2t = self.cross_attn_token_to_image, self.cross_attn_image_to_token
+        d = t2i.internal_dim
         if self.skip_first_layer_pe:
             queries = self.self_attn.run(queries, queries, queries, P)
         else:
             q = ops.add_rows(queries, query_pe)
             queries = self.self_attn.run(q, q, queries, P, residual=queries)
         queries = ln(queries, self.norm1)
+        wcat, rtab = self._image_side(key_pe)
+        proj = ops.linear(keys, wcat, residual=rtab, res_row_mod=hw)          # [1|P, hw, 3d]
+        kp, vp, qi = proj[..., :d], proj[..., d:2 * d], proj[..., 2 * d:]
         q = ops.add_rows(queries, query_pe)
-        k = ops.add_rows(keys, key_pe)  # key_pe has hw rows: broadcast over prompts by row modulo
-        queries = self.cross_attn_token_to_image.run(q, k, keys, P, residual=queries)
+        qp = ops.linear(q, t2i.q_proj.weight, t2i.q_proj.bias)
+        queries = t2i.run_projected(qp, kp, vp, P, residual=queries)
         queries = ln(queries, self.norm2)
         queries = self.mlp.rows(queries, residual=queries)
         queries = ln(queries, self.norm3)
         q = ops.add_rows(queries, query_pe)
-        keys = self.cross_attn_image_to_token.run(k, q, queries, P, residual=keys,
-                                                  res_row_mod=hw if keys.shape[0] == 1 and P > 1 else 0)
+        kq = ops.linear(q, i2t.k_proj.weight, i2t.k_proj.bias)
+        vq = ops.linear(queries, i2t.v_proj.weight, i2t.v_proj.bias)
+        keys = i2t.run_projected(qi, kq, vq, P, residual=keys, res_row_mod=hw if keys.shape[0] == 1 and P > 1 else 0)
         keys = ln(keys, self.norm4)
         return queries, keys
 
@@ -348,8 +388,17 @@ class TwoWayTransformer(nn.Module):
         for layer in self.layers:
             queries, keys = layer.run(queries, keys, point_embedding, pe_tokens, P)
         q = ops.add_rows(queries, point_embedding)
-        k = ops.add_rows(keys, pe_tokens)
-        queries = self.final_attn_token_to_image.run(q, k, keys, P, residual=queries)
+        fa = self.final_attn_token_to_image
+        key = (pe_tokens.data_ptr(), pe_tokens._version) + tuple((p.data_ptr(), p._version) for p in
+                                                                 (fa.k_proj.weight, fa.v_proj.weight, fa.k_proj.bias, fa.v_proj.bias))
+        if getattr(self, "_fin_key", None) != key:
+            self._fin_val = _pe_folded_projection(pe_tokens.reshape(-1, pe_tokens.shape[-1]), [(fa.k_proj, True), (fa.v_proj, False)])
+            self._fin_key = key
+        wcat, rtab = self._fin_val
+        proj = ops.linear(keys, wcat, residual=rtab, res_row_mod=keys.shape[1])
+        d = fa.internal_dim
+        qp = ops.linear(q, fa.q_proj.weight, fa.q_proj.bias)
+        queries = fa.run_projected(qp, proj[..., :d], proj[..., d:], P, residual=queries)
         queries = ops.layernorm(queries, self.norm_final_attn.weight, self.norm_final_attn.bias, self.norm_final_attn.eps)
         return queries, keys
 
