@@ -290,20 +290,11 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
                     }
                 }
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j < FJ; ++j) {
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float v = acc[half * 4 + i][j][e] + bv[j][e];
-                        if (g.act != WG_ACT_NONE) v = wg_act(v, g.act);
-                        o[e] = (bf16)v;
-                    }
-                    *(bf16x4*)(stg + (i * 16 + fr) * SROW + (j * 16 + fq * 4) * 2) = o;
-                }
-            }
+            WG_ACT_SWITCH(g.act,
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) {
+                    _Pragma("unroll") for (int j = 0; j < FJ; ++j)
+                        *(bf16x4*)(stg + (i * 16 + fr) * SROW + (j * 16 + fq * 4) * 2) = wg_epi_pack<ACT>(acc[half * 4 + i][j], bv[j]);
+                })
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -527,20 +518,13 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wg_gemm_persist_kernel(GemmArg
                     }
                 }
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-#pragma unroll
-                for (int j = 0; j < FJ; ++j) {
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = acc[half * 4 + i][j][e] + (float)bvp[j][e];
-                        if (g.act != WG_ACT_NONE) x = wg_act(x, g.act);
-                        o[e] = (bf16)x;
+            WG_ACT_SWITCH(g.act,
+                _Pragma("unroll") for (int i = 0; i < 4; ++i) {
+                    _Pragma("unroll") for (int j = 0; j < FJ; ++j) {
+                        const float b[4] = {(float)bvp[j][0], (float)bvp[j][1], (float)bvp[j][2], (float)bvp[j][3]};
+                        *(bf16x4*)(stg + (i * 16 + efr) * SROW + (j * 16 + efq * 4) * 2) = wg_epi_pack<ACT>(acc[half * 4 + i][j], b);
                     }
-                    *(bf16x4*)(stg + (i * 16 + efr) * SROW + (j * 16 + efq * 4) * 2) = o;
-                }
-            }
+                })
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -723,36 +707,20 @@ __global__ __launch_bounds__(256, 2) void wg_gemm_tail_kernel(GemmArgs g) {
             }
         }
     };
-#pragma unroll
-    for (int i = 0; i < FI; ++i)
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) {
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = acc[i][j][e] + bv[j][e];
-                if (g.act != WG_ACT_NONE) x = wg_act(x, g.act);
-                o[e] = (bf16)x;
-            }
-            *(bf16x4*)(stg + (i * 16 + fr) * SROW + (j * 16 + fq * 4) * 2) = o;
-        }
+    WG_ACT_SWITCH(g.act,
+        _Pragma("unroll") for (int i = 0; i < FI; ++i) {
+            _Pragma("unroll") for (int j = 0; j < FJ; ++j)
+                *(bf16x4*)(stg + (i * 16 + fr) * SROW + (j * 16 + fq * 4) * 2) = wg_epi_pack<ACT>(acc[i][j], bv[j]);
+        })
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     flush(m0 + wm * WTM, 64);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     if (own_tail) {
-#pragma unroll
-        for (int j = 0; j < FJ; ++j) {
-            bf16x4 o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float x = accx[j][e] + bv[j][e];
-                if (g.act != WG_ACT_NONE) x = wg_act(x, g.act);
-                o[e] = (bf16)x;
-            }
-            *(bf16x4*)(stg + fr * SROW + (j * 16 + fq * 4) * 2) = o;
-        }
+        WG_ACT_SWITCH(g.act,
+            _Pragma("unroll") for (int j = 0; j < FJ; ++j)
+                *(bf16x4*)(stg + fr * SROW + (j * 16 + fq * 4) * 2) = wg_epi_pack<ACT>(accx[j], bv[j]);)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
         flush(m0 + BM, 16);
@@ -866,6 +834,16 @@ extern "C" int wg_gemm_pick_tile_ex(int M, int N, int allow_tail) {
     const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
     const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
     if (t256 < 64 && t128 > t256) return 11;  // too few big tiles to matter: spread over more CUs
+    // round quantisation: 256x256 tiles run one workgroup per CU (256 slots), 128x128 tiles two (512 slots).  The big tile's
+    // main loop is ~15-20 % faster, so the small one wins only when it wastes clearly fewer slots in its last round
+    // (SAM proj / lin2: 384 big tiles = 1.5 rounds vs 1536 small ones = 3 whole rounds: +7..12 % for that GEMM alone).
+    // Only for callers that run one stream (allow_tail): with the towers overlapped on several streams the other
+    // stream's kernels fill those slots anyway and the rule costs 1-2 % end to end.
+    if (allow_tail) {
+        const double e256 = (double)t256 / (double)(((t256 + 255) / 256) * 256);
+        const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
+        if (e128 > 1.2 * e256) return 11;
+    }
     return 14;                                // 256x256 tiles, ping-pong schedule (+3..16 % over the plain loop at K <= 4096)
 }
 

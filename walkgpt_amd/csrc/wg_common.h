@@ -8,6 +8,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -75,3 +76,51 @@ __device__ __forceinline__ float wg_act(float x, int act) {
         default: return x;
     }
 }
+
+// ---- epilogue form of the activations: compile-time code, two values per instruction ---------------------------------------
+// The GEMM epilogues run the activation on every output (128 values per lane on a 256x256 tile), with the matrix pipe idle
+// meanwhile, so their cost is main-loop time.  These versions are straight-line (no per-element switch), written on float
+// pairs so that hipcc selects v_pk_mul/v_pk_fma_f32, and use the bare v_exp_f32 / v_rcp_f32 (no denormal range scaling:
+// exp2 of a very negative argument flushing to zero is exactly what both formulas want).
+//   GELU(x) = x/2 + |x/2| * (1 - p(t) t e^{-x^2/2}),  t = 1 / (1 + 0.3275911 |x| / sqrt2)   (A&S 7.1.26, as wg_erf above)
+template <int ACT> __device__ __forceinline__ f32x2 wg_act2(f32x2 x) {
+    if constexpr (ACT == WG_ACT_GELU_ERF) {
+        const f32x2 ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
+        const f32x2 d = ax * 0.23164189f + 1.0f;                       // 0.3275911 / sqrt(2)
+        const f32x2 t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+        f32x2 p = t * 1.061405429f - 1.453152027f;
+        p = p * t + 1.421413741f;
+        p = p * t - 0.284496736f;
+        p = p * t + 0.254829592f;
+        const f32x2 a = (x * x) * -0.72134752f;                         // -(x^2 / 2) log2(e)
+        const f32x2 e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+        const f32x2 r = 1.0f - (p * t) * e;                             // erf(|x| / sqrt2)
+        const f32x2 hx = x * 0.5f, ahx = ax * 0.5f;
+        return hx + ahx * r;
+    } else if constexpr (ACT == WG_ACT_QUICK_GELU) {
+        const f32x2 a = x * -2.4554669f;                                // -1.702 log2(e)
+        const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)} + 1.0f;
+        return x * (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    } else if constexpr (ACT == WG_ACT_RELU) {
+        return (f32x2){fmaxf(x.x, 0.0f), fmaxf(x.y, 0.0f)};
+    } else {
+        return x;
+    }
+}
+
+// four accumulator values (+ bias) -> activation -> packed bf16
+template <int ACT> __device__ __forceinline__ bf16x4 wg_epi_pack(f32x4 v, const float* b) {
+    f32x2 lo = {v[0] + b[0], v[1] + b[1]}, hi = {v[2] + b[2], v[3] + b[3]};
+    lo = wg_act2<ACT>(lo);
+    hi = wg_act2<ACT>(hi);
+    return (bf16x4){(bf16)lo.x, (bf16)lo.y, (bf16)hi.x, (bf16)hi.y};
+}
+
+// run BODY with `ACT` bound to the compile-time value of the (wave-uniform) runtime activation code
+#define WG_ACT_SWITCH(act, ...)                                                                  \
+    switch (act) {                                                                               \
+        case WG_ACT_GELU_ERF: { constexpr int ACT = WG_ACT_GELU_ERF; __VA_ARGS__ } break;        \
+        case WG_ACT_QUICK_GELU: { constexpr int ACT = WG_ACT_QUICK_GELU; __VA_ARGS__ } break;    \
+        case WG_ACT_RELU: { constexpr int ACT = WG_ACT_RELU; __VA_ARGS__ } break;                \
+        default: { constexpr int ACT = WG_ACT_NONE; __VA_ARGS__ } break;                         \
+    }
