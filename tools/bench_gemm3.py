@@ -12,15 +12,15 @@ def t(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-NAMES = {1: "128", 11: "128persist", 2: "256", 14: "256pp"}
+NAMES = {1: "128", 11: "128persist", 12: "128tail", 2: "256", 14: "256pp"}
 shapes = [("sam qkv", 32768, 2304, 768, "bias"), ("sam proj", 32768, 768, 768, "resid"), ("sam lin1", 32768, 3072, 768, "gelu"),
           ("sam lin2", 32768, 768, 3072, "resid"), ("clip qkv", 8200, 3072, 1024, "bias"), ("clip out", 8200, 1024, 1024, "resid"),
           ("clip fc1", 8200, 4096, 1024, "qgelu"), ("clip fc2", 8200, 1024, 4096, "resid"), ("8k", 8192, 8192, 8192, "none"),
           ("4k", 4096, 4096, 4096, "none"), ("sam qkv", 32768, 2304, 768, "none"), ("sam lin1", 32768, 3072, 768, "none"),
           ("sam lin1", 32768, 3072, 768, "bias"), ("sam lin2", 32768, 768, 3072, "none")]
 # correctness of every variant first
-a = torch.randn(777, 256, device=dev).to(torch.bfloat16); w = (torch.randn(520, 256, device=dev) / 16).to(torch.bfloat16)
-b = torch.randn(520, device=dev).to(torch.bfloat16); r = torch.randn(777, 520, device=dev).to(torch.bfloat16)
+a = torch.randn(1777, 256, device=dev).to(torch.bfloat16); w = (torch.randn(520, 256, device=dev) / 16).to(torch.bfloat16)
+b = torch.randn(520, device=dev).to(torch.bfloat16); r = torch.randn(1777, 520, device=dev).to(torch.bfloat16)
 ref = torch.nn.functional.gelu(a.float() @ w.float().t() + b.float()) + r.float()
 for tile in NAMES:
     out = ops.linear(a, w, b, act=ops.ACT_GELU, residual=r, tile=tile)

@@ -17,6 +17,7 @@
 //   * workgroup -> tile map is XCD-aware: blocks that share an XCD (same id mod 8) walk one contiguous
 //     stripe of the tile grid, so the A row panel and the weight slab are re-read from that XCD's L2.
 #include "wg_common.h"
+#include <type_traits>
 
 struct GemmArgs {
     const bf16* A; long lda;
@@ -28,6 +29,7 @@ struct GemmArgs {
     int act;
     int out_f32;
     int tiles_m, tiles_n;
+    unsigned c_bytes, r_bytes;   // extents of C and R for the staged epilogue's buffer descriptors (0: not addressable in 32 bits)
 };
 
 template <int N_> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N_) : "memory"); }
@@ -39,6 +41,54 @@ template <int N_> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile
 // distinct slots (the identity map would fold rows R and R+4 onto the same banks).
 template <int BK> __device__ __forceinline__ int wg_swz(int row) {
     return BK == 64 ? (row >> 1) & 7 : (0x78 >> (2 * ((row >> 2) & 3))) & 3;
+}
+
+// Staged epilogue, memory side.  The wave's 64 x WTN staging slab (rows padded to SROW bytes) goes out as whole row
+// segments, 16 bytes per lane; residual rows come in the same shape.  Both use raw buffer instructions so that rows past M are
+// dropped (stores) or read as zero (loads) by the hardware range check instead of by per-lane branches, and
+//   * all slab reads and residual adds happen BEFORE the first store, and
+//   * the code between the first residual load and the last store is branch-free,
+// because loads and stores share one in-order counter: a residual consumed between stores, or a store sequence cut by
+// exec-mask branches, makes hipcc guard every store with `s_waitcnt vmcnt(0)` -- each store then waits until memory has
+// acknowledged the previous one (microseconds per tile with the matrix pipe idle).
+#define WG_RSRC_FLAGS 0x00020000   // raw buffer, 32-bit data format
+template <int SROW, int CH, int NIT, bool HAS_R>
+__device__ __forceinline__ void wg_flush_slab(const char* stg, const u32x4* rres, __amdgpu_buffer_rsrc_t crs, int ldc, int N, int row0, int nbase, int el) {
+    constexpr int RPS = 64 / CH;
+    bf16x8 o[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) o[it] = *(const bf16x8*)(stg + (it * RPS + el / CH) * SROW + (el % CH) * 16);
+    if (HAS_R) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const bf16x8 r = __builtin_bit_cast(bf16x8, rres[it]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[it][e] = (bf16)((float)o[it][e] + (float)r[e]);
+        }
+    }
+    // pin the values here: otherwise LLVM sinks each add (and its wait) down to its store
+    u32x4 t[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        t[it] = __builtin_bit_cast(u32x4, o[it]);
+        asm volatile("" : "+v"(t[it]));
+    }
+    // columns past N: an offset beyond the descriptor's extent (< 2^31), so the range check drops those lanes too -- a branch
+    // around the stores would make hipcc assume at the join that they may not have been issued and tighten every later wait
+    const int n = nbase + (el % CH) * 8;
+    const int off0 = n < N ? ((row0 + el / CH) * ldc + n) * 2 : (int)0x80000000;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) __builtin_amdgcn_raw_buffer_store_b128(t[it], crs, off0 + it * RPS * ldc * 2, 0, 0);
+}
+template <int CH, int NIT>
+__device__ __forceinline__ void wg_load_residual(u32x4* rres, __amdgpu_buffer_rsrc_t rrs, int ldr, int res_mod, int row0, int nbase, int el) {
+    constexpr int RPS = 64 / CH;
+    const int n = nbase + (el % CH) * 8;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int m = row0 + it * RPS + el / CH;
+        rres[it] = __builtin_amdgcn_raw_buffer_load_b128(rrs, ((res_mod > 0 ? m % res_mod : m) * ldr + n) * 2, 0, 0);
+    }
 }
 
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, int PIPE>
@@ -275,45 +325,36 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
                 for (int e = 0; e < 4; ++e) bv[j][e] = 0.f;
             }
         }
+        // One straight-line copy of the rest per (residual? yes/no): with the residual handled by `if (g.R)` inside a common
+        // body, hipcc cannot tell at the control-flow joins that no load is pending and guards the second slab's stores with
+        // `s_waitcnt vmcnt(0)` -- which waits for the first slab's stores to be acknowledged.
+        const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.c_bytes, WG_RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.R, 0, g.r_bytes, WG_RSRC_FLAGS);
+        auto finish = [&](auto has_r) __attribute__((always_inline)) {
+            constexpr bool HAS_R = decltype(has_r)::value;
+            // residual rows of the whole wave tile: issued first (a load issued behind stores could only be waited for
+            // together with them), consumed after the LDS round trips
+            u32x4 rres[WTM / 64][64 / RPI];
+            if (HAS_R) {
 #pragma unroll
-        for (int half = 0; half < WTM / 64; ++half) {
-            // residual rows of this 64-row slab: issued first, consumed after the LDS round trip
-            bf16x8 rres[64 / RPI];
-            if (g.R) {
-#pragma unroll
-                for (int it = 0; it < 64 / RPI; ++it) {
-                    const int m = m0 + wm * WTM + half * 64 + it * RPI + lane / CH;
-                    const int n = nbase + (lane % CH) * 8;
-                    if (m < g.M && n < g.N) {
-                        const long rrow = (long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr;
-                        rres[it] = *(const bf16x8*)(g.R + rrow + n);
-                    }
-                }
+                for (int half = 0; half < WTM / 64; ++half)
+                    wg_load_residual<CH, 64 / RPI>(rres[half], rrs, (int)g.ldr, g.res_mod, m0 + wm * WTM + half * 64, nbase, lane);
             }
-            WG_ACT_SWITCH(g.act,
-                _Pragma("unroll") for (int i = 0; i < 4; ++i) {
-                    _Pragma("unroll") for (int j = 0; j < FJ; ++j)
-                        *(bf16x4*)(stg + (i * 16 + fr) * SROW + (j * 16 + fq * 4) * 2) = wg_epi_pack<ACT>(acc[half * 4 + i][j], bv[j]);
-                })
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int it = 0; it < 64 / RPI; ++it) {
-                const int r = it * RPI + lane / CH, ch = lane % CH;
-                const int m = m0 + wm * WTM + half * 64 + r;
-                const int n = nbase + ch * 8;
-                bf16x8 v = *(const bf16x8*)(stg + r * SROW + ch * 16);
-                if (m < g.M && n < g.N) {
-                    if (g.R) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (bf16)((float)v[e] + (float)rres[it][e]);
-                    }
-                    *(bf16x8*)((bf16*)g.C + (long)m * g.ldc + n) = v;
-                }
+            for (int half = 0; half < WTM / 64; ++half) {
+                WG_ACT_SWITCH(g.act,
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i) {
+                        _Pragma("unroll") for (int j = 0; j < FJ; ++j)
+                            *(bf16x4*)(stg + (i * 16 + fr) * SROW + (j * 16 + fq * 4) * 2) = wg_epi_pack<ACT>(acc[half * 4 + i][j], bv[j]);
+                    })
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                wg_flush_slab<SROW, CH, 64 / RPI, HAS_R>(stg, rres[half], crs, (int)g.ldc, g.N, m0 + wm * WTM + half * 64, nbase, lane);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-        }
+        };
+        if (g.R) finish(std::true_type{}); else finish(std::false_type{});
         return;
     }
 #pragma unroll
@@ -493,7 +534,6 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wg_gemm_persist_kernel(GemmArg
         const int vn = v + gridDim.x;
         const bool has_next = vn < nwg;
         const int cm0 = m0;
-        const bool full = (m0 + BM <= g.M) && (n0 + BN <= g.N);
         // opaque copies of the lane coordinates: keeps hipcc from hoisting the epilogue's (tile-invariant) address
         // arithmetic out of the tile loop, where it would stay live across the main loop and push it into spills
         int el = lane, efr = fr, efq = fq;
@@ -504,51 +544,38 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void wg_gemm_persist_kernel(GemmArg
             stage(0, 0);
         }
 
+        const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.c_bytes, WG_RSRC_FLAGS);
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.R, 0, g.r_bytes, WG_RSRC_FLAGS);
+        auto finish = [&](auto has_r) __attribute__((always_inline)) {   // see wg_gemm_kernel's staged epilogue
+            constexpr bool HAS_R = decltype(has_r)::value;
+            u32x4 rres[WTM / 64][64 / RPS];   // (ordinary loads: hipcc waits for the slab in flight too before their first use)
+            if (HAS_R) {
 #pragma unroll
-        for (int half = 0; half < WTM / 64; ++half) {
-            bf16x8 rres[64 / RPS];
-            if (g.R) {   // (ordinary loads: hipcc waits for the slab in flight too before their first use)
-#pragma unroll
-                for (int it = 0; it < 64 / RPS; ++it) {
-                    const int m = cm0 + wm * WTM + half * 64 + it * RPS + el / CH;
-                    const int n = nbase + (el % CH) * 8;
-                    if (m < g.M && n < g.N) {
-                        const long rrow = (long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr;
-                        rres[it] = *(const bf16x8*)(g.R + rrow + n);
-                    }
-                }
+                for (int half = 0; half < WTM / 64; ++half)
+                    wg_load_residual<CH, 64 / RPS>(rres[half], rrs, (int)g.ldr, g.res_mod, cm0 + wm * WTM + half * 64, nbase, el);
             }
-            WG_ACT_SWITCH(g.act,
-                _Pragma("unroll") for (int i = 0; i < 4; ++i) {
-                    _Pragma("unroll") for (int j = 0; j < FJ; ++j) {
-                        const float b[4] = {(float)bvp[j][0], (float)bvp[j][1], (float)bvp[j][2], (float)bvp[j][3]};
-                        *(bf16x4*)(stg + (i * 16 + efr) * SROW + (j * 16 + efq * 4) * 2) = wg_epi_pack<ACT>(acc[half * 4 + i][j], b);
-                    }
-                })
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int it = 0; it < 64 / RPS; ++it) {
-                const int r = it * RPS + el / CH, ch = el % CH;
-                const int m = cm0 + wm * WTM + half * 64 + r;
-                const int n = nbase + ch * 8;
-                bf16x8 o = *(const bf16x8*)(stg + r * SROW + ch * 16);
-                if (m < g.M && n < g.N) {
-                    if (g.R) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] + (float)rres[it][e]);
-                    }
-                    *(bf16x8*)((bf16*)g.C + (long)m * g.ldc + n) = o;
-                }
+            for (int half = 0; half < WTM / 64; ++half) {
+                WG_ACT_SWITCH(g.act,
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i) {
+                        _Pragma("unroll") for (int j = 0; j < FJ; ++j) {
+                            const float b[4] = {(float)bvp[j][0], (float)bvp[j][1], (float)bvp[j][2], (float)bvp[j][3]};
+                            *(bf16x4*)(stg + (i * 16 + efr) * SROW + (j * 16 + efq * 4) * 2) = wg_epi_pack<ACT>(acc[half * 4 + i][j], b);
+                        }
+                    })
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                wg_flush_slab<SROW, CH, 64 / RPS, HAS_R>(stg, rres[half], crs, (int)g.ldc, g.N, cm0 + wm * WTM + half * 64, nbase, el);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_wave_barrier();
-        }
+        };
+        if (g.R) finish(std::true_type{}); else finish(std::false_type{});
         if (!has_next) break;
         v = vn;
-        // the counted wait is exact only when every lane issued every store and nothing younger than the slab but
-        // older than the stores is pending: full tiles, no residual loads in the epilogue
-        stores_in_flight = full && !g.R;
+        // every wave issues all NSTORE store instructions of a tile (rows / columns outside the matrix are dropped by the buffer
+        // range check, not branched around), and residual loads are consumed before the stores issue: the count is exact
+        stores_in_flight = true;
     }
 }
 
@@ -690,41 +717,35 @@ __global__ __launch_bounds__(256, 2) void wg_gemm_tail_kernel(GemmArgs g) {
             for (int e = 0; e < 4; ++e) bv[j][e] = 0.f;
         }
     }
-    auto flush = [&](int row0, int nrows) {   // staging rows [0, nrows) hold output rows row0 .. ; 16 bytes per lane out
-        for (int it = 0; it * RPS < nrows; ++it) {
-            const int r = it * RPS + lane / CH, ch = lane % CH;
-            const int m = row0 + r;
-            const int n = nbase + ch * 8;
-            bf16x8 o = *(const bf16x8*)(stg + r * SROW + ch * 16);
-            if (m < g.M && n < g.N) {
-                if (g.R) {
-                    const long rrow = (long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr;
-                    const bf16x8 rr = *(const bf16x8*)(g.R + rrow + n);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)o[e] + (float)rr[e]);
-                }
-                *(bf16x8*)((bf16*)g.C + (long)m * g.ldc + n) = o;
-            }
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.c_bytes, WG_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.R, 0, g.r_bytes, WG_RSRC_FLAGS);
+    auto finish = [&](auto has_r) __attribute__((always_inline)) {   // see wg_gemm_kernel's staged epilogue
+        constexpr bool HAS_R = decltype(has_r)::value;
+        u32x4 rres[8], rrx[2];
+        if (HAS_R) {
+            wg_load_residual<CH, 8>(rres, rrs, (int)g.ldr, g.res_mod, m0 + wm * WTM, nbase, lane);
+            if (own_tail) wg_load_residual<CH, 2>(rrx, rrs, (int)g.ldr, g.res_mod, m0 + BM, nbase, lane);
         }
-    };
-    WG_ACT_SWITCH(g.act,
-        _Pragma("unroll") for (int i = 0; i < FI; ++i) {
-            _Pragma("unroll") for (int j = 0; j < FJ; ++j)
-                *(bf16x4*)(stg + (i * 16 + fr) * SROW + (j * 16 + fq * 4) * 2) = wg_epi_pack<ACT>(acc[i][j], bv[j]);
-        })
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    flush(m0 + wm * WTM, 64);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    if (own_tail) {
         WG_ACT_SWITCH(g.act,
-            _Pragma("unroll") for (int j = 0; j < FJ; ++j)
-                *(bf16x4*)(stg + fr * SROW + (j * 16 + fq * 4) * 2) = wg_epi_pack<ACT>(accx[j], bv[j]);)
+            _Pragma("unroll") for (int i = 0; i < FI; ++i) {
+                _Pragma("unroll") for (int j = 0; j < FJ; ++j)
+                    *(bf16x4*)(stg + (i * 16 + fr) * SROW + (j * 16 + fq * 4) * 2) = wg_epi_pack<ACT>(acc[i][j], bv[j]);
+            })
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
-        flush(m0 + BM, 16);
-    }
+        wg_flush_slab<SROW, CH, 8, HAS_R>(stg, rres, crs, (int)g.ldc, g.N, m0 + wm * WTM, nbase, lane);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (own_tail) {
+            WG_ACT_SWITCH(g.act,
+                _Pragma("unroll") for (int j = 0; j < FJ; ++j)
+                    *(bf16x4*)(stg + fr * SROW + (j * 16 + fq * 4) * 2) = wg_epi_pack<ACT>(accx[j], bv[j]);)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            wg_flush_slab<SROW, CH, 2, HAS_R>(stg, rrx, crs, (int)g.ldc, g.N, m0 + BM, nbase, lane);
+        }
+    };
+    if (g.R) finish(std::true_type{}); else finish(std::false_type{});
 }
 
 static int launch_tail(GemmArgs& g, hipStream_t st) {
@@ -804,7 +825,8 @@ static int launch_persist(GemmArgs& g, hipStream_t st) {
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, int PIPE = 0>
 static int launch_tile(GemmArgs& g, hipStream_t st) {
     // staged (LDS-transposed, 16-byte) epilogue for bf16 outputs whose rows are 16-byte addressable
-    const bool staged = !g.out_f32 && g.N % 8 == 0 && g.ldc % 8 == 0 && (!g.R || (g.ldr % 8 == 0 && ((uintptr_t)g.R & 15) == 0));
+    const bool staged = !g.out_f32 && g.N % 8 == 0 && g.ldc % 8 == 0 && g.c_bytes != 0 &&
+                        (!g.R || (g.ldr % 8 == 0 && ((uintptr_t)g.R & 15) == 0 && g.r_bytes != 0));
     return staged ? launch_tile_impl<BM, BN, BK, STAGES, WM, WN, true, PIPE>(g, st)
                   : launch_tile_impl<BM, BN, BK, STAGES, WM, WN, false, PIPE>(g, st);
 }
@@ -862,6 +884,13 @@ extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, lon
     g.bias = (const bf16*)bias; g.R = (const bf16*)residual; g.ldr = ldr; g.res_mod = res_row_mod;
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act; g.out_f32 = out_f32;
     g.tiles_m = g.tiles_n = 0;
+    {   // byte extents for the staged epilogue's buffer descriptors (it addresses C and R with 32-bit byte offsets)
+        const long cb = ((long)(M - 1) * ldc + N) * 2;
+        const long rrows = res_row_mod > 0 ? (res_row_mod < M ? res_row_mod : M) : M;
+        const long rb = residual ? ((rrows - 1) * ldr + N) * 2 : 0;
+        g.c_bytes = cb < (1L << 31) ? (unsigned)cb : 0;
+        g.r_bytes = rb < (1L << 31) ? (unsigned)rb : 0;
+    }
     hipStream_t st = (hipStream_t)stream;
     const bool mfma_ok = (K % 64 == 0) && (N % 4 == 0) && (lda % 8 == 0) && (ldw % 8 == 0) && (ldc % 4 == 0) &&
                          (!residual || ldr % 4 == 0) && (((uintptr_t)A | (uintptr_t)W) % 16 == 0) &&
@@ -873,7 +902,8 @@ extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, lon
     }
     int tile = tile_hint;
     if (tile <= 0) tile = wg_gemm_pick_tile(M, N);
-    const bool can_stage = !out_f32 && N % 8 == 0 && ldc % 8 == 0 && (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0));
+    const bool can_stage = !out_f32 && N % 8 == 0 && ldc % 8 == 0 && g.c_bytes != 0 &&
+                           (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0 && g.r_bytes != 0));
     const bool small_ops = (long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31);
     if (tile == 11 && !(can_stage && small_ops)) tile = 1;
     if (tile != 1 && tile != 2 && tile != 11 && tile != 12 && tile != 14) tile = 1;
