@@ -12,7 +12,7 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libwalkgpt_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-ffast-math", "-fno-finite-math-only",
-         "-Wno-unused-result", "-I", CSRC]
+         "-Wno-unused-result", "-I", CSRC] + os.environ.get("WG_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DWG_ATTN_STAMP (diagnostics)
 
 
 def _digest(paths):

@@ -57,7 +57,11 @@ template <int HD> __device__ __forceinline__ int swzV(int row) {
 
 // raw v_exp_f32: exp2f() adds a denormal-range fix-up (compare, select, ldexp) around it that triples the cost of the
 // one instruction softmax cannot avoid; arguments here are <= RESCALE_THR and results below 2^-126 may flush to zero.
+#if defined(WG_ATTN_ABL) && WG_ATTN_ABL == 1
+__device__ __forceinline__ float wg_exp2(float x) { return x * 0.001f; }   // ablation build: no exponentials
+#else
 __device__ __forceinline__ float wg_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif
 
 // ds_read_b64_tr_b16 through inline asm.  The builtin form makes hipcc park an `s_waitcnt vmcnt(0)` in front of the
 // first transposed read (it cannot tell the V tile being read from the LDS-DMA still writing the NEXT tile), which
@@ -68,6 +72,24 @@ template <int OFF> __device__ __forceinline__ u32x2 wg_ds_read_tr(unsigned lds_a
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "i"(OFF));
     return v;
 }
+
+// Diagnostic build only (-DWG_ATTN_STAMP, tools/attn_stamps.py): lane 0 of every wave of workgroup 0 records s_memtime at the
+// phase boundaries of its first 12 tiles into LDS and dumps them at the end.  No stamp executes in the normal build.
+#ifdef WG_ATTN_STAMP
+__device__ unsigned* wg_attn_stamp_ptr = nullptr;
+extern "C" int wg_debug_attn_stamps(unsigned* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(wg_attn_stamp_ptr), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#define WG_STAMP(k)                                                                                                  \
+    do {                                                                                                             \
+        if (blockIdx.x == 0 && t < 12) {                                                                             \
+            const unsigned now = (unsigned)__builtin_amdgcn_s_memtime();                                             \
+            if (lane == 0) ((volatile unsigned*)(smem + 156 * 1024))[(wave * 12 + t) * 8 + (k)] = now;              \
+        }                                                                                                            \
+    } while (0)
+#else
+#define WG_STAMP(k) do { } while (0)
+#endif
 
 template <int HD, int S, int NW, bool KB>
 __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
@@ -151,42 +173,94 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     }
 
     // ---- K/V staging (LDS-DMA, swizzle on the source address) -----------------------------------------------
-    auto stage = [&](int t, int buf) {
-        char* kbuf = kv + buf * 2 * TILE;
-        char* vbuf = kbuf + TILE;
-        constexpr int NINST = TILE / 1024;  // wave-instructions per tile
-        for (int i = wave; i < 2 * NINST; i += NW) {
-            const bool isV = i >= NINST;
-            const int ii = isV ? i - NINST : i;
+    // Piece i of this wave (1 KiB = 64 lanes x 16 bytes) covers fixed key slots of every tile, so its source is a running
+    // per-lane pointer that advances by one tile of rows per call (softmax at head_dim 64 is VALU-bound: the general index
+    // arithmetic -- window -> image coordinates, clamps, 64-bit row offsets -- was ~25 VALU instructions per piece per tile,
+    // as much as the exponentials).  Slots that do not exist in a tile (keys beyond Lk; window rows beyond the window or the
+    // image) read the substitute row instead: the last key (plain) or the qkv-bias row that stands for zero padding (grid);
+    // slots beyond the window width do so in every tile and keep a stride of 0.  Their scores are masked by the bias tables.
+    constexpr int NINST = TILE / 1024;               // wave-instructions per K (or V) tile
+    constexpr int NPW = (NINST + NW - 1) / NW;       // ... per wave
+    const bf16* altK = GRID ? a.padK + hcol : a.K + ((long)b * a.k_bs + (a.Lk - 1)) * a.ldk + hcol;
+    const bf16* altV = GRID ? a.padV + hcol : a.V + ((long)b * a.k_bs + (a.Lk - 1)) * a.ldv + hcol;
+    const int klim0 = GRID ? (S < a.Hg - wy * S ? S : a.Hg - wy * S) : a.Lk;   // rows (grid) / keys (plain) that exist
+    constexpr bool RUNP = NPW <= 3;   // (one-wave workgroups issue every piece themselves: they keep the general form)
+    constexpr int NRP = RUNP ? NPW : 1;
+    const bf16* runp[2][NRP];
+    unsigned coff[2][NRP];
+    int kslot[NRP];
+    bool padx[NRP];
+    if constexpr (RUNP) {
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int ii = wave + i * NW < NINST ? wave + i * NW : NINST - 1;
             const int ci = ii * 64 + lane;
-            const int row = ci / CPR;       // key slot inside the tile
-            const int cs = ci % CPR;
-            int c = cs ^ (isV ? swzV<HD>(row) : swzK<HD>(row));
-            if (HDP != HD && c * 8 >= HD) c = HD / 8 - 1;   // pad columns: any readable bytes will do
-            const bf16* src;
+            const int row = ci / CPR, cs = ci % CPR;        // key slot inside the tile, 16-byte chunk inside the row
+            int cK = cs ^ swzK<HD>(row), cV = cs ^ swzV<HD>(row);
+            if (HDP != HD && cK * 8 >= HD) cK = HD / 8 - 1;   // pad columns: any readable bytes will do
+            if (HDP != HD && cV * 8 >= HD) cV = HD / 8 - 1;
+            coff[0][i] = cK * 8;
+            coff[1][i] = cV * 8;
+            long r;
             if (GRID) {
-                int kh = t * RPT + row / RP, kw = row % RP;
-                kh = kh < S ? kh : S - 1;   // padding slots fetch a valid row; the bias tables mask them
+                int kw = row % RP;
                 kw = kw < S ? kw : S - 1;
-                const int gy = wy * S + kh, gx = wx * S + kw;
-                if (gy < a.Hg && gx < a.Hg) {
-                    const long r = (long)b * a.Hg * a.Hg + gy * a.Hg + gx;
-                    src = (isV ? a.V + r * a.ldv : a.K + r * a.ldk) + hcol + c * 8;
-                } else {
-                    src = (isV ? a.padV : a.padK) + hcol + c * 8;
-                }
+                kslot[i] = row / RP;
+                padx[i] = wx * S + kw >= a.Hg;
+                r = (long)b * a.Hg * a.Hg + (long)(wy * S + kslot[i]) * a.Hg + wx * S + kw;
             } else {
-                int kl = t * 64 + row;
-                kl = kl < Lk ? kl : Lk - 1;
-                const long r = (long)b * a.k_bs + kl;
-                src = (isV ? a.V + r * a.ldv : a.K + r * a.ldk) + hcol + c * 8;
+                kslot[i] = row;
+                padx[i] = false;
+                r = (long)b * a.k_bs + row;
             }
-            __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(src), WG_LDS_PTR((isV ? vbuf : kbuf) + ii * 1024), 16, 0, 0);
+            runp[0][i] = padx[i] ? altK + coff[0][i] : a.K + r * a.ldk + hcol + coff[0][i];
+            runp[1][i] = padx[i] ? altV + coff[1][i] : a.V + r * a.ldv + hcol + coff[1][i];
+        }
+    }
+    const unsigned strideK = (unsigned)((GRID ? (long)RPT * a.Hg : 64L) * a.ldk);
+    const unsigned strideV = (unsigned)((GRID ? (long)RPT * a.Hg : 64L) * a.ldv);
+    // tile t of K (or V) -> buffer `buf`; per operand the tiles must be staged in order 0, 1, 2, ... (running pointers)
+    auto stage = [&](int t, int buf, bool isV) __attribute__((always_inline)) {
+        char* dst = kv + buf * 2 * TILE + (isV ? TILE : 0);
+        const int lim = klim0 - t * (GRID ? RPT : 64);
+        const int o = isV ? 1 : 0;
+        if constexpr (RUNP) {
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) {
+                const int ii = wave + i * NW;
+                if (ii < NINST) {
+                    const bf16* src = kslot[i] < lim ? runp[o][i] : (isV ? altV : altK) + coff[o][i];
+                    __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(src), WG_LDS_PTR(dst + ii * 1024), 16, 0, 0);
+                }
+                runp[o][i] += padx[i] ? 0u : (isV ? strideV : strideK);
+            }
+        } else {
+            for (int ii = wave; ii < NINST; ii += NW) {
+                const int ci = ii * 64 + lane;
+                const int row = ci / CPR, cs = ci % CPR;
+                int c = cs ^ (isV ? swzV<HD>(row) : swzK<HD>(row));
+                if (HDP != HD && c * 8 >= HD) c = HD / 8 - 1;
+                const bf16* src = (isV ? altV : altK) + c * 8;
+                if (GRID) {
+                    int kw = row % RP;
+                    kw = kw < S ? kw : S - 1;
+                    const int kh = t * RPT + row / RP;
+                    if (row / RP < lim && wx * S + kw < a.Hg) {
+                        const long r = (long)b * a.Hg * a.Hg + (long)(wy * S + kh) * a.Hg + wx * S + kw;
+                        src = (isV ? a.V + r * a.ldv : a.K + r * a.ldk) + hcol + c * 8;
+                    }
+                } else if (row < lim) {
+                    const long r = (long)b * a.k_bs + t * 64 + row;
+                    src = (isV ? a.V + r * a.ldv : a.K + r * a.ldk) + hcol + c * 8;
+                }
+                __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(src), WG_LDS_PTR(dst + ii * 1024), 16, 0, 0);
+            }
         }
     };
 
     const int nt = GRID ? NTG : (Lk + 63) / 64;
-    stage(0, 0);
+    stage(0, 0, false);
+    stage(0, 0, true);
 
     // ---- rel-pos tables (grid) / key bias row (plain) -----------------------------------------------------------
     float relw_reg[NRW];
@@ -245,109 +319,99 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     for (int d = 0; d < DB; ++d)
 #pragma unroll
         for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
-    float m_run = NEG_BIG, l_run = 0.f;
+    float m_run = NEG_BIG;
+    float l_run = 0.f;   // running softmax denominator (this lane's half of the keys)
     const float sc2 = a.scale * LOG2E;
 
-    for (int t = 0; t < nt; ++t) {
-        const int buf = t & 1;
-        if (t + 1 < nt) stage(t + 1, buf ^ 1);
-        const char* kbuf = kv + buf * 2 * TILE;
-        const char* vbuf = kbuf + TILE;
+    // ---- main loop ---------------------------------------------------------------------------------------------------------------
+    // Per tile: S^T MFMAs -> bias / running max -> exponentials -> P.V MFMAs, one barrier.  Measured alternatives (in-kernel
+    // stamps, PMC, ablation builds): a ping-pong of the two workgroup halves across two barriers per tile, and
+    // a software pipeline that interleaves S^T(t+1) with the exponentials of tile t and P.V(t) with the maxima of t+1 (+32 live
+    // registers) were both SLOWER than this order once the per-tile index arithmetic of the staging was gone: the loop is a
+    // latency chain in an in-order pipeline (matrix pipe 35 %, VALU 46 % busy, 18 % of the time together), not a throughput
+    // problem of either unit.
+    constexpr float RESCALE_THR = 6.0f;
+    constexpr bool RAW = !GRID && !KB;           // no additive bias: scores stay unscaled, p = exp2(s*sc2 - off)
+    constexpr int NQK = 2 * KSTEPS;              // S^T MFMAs per tile
+    constexpr int NPV = 4 * DB;                  // P.V MFMAs per tile
+    f32x16 sa[2];                                // scores of the tile
+    u32x2 vt[4][DB][2];
+    bf16x8 pf[4];  // P^T fragments: k-step (kb, s2) uses registers 8*s2 .. 8*s2+7 of block kb
+    const bool ragged = !GRID && (Lk & 63) != 0;  // plain mode: keys beyond Lk exist on the last tile only
 
-        // S^T (two 32-key blocks)
-        f32x16 st[2];
+    // S^T MFMA g of a tile: k-step s of key block kb (the two accumulation chains alternate); its K fragment is read from LDS
+    // two MFMAs ahead
+    bf16x8 kfr[NQK];
+    auto qk_read = [&](const char* kbuf, int g) __attribute__((always_inline)) {
+        const int kb = g & 1, s = g >> 1;
+        const int row = kb * 32 + ql_lane;
+        const int c = (2 * s + hi) ^ swzK<HD>(row);
+#if defined(WG_ATTN_ABL) && WG_ATTN_ABL == 6
+        kfr[g] = qf[s];   // ablation build: no K fragment reads
+        return;
+#endif
+        kfr[g] = *(const bf16x8*)(kbuf + row * ROWB + c * 16);
+    };
+    auto qk_one = [&](f32x16* st, int g) __attribute__((always_inline)) {
+        const int kb = g & 1, s = g >> 1;
+#if defined(WG_ATTN_ABL) && WG_ATTN_ABL == 3
+        asm volatile("" ::"v"(kfr[g]));   // ablation build: no S^T MFMAs
+        if (s == 0) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = 0.f;
-            const int row = kb * 32 + ql_lane;
-#pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                const int c = (2 * s + hi) ^ swzK<HD>(row);
-                const bf16x8 kf = *(const bf16x8*)(kbuf + row * ROWB + c * 16);
-                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], st[kb], 0, 0, 0);
-            }
+            for (int r = 0; r < 16; ++r) st[kb][r] = 0.01f * r;
         }
-
-        // V^T fragments of this tile: 4 k-steps x DB d-blocks x 2 transposed reads, issued now so that their LDS
-        // latency hides under the softmax below.  Lane (g = lane>>4, i16 = lane&15) supplies the address of key row
-        // 16*ks + 4*hi + (i16>>2) (+8 for the second read), d columns 32*d + 16*(g&1) + 4*(i16&3) .. +3; the swizzle
-        // bit(s) depend only on i16>>2, so each d block needs one lane-dependent base and compile-time offsets.
-        u32x2 vt[4][DB][2];
-        {
-            const int g = lane >> 4, i16 = lane & 15;
-            const int rq = i16 >> 2, cp = i16 & 3;
-            const unsigned vbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem) +
-                                   (unsigned)(buf * 2 * TILE + TILE);
-#pragma unroll
-            for (int d = 0; d < DB; ++d) {
-                const int col = 32 * d + 16 * (g & 1) + 4 * cp;
-                const int chunk = col >> 3;
-                const unsigned ad = vbase + (4 * hi + rq) * ROWB + ((chunk ^ swzV<HD>(4 * hi + rq)) << 4) + (col & 7) * 2;
-                // swzV depends on the key only through its low bits, which 16*ks and +8 leave untouched
-                vt[0][d][0] = wg_ds_read_tr<0 * 16 * ROWB>(ad);
-                vt[0][d][1] = wg_ds_read_tr<0 * 16 * ROWB + 8 * ROWB>(ad);
-                vt[1][d][0] = wg_ds_read_tr<1 * 16 * ROWB>(ad);
-                vt[1][d][1] = wg_ds_read_tr<1 * 16 * ROWB + 8 * ROWB>(ad);
-                vt[2][d][0] = wg_ds_read_tr<2 * 16 * ROWB>(ad);
-                vt[2][d][1] = wg_ds_read_tr<2 * 16 * ROWB + 8 * ROWB>(ad);
-                vt[3][d][0] = wg_ds_read_tr<3 * 16 * ROWB>(ad);
-                vt[3][d][1] = wg_ds_read_tr<3 * 16 * ROWB + 8 * ROWB>(ad);
-            }
+        return;
+#endif
+        if (s == 0) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g], qf[s], z, 0, 0, 0);
+        } else {
+            st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g], qf[s], st[kb], 0, 0, 0);
         }
-
-        // ---- softmax bookkeeping in the exp2 domain.  VALU-bound at head_dim 64 (2 MFMA per 4 exp), so every
-        // per-element instruction counts: s = fma(acc, scale*log2e, bias) only where a bias exists; with one window row
-        // per tile the row term of the rel-pos bias and the running max fold into one per-lane offset; keys beyond Lk
-        // are masked on the last tile only (plain mode) or by the bias tables (grid mode); O is rescaled only when some
-        // row's max grew by more than RESCALE_THR (p then stays below 2^RESCALE_THR).
-        constexpr float RESCALE_THR = 6.0f;
-        constexpr bool RAW = !GRID && !KB;           // no additive bias: scores stay unscaled, p = exp2(s*sc2 - off)
-        float rowh = 0.f;
+    };
+    // bias + running max over score elements [e0, e1) of tile t (flattened index e = 16*kb + r)
+    float rh[GRID ? RPT : 1];
+    f32x4 kbv[2][4];
+    auto bias_begin = [&](int t) __attribute__((always_inline)) {
         if constexpr (GRID) {
-            float rh[RPT];
 #pragma unroll
             for (int i = 0; i < RPT; ++i) rh[i] = relh_tab[t * RPT + i];
-            if constexpr (RPT == 1) rowh = rh[0];
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    constexpr int dummy = 0;
-                    const int sl0 = 32 * kb + (r & 3) + 8 * (r >> 2);        // slot in tile without the lane-half bit
-                    const int slr = sl0 % RP;                                  // slot in its padded row
-                    const int j = (slr & 3) + 4 * (slr >> 3);                  // which of this lane's column registers
-                    const int rt = sl0 / RP;                                   // row inside the tile
-                    float v = st[kb][r] * sc2 + relw_reg[j];
-                    if constexpr (RPT > 1) v += rh[rt];
-                    st[kb][r] = v;
-                    (void)dummy;
-                }
         } else if constexpr (KB) {
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                f32x4 kbv[4];
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) kbv[g4] = *(const f32x4*)(tab + t * 64 + kb * 32 + 8 * g4 + 4 * hi);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) st[kb][r] = st[kb][r] * sc2 + kbv[r >> 2][r & 3];
-            }
-        }
-        if (!GRID && t == nt - 1 && (Lk & 63) != 0) {  // plain mode: keys beyond Lk exist on the last tile only
-#pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk) st[kb][r] = NEG_BIG;
+                for (int g4 = 0; g4 < 4; ++g4) kbv[kb][g4] = *(const f32x4*)(tab + t * 64 + kb * 32 + 8 * g4 + 4 * hi);
         }
-        float mt = NEG_BIG;
+    };
+    auto bias_max = [&](f32x16* st, int t, int e0, int e1, float& mt, bool mask_tail) __attribute__((always_inline)) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mt = fmaxf(mt, st[kb][r]);
+        for (int e = e0; e < e1; ++e) {
+            const int kb = e >> 4, r = e & 15;
+            float v = st[kb][r];
+            if constexpr (GRID) {
+                const int sl0 = 32 * kb + (r & 3) + 8 * (r >> 2);        // slot in tile without the lane-half bit
+                const int slr = sl0 % RP;                                  // slot in its padded row
+                const int j = (slr & 3) + 4 * (slr >> 3);                  // which of this lane's column registers
+                v = v * sc2 + relw_reg[j];
+                if constexpr (RPT > 1) v += rh[sl0 / RP];
+            } else if constexpr (KB) {
+                v = v * sc2 + kbv[kb][r >> 2][r & 3];
+            }
+            if (mask_tail && t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk) v = NEG_BIG;
+            st[kb][r] = v;
+            mt = fmaxf(mt, v);
+        }
+    };
+    // running max across the lane pair, lazy rescale of O; returns the exponent offset of the tile
+    auto bias_end = [&](float mt) __attribute__((always_inline)) -> float {
+        float rowh = 0.f;
+        if constexpr (GRID && RPT == 1) rowh = rh[0];
         if constexpr (RAW) mt *= sc2;
         mt += rowh;
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mt), __builtin_bit_cast(unsigned, mt), false, false);
+            mt = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        }
         if (__any(mt > m_run + RESCALE_THR)) {
             const float m_new = fmaxf(m_run, mt);
             const float alpha = wg_exp2(m_run - m_new);
@@ -358,36 +422,114 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
         }
-        const float off = m_run - rowh;
-        float ls = 0.f;
-        bf16x8 pf[4];  // P^T fragments: k-step (kb, s2) uses registers 8*s2 .. 8*s2+7 of block kb
+        return m_run - rowh;
+    };
+    // V^T fragments of a tile: 4 k-steps x DB d-blocks x 2 transposed reads.  Lane (g = lane>>4, i16 = lane&15) supplies the
+    // address of key row 16*ks + 4*hi + (i16>>2) (+8 for the second read), d columns 32*d + 16*(g&1) + 4*(i16&3) .. +3; the
+    // swizzle bit(s) depend only on i16>>2, so each d block needs one lane-dependent base and compile-time offsets.
+    unsigned vt_ad[DB];
+    {
+        const int g = lane >> 4, i16 = lane & 15;
+        const int rq = i16 >> 2, cp = i16 & 3;
+        const unsigned vbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem) + (unsigned)TILE;
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = RAW ? wg_exp2(st[kb][r] * sc2 - off) : wg_exp2(st[kb][r] - off);
-                ls += p;
-                pf[kb * 2 + (r >> 3)][r & 7] = (bf16)p;
-            }
+        for (int d = 0; d < DB; ++d) {
+            const int col = 32 * d + 16 * (g & 1) + 4 * cp;
+            const int chunk = col >> 3;
+            // swzV depends on the key only through its low bits, which 16*ks and +8 leave untouched
+            vt_ad[d] = vbase + (4 * hi + rq) * ROWB + ((chunk ^ swzV<HD>(4 * hi + rq)) << 4) + (col & 7) * 2;
         }
-        l_run += ls;
+    }
+    // the two transposed reads that feed P.V MFMA g = ks*DB + d (the offset must be an immediate: switch on the unrolled ks)
+    auto vt_pair = [&](int g, int buf) __attribute__((always_inline)) {
+        const int ks = g / DB, d = g % DB;
+        const unsigned ad = vt_ad[d] + (unsigned)(buf * 2 * TILE);
+#if defined(WG_ATTN_ABL) && WG_ATTN_ABL == 7
+        vt[ks][d][0] = (u32x2){ad, ad}; vt[ks][d][1] = (u32x2){ad, ad};   // ablation build: no V^T reads
+        return;
+#endif
+        switch (ks) {
+            case 0: vt[0][d][0] = wg_ds_read_tr<0 * 16 * ROWB>(ad); vt[0][d][1] = wg_ds_read_tr<0 * 16 * ROWB + 8 * ROWB>(ad); break;
+            case 1: vt[1][d][0] = wg_ds_read_tr<1 * 16 * ROWB>(ad); vt[1][d][1] = wg_ds_read_tr<1 * 16 * ROWB + 8 * ROWB>(ad); break;
+            case 2: vt[2][d][0] = wg_ds_read_tr<2 * 16 * ROWB>(ad); vt[2][d][1] = wg_ds_read_tr<2 * 16 * ROWB + 8 * ROWB>(ad); break;
+            default: vt[3][d][0] = wg_ds_read_tr<3 * 16 * ROWB>(ad); vt[3][d][1] = wg_ds_read_tr<3 * 16 * ROWB + 8 * ROWB>(ad); break;
+        }
+    };
+    // exponentials, row sum and bf16 packing of score elements [e0, e1)
+    auto probs = [&](const f32x16* st, float off, int e0, int e1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = e0; e < e1; ++e) {
+            const int kb = e >> 4, r = e & 15;
+            const float p = RAW ? wg_exp2(st[kb][r] * sc2 - off) : wg_exp2(st[kb][r] - off);
+            l_run += p;
+            pf[kb * 2 + (r >> 3)][r & 7] = (bf16)p;
+        }
+    };
+    auto pv_one = [&](int g) __attribute__((always_inline)) {
+        const int ks = g / DB, d = g % DB;
+        u32x4 vv = {vt[ks][d][0][0], vt[ks][d][0][1], vt[ks][d][1][0], vt[ks][d][1][1]};
+        const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+#if defined(WG_ATTN_ABL) && WG_ATTN_ABL == 2
+        asm volatile("" ::"v"(vf), "v"(pf[ks]));   // ablation build: no P.V MFMAs
+        return;
+#endif
+        ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], ot[d], 0, 0, 0);
+    };
 
+    for (int t = 0; t < nt; ++t) {
+        const int buf = t & 1;
+        WG_STAMP(0);
+        if (t + 1 < nt) {
+            stage(t + 1, buf ^ 1, false);
+            stage(t + 1, buf ^ 1, true);
+        }
+        bias_begin(t);
+#pragma unroll
+        for (int g = 0; g < NQK; ++g) qk_read(kv + buf * 2 * TILE, g);
+#pragma unroll
+        for (int g = 0; g < NQK; ++g) qk_one(sa, g);
+        // V^T fragments: inline-asm reads (invisible to hipcc's wait insertion), issued as early as the registers allow so that
+        // their LDS latency hides under the softmax: right behind the S^T MFMAs, or -- key-bias variants, whose bias row
+        // occupies 32 registers until it is applied -- after the running max.  Every LDS read hipcc does know about is retired
+        // first: its wait would cover these too.
+        constexpr bool EARLY_VT = !KB;
+        if constexpr (GRID) {
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) asm volatile("" : "+v"(rh[i]));
+        }
+        if constexpr (EARLY_VT) {
+#pragma unroll
+            for (int g = 0; g < NPV; ++g) vt_pair(g, buf);
+        }
+        float mt = NEG_BIG;
+        if (ragged && t + 1 == nt) bias_max(sa, t, 0, 32, mt, true);
+        else bias_max(sa, t, 0, 32, mt, false);
+        const float off = bias_end(mt);
+        if constexpr (!EARLY_VT) {
+#pragma unroll
+            for (int g = 0; g < NPV; ++g) vt_pair(g, buf);
+        }
+        WG_STAMP(1);
+        probs(sa, off, 0, 32);
+        WG_STAMP(2);
         // O^T += V^T . P^T  (operands of the asm reads above: wait for them here, fenced from the MFMAs)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int d = 0; d < DB; ++d) {
-                u32x4 vv = {vt[ks][d][0][0], vt[ks][d][0][1], vt[ks][d][1][0], vt[ks][d][1][1]};
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
-                ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], ot[d], 0, 0, 0);
-            }
-        }
+        for (int g = 0; g < NPV; ++g) pv_one(g);
+        WG_STAMP(3);
+#if !(defined(WG_ATTN_ABL) && WG_ATTN_ABL == 5)   // (ablation build 5: no per-tile wait / barrier -- wrong results, timing only)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+#endif
+        WG_STAMP(4);
     }
 
+#ifdef WG_ATTN_STAMP
+    __syncthreads();
+    if (blockIdx.x == 0 && wg_attn_stamp_ptr)
+        for (int i = tid; i < NW * 12 * 8; i += NW * 64) wg_attn_stamp_ptr[i] = ((unsigned*)(smem + 156 * 1024))[i];
+#endif
     // ---- epilogue: O = O^T / l, 8-byte stores ---------------------------------------------------------------------------
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     if (qvalid) {
@@ -428,6 +570,9 @@ static int launch_attn_impl(const AttnArgs& a, int groups, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)wg_attn_kernel<HD, S, NW, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_done = true;
     }
+#ifdef WG_ATTN_STAMP
+    lds = 160 * 1024;
+#endif
     hipLaunchKernelGGL((wg_attn_kernel<HD, S, NW, KB>), dim3(groups * a.qchunks), dim3(NW * 64), lds, st, a);
     return wg_check_launch("wg_attn");
 }
