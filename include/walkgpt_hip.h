@@ -126,6 +126,25 @@ int wg_mask_iou_f32(const float* pred_logits, const float* gt, float* out6, floa
 int wg_mask_losses_f32(const float* pred_logits, const float* targets, float* out2, float* workspace, long workspace_floats,
                        int N, long hw, float dice_scale, float dice_eps, void* stream);
 
+/* region-alignment InfoNCE forward -- infonce_loss() + TinyCrossAttn.forward()
+ * (utils/utils_walkgpt.py:8-73, 330-357; called at model/walkgpt.py:459-473), normalize=True.
+ *   wg_row_inv_norm_bf16      out[r] = 1 / max(||x_r||, eps)                  (F.normalize of the SAM tokens, :53-54)
+ *   wg_l2_normalize_rows_bf16 y_r = x_r / max(||x_r||, eps), bf16             (F.normalize of the [SEG] embeddings, :46-48)
+ *   wg_nce_attn_f32           ST is the fp32 GEMM [2M, rows*N] = [Zn ; Wk^T q] . tokens^T (wg_gemm_bias_act_bf16, out_f32).
+ *                             Per [SEG] m: attn_w[m, :] = softmax(ST[M+m, own row] * attn_scale) (:349-351); vraw[m, :] = the
+ *                             top-k refinement sum_k alpha_k kv[idx_k] (:35-39) when 0 < top_k < N (top_k <= 32), else the
+ *                             attention-pooled raw token sum_n attn_n kv_n (the caller applies Wv / Wo: weights sum to 1).
+ *   wg_nce_loss_f32           pos = Zn_m . normalize(vpos_m); logits = [pos, ST[m, t] * inv_norm[t]] / temperature with the
+ *                             own row at -inf if exclude_same_row; loss_m = cross entropy with label 0 (:56-71);
+ *                             loss[0] = mean(loss_m); logits (optional, [M, 1 + rows*N]) receives the rows. */
+int wg_row_inv_norm_bf16(const void* x, long ld, float* out, long R, int D, float eps, void* stream);
+int wg_l2_normalize_rows_bf16(const void* x, long ldx, void* y, long ldy, long R, int D, float eps, void* stream);
+int wg_nce_attn_f32(const float* ST, long ldst, const void* tokens, long ldt, const int* seg_row, float* attn_w, float* vraw,
+                    int M, int N, int rows, int D, int top_k, float attn_scale, void* stream);
+int wg_nce_loss_f32(const float* ST, long ldst, const float* inv_norm, const void* Zn, const float* vpos, const int* seg_row,
+                    float* loss_m, float* loss, float* logits, int M, int N, int rows, int D, int exclude_same_row,
+                    float temperature, void* stream);
+
 /* MSQP pieces (utils/utils_walkgpt.py): _pool_grid_tokens :195-201, _global_token :256-257, SegAwareGate tail :213-217. */
 int wg_avgpool_tokens_bf16(const void* x, void* y, int B, int H, int W, int C, int s, void* stream);
 int wg_mean_tokens_bf16(const void* x, void* y, int B, int L, int C, void* stream);

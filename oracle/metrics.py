@@ -4,7 +4,9 @@ forward.
   intersection_and_union()  /root/reference/utils/utils.py:192-204 (as called at evaluation_walkgpt.py:936-944)
   sigmoid_ce_loss()          /root/reference/utils/utils_walkgpt.py:103-120
   dice_loss()                /root/reference/utils/utils_walkgpt.py:76-99
-Pinned by tests/golden/metrics.npz (outputs of the reference functions on synthetic masks).
+  tiny_xattn()               /root/reference/utils/utils_walkgpt.py:330-357 (TinyCrossAttn.forward)
+  infonce_loss()             /root/reference/utils/utils_walkgpt.py:8-73 (as called at model/walkgpt.py:459-473)
+Pinned by tests/golden/metrics_*.npz and nce_*.npz (outputs of the reference functions on synthetic inputs).
 """
 import torch
 import torch.nn.functional as F
@@ -33,3 +35,35 @@ def dice_loss(inputs, targets, num_masks, scale=1000, eps=1e-6):
     num = 2 * (s / scale * t).sum(-1)
     den = (s / scale).sum(-1) + (t / scale).sum(-1)
     return (1 - (num + eps) / (den + eps)).sum() / (num_masks + 1e-8)
+
+
+def tiny_xattn(w, q_vec, kv):
+    """w: {wq,wk,wv,out}.weight (+ optional .bias); q_vec [M,d], kv [M,N,d] -> (v_pos [M,d], attn [M,N])."""
+    lin = lambda x, n: F.linear(x, w[n + ".weight"], w.get(n + ".bias"))
+    d = kv.shape[-1]
+    q = lin(q_vec, "wq").unsqueeze(1)
+    k, v = lin(kv, "wk"), lin(kv, "wv")
+    attn = (q @ k.transpose(1, 2) / d ** 0.5).softmax(-1)
+    return lin((attn @ v).squeeze(1), "out"), attn.squeeze(1)
+
+
+def infonce_loss(w, pred, sam_tokens, seg_row_ids, temperature=0.07, top_k=None, exclude_same_row=True):
+    """normalize=True form.  Returns (loss, dict(v_pos, attn_w, logits))."""
+    M = pred.shape[0]
+    rows, N, D = sam_tokens.shape
+    KV = sam_tokens[seg_row_ids]
+    v_pos, attn_w = tiny_xattn(w, pred, KV)
+    if top_k is not None and 0 < top_k < N:
+        vals, idx = torch.topk(attn_w, k=top_k, dim=1)
+        alpha = vals / (vals.sum(1, keepdim=True) + 1e-12)
+        v_pos = torch.einsum("mk,mkd->md", alpha, torch.gather(KV, 1, idx.unsqueeze(-1).expand(-1, -1, D)))
+    Z, Vp = F.normalize(pred, dim=-1), F.normalize(v_pos, dim=-1)
+    pos = (Z * Vp).sum(-1, keepdim=True)
+    sim = Z @ F.normalize(sam_tokens.reshape(-1, D), dim=-1).T
+    if exclude_same_row:
+        own = torch.zeros(M, rows, dtype=torch.bool)
+        own[torch.arange(M), seg_row_ids] = True
+        sim = sim.masked_fill(own.unsqueeze(-1).expand(M, rows, N).reshape(M, rows * N), float("-inf"))
+    logits = torch.cat([pos, sim], 1) / temperature
+    loss = F.cross_entropy(logits, torch.zeros(M, dtype=torch.long))
+    return loss, {"v_pos": v_pos, "attn_w": attn_w, "logits": logits}

@@ -223,3 +223,29 @@ def metric_inputs(c):
 
 def load(name):
     return dict(np.load(os.path.join(HERE, name + ".npz")))
+
+
+# ---- region-alignment InfoNCE (utils_walkgpt.py:8-73, 330-357) ---------------------------------------------------------
+NCES = {
+    "k8": dict(rows=3, side=8, D=256, M=5, seg_rows=[0, 0, 1, 2, 2], top_k=8, exclude=True, bias=False, seed=71),
+    "pool": dict(rows=2, side=8, D=256, M=3, seg_rows=[1, 0, 1], top_k=None, exclude=True, bias=True, seed=72),
+    "one_row": dict(rows=1, side=8, D=256, M=2, seg_rows=[0, 0], top_k=8, exclude=False, bias=False, seed=73),
+}
+
+
+def nce_weights(c):
+    names = ["wq", "wk", "wv", "out"]
+    w = {}
+    for n in names:
+        w[n + ".weight"] = torch.from_numpy(synth.normal(c["seed"], "tiny_xattn.%s.weight" % n, (c["D"], c["D"]), c["D"] ** -0.5))
+        if c["bias"]:
+            w[n + ".bias"] = torch.from_numpy(synth.normal(c["seed"], "tiny_xattn.%s.bias" % n, (c["D"],), 0.1))
+    return w
+
+
+def nce_inputs(c):
+    """(pred [M,D], sam_tokens [rows,N,D], seg_row_ids [M]) fp32; bf16-representable so that the HIP path sees the same numbers."""
+    N = c["side"] ** 2
+    pred = torch.from_numpy(synth.normal(c["seed"], "input.pred", (c["M"], c["D"]), 1.0)).bfloat16().float()
+    tok = torch.from_numpy(synth.normal(c["seed"], "input.sam_tokens", (c["rows"], N, c["D"]), 1.0)).bfloat16().float()
+    return pred, tok, torch.tensor(c["seg_rows"], dtype=torch.long)

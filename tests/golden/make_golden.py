@@ -165,6 +165,21 @@ def make_metrics(name):
                         dice=uw.dice_loss(pred, tg, num_masks=c["n"]).numpy())
 
 
+def make_nce(name):
+    """infonce_loss + TinyCrossAttn of the reference (utils/utils_walkgpt.py:8-73, 330-357)."""
+    _, uw = _import_reference()
+    c = cases.NCES[name]
+    xa = uw.TinyCrossAttn(d=c["D"], bias=c["bias"])
+    xa.load_state_dict(cases.nce_weights(c), strict=True)
+    pred, tok, seg = cases.nce_inputs(c)
+    with torch.no_grad():
+        loss, aux = uw.infonce_loss(pred, tok, seg, xa, temperature=0.07, top_k=c["top_k"], exclude_same_row=c["exclude"],
+                                    normalize=True, return_aux=True)
+        v_x, a_x = xa(pred, tok[seg])
+    np.savez_compressed(os.path.join(HERE, "nce_%s.npz" % name), loss=loss.numpy(), v_pos=aux["v_pos"].numpy(),
+                        attn_w=aux["attn_w"].numpy(), logits=aux["logits"].numpy(), xattn_out=v_x.numpy(), xattn_attn=a_x.numpy())
+
+
 def make_state_dict_shapes(_name):
     """Key -> shape tables of the reference modules (data, not source): the de-facto checkpoint ABI."""
     import json
@@ -183,6 +198,7 @@ def make_state_dict_shapes(_name):
 ALL = {
     "state_dict_shapes": (make_state_dict_shapes, {"all": None}),
     "metrics": (make_metrics, cases.METRICS),
+    "nce": (make_nce, cases.NCES),
     "sam_encoder": (make_sam_encoder, cases.SAM_ENCODERS),
     "decoder": (make_decoder, cases.DECODERS),
     "projectors": (make_projectors, cases.PROJECTORS),

@@ -114,3 +114,54 @@ def test_mask_iou_and_losses_vs_reference_golden(dev):
     g = (big > 0).float()
     i2, u2, _ = ops.mask_iou(big, g)
     assert torch.equal(i2, u2) and float(i2.sum()) == 2 * 1024 * 1024
+
+
+@pytest.mark.parametrize("name", ["k8", "pool", "one_row"])
+def test_infonce_vs_reference_golden(dev, name):
+    """walkgpt_amd.utils_walkgpt.infonce_loss / TinyCrossAttn (HIP) against the reference's outputs.
+    Tolerances: the HIP path rounds the normalised [SEG] rows and the two query projections to bf16 (2^-9 relative) before
+    the fp32-accumulating GEMM; logits are cosines / 0.07, so 1e-2 absolute there is 7e-4 in the cosine."""
+    from tests.golden import cases
+    from walkgpt_amd.utils_walkgpt import TinyCrossAttn, infonce_loss
+    c = cases.NCES[name]
+    gold = cases.load("nce_" + name)
+    xa = TinyCrossAttn(d=c["D"], bias=c["bias"])
+    xa.load_state_dict(cases.nce_weights(c), strict=True)
+    xa = xa.to(dev).bfloat16()
+    pred, tok, seg = cases.nce_inputs(c)
+    loss, aux = infonce_loss(pred.to(dev).bfloat16(), tok.to(dev).bfloat16(), seg.to(dev), xa, temperature=0.07, top_k=c["top_k"],
+                             exclude_same_row=c["exclude"], normalize=True, return_aux=True)
+    torch.cuda.synchronize()
+    gl = torch.from_numpy(gold["logits"])
+    lg = aux["logits"].cpu()
+    assert torch.equal(torch.isinf(lg), torch.isinf(gl))
+    fin = ~torch.isinf(gl)
+    assert (lg[fin] - gl[fin]).abs().max().item() < 2e-2
+    assert abs(loss.item() - float(gold["loss"])) < 5e-3 * max(1.0, abs(float(gold["loss"])))
+    aw = torch.from_numpy(gold["attn_w"])
+    assert (aux["attn_w"].cpu() - aw).abs().max().item() < 2e-2 * aw.max().item()
+    vp = torch.from_numpy(gold["v_pos"])
+    assert ((aux["v_pos"].float().cpu() - vp).norm() / vp.norm()).item() < 2e-2
+    # TinyCrossAttn.forward itself (attention-pooled path)
+    v, a = xa(pred.to(dev).bfloat16(), tok[seg].to(dev).bfloat16())
+    vx = torch.from_numpy(gold["xattn_out"])
+    assert ((v.float().cpu() - vx).norm() / vx.norm()).item() < 2e-2
+    assert (a.cpu() - torch.from_numpy(gold["xattn_attn"])).abs().max().item() < 2e-2 * float(gold["xattn_attn"].max())
+
+
+def test_infonce_full_size_properties(dev):
+    """C2-sized call (8 rows x 4096 tokens, 14 [SEG] per row): loss = mean of per-token cross entropies of the returned logits."""
+    from walkgpt_amd.utils_walkgpt import TinyCrossAttn, infonce_loss
+    g = torch.Generator().manual_seed(5)
+    xa = TinyCrossAttn().to(dev).bfloat16()
+    tok = torch.randn(8, 4096, 256, generator=g).to(dev).bfloat16()
+    z = torch.randn(112, 256, generator=g).to(dev).bfloat16()
+    seg = torch.arange(8).repeat_interleave(14).to(dev)
+    loss, aux = infonce_loss(z, tok, seg, xa, top_k=8, return_aux=True)
+    lg = aux["logits"]
+    assert lg.shape == (112, 1 + 8 * 4096)
+    ref = F.cross_entropy(lg, torch.zeros(112, dtype=torch.long, device=dev))
+    assert abs(loss.item() - ref.item()) < 1e-4 * max(1.0, ref.item())
+    own = lg[0, 1:1 + 4096]
+    assert torch.isinf(own).all() and not torch.isinf(lg[0, 1 + 4096:]).any()
+    assert (aux["attn_w"].sum(1) - 1).abs().max().item() < 1e-4

@@ -131,3 +131,21 @@ def test_metrics_and_losses_match_reference():
     tg = (gt == 1).float()
     assert abs(om.sigmoid_ce_loss(pred, tg, c["n"]).item() - float(gold["bce"])) < 1e-6
     assert abs(om.dice_loss(pred, tg, c["n"]).item() - float(gold["dice"])) < 1e-6
+
+
+@pytest.mark.parametrize("name", list(cases.NCES))
+def test_infonce_matches_reference(name):
+    """oracle/metrics.py infonce_loss / tiny_xattn against the outputs of the reference's own functions."""
+    from oracle import metrics as om
+    c = cases.NCES[name]
+    gold = cases.load("nce_" + name)
+    w = cases.nce_weights(c)
+    pred, tok, seg = cases.nce_inputs(c)
+    loss, aux = om.infonce_loss(w, pred, tok, seg, 0.07, c["top_k"], c["exclude"])
+    assert abs(loss.item() - float(gold["loss"])) < 1e-5
+    assert np.allclose(aux["attn_w"].numpy(), gold["attn_w"], atol=1e-6)
+    assert np.allclose(aux["v_pos"].numpy(), gold["v_pos"], atol=1e-5)
+    lg, gl = aux["logits"].numpy(), gold["logits"]
+    assert np.array_equal(np.isinf(lg), np.isinf(gl)) and np.allclose(lg[~np.isinf(lg)], gl[~np.isinf(gl)], atol=1e-4)
+    v, a = om.tiny_xattn(w, pred, tok[seg])
+    assert np.allclose(v.numpy(), gold["xattn_out"], atol=1e-5) and np.allclose(a.numpy(), gold["xattn_attn"], atol=1e-6)

@@ -349,3 +349,46 @@ def mask_losses(pred_logits, targets, num_masks, dice_scale=1000.0, dice_eps=1e-
                                              float(dice_scale), float(dice_eps), _stream()), "wg_mask_losses_f32")
     per = out.sum(0) / (num_masks + 1e-8)
     return per[0], per[1]
+
+
+def nce_forward(z, sam_tokens, seg_row_ids, wq, bq, wk_t, temperature, top_k, exclude_same_row, want_logits=False):
+    """Device part of infonce_loss() (utils_walkgpt.py:8-73) for normalize=True.
+
+    z [M, D] bf16 [SEG] embeddings; sam_tokens [rows, N, D] bf16; seg_row_ids [M] int; wq/bq the query projection of
+    TinyCrossAttn and wk_t = Wk^T (contiguous [D, D]): q.(Wk kv) = (Wk^T q).kv.  Returns a dict with the fp32 GEMM `st`,
+    `inv_norm`, `zn`, `attn_w` [M, N], `vraw` [M, D] (top-k refined positive, or the attention-pooled raw token when the
+    refinement is off) and a `finish(vpos)` closure producing (loss, loss_m, logits)."""
+    _need_gpu(z, sam_tokens, seg_row_ids)
+    assert z.dtype == _BF16 and sam_tokens.dtype == _BF16 and sam_tokens.is_contiguous() and z.dim() == 2
+    rows, N, D = sam_tokens.shape
+    M = z.shape[0]
+    assert z.shape[1] == D and seg_row_ids.shape == (M,)
+    dev = z.device
+    L = _lib.lib()
+    tok2 = sam_tokens.reshape(rows * N, D)
+    seg = seg_row_ids.to(torch.int32).contiguous()
+    zc = z.contiguous()
+    qcat = torch.empty(2 * M, D, device=dev, dtype=_BF16)
+    _lib.check(L.wg_l2_normalize_rows_bf16(zc.data_ptr(), D, qcat.data_ptr(), D, M, D, 1e-12, _stream()), "wg_l2_normalize_rows_bf16")
+    q = linear(zc, wq, bq)                       # [M, D]   TinyCrossAttn.wq
+    linear(q, wk_t, out=qcat[M:])                # rows M..2M-1: Wk^T q
+    inv_norm = torch.empty(rows * N, device=dev, dtype=torch.float32)
+    _lib.check(L.wg_row_inv_norm_bf16(tok2.data_ptr(), D, inv_norm.data_ptr(), rows * N, D, 1e-12, _stream()), "wg_row_inv_norm_bf16")
+    st = linear(qcat, tok2, out_f32=True)        # [2M, rows*N] fp32
+    attn_w = torch.empty(M, N, device=dev, dtype=torch.float32)
+    vraw = torch.empty(M, D, device=dev, dtype=torch.float32)
+    k = int(top_k) if (top_k is not None and 0 < top_k < N) else 0
+    _lib.check(L.wg_nce_attn_f32(st.data_ptr(), st.stride(0), tok2.data_ptr(), D, seg.data_ptr(), attn_w.data_ptr(), vraw.data_ptr(),
+                                 M, N, rows, D, k, float(D) ** -0.5, _stream()), "wg_nce_attn_f32")
+
+    def finish(vpos):
+        assert vpos.dtype == torch.float32 and vpos.is_contiguous() and vpos.shape == (M, D)
+        loss_m = torch.empty(M, device=dev, dtype=torch.float32)
+        loss = torch.empty(1, device=dev, dtype=torch.float32)
+        logits = torch.empty(M, 1 + rows * N, device=dev, dtype=torch.float32) if want_logits else None
+        _lib.check(L.wg_nce_loss_f32(st.data_ptr(), st.stride(0), inv_norm.data_ptr(), qcat.data_ptr(), vpos.data_ptr(), seg.data_ptr(),
+                                     loss_m.data_ptr(), loss.data_ptr(), _ptr(logits), M, N, rows, D, 1 if exclude_same_row else 0,
+                                     float(temperature), _stream()), "wg_nce_loss_f32")
+        return loss[0], loss_m, logits
+
+    return {"st": st, "inv_norm": inv_norm, "zn": qcat[:M], "attn_w": attn_w, "vraw": vraw, "refined": k > 0, "finish": finish}

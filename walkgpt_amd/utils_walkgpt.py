@@ -160,3 +160,48 @@ class CalibratedTextProjector(nn.Module):
         y = ops.linear(y, self.net[1].weight, self.net[1].bias, act=ops.ACT_GELU)
         y = ops.linear(y, self.net[3].weight, self.net[3].bias)
         return ops.ctp_tail(y, self.net[4].weight, self.net[4].bias, self.text_type.reshape(-1), self.log_temp, self.net[4].eps)
+
+
+class TinyCrossAttn(nn.Module, _Prepared):
+    """utils_walkgpt.py:330-357: single-head cross attention, Q = one [SEG] embedding, K/V = its row's SAM tokens."""
+
+    def __init__(self, d=256, bias=False):
+        super().__init__()
+        self.wq = nn.Linear(d, d, bias=bias)
+        self.wk = nn.Linear(d, d, bias=bias)
+        self.wv = nn.Linear(d, d, bias=bias)
+        self.out = nn.Linear(d, d, bias=bias)
+        self.dropout = nn.Dropout(p=0.0)
+
+    def _build(self):
+        return {"wk_t": self.wk.weight.t().contiguous()}   # q.(Wk kv + bk) = (Wk^T q).kv + const; the constant cancels in the softmax
+
+    def project_pooled(self, pooled):
+        """out(wv(.)) applied to the attention-pooled raw token (fp32 [M, d]): sum_n a_n (Wv kv_n + bv) = Wv pooled + bv."""
+        ctx = ops.linear(pooled.to(BF16), self.wv.weight, self.wv.bias)
+        return ops.linear(ctx, self.out.weight, self.out.bias)
+
+    def forward(self, q_vec, kv):
+        """q_vec [M, d], kv [M, N, d] (bf16) -> (v_pos [M, d] bf16, attn [M, N] fp32)."""
+        _check_bf16_gpu(q_vec, "q_vec")
+        M = q_vec.shape[0]
+        r = ops.nce_forward(q_vec, kv.contiguous(), torch.arange(M, device=q_vec.device), self.wq.weight, self.wq.bias,
+                            self._prep_get(self._build)["wk_t"], 1.0, None, False)
+        return self.project_pooled(r["vraw"]), r["attn_w"]
+
+
+def infonce_loss(pred_embeddings, sam_tokens_256, seg_row_ids, tiny_xattn, *, temperature=0.07, top_k=None,
+                 exclude_same_row=True, normalize=True, return_aux=False):
+    """utils_walkgpt.py:8-73 (forward).  pred_embeddings [M, 256] bf16, sam_tokens_256 [rows, N, 256] bf16, seg_row_ids [M]."""
+    if not normalize:
+        raise NotImplementedError("WalkGPT always calls infonce_loss(normalize=True) (model/walkgpt.py:463-472)")
+    _check_bf16_gpu(pred_embeddings, "pred_embeddings")
+    assert sam_tokens_256.shape[-1] == pred_embeddings.shape[-1], "Vision/text feature dims must match for InfoNCE."
+    r = ops.nce_forward(pred_embeddings, sam_tokens_256.contiguous(), seg_row_ids, tiny_xattn.wq.weight, tiny_xattn.wq.bias,
+                        tiny_xattn._prep_get(tiny_xattn._build)["wk_t"], temperature, top_k, exclude_same_row, want_logits=return_aux)
+    v_pos = r["vraw"] if r["refined"] else tiny_xattn.project_pooled(r["vraw"]).float().contiguous()
+    loss, _, logits = r["finish"](v_pos)
+    if return_aux:
+        labels = torch.zeros(pred_embeddings.shape[0], dtype=torch.long, device=pred_embeddings.device)
+        return loss, {"v_pos": v_pos, "attn_w": r["attn_w"], "logits": logits, "labels": labels}
+    return loss
