@@ -126,6 +126,13 @@ int wg_mask_iou_f32(const float* pred_logits, const float* gt, float* out6, floa
 int wg_mask_losses_f32(const float* pred_logits, const float* targets, float* out2, float* workspace, long workspace_floats,
                        int N, long hw, float dice_scale, float dice_eps, void* stream);
 
+/* cost matrix of match_pred() (utils/matcher.py:93-133): P predicted logit masks and T target masks
+ * [., H, W] fp32, sampled bilinearly (grid_sample, align_corners=False, zero padding) at NP shared points in [0,1]^2 (x, y);
+ * cost[p*T + t] = batch_sigmoid_ce_loss + batch_dice_loss (:10-56).  Scratch: wg_match_cost_workspace_floats(P, T, NP). */
+long wg_match_cost_workspace_floats(int P, int T, int NP);
+int wg_match_cost_f32(const float* pred_logits, const float* targets, const float* points, float* cost, float* workspace,
+                      long workspace_floats, int P, int T, int H, int W, int NP, void* stream);
+
 /* region-alignment InfoNCE forward -- infonce_loss() + TinyCrossAttn.forward()
  * (utils/utils_walkgpt.py:8-73, 330-357; called at model/walkgpt.py:459-473), normalize=True.
  *   wg_row_inv_norm_bf16      out[r] = 1 / max(||x_r||, eps)                  (F.normalize of the SAM tokens, :53-54)

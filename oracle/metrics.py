@@ -6,7 +6,8 @@ forward.
   dice_loss()                /root/reference/utils/utils_walkgpt.py:76-99
   tiny_xattn()               /root/reference/utils/utils_walkgpt.py:330-357 (TinyCrossAttn.forward)
   infonce_loss()             /root/reference/utils/utils_walkgpt.py:8-73 (as called at model/walkgpt.py:459-473)
-Pinned by tests/golden/metrics_*.npz and nce_*.npz (outputs of the reference functions on synthetic inputs).
+  match_cost()               /root/reference/utils/matcher.py:10-56,64-90,93-127 (match_pred's cost matrix for given points)
+Pinned by tests/golden/metrics_*.npz, nce_*.npz and match_*.npz (outputs of the reference functions on synthetic inputs).
 """
 import torch
 import torch.nn.functional as F
@@ -67,3 +68,17 @@ def infonce_loss(w, pred, sam_tokens, seg_row_ids, temperature=0.07, top_k=None,
     logits = torch.cat([pos, sim], 1) / temperature
     loss = F.cross_entropy(logits, torch.zeros(M, dtype=torch.long))
     return loss, {"v_pos": v_pos, "attn_w": attn_w, "logits": logits}
+
+
+def match_cost(out_mask, tgt_mask, point_coords):
+    """out_mask [P,H,W] logits, tgt_mask [T,H,W], point_coords [NP,2] in [0,1]^2 (x, y) -> cost [P,T]."""
+    def sample(m):
+        g = (2.0 * point_coords - 1.0)[None, :, None, :].expand(m.shape[0], -1, -1, -1)
+        return F.grid_sample(m[:, None].float(), g, align_corners=False)[:, 0, :, 0]
+    x, y = sample(out_mask), sample(tgt_mask)
+    pos = F.binary_cross_entropy_with_logits(x, torch.ones_like(x), reduction="none")
+    neg = F.binary_cross_entropy_with_logits(x, torch.zeros_like(x), reduction="none")
+    ce = (pos @ y.T + neg @ (1 - y).T) / x.shape[1]
+    s = x.sigmoid()
+    dice = 1 - (2 * s @ y.T + 1) / (s.sum(-1)[:, None] + y.sum(-1)[None, :] + 1)
+    return ce + dice

@@ -249,3 +249,17 @@ def nce_inputs(c):
     pred = torch.from_numpy(synth.normal(c["seed"], "input.pred", (c["M"], c["D"]), 1.0)).bfloat16().float()
     tok = torch.from_numpy(synth.normal(c["seed"], "input.sam_tokens", (c["rows"], N, c["D"]), 1.0)).bfloat16().float()
     return pred, tok, torch.tensor(c["seg_rows"], dtype=torch.long)
+
+
+# ---- match_pred cost matrix (utils/matcher.py:93-133) ---------------------------------------------------------------------
+MATCHES = {"p5t4": dict(P=5, T=4, h=61, w=83, points=1024, seed=81)}
+
+
+def match_inputs(c):
+    """pred logits [P,h,w]; targets [T,h,w] in {0,1}; points [NP,2] in [0,1) (x, y).  Targets are noisy copies of thresholded
+    predictions so that the assignment is well determined."""
+    pred = torch.from_numpy(synth.normal(c["seed"], "input.pred", (c["P"], c["h"], c["w"]), 3.0))
+    u = torch.from_numpy(synth.uniform01(c["seed"], "input.flip", c["T"] * c["h"] * c["w"]).astype(np.float32)).reshape(c["T"], c["h"], c["w"])
+    tgt = ((pred[[3, 0, 4, 1][:c["T"]]] > 0).float() + (u > 0.9).float()).remainder(2.0)
+    pts = torch.from_numpy(synth.uniform01(c["seed"], "input.points", c["points"] * 2).astype(np.float32)).reshape(c["points"], 2)
+    return pred, tgt, pts

@@ -180,6 +180,22 @@ def make_nce(name):
                         attn_w=aux["attn_w"].numpy(), logits=aux["logits"].numpy(), xattn_out=v_x.numpy(), xattn_attn=a_x.numpy())
 
 
+def make_match(name):
+    """The cost matrix of match_pred (utils/matcher.py:93-127) from the reference's own point_sample / batch_* functions at
+    fixed points (match_pred itself draws them with torch.rand), and scipy's assignment on it."""
+    _import_reference()
+    from utils import matcher as rm
+    from scipy.optimize import linear_sum_assignment
+    c = cases.MATCHES[name]
+    pred, tgt, pts = cases.match_inputs(c)
+    pc = pts[None]
+    y = rm.point_sample(tgt[:, None], pc.repeat(tgt.shape[0], 1, 1), align_corners=False).squeeze(1)
+    x = rm.point_sample(pred[:, None], pc.repeat(pred.shape[0], 1, 1), align_corners=False).squeeze(1)
+    C = rm.batch_sigmoid_ce_loss(x.float(), y.float()) + rm.batch_dice_loss(x.float(), y.float())
+    r, cidx = linear_sum_assignment(C)
+    np.savez_compressed(os.path.join(HERE, "match_%s.npz" % name), cost=C.numpy(), rows=r, cols=cidx)
+
+
 def make_state_dict_shapes(_name):
     """Key -> shape tables of the reference modules (data, not source): the de-facto checkpoint ABI."""
     import json
@@ -199,6 +215,7 @@ ALL = {
     "state_dict_shapes": (make_state_dict_shapes, {"all": None}),
     "metrics": (make_metrics, cases.METRICS),
     "nce": (make_nce, cases.NCES),
+    "match": (make_match, cases.MATCHES),
     "sam_encoder": (make_sam_encoder, cases.SAM_ENCODERS),
     "decoder": (make_decoder, cases.DECODERS),
     "projectors": (make_projectors, cases.PROJECTORS),

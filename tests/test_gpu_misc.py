@@ -165,3 +165,23 @@ def test_infonce_full_size_properties(dev):
     own = lg[0, 1:1 + 4096]
     assert torch.isinf(own).all() and not torch.isinf(lg[0, 1 + 4096:]).any()
     assert (aux["attn_w"].sum(1) - 1).abs().max().item() < 1e-4
+
+
+def test_match_pred_vs_reference_golden(dev):
+    """match_pred's cost matrix through the C-ABI against the reference's own functions; same assignment."""
+    import numpy as np
+    from tests.golden import cases
+    from walkgpt_amd.matcher import match_pred
+    c = cases.MATCHES["p5t4"]
+    gold = cases.load("match_p5t4")
+    pred, tgt, pts = cases.match_inputs(c)
+    cost = ops.match_cost(pred.to(dev), tgt.to(dev), pts.to(dev)).cpu().numpy()
+    assert np.allclose(cost, gold["cost"], rtol=2e-5, atol=2e-5)
+    r, cidx = match_pred(pred.to(dev), tgt.to(dev), pts.to(dev))
+    assert np.array_equal(r, gold["rows"]) and np.array_equal(cidx, gold["cols"])
+    # full size, reference-style random points: every target is matched to the prediction it was derived from
+    g = torch.Generator().manual_seed(3)
+    big = torch.randn(6, 448, 448, generator=g) * 3
+    t2 = (big[[4, 2, 0]] > 0).float()
+    r2, c2 = match_pred(big.to(dev), t2.to(dev))
+    assert sorted(zip(r2.tolist(), c2.tolist())) == [(0, 2), (2, 1), (4, 0)]

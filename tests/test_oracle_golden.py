@@ -149,3 +149,11 @@ def test_infonce_matches_reference(name):
     assert np.array_equal(np.isinf(lg), np.isinf(gl)) and np.allclose(lg[~np.isinf(lg)], gl[~np.isinf(gl)], atol=1e-4)
     v, a = om.tiny_xattn(w, pred, tok[seg])
     assert np.allclose(v.numpy(), gold["xattn_out"], atol=1e-5) and np.allclose(a.numpy(), gold["xattn_attn"], atol=1e-6)
+
+
+def test_match_cost_matches_reference():
+    from oracle import metrics as om
+    c = cases.MATCHES["p5t4"]
+    gold = cases.load("match_p5t4")
+    pred, tgt, pts = cases.match_inputs(c)
+    assert np.allclose(om.match_cost(pred, tgt, pts).numpy(), gold["cost"], atol=1e-5)

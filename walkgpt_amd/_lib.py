@@ -35,6 +35,7 @@ SIGNATURES = {
     "wg_mask_score_f32": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_void_p],
     "wg_mask_iou_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_void_p],
     "wg_mask_losses_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_float, c_void_p],
+    "wg_match_cost_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_row_inv_norm_bf16": [c_void_p, c_long, c_void_p, c_long, c_int, c_float, c_void_p],
     "wg_l2_normalize_rows_bf16": [c_void_p, c_long, c_void_p, c_long, c_long, c_int, c_float, c_void_p],
     "wg_nce_attn_f32": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
@@ -51,6 +52,7 @@ SIGNATURES = {
 _SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, []),
             "wg_mask_score_workspace_floats": (c_long, [c_int, c_long]),
             "wg_mask_stats_workspace_floats": (c_long, [c_int, c_long]),
+            "wg_match_cost_workspace_floats": (c_long, [c_int, c_int, c_int]),
             "wg_gemm_pick_tile": (c_int, [c_int, c_int]),
             "wg_gemm_pick_tile_ex": (c_int, [c_int, c_int, c_int])}
 

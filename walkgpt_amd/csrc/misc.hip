@@ -465,3 +465,69 @@ extern "C" int wg_mask_losses_f32(const float* pred_logits, const float* targets
                        dice_scale, dice_eps);
     return wg_check_launch("wg_mask_losses_f32");
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// the cost matrix of match_pred() (/root/reference/utils/matcher.py:93-133, called at
+// evaluation_walkgpt.py:751 and train_walkgpt.py:937) -- both mask sets bilinearly sampled at one shared set of points
+// (point_sample :64-90 = grid_sample(2p-1, align_corners=False, zero padding)), then
+//   C[p,t] = mean_n( BCE(x_pn, 1) y_tn + BCE(x_pn, 0) (1 - y_tn) )  +  1 - (2 sum_n s_pn y_tn + 1) / (sum_n s_pn + sum_n y_tn + 1)
+// (batch_sigmoid_ce_loss :33-56, batch_dice_loss :10-25; s = sigmoid(x)).  The Hungarian assignment on the [P,T] matrix stays
+// on the host (scipy), as in the reference.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wg_point_sample_kernel(const float* masks, const float* points, float* out, int H, int W, int NP) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= NP) return;
+    const float* m = masks + (long)blockIdx.y * H * W;
+    // grid_sample, align_corners=False: pixel coordinate = ((2p - 1 + 1) * size - 1) / 2 = p * size - 0.5
+    const float x = points[2 * n] * (float)W - 0.5f, y = points[2 * n + 1] * (float)H - 0.5f;
+    const float fx = floorf(x), fy = floorf(y);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const float wx1 = x - fx, wy1 = y - fy, wx0 = 1.f - wx1, wy0 = 1.f - wy1;
+    auto at = [&](int yy, int xx) { return (yy >= 0 && yy < H && xx >= 0 && xx < W) ? m[(long)yy * W + xx] : 0.f; };
+    out[(long)blockIdx.y * NP + n] = at(y0, x0) * wy0 * wx0 + at(y0, x0 + 1) * wy0 * wx1 + at(y0 + 1, x0) * wy1 * wx0 + at(y0 + 1, x0 + 1) * wy1 * wx1;
+}
+
+__global__ __launch_bounds__(256) void wg_match_cost_kernel(const float* sp, const float* st, float* cost, int T, int NP) {
+    __shared__ float red[4][4];
+    const int p = blockIdx.x / T, t = blockIdx.x % T;
+    const float* x = sp + (long)p * NP;
+    const float* y = st + (long)t * NP;
+    float ce = 0.f, num = 0.f, ss = 0.f, sy = 0.f;
+    for (int n = threadIdx.x; n < NP; n += 256) {
+        const float v = x[n], g = y[n];
+        const float l1p = log1pf(__expf(-fabsf(v)));
+        const float pos = fmaxf(v, 0.f) - v + l1p;     // BCE-with-logits against 1
+        const float neg = fmaxf(v, 0.f) + l1p;         //                 against 0
+        ce += pos * g + neg * (1.f - g);
+        const float s = 1.f / (1.f + __expf(-v));
+        num += s * g; ss += s; sy += g;
+    }
+    float v4[4] = {ce, num, ss, sy};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v4[i] = wg_wave_sum(v4[i]);
+        if ((threadIdx.x & 63) == 0) red[i][threadIdx.x >> 6] = v4[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = red[i][0] + red[i][1] + red[i][2] + red[i][3];
+        cost[blockIdx.x] = r[0] / (float)NP + 1.f - (2.f * r[1] + 1.f) / (r[2] + r[3] + 1.f);
+    }
+}
+
+extern "C" long wg_match_cost_workspace_floats(int P, int T, int NP) { return (long)(P + T) * NP; }
+
+extern "C" int wg_match_cost_f32(const float* pred_logits, const float* targets, const float* points, float* cost, float* workspace,
+                                 long workspace_floats, int P, int T, int H, int W, int NP, void* stream) {
+    WG_REQUIRE(pred_logits && targets && points && cost && workspace, "match_cost: null operand");
+    WG_REQUIRE(P > 0 && T > 0 && H > 0 && W > 0 && NP > 0, "match_cost: bad shape");
+    WG_REQUIRE(workspace_floats >= (long)(P + T) * NP, "match_cost: workspace too small (need %ld floats)", (long)(P + T) * NP);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wg_point_sample_kernel, dim3((NP + 255) / 256, P), dim3(256), 0, st, pred_logits, points, workspace, H, W, NP);
+    hipLaunchKernelGGL(wg_point_sample_kernel, dim3((NP + 255) / 256, T), dim3(256), 0, st, targets, points, workspace + (long)P * NP, H, W, NP);
+    hipLaunchKernelGGL(wg_match_cost_kernel, dim3(P * T), dim3(256), 0, st, (const float*)workspace, (const float*)(workspace + (long)P * NP), cost, T, NP);
+    return wg_check_launch("wg_match_cost_f32");
+}

@@ -392,3 +392,21 @@ def nce_forward(z, sam_tokens, seg_row_ids, wq, bq, wk_t, temperature, top_k, ex
         return loss[0], loss_m, logits
 
     return {"st": st, "inv_norm": inv_norm, "zn": qcat[:M], "attn_w": attn_w, "vraw": vraw, "refined": k > 0, "finish": finish}
+
+
+def match_cost(pred_logits, targets, point_coords):
+    """[P, T] matching cost of utils/matcher.py:93-133 (point-sampled BCE + dice).  pred_logits [P,H,W], targets [T,H,W]
+    fp32, point_coords [NP, 2] fp32 in [0,1]^2 as (x, y)."""
+    _need_gpu(pred_logits, targets, point_coords)
+    assert pred_logits.dtype == torch.float32 and targets.dtype == torch.float32 and point_coords.dtype == torch.float32
+    assert pred_logits.is_contiguous() and targets.is_contiguous() and point_coords.is_contiguous()
+    P, H, W = pred_logits.shape
+    T = targets.shape[0]
+    assert targets.shape[1:] == (H, W) and point_coords.dim() == 2 and point_coords.shape[1] == 2
+    NP = point_coords.shape[0]
+    cost = torch.empty(P, T, device=pred_logits.device, dtype=torch.float32)
+    nws = _lib.lib().wg_match_cost_workspace_floats(P, T, NP)
+    ws = torch.empty(nws, device=pred_logits.device, dtype=torch.float32)
+    _lib.check(_lib.lib().wg_match_cost_f32(pred_logits.data_ptr(), targets.data_ptr(), point_coords.data_ptr(), cost.data_ptr(),
+                                            ws.data_ptr(), nws, P, T, H, W, NP, _stream()), "wg_match_cost_f32")
+    return cost
