@@ -126,6 +126,16 @@ int wg_mask_iou_f32(const float* pred_logits, const float* gt, float* out6, floa
 int wg_mask_losses_f32(const float* pred_logits, const float* targets, float* out2, float* workspace, long workspace_floats,
                        int N, long hw, float dice_scale, float dice_eps, void* stream);
 
+/* input pipeline.  frames [B,H,W,3] uint8 (HBM) -> images [B,3,S,S] bf16 (out_bf16) or fp32:
+ * ResizeLongestSide(S).apply_image (segment_anything/utils/transforms.py:27-36 = Pillow's two-pass 8-bit bilinear resize,
+ * reproduced bit for bit from its coefficient tables), (x - mean) / std and zero padding to S x S (utils/PAVE_dataset.py:115-121).
+ * h_bounds [Wo,2] / h_kk [Wo,h_ksize] and v_bounds [Ho,2] / v_kk [Ho,v_ksize]: int32 tables of Resample.c's precompute_coeffs +
+ * normalize_coeffs_8bpc for (W -> Wo) and (H -> Ho); null = that pass is the identity.  tmp: B*H*Wo*3 bytes; resized
+ * (optional): the uint8 resized frames [B,Ho,Wo,3]; norm_lut: device fp32 [3][256] = (v - mean_c) / std_c in IEEE fp32. */
+int wg_preprocess_frames_u8(const void* frames, void* tmp, void* resized, void* out, int out_bf16, const int* h_bounds,
+                            const int* h_kk, int h_ksize, const int* v_bounds, const int* v_kk, int v_ksize, int B, int H, int W,
+                            int Ho, int Wo, int S, const float* norm_lut, void* stream);
+
 /* cost matrix of match_pred() (utils/matcher.py:93-133): P predicted logit masks and T target masks
  * [., H, W] fp32, sampled bilinearly (grid_sample, align_corners=False, zero padding) at NP shared points in [0,1]^2 (x, y);
  * cost[p*T + t] = batch_sigmoid_ce_loss + batch_dice_loss (:10-56).  Scratch: wg_match_cost_workspace_floats(P, T, NP). */

@@ -263,3 +263,19 @@ def match_inputs(c):
     tgt = ((pred[[3, 0, 4, 1][:c["T"]]] > 0).float() + (u > 0.9).float()).remainder(2.0)
     pts = torch.from_numpy(synth.uniform01(c["seed"], "input.points", c["points"] * 2).astype(np.float32)).reshape(c["points"], 2)
     return pred, tgt, pts
+
+
+# ---- input pipeline (transforms.py:27-36, PAVE_dataset.py:115-121) ---------------------------------------------------------
+PREPS = {
+    "down": dict(h=37, w=53, target=32, seed=91),     # antialiased down-scale (5 taps), landscape
+    "up": dict(h=31, w=20, target=48, seed=92),       # up-scale (3 taps), portrait
+    "square": dict(h=40, w=40, target=40, seed=93),   # no resize at all
+    "big": dict(h=270, w=480, target=128, seed=94),   # 3.75x down-scale (9 taps)
+}
+
+
+def prep_frame(c):
+    u = synth.uniform01(c["seed"], "input.frame", c["h"] * c["w"] * 3).reshape(c["h"], c["w"], 3)
+    yy, xx = np.mgrid[0:c["h"], 0:c["w"]]
+    smooth = 0.5 + 0.5 * np.sin(yy[..., None] / 7.0 + xx[..., None] / 5.0 + np.arange(3))
+    return np.clip((0.6 * smooth + 0.4 * u) * 255.0, 0, 255).astype(np.uint8)

@@ -196,6 +196,30 @@ def make_match(name):
     np.savez_compressed(os.path.join(HERE, "match_%s.npz" % name), cost=C.numpy(), rows=r, cols=cidx)
 
 
+def make_prep(name):
+    """ResizeLongestSide.apply_image of the reference (transforms.py:27-36).  torchvision is not installed: its two functions
+    the method calls are stood in by what they are for a PIL input -- to_pil_image(ndarray) = Image.fromarray and
+    resize(pil, (h, w)) = pil.resize((w, h), BILINEAR) -- so the arithmetic is the installed Pillow's.  The normalise / pad of
+    PAVE_dataset.py:115-121 (its class needs cv2) is the three torch lines below."""
+    from PIL import Image
+    import torch.nn.functional as F
+    _import_reference()
+    tvf = sys.modules["torchvision.transforms.functional"]
+    tvf.to_pil_image = lambda a: Image.fromarray(a)
+    tvf.resize = lambda im, size: im.resize((size[1], size[0]), Image.BILINEAR)
+    import importlib
+    tr = importlib.import_module("model.segment_anything.utils.transforms")
+    tr.to_pil_image, tr.resize = tvf.to_pil_image, tvf.resize
+    c = cases.PREPS[name]
+    frame = cases.prep_frame(c)
+    resized = tr.ResizeLongestSide(c["target"]).apply_image(frame)
+    mean = torch.Tensor([97.17, 105.73, 108.16]).view(-1, 1, 1)
+    std = torch.Tensor([53.05, 56.40, 61.93]).view(-1, 1, 1)
+    x = (torch.from_numpy(resized).permute(2, 0, 1).contiguous().float() - mean) / std
+    x = F.pad(x, (0, c["target"] - x.shape[-1], 0, c["target"] - x.shape[-2]))
+    np.savez_compressed(os.path.join(HERE, "prep_%s.npz" % name), resized=resized, image=x.numpy())
+
+
 def make_state_dict_shapes(_name):
     """Key -> shape tables of the reference modules (data, not source): the de-facto checkpoint ABI."""
     import json
@@ -216,6 +240,7 @@ ALL = {
     "metrics": (make_metrics, cases.METRICS),
     "nce": (make_nce, cases.NCES),
     "match": (make_match, cases.MATCHES),
+    "prep": (make_prep, cases.PREPS),
     "sam_encoder": (make_sam_encoder, cases.SAM_ENCODERS),
     "decoder": (make_decoder, cases.DECODERS),
     "projectors": (make_projectors, cases.PROJECTORS),

@@ -185,3 +185,36 @@ def test_match_pred_vs_reference_golden(dev):
     t2 = (big[[4, 2, 0]] > 0).float()
     r2, c2 = match_pred(big.to(dev), t2.to(dev))
     assert sorted(zip(r2.tolist(), c2.tolist())) == [(0, 2), (2, 1), (4, 0)]
+
+
+@pytest.mark.parametrize("name", ["down", "up", "square", "big"])
+def test_preprocess_frames_bit_exact(dev, name):
+    """the GPU input pipeline against the reference's ResizeLongestSide.apply_image (Pillow) output --
+    uint8 resize bit-exact, normalised / padded fp32 image bit-exact, bf16 image = its rounding."""
+    import numpy as np
+    from tests.golden import cases
+    from walkgpt_amd.preprocess import preprocess_frames, ResizeLongestSide
+    c = cases.PREPS[name]
+    gold = cases.load("prep_" + name)
+    frame = torch.from_numpy(cases.prep_frame(c)).to(dev)
+    img, resized, hw = preprocess_frames(torch.stack([frame, frame.flip(0)]), c["target"], out_dtype=torch.float32, want_resized=True)
+    assert hw == gold["resized"].shape[:2]
+    assert np.array_equal(resized[0].cpu().numpy(), gold["resized"])
+    assert np.array_equal(img[0].cpu().numpy(), gold["image"])
+    img16, _, _ = preprocess_frames(frame[None], c["target"])
+    assert torch.equal(img16[0].cpu(), torch.from_numpy(gold["image"]).bfloat16())
+    assert np.array_equal(ResizeLongestSide(c["target"]).apply_image(frame).cpu().numpy(), gold["resized"])
+
+
+def test_preprocess_full_size_vs_oracle(dev):
+    """1080p frame -> 1024 (SAM) and 448 (CLIP) against the oracle's numpy restatement, bit for bit."""
+    import numpy as np
+    from oracle import preprocess as op
+    from walkgpt_amd.preprocess import preprocess_frames
+    g = np.random.default_rng(7)
+    frame = g.integers(0, 256, size=(1080, 1920, 3), dtype=np.uint8)
+    for target in (1024, 448):
+        img, resized, hw = preprocess_frames(torch.from_numpy(frame).to(dev)[None], target, out_dtype=torch.float32, want_resized=True)
+        ref = op.resize_longest_side(frame, target)
+        assert np.array_equal(resized[0].cpu().numpy(), ref)
+        assert np.array_equal(img[0].cpu().numpy(), op.preprocess(ref, target, (97.17, 105.73, 108.16), (53.05, 56.40, 61.93)))

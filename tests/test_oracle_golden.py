@@ -157,3 +157,21 @@ def test_match_cost_matches_reference():
     gold = cases.load("match_p5t4")
     pred, tgt, pts = cases.match_inputs(c)
     assert np.allclose(om.match_cost(pred, tgt, pts).numpy(), gold["cost"], atol=1e-5)
+
+
+@pytest.mark.parametrize("name", list(cases.PREPS))
+def test_preprocess_matches_reference_and_pillow(name):
+    """oracle/preprocess.py (Pillow's 8-bit resample restated) and the product's coefficient tables, bit for bit."""
+    from oracle import preprocess as op
+    from walkgpt_amd.preprocess import ResizeLongestSide, pil_bilinear_coeffs
+    c = cases.PREPS[name]
+    gold = cases.load("prep_" + name)
+    frame = cases.prep_frame(c)
+    r = op.resize_longest_side(frame, c["target"])
+    assert r.shape == gold["resized"].shape and np.array_equal(r, gold["resized"])
+    assert np.array_equal(op.preprocess(r, c["target"], (97.17, 105.73, 108.16), (53.05, 56.40, 61.93)), gold["image"])
+    assert ResizeLongestSide.get_preprocess_shape(c["h"], c["w"], c["target"]) == r.shape[:2]
+    if r.shape[1] != c["w"]:   # host tables of the product path == the oracle's
+        b, k, ks = pil_bilinear_coeffs(c["w"], r.shape[1])
+        co, ks2 = op._coeffs(c["w"], r.shape[1])
+        assert ks == ks2 and all(b[i, 0] == lo and list(k[i, :len(kk)]) == kk for i, (lo, kk) in enumerate(co))
