@@ -126,6 +126,17 @@ int wg_mask_iou_f32(const float* pred_logits, const float* gt, float* out6, floa
 int wg_mask_losses_f32(const float* pred_logits, const float* targets, float* out2, float* workspace, long workspace_floats,
                        int N, long hw, float dice_scale, float dice_eps, void* stream);
 
+/* LLM-side multimodal splice = prepare_inputs_labels_for_multimodal (llava_arch.py:265-518) for rows
+ * with exactly one IMAGE_TOKEN_INDEX placeholder, fused with the embed_tokens gather, plus WalkGPT's [SEG] read-out mask in
+ * spliced coordinates (model/walkgpt.py:293-306).  ids [rows,L] int64; table [V,H] bf16; image_features [rows,T,H] bf16;
+ * mask_in [rows,L] / vit_mask [rows,T] bool bytes (null = ones); labels_in [rows,L] int64 (optional); seg_ids [nseg] int64
+ * (device, optional).  Outputs: embeds [rows,L+T-1,H]; mask_out, labels_out, seg_mask [rows,L+T-1] (optional);
+ * img_pos / img_cnt [rows] int32 -- the caller must reject rows whose img_cnt != 1. */
+int wg_splice_multimodal_bf16(const long* ids, const void* table, const void* image_features, const void* mask_in,
+                              const void* vit_mask, const long* labels_in, const long* seg_ids, int nseg, void* embeds,
+                              void* mask_out, long* labels_out, void* seg_mask, int* img_pos, int* img_cnt, int rows, int L, int T,
+                              int H, int V, long image_token, long ignore_index, void* stream);
+
 /* input pipeline.  frames [B,H,W,3] uint8 (HBM) -> images [B,3,S,S] bf16 (out_bf16) or fp32:
  * ResizeLongestSide(S).apply_image (segment_anything/utils/transforms.py:27-36 = Pillow's two-pass 8-bit bilinear resize,
  * reproduced bit for bit from its coefficient tables), (x - mean) / std and zero padding to S x S (utils/PAVE_dataset.py:115-121).

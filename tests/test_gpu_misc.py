@@ -218,3 +218,40 @@ def test_preprocess_full_size_vs_oracle(dev):
         ref = op.resize_longest_side(frame, target)
         assert np.array_equal(resized[0].cpu().numpy(), ref)
         assert np.array_equal(img[0].cpu().numpy(), op.preprocess(ref, target, (97.17, 105.73, 108.16), (53.05, 56.40, 61.93)))
+
+
+def test_multimodal_splice_vs_oracle(dev):
+    """the fused gather against the oracle's row-by-row restatement (bit-exact: pure data movement)."""
+    from oracle import splice as osp
+    from walkgpt_amd.llava_splice import prepare_inputs_labels_for_multimodal
+    g = torch.Generator().manual_seed(11)
+    rows, L, T, H, V = 5, 37, 16, 64, 101
+    ids = torch.randint(0, V, (rows, L), generator=g)
+    seg = [97, 99]
+    for r, s in enumerate([0, 5, 36, 17, 20]):      # placeholder first / last / in the middle
+        ids[r, s] = -200
+        if s + 3 < L:
+            ids[r, s + 3] = seg[r % 2]
+    labels = torch.randint(-100, V, (rows, L), generator=g)
+    mask = torch.rand(rows, L, generator=g) > 0.2
+    vit = torch.rand(rows, T, generator=g) > 0.1
+    table = torch.randn(V, H, generator=g).bfloat16()
+    img = torch.randn(rows, T, H, generator=g).bfloat16()
+    em, ee, el = osp.prepare_inputs_labels_for_multimodal(ids, mask, labels, img, table, vit)
+    m, e, l, sm = prepare_inputs_labels_for_multimodal(ids.to(dev), mask.to(dev), labels.to(dev), img.to(dev), table.to(dev), vit.to(dev), seg)
+    assert torch.equal(m.cpu(), em) and torch.equal(e.cpu(), ee) and torch.equal(l.cpu(), el)
+    assert torch.equal(sm.cpu(), osp.seg_token_mask(ids, seg, T))
+    # defaults (no masks, no labels) and WalkGPT's sizes: 256 image tokens, hidden 4096
+    rows, L, T, H, V = 3, 130, 256, 4096, 32003
+    ids = torch.randint(0, V, (rows, L), generator=g)
+    ids[:, 35] = -200
+    ids[:, 100] = 32000
+    table = torch.randn(V, H, generator=g).bfloat16()
+    img = torch.randn(rows, T, H, generator=g).bfloat16()
+    em, ee, _ = osp.prepare_inputs_labels_for_multimodal(ids, None, None, img, table)
+    m, e, l, sm = prepare_inputs_labels_for_multimodal(ids.to(dev), None, None, img.to(dev), table.to(dev), None, 32000)
+    assert l is None and torch.equal(m.cpu(), em) and torch.equal(e.cpu(), ee)
+    assert torch.equal(sm.cpu(), osp.seg_token_mask(ids, [32000], 256)) and int(sm.sum()) == rows and bool(sm[:, 99 + 255].all())
+    bad = ids.clone(); bad[1, 36] = -200
+    with pytest.raises(RuntimeError):
+        prepare_inputs_labels_for_multimodal(bad.to(dev), None, None, img.to(dev), table.to(dev))

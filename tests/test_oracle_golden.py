@@ -175,3 +175,16 @@ def test_preprocess_matches_reference_and_pillow(name):
         b, k, ks = pil_bilinear_coeffs(c["w"], r.shape[1])
         co, ks2 = op._coeffs(c["w"], r.shape[1])
         assert ks == ks2 and all(b[i, 0] == lo and list(k[i, :len(kk)]) == kk for i, (lo, kk) in enumerate(co))
+
+
+def test_splice_oracle_hand_case():
+    """oracle/splice.py is parity-unpinned (llava_arch.py does not import here): a hand-built row checks the restatement."""
+    from oracle import splice as osp
+    ids = torch.tensor([[7, -200, 3, 9, 4]])
+    table = torch.arange(10, dtype=torch.float32)[:, None].repeat(1, 2)
+    img = torch.full((1, 3, 2), -1.0)
+    labels = torch.tensor([[1, 2, 3, 4, 5]])
+    m, e, l = osp.prepare_inputs_labels_for_multimodal(ids, None, labels, img, table)
+    assert e[0, :, 0].tolist() == [7, -1, -1, -1, 3, 9, 4] and l[0].tolist() == [1, -100, -100, -100, 3, 4, 5] and bool(m.all())
+    # walkgpt.py:293-306 with 3 image tokens: [SEG]=9 sits at un-spliced index 3 -> hidden state read at spliced position 2 + (3-1) = 4
+    assert osp.seg_token_mask(ids, [9], 3)[0].tolist() == [False, False, False, False, True, False, False]

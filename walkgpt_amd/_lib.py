@@ -35,6 +35,8 @@ SIGNATURES = {
     "wg_mask_score_f32": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_void_p],
     "wg_mask_iou_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_void_p],
     "wg_mask_losses_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_float, c_void_p],
+    "wg_splice_multimodal_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_long, c_long, c_void_p],
     "wg_preprocess_frames_u8": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int,
                                 c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p],
     "wg_match_cost_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_void_p],
