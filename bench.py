@@ -263,6 +263,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(record_decode=True)
+    t_enq = time.perf_counter() - t0   # host time to enqueue the launches of all steps (no synchronisation inside)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -324,7 +325,7 @@ def main():
     out = {"metric": "images/sec", "value": round(images_per_s, 2), "unit": "images/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "mask_decode_ms": round(decode_ms, 3),
+           "mask_decode_ms": round(decode_ms, 3), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
            "config": {"workload": "C2: bs=%d/GPU 448x448 source images (CLIP input 448^2, SAM input 1024^2), CLIP ViT-L/14 + SAM %s "
                                   "encoder%s + CTP + prompt encoder + mask decoder + postprocess, T=%d [SEG]/image, random-init weights"
                                   % (B, args.sam, " + MSQP" if args.with_msqp else "", T),
