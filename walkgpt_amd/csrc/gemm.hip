@@ -29,8 +29,29 @@ struct GemmArgs {
     int act;
     int out_f32;
     int tiles_m, tiles_n;
+    int col_block;               // tile order: column blocks of this many tile columns, row-major inside a block (0 = plain row-major)
     unsigned c_bytes, r_bytes;   // extents of C and R for the staged epilogue's buffer descriptors (0: not addressable in 32 bits)
 };
+
+// Linear tile index -> (tile row, tile column).  With col_block = c > 0 the grid is walked in blocks of c tile columns, row-major
+// inside a block: the workgroups that share an XCD (a contiguous range of this order) then touch only c column panels of W,
+// which stay in that XCD's 4 MiB L2 while the A row panels stream past (plain row-major makes every XCD cycle through ALL
+// of W once per round of tiles: at N = 2304..4096 that is 3.5-8 MB per round, and the measured HBM-side reads were 2-4x
+// the operands, profiles/r01_gemm_traffic_by_shape.md).
+__device__ __forceinline__ void wg_tile_of(int wgid, int tiles_m, int tiles_n, int col_block, int& tile_m, int& tile_n) {
+    if (col_block <= 0 || col_block >= tiles_n) {
+        tile_m = wgid / tiles_n;
+        tile_n = wgid % tiles_n;
+        return;
+    }
+    const int per_block = tiles_m * col_block;
+    const int b = wgid / per_block;                    // column block
+    const int c0 = b * col_block;
+    const int w = (tiles_n - c0) < col_block ? (tiles_n - c0) : col_block;   // width of this (possibly last, narrower) block
+    const int idx = wgid - b * per_block;
+    tile_m = idx / w;
+    tile_n = c0 + idx % w;
+}
 
 template <int N_> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N_) : "memory"); }
 
@@ -121,7 +142,8 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
         const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
         wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
     }
-    const int tile_m = wgid / g.tiles_n, tile_n = wgid % g.tiles_n;
+    int tile_m, tile_n;
+    wg_tile_of(wgid, g.tiles_m, g.tiles_n, g.col_block, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // per-lane source pointers of this wave's LDS-DMA pieces (K offset 0); they advance by BK elements per stage
@@ -788,6 +810,14 @@ template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, int P
 static int launch_tile_impl(GemmArgs& g, hipStream_t st) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
+    {   // tile order (wg_tile_of): column blocks when the weight matrix cannot stay in an XCD's 4 MiB L2 beside the streaming A
+        // panels (> 3 MiB) and at least two of its column panels (BN x K bf16) fit in ~1.5 MiB; otherwise plain row-major,
+        // which reads A once.  Measured (rocprofv3 FETCH_SIZE, tools/pmc_gemm.py): CLIP qkv 125 -> 92 MB, CLIP fc1 170 -> 114 MB,
+        // SAM lin1 292 -> 227 MB per launch; SAM qkv (3.5 MB of weights) unchanged; no effect on run time either way.
+        const long panel = (long)BN * g.K * 2, wbytes = (long)g.N * g.K * 2;
+        const int cb = (int)((3L << 19) / (panel > 0 ? panel : 1));
+        g.col_block = (wbytes > (3L << 20) && cb >= 2 && cb < g.tiles_n) ? cb : 0;
+    }
     constexpr int lds_main = STAGES * (BM + BN) * BK * 2;
     constexpr int lds_stg = WM * WN * 64 * ((BN / WN) * 2 + 16);
     constexpr int lds = lds_main > lds_stg ? lds_main : lds_stg;
@@ -884,6 +914,7 @@ extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, lon
     g.bias = (const bf16*)bias; g.R = (const bf16*)residual; g.ldr = ldr; g.res_mod = res_row_mod;
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act; g.out_f32 = out_f32;
     g.tiles_m = g.tiles_n = 0;
+    g.col_block = 0;
     {   // byte extents for the staged epilogue's buffer descriptors (it addresses C and R with 32-bit byte offsets)
         const long cb = ((long)(M - 1) * ldc + N) * 2;
         const long rrows = res_row_mod > 0 ? (res_row_mod < M ? res_row_mod : M) : M;
