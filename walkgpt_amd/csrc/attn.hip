@@ -408,10 +408,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         if constexpr (GRID && RPT == 1) rowh = rh[0];
         if constexpr (RAW) mt *= sc2;
         mt += rowh;
-        {
-            const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mt), __builtin_bit_cast(unsigned, mt), false, false);
-            mt = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
-        }
+        mt = wg_xor32_max(mt);   // the other half of the keys of this query lives in lane ^ 32
         if (__any(mt > m_run + RESCALE_THR)) {
             const float m_new = fmaxf(m_run, mt);
             const float alpha = wg_exp2(m_run - m_new);
@@ -531,7 +528,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         for (int i = tid; i < NW * 12 * 8; i += NW * 64) wg_attn_stamp_ptr[i] = ((unsigned*)(smem + 156 * 1024))[i];
 #endif
     // ---- epilogue: O = O^T / l, 8-byte stores ---------------------------------------------------------------------------
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float l_tot = wg_xor32_sum(l_run);
     if (qvalid) {
         const float inv = 1.0f / l_tot;
         long orow;

@@ -39,15 +39,38 @@ int wg_check_launch(const char* what);
 __device__ __forceinline__ float wg_bf2f(bf16 x) { return (float)x; }
 __device__ __forceinline__ bf16 wg_f2bf(float x) { return (bf16)x; }
 
+// ---- wave-wide reductions on the VALU (DPP + gfx950 permlane swaps) instead of six ds_bpermute round trips through the LDS crossbar.
+// v_permlaneNN_swap exchanges the upper half (odd rows) of its first register with the lower half (even rows) of the second;
+// fed with two copies of v it leaves {lo, lo} and {hi, hi}, whose combination is the xor-32 (xor-16) butterfly step.
+// Inline asm on purpose: __builtin_amdgcn_permlane{16,32}_swap of this hipcc (ROCm 7.2) hands back the FIRST register for both
+// elements of its result, i.e. code using the builtin silently computes op(lo, lo) (checked on the GPU: a wave sum of 1..64
+// returned 544).  s_nop 1 covers the VALU-write -> permlane-read hazard the compiler would otherwise pad.
+template <int ROWS32> __device__ __forceinline__ void wg_permlane_swap(float v, float& a, float& b) {
+    a = v; b = v;
+    if constexpr (ROWS32) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+// value of lane (l ^ 32) combined with lane l
+__device__ __forceinline__ float wg_xor32_max(float v) { float a, b; wg_permlane_swap<1>(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float wg_xor32_sum(float v) { float a, b; wg_permlane_swap<1>(v, a, b); return a + b; }
+#define WG_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, (v)), (ctrl), 0xF, 0xF, true))
 __device__ __forceinline__ float wg_wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += WG_DPP(v, 0xB1);    // quad_perm [1,0,3,2]
+    v += WG_DPP(v, 0x4E);    // quad_perm [2,3,0,1]
+    v += WG_DPP(v, 0x124);   // row_ror:4
+    v += WG_DPP(v, 0x128);   // row_ror:8  -> every lane of a 16-lane row holds the row total
+    float a, b;
+    wg_permlane_swap<0>(v, a, b); v = a + b;
+    wg_permlane_swap<1>(v, a, b); return a + b;
 }
 __device__ __forceinline__ float wg_wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, WG_DPP(v, 0xB1));
+    v = fmaxf(v, WG_DPP(v, 0x4E));
+    v = fmaxf(v, WG_DPP(v, 0x124));
+    v = fmaxf(v, WG_DPP(v, 0x128));
+    float a, b;
+    wg_permlane_swap<0>(v, a, b); v = fmaxf(a, b);
+    wg_permlane_swap<1>(v, a, b); return fmaxf(a, b);
 }
 
 // activation codes shared by the GEMM epilogue and the elementwise kernels
