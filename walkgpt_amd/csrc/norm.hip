@@ -50,22 +50,22 @@ __global__ __launch_bounds__(256) void wg_layernorm_kernel(LnArgs a) {
     }
     const float rstd = 1.0f / sqrtf(wg_wave_sum(q) / (float)a.D + a.eps);
     bf16* y = a.y + (long)m * a.ldy;
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        const int d = c * 512 + lane * 8;
-        if (d < a.D) {
-            const bf16x8 gm = *(const bf16x8*)(a.gamma + d);
-            const bf16x8 bt = *(const bf16x8*)(a.beta + d);
-            bf16x8 o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = (v[c][e] - mean) * rstd * (float)gm[e] + (float)bt[e];
-                if (a.act != WG_ACT_NONE) t = wg_act(t, a.act);
-                o[e] = (bf16)t;
+    // (the activation is resolved once per wave, not per element: see WG_ACT_SWITCH)
+    WG_ACT_SWITCH(a.act,
+        _Pragma("unroll") for (int c = 0; c < MAXC; ++c) {
+            const int d = c * 512 + lane * 8;
+            if (d < a.D) {
+                const bf16x8 gm = *(const bf16x8*)(a.gamma + d);
+                const bf16x8 bt = *(const bf16x8*)(a.beta + d);
+                bf16x8 o;
+                _Pragma("unroll") for (int e = 0; e < 8; e += 2) {
+                    f32x2 t = {(v[c][e] - mean) * rstd * (float)gm[e] + (float)bt[e], (v[c][e + 1] - mean) * rstd * (float)gm[e + 1] + (float)bt[e + 1]};
+                    t = wg_act2<ACT>(t);
+                    o[e] = (bf16)t.x; o[e + 1] = (bf16)t.y;
+                }
+                *(bf16x8*)(y + d) = o;
             }
-            *(bf16x8*)(y + d) = o;
-        }
-    }
+        })
 }
 
 // D <= 128 (the mask decoder's LayerNorm2d over 64 channels runs on P*16384 rows): D/8 lanes per row, 512/D rows per
@@ -101,12 +101,12 @@ __global__ __launch_bounds__(256) void wg_layernorm_small_kernel(LnArgs a) {
         const bf16x8 gm = *(const bf16x8*)(a.gamma + d);
         const bf16x8 bt = *(const bf16x8*)(a.beta + d);
         bf16x8 o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float t = (v[e] - mean) * rstd * (float)gm[e] + (float)bt[e];
-            if (a.act != WG_ACT_NONE) t = wg_act(t, a.act);
-            o[e] = (bf16)t;
-        }
+        WG_ACT_SWITCH(a.act,
+            _Pragma("unroll") for (int e = 0; e < 8; e += 2) {
+                f32x2 t = {(v[e] - mean) * rstd * (float)gm[e] + (float)bt[e], (v[e + 1] - mean) * rstd * (float)gm[e + 1] + (float)bt[e + 1]};
+                t = wg_act2<ACT>(t);
+                o[e] = (bf16)t.x; o[e + 1] = (bf16)t.y;
+            })
         *(bf16x8*)(a.y + m * a.ldy + d) = o;
     }
 }
