@@ -134,3 +134,36 @@ def test_mha_small(dev, B, Lq, Lk, heads, hd):
     ref = _ref_mha(q, k, v, heads, scale)
     out = ops.mha(q.to(dev), k.to(dev), v.to(dev), heads, scale, small=True)
     assert (out.float().cpu() - ref).abs().max().item() < 0.03
+
+
+@pytest.mark.parametrize("mode", ["global", "plain"])
+def test_attention_large_uneven_scores(dev, mode):
+    """Scores of +-100s with the dominant keys confined to ONE lane half of each key tile (slots 4..7, 12..15, ... of every 32-key
+    block belong to lanes >= 32): the running maximum must be the true maximum over both halves of the key tile, or the
+    probabilities overflow.  (Regression: hipcc's permlane32_swap builtin returned the lower half's maximum for both halves.)"""
+    g = torch.Generator().manual_seed(21)
+    heads, hd = 2, 64
+    D = heads * hd
+    if mode == "global":
+        B, grid = 1, 64
+        qkv = torch.randn(B * grid * grid, 3 * D, generator=g)
+        k = qkv[:, D:2 * D].reshape(-1, heads, hd)
+        slot = torch.arange(grid * grid) % 64
+        upper = ((slot % 8) >= 4)                         # key slots held by the upper lane half
+        k[upper] *= 6.0                                   # those keys get scores up to several hundred
+        qkv = qkv.to(torch.bfloat16)
+        bias = _rand((3 * D,), 2, 0.5)
+        rel_h, rel_w = _rand((2 * grid - 1, hd), 3, 0.2), _rand((2 * grid - 1, hd), 4, 0.2)
+        ref = _ref_sam_attention(qkv, bias, rel_h, rel_w, B, grid, grid, heads)
+        out = ops.sam_attention(qkv.to(dev), bias.to(dev), rel_h.to(dev), rel_w.to(dev), B, grid, grid, heads)
+    else:
+        B, L = 2, 1025
+        q, k, v = torch.randn(B, L, D, generator=g), torch.randn(B, L, D, generator=g), torch.randn(B, L, D, generator=g)
+        upper = ((torch.arange(L) % 8) >= 4)
+        k[:, upper] *= 6.0
+        q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+        ref = _ref_mha(q, k, v, heads, hd ** -0.5)
+        out = ops.mha(q.to(dev), k.to(dev), v.to(dev), heads, hd ** -0.5, small=False)
+    o = out.float().cpu()
+    assert torch.isfinite(o).all()
+    assert (o - ref).abs().max().item() < 0.06
