@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--side-priority", type=int, default=0, help="HIP priority of the CLIP stream (-1 = high)")
     ap.add_argument("--single-stream", action="store_true", help="run the CLIP tower and the SAM branch back to back")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-decode-graph", action="store_true", help="launch the decode chain eagerly instead of replaying its captured HIP graph")
     return ap.parse_args()
 
 
@@ -232,7 +233,9 @@ def main():
                     e0 = torch.cuda.Event(enable_timing=True)
                     e1 = torch.cuda.Event(enable_timing=True)
                     e0.record()
-                masks, scores = model.decode_from_hidden(emb, inp["seg_hidden"], inp["resize_list"], inp["original_size_list"])
+                # the ~75 small launches of the chain are replayed from one captured HIP graph (same kernels, same arguments)
+                dec_fn = model.decode_from_hidden if args.no_decode_graph else model.decode_from_hidden_graphed
+                masks, scores = dec_fn(emb, inp["seg_hidden"], inp["resize_list"], inp["original_size_list"])
                 if record_decode:
                     e1.record()
                     decode_ev.append((e0, e1))

@@ -198,3 +198,13 @@ def test_grounding_pipeline_end_to_end_vs_oracle(dev):
             a, b = got.numpy() > 0, ref.numpy() > 0
             assert (a & b).sum() / max(1, (a | b).sum()) > 0.98
             assert torch.allclose(out["mask_scores"][i].cpu(), osam.mask_score(ref), atol=0.02)
+    # the decode chain replayed from its captured HIP graph is the same kernels with the same arguments: bit-identical, also
+    # on a second replay with fresh inputs copied into the graph's static buffers (ragged prompt counts 2 + 3, two image sizes)
+    hid = [h.to(dev, torch.bfloat16) for h in hidden]
+    emb_t = model.get_visual_emb_tokens(x.to(dev, torch.bfloat16))
+    for rep in range(2):
+        hid = [h * (1.0 + rep) for h in hid]
+        em, es = model.decode_from_hidden(emb_t, hid, resize, orig)
+        gm, gs = model.decode_from_hidden_graphed(emb_t, hid, resize, orig)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(em, gm)) and all(torch.equal(a, b) for a, b in zip(es, gs))
