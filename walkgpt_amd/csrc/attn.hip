@@ -597,15 +597,20 @@ extern "C" int wg_mha_bf16(const void* Q, long ldq, long q_rows_per_batch, const
     hipStream_t st = (hipStream_t)stream;
     const int groups = B * heads;
     const int qblocks = (Lq + 31) / 32;
-    // waves per workgroup: the candidate that wastes the fewest 32-query slots (1025 CLIP tokens = 33 blocks = 11 x 3)
+    // waves per workgroup: query-slot utilisation x a measured per-size factor (tools/bench_attn.py, 4096 and 1025 keys).  At head_dim
+    // <= 64 four-wave workgroups (three or more of them per CU) beat one eight-wave workgroup by 5 % and three-wave ones by 13 %
+    // even at 1025 queries, where they leave 11 % of the query slots empty (CLIP: 67 -> 58 us); at head_dim 128 eight waves win.
     int nw = 1;
     if (qblocks > 1) {
         const int cand[3] = {8, 4, 3};
+        const double eff_small[3] = {0.95, 1.0, 0.87}, eff_128[3] = {1.0, 0.86, 0.0};
         double best = -1.0;
-        for (int c : cand) {
+        for (int i = 0; i < 3; ++i) {
+            const int c = cand[i];
             if (head_dim != 64 && c == 3) continue;
             const double util = (double)qblocks / (double)(((qblocks + c - 1) / c) * c);
-            if (util > best + 1e-9) { best = util; nw = c; }
+            const double score = util * (head_dim == 128 ? eff_128[i] : eff_small[i]);
+            if (score > best + 1e-9) { best = score; nw = c; }
         }
     }
     a.qchunks = (qblocks + nw - 1) / nw;
@@ -645,7 +650,7 @@ extern "C" int wg_sam_attn_relpos_bf16(const void* qkv, const void* qkv_bias, co
         a.qchunks = (qblocks + NW_ - 1) / NW_;                     \
         return launch_attn<HD_, S_, NW_>(a, groups, st);           \
     }
-    WG_SAM_CASE(64, 14, 7)
+    WG_SAM_CASE(64, 14, 4)   // two 4-wave workgroups per window (one idle query slot in eight) measured 5 % faster than one of 7 waves
     WG_SAM_CASE(64, 64, 8)
     WG_SAM_CASE(64, 32, 8)
     WG_SAM_CASE(32, 14, 7)
