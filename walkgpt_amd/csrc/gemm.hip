@@ -53,6 +53,24 @@ __device__ __forceinline__ void wg_tile_of(int wgid, int tiles_m, int tiles_n, i
     tile_n = c0 + idx % w;
 }
 
+// Diagnostic build only (-DWG_GEMM_STAMP, tools/gemm_stamps.py): lane 0 of waves 0 and 4 of workgroup 0 records s_memtime at the
+// half-phase boundaries of K slabs 2..9 of the ping-pong loop into the LDS bytes behind the two slabs.  No stamp in normal builds.
+#ifdef WG_GEMM_STAMP
+__device__ unsigned* wg_gemm_stamp_ptr = nullptr;
+extern "C" int wg_debug_gemm_stamps(unsigned* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(wg_gemm_stamp_ptr), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#define WG_GSTAMP(k)                                                                                                              \
+    do {                                                                                                                          \
+        if (blockIdx.x == 0 && (wave & 3) == 0 && kt >= 2 && kt < 10) {                                                            \
+            const unsigned now = (unsigned)__builtin_amdgcn_s_memtime();                                                          \
+            if (lane == 0) ((volatile unsigned*)(smem + 2 * STAGE))[(((wave >> 2) * 8 + (kt - 2)) * 4 + c) * 8 + (k)] = now;       \
+        }                                                                                                                         \
+    } while (0)
+#else
+#define WG_GSTAMP(k) do { } while (0)
+#endif
+
 template <int N_> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N_) : "memory"); }
 
 // swizzle of 16-byte chunk slots inside a K slab row (BK*2 bytes): spreads 16 rows x one chunk over all 16 slots of
@@ -188,17 +206,23 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
     const int fr = lane & 15, fq = lane >> 4;
     if constexpr (PIPE == 2) {
         // ---- ping-pong between the two waves of every SIMD (waves w and w+4 = the two M halves of the tile) -------------
-        // A slab's 64 MFMAs per wave are cut into four clusters of 16 (64 rows x 32 columns x K 64).  Every cluster is two
-        // half-phases separated by s_barrier:  M = issue this cluster's ds_reads (+ the next slab's LDS-DMA in the
-        // first cluster), wait for them;  C = the 16 MFMAs.  The bottom-half waves run one half-phase behind the top-half
-        // ones (one extra barrier up front, one at the end for the others), so on each SIMD one wave is always in C while
-        // its partner is in M: the matrix pipe sees back-to-back clusters and LDS / DMA latency sits under them.
+        // A slab's 64 MFMAs per wave are cut into two clusters of 32 (64 rows x 64 columns x K 64).  Every cluster is two
+        // half-phases separated by s_barrier:  M = this cluster's ds_reads + the next slab's LDS-DMA pieces, retire them;
+        // C = the 32 MFMAs.  The bottom-half waves run one half-phase behind the top-half ones (one extra barrier up front,
+        // one at the end for the others), so on each SIMD one wave is always in C while its partner is in M: the matrix
+        // pipe sees back-to-back clusters and LDS / DMA latency sits under them.
+        // Why two clusters and not four (the 8-phase template of cdna_hip_programming.md): in-kernel stamps
+        // (tools/gemm_stamps.py) showed every s_barrier releasing ~125 cycles after its last arrival; eight barriers per slab
+        // were ~20 % of the loop.  Both W halves were already resident, so merging the two clusters that share an A half
+        // costs no registers: +2..10 % (8192^3: 1071 -> 1183 TFLOP/s, SAM lin2 899 -> 979).
         // Hazards: reads are retired (lgkmcnt(0)) inside their own M half-phase, so a buffer is re-staged at the earliest
-        // one barrier after its last read was complete; a slab's DMA is issued in the first cluster of the previous slab
-        // and waited (vmcnt(0)) in that slab's last M, i.e. before the barrier that precedes its first read.
+        // one barrier after its last read was complete.  Slab kt+1 is sent during slab kt: W and the early A rows (6 pieces
+        // per wave) in the first M, the late A rows (2 pieces) in the second; the counted waits leave exactly the pieces
+        // that are not needed by the next M in flight (memory operations retire in issue order).
         static_assert(FI == 8 && FJ == 4, "written for 128x64 wave tiles");
-        const int grp = wm;   // 0: top half (leads), 1: bottom half (lags by one half-phase)
-        bf16x8 af[4][2], wf2[2][2][2];   // A fragments of the current 64-row half; W fragments of BOTH 32-column halves stay resident
+        static_assert(BM / ROWS_PER_ROUND == 4 && BN / ROWS_PER_ROUND == 4, "piece schedule assumes four 64-row rounds per operand");
+        const int grp = wm;
+        bf16x8 af[4][2], wf2[2][2][2];
         auto read_a = [&](const char* ldsA, int ci) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -217,12 +241,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
                     wf2[cj][j][ks] = *(const bf16x8*)(ldsW + r * ROWB + (((ks * 4 + fq) ^ wg_swz<BK>(r)) << 4));
                 }
         };
-        // The next slab's 8 LDS-DMA pieces per wave are spread over the four M half-phases (2 each; a piece costs ~60+ issue
-        // cycles, so all eight in one half-phase would outlast the partner's 256-cycle MFMA cluster).  Issue order
-        // W rows 0-127, W rows 128-255, A rows {0-63, 128-191}, A rows {64-127, 192-255}: the first cluster of the next slab
-        // needs all of W and the first 64 rows of each A half, its third cluster the rest -- so the pieces issued last are
-        // the ones read last, and the waits are counted (memory operations retire in issue order).
-        auto piece = [&](int kt, int which) {   // which: 0,1 = W round pairs; 2 = A rounds 0,2; 3 = A rounds 1,3
+        auto piece = [&](int kt, int which) {   // which: 0,1 = W round pairs; 2 = A rounds 0,2 (early); 3 = A rounds 1,3 (late)
             char* ldsA = smem + (kt & 1) * STAGE;
             char* ldsW = ldsA + BM * ROWB;
             const int k0 = kt * BK;
@@ -237,47 +256,55 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
                 }
             }
         };
-        static_assert(BM / ROWS_PER_ROUND == 4 && BN / ROWS_PER_ROUND == 4, "piece schedule assumes four 64-row rounds per operand");
         stage(0, 0);
         wg_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (grp == 1) __builtin_amdgcn_s_barrier();   // half-phase 0: only the leading group works
+        if (grp == 1) __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nk; ++kt) {
             const char* ldsA = smem + (kt & 1) * STAGE;
             const char* ldsW = ldsA + BM * ROWB;
             const bool more = kt + 1 < nk;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int ci = c >> 1, cj = (c == 1 || c == 2) ? 1 : 0;   // (0,0) (0,1) (1,1) (1,0)
-                // ---- M half-phase ----
-                // LDS reads per slab: 12 + 4 + 8 + 0 (each W half is read once and reused by the second A half)
-                if (c == 0 || c == 2) read_a(ldsA, ci);
-                if (c < 2) read_w(ldsW, cj);
-                if (more) piece(kt + 1, c);
-                // in flight at this point (oldest first): [A-late pieces of THIS slab, issued in the previous slab's c=3]
-                // then this slab's pieces for kt+1.  c=1: the A-late pieces must be in before cluster 2 reads them (all but
-                // the 4 youngest); c=3: everything for kt+1 except the 2 just issued must be in before its cluster 0.
-                if (c == 1) { if (more) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
-                else if (c == 3) { if (more) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            for (int sc = 0; sc < 2; ++sc) {
+                const int c = sc;   // (stamp index)
+                // ---- M half-phase: 16 reads + 6 pieces, then 8 reads + 2 pieces
+                WG_GSTAMP(0);
+                read_a(ldsA, sc);
+                if (sc == 0) { read_w(ldsW, 0); read_w(ldsW, 1); }
+                if (more) {
+                    if (sc == 0) { piece(kt + 1, 0); piece(kt + 1, 1); piece(kt + 1, 2); }
+                    else piece(kt + 1, 3);
+                }
+                // sc 0: the late A rows of THIS slab (sent in the previous slab's sc 1) must be in before sc 1 reads them;
+                // sc 1: everything of slab kt+1 except the two pieces just sent must be in before its sc 0
+                if (sc == 0) { if (more) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+                else { if (more) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
                 __builtin_amdgcn_sched_barrier(0);
+                WG_GSTAMP(1);
                 __builtin_amdgcn_s_barrier();
-                // ---- C half-phase ----
+                WG_GSTAMP(2);
+                // ---- C half-phase: 64 rows x 64 columns x K 64
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < 2; ++j)
-                            acc[4 * ci + i][2 * cj + j] =
-                                __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[cj][j][ks], af[i][ks], acc[4 * ci + i][2 * cj + j], 0, 0, 0);
+                        for (int j = 0; j < 4; ++j)
+                            acc[4 * sc + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[j >> 1][j & 1][ks], af[i][ks], acc[4 * sc + i][j], 0, 0, 0);
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
+                WG_GSTAMP(3);
                 __builtin_amdgcn_s_barrier();
+                WG_GSTAMP(4);
             }
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();   // last half-phase: only the lagging group works
+#ifdef WG_GEMM_STAMP
+        __syncthreads();
+        if (blockIdx.x == 0 && wg_gemm_stamp_ptr)
+            for (int i = tid; i < 2 * 8 * 4 * 8; i += NT) wg_gemm_stamp_ptr[i] = ((unsigned*)(smem + 2 * STAGE))[i];
+#endif
     } else {
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
@@ -820,7 +847,11 @@ static int launch_tile_impl(GemmArgs& g, hipStream_t st) {
     }
     constexpr int lds_main = STAGES * (BM + BN) * BK * 2;
     constexpr int lds_stg = WM * WN * 64 * ((BN / WN) * 2 + 16);
+#ifdef WG_GEMM_STAMP
+    constexpr int lds = (lds_main > lds_stg ? lds_main : lds_stg) + 4096;
+#else
     constexpr int lds = lds_main > lds_stg ? lds_main : lds_stg;
+#endif
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)wg_gemm_kernel<BM, BN, BK, STAGES, WM, WN, STAGED, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
