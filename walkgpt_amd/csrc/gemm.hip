@@ -403,6 +403,9 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
                 __builtin_amdgcn_wave_barrier();
             }
         };
+        // (Measured alternative: no LDS round trip -- one v_permlane16_swap between the packed halves of fragments j and j+1 gives
+        // every lane 16 contiguous bytes, stored as 64-byte row segments.  Correct, but 3-6 % slower than this staged form on every
+        // shape: half-line stores cost more than the LDS transpose.)
         if (g.R) finish(std::true_type{}); else finish(std::false_type{});
         return;
     }
