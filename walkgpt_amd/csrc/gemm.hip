@@ -256,8 +256,10 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
                 }
             }
         };
-        stage(0, 0);
-        wg_wait_vmcnt<0>();
+        // first slab in the order the loop consumes it; its late A rows (the two youngest pieces) may still be in flight when
+        // cluster 0 starts -- the loop's own counted wait in its first M half-phase covers them
+        piece(0, 0); piece(0, 1); piece(0, 2); piece(0, 3);
+        wg_wait_vmcnt<2>();
         __builtin_amdgcn_s_barrier();
         if (grp == 1) __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nk; ++kt) {
