@@ -9,14 +9,19 @@ a = torch.randn(M, K, device=dev).to(torch.bfloat16)
 w = (torch.randn(N, K, device=dev) / K ** 0.5).to(torch.bfloat16)
 b = torch.randn(N, device=dev).to(torch.bfloat16)
 out = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
-buf = torch.zeros(2 * 8 * 4 * 8, device=dev, dtype=torch.int32)
+buf = torch.zeros(1024, device=dev, dtype=torch.int32)
 lib = _lib.lib()
 lib.wg_debug_gemm_stamps.argtypes = [ctypes.c_void_p]
 assert lib.wg_debug_gemm_stamps(buf.data_ptr()) == 0
 for _ in range(20):
     ops.linear(a, w, b, out=out, tile=14)
 torch.cuda.synchronize()
-s = buf.cpu().numpy().astype("int64").reshape(2, 8, 4, 8) & 0xffffffff
+raw = buf.cpu().numpy().astype("int64") & 0xffffffff
+s = raw[:512].reshape(2, 8, 4, 8)
+for blk in (0, 1):
+    for g in (0, 1):
+        t = raw[512 + blk * 16 + g * 8: 512 + blk * 16 + g * 8 + 4]
+        print("tile stamps block %s group %d: prologue %d  main loop %d  epilogue (incl. store drain) %d  total %d" % ([0, 1024][blk], g, t[1] - t[0], t[2] - t[1], t[3] - t[2], t[3] - t[0]))
 base = s[0, 0, 0, 0]
 for g in (0, 1):
     print("group", g, "(wave %d)" % (4 * g))

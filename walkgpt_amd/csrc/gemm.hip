@@ -67,8 +67,17 @@ extern "C" int wg_debug_gemm_stamps(unsigned* buf) {
             if (lane == 0) ((volatile unsigned*)(smem + 2 * STAGE))[(((wave >> 2) * 8 + (kt - 2)) * 4 + c) * 8 + (k)] = now;       \
         }                                                                                                                         \
     } while (0)
+// tile-level stamps: [wave half][k]: 0 kernel entry, 1 first slab landed, 2 main loop done, 3 epilogue done
+#define WG_TSTAMP(k)                                                                                                              \
+    do {                                                                                                                          \
+        if ((blockIdx.x == 0 || blockIdx.x == 1024) && (wave & 3) == 0) {                                                         \
+            const unsigned now = (unsigned)__builtin_amdgcn_s_memtime();                                                          \
+            if (lane == 0 && wg_gemm_stamp_ptr) wg_gemm_stamp_ptr[512 + (blockIdx.x ? 16 : 0) + (wave >> 2) * 8 + (k)] = now;    \
+        }                                                                                                                         \
+    } while (0)
 #else
 #define WG_GSTAMP(k) do { } while (0)
+#define WG_TSTAMP(k) do { } while (0)
 #endif
 
 template <int N_> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N_) : "memory"); }
@@ -258,9 +267,11 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
         };
         // first slab in the order the loop consumes it; its late A rows (the two youngest pieces) may still be in flight when
         // cluster 0 starts -- the loop's own counted wait in its first M half-phase covers them
+        WG_TSTAMP(0);
         piece(0, 0); piece(0, 1); piece(0, 2); piece(0, 3);
         wg_wait_vmcnt<2>();
         __builtin_amdgcn_s_barrier();
+        WG_TSTAMP(1);
         if (grp == 1) __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nk; ++kt) {
             const char* ldsA = smem + (kt & 1) * STAGE;
@@ -351,6 +362,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
     }
     }
     __syncthreads();  // every wave is done with the last K slab before the staging slabs reuse the LDS
+    if constexpr (PIPE == 2) { WG_TSTAMP(2); }
 
     // ---- epilogue -------------------------------------------------------------------------------------------------------
     // acc[i][j][e]: output row m = .. + i*16 + (lane&15), column n = .. + j*16 + (lane>>4)*4 + e.
@@ -409,6 +421,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
         // every lane 16 contiguous bytes, stored as 64-byte row segments.  Correct, but 3-6 % slower than this staged form on every
         // shape: half-line stores cost more than the LDS transpose.)
         if (g.R) finish(std::true_type{}); else finish(std::false_type{});
+        if constexpr (PIPE == 2) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); WG_TSTAMP(3); }
         return;
     }
 #pragma unroll
