@@ -17,7 +17,7 @@ def _ref_act(y, act):
     return y
 
 
-@pytest.mark.parametrize("tile", [1, 2, 14, 11])
+@pytest.mark.parametrize("tile", [1, 2, 14, 11, 16])
 def test_gemm_exact_integer_asymmetric(dev, tile):
     # small integers: every product and partial sum is exact in bf16 x bf16 -> fp32, so the result must be
     # bit-exact; W is asymmetric so a transposed / permuted fragment map cannot pass.
@@ -34,7 +34,8 @@ def test_gemm_exact_integer_asymmetric(dev, tile):
 @pytest.mark.parametrize("M,N,K,tile", [(8200, 1024, 1024, 1), (8200, 3072, 1024, 2), (4096, 768, 3072, 2),
                                         (77, 256, 256, 1), (1, 512, 4096, 1), (1000, 2304, 768, 0),
                                         (8200, 3072, 1024, 14), (4096, 768, 3072, 14), (300, 512, 64, 14), (700, 256, 128, 14),
-                                        (5000, 1024, 192, 11)])
+                                        (5000, 1024, 192, 11), (8200, 3072, 1024, 16), (4096, 768, 3072, 16), (300, 512, 64, 16),
+                                        (33000, 1280, 256, 16)])
 @pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_GELU, ops.ACT_QUICK_GELU, ops.ACT_RELU])
 def test_gemm_epilogues(dev, M, N, K, tile, act):
     g = torch.Generator().manual_seed(M + N + K + act)

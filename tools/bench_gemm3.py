@@ -12,7 +12,7 @@ def t(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n
-NAMES = {1: "128", 11: "128persist", 12: "128tail", 2: "256", 14: "256pp"}
+NAMES = {11: "128persist", 14: "256pp", 16: "256ppP"}
 shapes = [("sam qkv", 32768, 2304, 768, "bias"), ("sam proj", 32768, 768, 768, "resid"), ("sam lin1", 32768, 3072, 768, "gelu"),
           ("sam lin2", 32768, 768, 3072, "resid"), ("clip qkv", 8200, 3072, 1024, "bias"), ("clip out", 8200, 1024, 1024, "resid"),
           ("clip fc1", 8200, 4096, 1024, "qgelu"), ("clip fc2", 8200, 1024, 4096, "resid"), ("8k", 8192, 8192, 8192, "none"),

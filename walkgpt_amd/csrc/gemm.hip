@@ -901,6 +901,257 @@ static int launch_persist(GemmArgs& g, hipStream_t st) {
     return wg_check_launch("wg_gemm_bias_act_bf16(persistent)");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent 256x256 tiles with the two-cluster ping-pong loop of wg_gemm_kernel (bf16 output, staged epilogue).
+// Tile-level stamps on the K = 768 shapes put 5 % of a tile's life into the first-slab latency and ~6 % into waiting for
+// its 128 KiB of output stores before the workgroup may retire.  One workgroup per CU walks tiles v, v+grid, ...:
+//   * the next tile's first slab (and its bias row, by LDS-DMA) is sent right after the last slab's barrier and lands under
+//     the epilogue, which stages through buffer 1's region (+ a 9 KiB extension for wave 7);
+//   * the next main loop starts behind a COUNTED wait: memory operations retire in issue order, so `vmcnt(NSTORE)` waits
+//     for the slab (older) and leaves the tile's 16 output stores per wave (younger) draining under the next loop;
+//   * residual rows are loaded one 64-row slab at a time, the second slab's loads issued after the first slab's sums are
+//     formed but BEFORE its stores (registers reused; the later wait for them then never includes a store).
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 64, WN = 4;
+    constexpr int WTM = 128, WTN = 64, FJ = 4;
+    constexpr int ROWB = 128, STAGE = (BM + BN) * ROWB, RPI = 8, RPR = 64;   // RPR: rows per LDS-DMA round of the 8 waves
+    constexpr int SROW = WTN * 2 + 16, CH = 8, RPS = 8;
+    constexpr int NIT = 64 / RPS;                        // store instructions per 64-row slab
+    constexpr int NSTORE = (WTM / 64) * NIT;             // ... per wave per tile
+    constexpr int SLAB = 64 * SROW;
+    constexpr int FIT = STAGE / SLAB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int grp = wm;
+    char* stg = wave < FIT ? smem + STAGE + wave * SLAB : smem + 2 * STAGE + (wave - FIT) * SLAB;
+    char* biasbuf = smem + 2 * STAGE + SLAB;   // [2][256] bf16, double-buffered by tile parity
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int nk = g.K / BK;
+    auto tile_of = [&](int v, int& m0, int& n0) {
+        const int q = nwg >> 3, r = nwg & 7, xcd = v & 7;
+        const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        int tm, tn;
+        wg_tile_of(wgid, g.tiles_m, g.tiles_n, g.col_block, tm, tn);
+        m0 = tm * BM;
+        n0 = tn * BN;
+    };
+    const bf16* srcA[4];
+    const bf16* srcW[4];
+    auto set_sources = [&](int m0, int n0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * RPR + wave * RPI + (lane >> 3);
+            const int c = (lane & 7) ^ wg_swz<BK>(r);
+            int ga = m0 + r, gw = n0 + r;
+            ga = ga < g.M ? ga : g.M - 1;
+            gw = gw < g.N ? gw : g.N - 1;
+            srcA[i] = g.A + (long)ga * g.lda + c * 8;
+            srcW[i] = g.W + (long)gw * g.ldw + c * 8;
+        }
+    };
+    auto piece = [&](int kt, int which) {   // which: 0,1 = W round pairs; 2 = A rounds 0,2 (early); 3 = A rounds 1,3 (late)
+        char* ldsA = smem + (kt & 1) * STAGE;
+        char* ldsW = ldsA + BM * ROWB;
+        const int k0 = kt * BK;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (which < 2) {
+                const int i = which * 2 + u;
+                __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcW[i] + k0), WG_LDS_PTR(ldsW + (i * RPR + wave * RPI) * ROWB), 16, 0, 0);
+            } else {
+                const int i = (which - 2) + 2 * u;
+                __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcA[i] + k0), WG_LDS_PTR(ldsA + (i * RPR + wave * RPI) * ROWB), 16, 0, 0);
+            }
+        }
+    };
+    auto first_slab = [&](int n0, int par) {
+        if (g.bias && wave == 0 && lane < 32) {   // the tile's 256 bias values: one 512-byte LDS-DMA
+            int n = n0 + lane * 8;
+            n = n + 8 <= g.N ? n : 0;             // columns past N are never stored
+            __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(g.bias + n), WG_LDS_PTR(biasbuf + par * 512), 16, 0, 0);
+        }
+        piece(0, 0); piece(0, 1); piece(0, 2); piece(0, 3);
+    };
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.c_bytes, WG_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.R, 0, g.r_bytes, WG_RSRC_FLAGS);
+
+    int v = blockIdx.x;
+    int m0, n0;
+    tile_of(v, m0, n0);
+    set_sources(m0, n0);
+    first_slab(n0, 0);
+    bool stores_in_flight = false;
+    int par = 0;
+
+    while (true) {
+        const int nbase = n0 + wn * WTN;
+        f32x4 acc[8][FJ];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 af[4][2], wf2[2][2][2];
+        auto read_a = [&](const char* ldsA, int ci) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int r = wm * WTM + (4 * ci + i) * 16 + fr;
+                    af[i][ks] = *(const bf16x8*)(ldsA + r * ROWB + (((ks * 4 + fq) ^ wg_swz<BK>(r)) << 4));
+                }
+        };
+        auto read_w = [&](const char* ldsW, int cj) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int r = wn * WTN + (2 * cj + j) * 16 + fr;
+                    wf2[cj][j][ks] = *(const bf16x8*)(ldsW + r * ROWB + (((ks * 4 + fq) ^ wg_swz<BK>(r)) << 4));
+                }
+        };
+        // the whole first slab (older than the previous tile's stores) has landed; those stores may still be draining
+        if (stores_in_flight) wg_wait_vmcnt<NSTORE>(); else wg_wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (grp == 1) __builtin_amdgcn_s_barrier();
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* ldsA = smem + (kt & 1) * STAGE;
+            const char* ldsW = ldsA + BM * ROWB;
+            const bool more = kt + 1 < nk;
+#pragma unroll
+            for (int sc = 0; sc < 2; ++sc) {
+                read_a(ldsA, sc);
+                if (sc == 0) { read_w(ldsW, 0); read_w(ldsW, 1); }
+                if (more) {
+                    if (sc == 0) { piece(kt + 1, 0); piece(kt + 1, 1); piece(kt + 1, 2); }
+                    else piece(kt + 1, 3);
+                }
+                if (sc == 0) {
+                    // late A rows of this slab must be in.  In slab 0 they are (first-slab wait above) and the queue may still hold
+                    // the previous tile's stores in front of the six pieces just sent: do not wait for those here.
+                    if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    else if (kt == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+                } else {
+                    if (more) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[4 * sc + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[j >> 1][j & 1][ks], af[i][ks], acc[4 * sc + i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        if (grp == 0) __builtin_amdgcn_s_barrier();
+        // every wave is past its last LDS read of this tile (each M half-phase retired its reads before its barrier)
+
+        const int vn = v + gridDim.x;
+        const bool has_next = vn < nwg;
+        const int cm0 = m0;
+        // opaque copies of the lane coordinates: keeps hipcc from hoisting the epilogue's tile-invariant address arithmetic
+        // out of the tile loop, where it would stay live across the main loop
+        int el = lane, efr = fr, efq = fq;
+        asm volatile("" : "+v"(el), "+v"(efr), "+v"(efq));
+        float bv[FJ][4];
+#pragma unroll
+        for (int j = 0; j < FJ; ++j) {
+            bf16x4 b = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+            if (g.bias) b = *(const bf16x4*)(biasbuf + par * 512 + (wn * WTN + j * 16 + efq * 4) * 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[j][e] = (float)b[e];
+        }
+        if (has_next) {
+            tile_of(vn, m0, n0);
+            set_sources(m0, n0);
+            first_slab(n0, par ^ 1);
+        }
+        auto finish = [&](auto has_r) __attribute__((always_inline)) {
+            constexpr bool HAS_R = decltype(has_r)::value;
+            u32x4 rres[NIT];
+            if (HAS_R) wg_load_residual<CH, NIT>(rres, rrs, (int)g.ldr, g.res_mod, cm0 + wm * WTM, nbase, el);
+#pragma unroll
+            for (int half = 0; half < WTM / 64; ++half) {
+                WG_ACT_SWITCH(g.act,
+                    _Pragma("unroll") for (int i = 0; i < 4; ++i) {
+                        _Pragma("unroll") for (int j = 0; j < FJ; ++j)
+                            *(bf16x4*)(stg + (i * 16 + efr) * SROW + (j * 16 + efq * 4) * 2) = wg_epi_pack<ACT>(acc[half * 4 + i][j], bv[j]);
+                    })
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+                // slab reads + residual sums, then (first slab) the second slab's residual loads into the same registers, then
+                // the stores: no load is ever issued behind a store that a later wait would have to cover
+                constexpr int RPSl = 64 / CH;
+                bf16x8 o[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) o[it] = *(const bf16x8*)(stg + (it * RPSl + el / CH) * SROW + (el % CH) * 16);
+                if (HAS_R) {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const bf16x8 r = __builtin_bit_cast(bf16x8, rres[it]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) o[it][e] = (bf16)((float)o[it][e] + (float)r[e]);
+                    }
+                }
+                u32x4 t[NIT];
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    t[it] = __builtin_bit_cast(u32x4, o[it]);
+                    asm volatile("" : "+v"(t[it]));
+                }
+                if (HAS_R && half + 1 < WTM / 64) wg_load_residual<CH, NIT>(rres, rrs, (int)g.ldr, g.res_mod, cm0 + wm * WTM + (half + 1) * 64, nbase, el);
+                const int n = nbase + (el % CH) * 8;
+                const int off0 = n < g.N ? ((cm0 + wm * WTM + half * 64 + el / CH) * (int)g.ldc + n) * 2 : (int)0x80000000;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) __builtin_amdgcn_raw_buffer_store_b128(t[it], crs, off0 + it * RPSl * (int)g.ldc * 2, 0, 0);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+        if (g.R) finish(std::true_type{}); else finish(std::false_type{});
+        if (!has_next) break;
+        v = vn;
+        par ^= 1;
+        // every wave issues all NSTORE store instructions of a tile (rows / columns outside the matrix are dropped by the buffer
+        // range check, not branched around) and every load of the epilogue is consumed before the last stores issue: exact count
+        stores_in_flight = true;
+    }
+}
+
+static int launch_pp_persist(GemmArgs& g, hipStream_t st) {
+    g.tiles_m = (g.M + 255) / 256;
+    g.tiles_n = (g.N + 255) / 256;
+    {
+        const long panel = 256L * g.K * 2, wbytes = (long)g.N * g.K * 2;
+        const int cb = (int)((3L << 19) / (panel > 0 ? panel : 1));
+        g.col_block = (wbytes > (3L << 20) && cb >= 2 && cb < g.tiles_n) ? cb : 0;
+    }
+    constexpr int stage = 512 * 128, slab = 64 * (64 * 2 + 16);
+    constexpr int lds = 2 * stage + (8 - stage / slab) * slab + 2 * 512;   // + the double-buffered bias row
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int grid = nwg < 256 ? nwg : 256;   // one resident workgroup per CU; a multiple of 8 keeps a workgroup's tiles on one XCD
+    hipLaunchKernelGGL(wg_gemm_pp_persist_kernel, dim3(grid), dim3(512), lds, st, g);
+    return wg_check_launch("wg_gemm_bias_act_bf16(ping-pong persistent)");
+}
+
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, int PIPE = 0>
 static int launch_tile(GemmArgs& g, hipStream_t st) {
     // staged (LDS-transposed, 16-byte) epilogue for bf16 outputs whose rows are 16-byte addressable
@@ -945,7 +1196,8 @@ extern "C" int wg_gemm_pick_tile_ex(int M, int N, int allow_tail) {
         const double e128 = (double)t128 / (double)(((t128 + 511) / 512) * 512);
         if (e128 > 1.2 * e256) return 11;
     }
-    return 14;                                // 256x256 tiles, ping-pong schedule (+3..16 % over the plain loop at K <= 4096)
+    return 16;                                // 256x256 tiles, ping-pong schedule, persistent (falls back to 14 = one tile per workgroup
+                                              // when the output cannot take the staged epilogue)
 }
 
 extern "C" int wg_gemm_pick_tile(int M, int N) { return wg_gemm_pick_tile_ex(M, N, 0); }
@@ -986,13 +1238,15 @@ extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, lon
                            (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0 && g.r_bytes != 0));
     const bool small_ops = (long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31);
     if (tile == 11 && !(can_stage && small_ops)) tile = 1;
-    if (tile != 1 && tile != 2 && tile != 11 && tile != 12 && tile != 14) tile = 1;
+    if (tile == 16 && !(can_stage && small_ops && (!bias || ((uintptr_t)bias % 16 == 0 && N % 8 == 0)))) tile = 14;
+    if (tile != 1 && tile != 2 && tile != 11 && tile != 12 && tile != 14 && tile != 16) tile = 1;
     if (tile == 12 && !(can_stage && M >= 128 && M % 128 >= 1 && M % 128 <= 16)) tile = 1;
     switch (tile) {
         case 12: return launch_tail(g, st);                            // 128x128 tiles, last row tile absorbs M % 128 <= 16 rows
         case 11: return launch_persist<128, 128, 2, 2>(g, st);         // persistent 128x128 tiles, 2 workgroups / CU
         case 2: return launch_tile<256, 256, 64, 2, 2, 4>(g, st);      // 256x256, plain two-slab loop (best at K >= 8192)
         case 14: return launch_tile<256, 256, 64, 2, 2, 4, 2>(g, st);  // 256x256, ping-pong between the two waves of each SIMD
+        case 16: return launch_pp_persist(g, st);                      // the same loop, persistent tiles (first slab / store drain hidden)
         default: return launch_tile<128, 128, 64, 2, 2, 2>(g, st);  //  64 KiB LDS, 4 waves, 2 workgroups / CU
     }
 }
