@@ -43,7 +43,9 @@ const char* wg_last_error(void);    /* thread-local, valid until the next failin
  * MFMA path needs K%64==0, N%4==0, N>=16, lda/ldw %8==0, ldc/ldr %4==0, 16-byte aligned A/W/C; anything else takes a
  * slower one-wave-per-row kernel.  tile_hint: 0 = auto (wg_gemm_pick_tile), 1 = 128x128 tiles (2 workgroups/CU),
  * 11 = persistent 128x128 tiles, 12 = 128x128 tiles whose last row tile absorbs M % 128 <= 16 rows, 2 = 256x256 tiles
- * (8 waves, 1 workgroup/CU), 14 = 256x256 tiles with the ping-pong schedule, 3 = force row-wave. */
+ * (8 waves, 1 workgroup/CU), 14 = 256x256 tiles with the ping-pong schedule, 16 = the same as persistent tiles (one resident
+ * workgroup per CU walks the tile grid; the auto choice for big shapes), 3 = force row-wave.  Variants that need the staged
+ * 16-byte epilogue (11, 12, 16) fall back to 1 / 14 when the output is fp32, misaligned or larger than 2 GiB. */
 int wg_gemm_pick_tile(int M, int N);
 /* same, optionally allowing tile 12 = 128x128 tiles whose last row tile absorbs M % 128 <= 16 leftover rows (CLIP's
  * M = B*1025): faster when GEMMs run back to back on one stream, slower when two streams share the chip. */
