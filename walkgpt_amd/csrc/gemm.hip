@@ -1161,7 +1161,7 @@ static int launch_tile(GemmArgs& g, hipStream_t st) {
                   : launch_tile_impl<BM, BN, BK, STAGES, WM, WN, false, PIPE>(g, st);
 }
 
-// Tile choice (measured, tools/bench_gemm3.py and bench.py with WG_GEMM_TILE=n on MI355X): the 256x256 kernel
+// Tile choice (measured, tools/bench_gemm.py and bench.py with WG_GEMM_TILE=n on MI355X): the 256x256 kernel
 // (8 waves, 1 workgroup / CU) is ~15 % better per tile-slot than the 128x128 one, and with the CLIP tower and the SAM
 // branch on two streams a partially filled last round is back-filled by the other stream -- so wave quantisation
 // decides only for shapes that cannot fill even one round of big tiles.
