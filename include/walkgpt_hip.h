@@ -54,6 +54,18 @@ int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, cons
                           long ldr, int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32,
                           int tile_hint, void* stream);
 
+/* The same product with the LayerNorm in front of it folded in (image_encoder.py:177-178 norm1 -> attn.qkv, :191 norm2 ->
+ * mlp.lin1; HF CLIPEncoderLayer layer_norm1 -> q/k/v_proj, layer_norm2 -> mlp.fc1):
+ *   C = act(rstd_m * (A Wg^T - mean_m * colsum) + bias_f32),  Wg = bf16(W * gamma), colsum[n] = sum_k Wg[n,k] (fp32),
+ *   bias_f32[n] = b[n] + sum_k W[n,k] beta[k] (fp32), stats[m] = {mean, rstd} of row m of A from wg_row_stats_bf16.
+ * A is the RAW residual stream, so the normalised rows never travel through HBM.  stats must be 16-byte aligned and hold M
+ * rounded up to an even number of rows.  Runs on the persistent 256x256 kernel only: wg_gemm_ln_supported() != 0 says whether
+ * a shape qualifies (callers otherwise run wg_layernorm_rows + wg_gemm_bias_act_bf16). */
+int wg_row_stats_bf16(const void* x, long ldx, float* stats, int M, int D, float eps, void* stream);
+int wg_gemm_ln_supported(int M, int N, int K, long lda, long ldw, long ldc);
+int wg_gemm_ln_bias_act_bf16(const void* A, long lda, const void* Wg, long ldw, const float* bias_f32, const float* colsum,
+                             const float* stats, void* C, long ldc, int M, int N, int K, int act, void* stream);
+
 /* y = act(LayerNorm(x) * gamma + beta) per row, biased variance, eps inside the sqrt.
  * nn.LayerNorm: image_encoder.py:177,191 (eps 1e-6), transformer.py:157-181, utils_walkgpt.py:166-167,207,311,315,
  * HF CLIP layer norms; LayerNorm2d (common.py:31-43) on channels-last rows: neck (image_encoder.py:98,106),

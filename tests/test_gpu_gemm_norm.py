@@ -111,3 +111,29 @@ def test_layernorm_rows(dev, M, D, eps):
     out = ops.layernorm(x.to(dev), gm.to(dev), bt.to(dev), eps)
     # output is rounded to bf16: half an ulp of the largest value
     assert (out.float().cpu() - ref).abs().max().item() <= 0.004 * ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(8200, 3072, 1024), (8200, 4096, 1024), (32768, 2304, 768), (4096, 3072, 768),
+                                   (1025, 3072, 1024), (300, 512, 256), (5125, 1280, 320)])
+@pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_GELU, ops.ACT_QUICK_GELU])
+def test_ln_linear_folded(dev, M, N, K, act):
+    """LayerNorm folded into the GEMM (row statistics + persistent kernel epilogue) against fp32 LayerNorm -> linear; rows carry
+    a mean several times their spread, so a wrong mean / column-sum term cannot hide.  Small or odd shapes take the two-kernel
+    route inside ops.ln_linear and must agree as well."""
+    g = torch.Generator().manual_seed(M + N + K + act)
+    x = (torch.randn(M, K, generator=g) * (0.5 + torch.rand(M, 1, generator=g)) + 3.0 * torch.randn(M, 1, generator=g)).to(torch.bfloat16)
+    gamma = (1.0 + 0.3 * torch.randn(K, generator=g)).to(torch.bfloat16)
+    beta = (0.2 * torch.randn(K, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16)
+    ref = _ref_act(torch.nn.functional.linear(torch.nn.functional.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-6),
+                                              w.float(), b.float()), act)
+    fold = ops.fold_layernorm(gamma.to(dev), beta.to(dev), w.to(dev), b.to(dev))
+    out = ops.ln_linear(x.to(dev), fold, 1e-6, act=act)
+    assert out.shape == (M, N) and out.dtype == torch.bfloat16
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err <= 0.03 * max(1.0, ref.abs().max().item()), err
+    st = ops.row_stats(x.to(dev), 1e-6)[:M].cpu()
+    xf = x.float()
+    assert torch.allclose(st[:, 0], xf.mean(1), atol=1e-5, rtol=1e-5)
+    assert torch.allclose(st[:, 1], (xf.var(1, unbiased=False) + 1e-6).rsqrt(), atol=1e-5, rtol=1e-4)

@@ -69,21 +69,22 @@ class _EncoderLayer(nn.Module, _Prepared):
         self.layer_norm2 = nn.LayerNorm(D, eps=cfg.layer_norm_eps)
 
     def _build(self):
-        a = self.self_attn
-        return {"w": torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).contiguous(),
-                "b": torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).contiguous()}
+        a, n1, n2, m = self.self_attn, self.layer_norm1, self.layer_norm2, self.mlp
+        w = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).contiguous()
+        b = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).contiguous()
+        return {"qkv": ops.fold_layernorm(n1.weight, n1.bias, w, b),
+                "fc1": ops.fold_layernorm(n2.weight, n2.bias, m.fc1.weight, m.fc1.bias)}
 
     def run(self, x, key_bias):
-        """HF CLIPEncoderLayer: pre-LN attention + pre-LN quick-GELU MLP, both residual.  x [B, L, D]."""
+        """HF CLIPEncoderLayer: pre-LN attention + pre-LN quick-GELU MLP, both residual.  x [B, L, D].
+        Both LayerNorms are folded into the GEMM behind them (ops.ln_linear)."""
         a = self.self_attn
         p = self._prep_get(self._build)
         D = x.shape[-1]
-        y = ops.layernorm(x, self.layer_norm1.weight, self.layer_norm1.bias, self.layer_norm1.eps)
-        qkv = ops.linear(y, p["w"], p["b"])
+        qkv = ops.ln_linear(x, p["qkv"], self.layer_norm1.eps)
         o = ops.mha(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], a.num_heads, a.scale, key_bias, small=False)
         x = ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=x)
-        y = ops.layernorm(x, self.layer_norm2.weight, self.layer_norm2.bias, self.layer_norm2.eps)
-        h = ops.linear(y, self.mlp.fc1.weight, self.mlp.fc1.bias, act=ops.ACT_QUICK_GELU)
+        h = ops.ln_linear(x, p["fc1"], self.layer_norm2.eps, act=ops.ACT_QUICK_GELU)
         return ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x)
 
 

@@ -30,6 +30,9 @@ struct GemmArgs {
     int out_f32;
     int tiles_m, tiles_n;
     int col_block;               // tile order: column blocks of this many tile columns, row-major inside a block (0 = plain row-major)
+    const float* ln_stats;       // LayerNorm folded into this GEMM (persistent kernel only): [M][2] = {mean, rstd} of the rows of A,
+    const float* ln_s;           //   [N] column sums of the (gamma-scaled, bf16) weight rows,
+    const float* ln_b;           //   [N] folded bias  b + W beta:   C = rstd * (A W'^T - mean * s) + b'
     unsigned c_bytes, r_bytes;   // extents of C and R for the staged epilogue's buffer descriptors (0: not addressable in 32 bits)
 };
 
@@ -912,6 +915,7 @@ static int launch_persist(GemmArgs& g, hipStream_t st) {
 //   * residual rows are loaded one 64-row slab at a time, the second slab's loads issued after the first slab's sums are
 //     formed but BEFORE its stores (registers reused; the later wait for them then never includes a store).
 // ---------------------------------------------------------------------------------------------------------------------
+template <bool LN>
 __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) {
     constexpr int BM = 256, BN = 256, BK = 64, WN = 4;
     constexpr int WTM = 128, WTN = 64, FJ = 4;
@@ -971,8 +975,24 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
             }
         }
     };
-    auto first_slab = [&](int n0, int par) {
-        if (g.bias && wave == 0 && lane < 32) {   // the tile's 256 bias values: one 512-byte LDS-DMA
+    // LN: per tile parity  s[256] f32 | b'[256] f32 | stats[256][2] f32  (4 KiB), all by LDS-DMA like the bias row
+    constexpr int EPIB = LN ? 4096 : 512;
+    auto first_slab = [&](int m0, int n0, int par) {
+        if (LN) {
+            if (wave == 0) {
+                int n = n0 + lane * 4;
+                n = n + 4 <= g.N ? n : 0;         // columns past N are never stored
+                __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(g.ln_s + n), WG_LDS_PTR(biasbuf + par * EPIB), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(g.ln_b + n), WG_LDS_PTR(biasbuf + par * EPIB + 1024), 16, 0, 0);
+            } else if (wave == 1) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    int m = m0 + u * 128 + lane * 2;
+                    m = m < g.M ? m : 0;          // rows past M are never stored; the buffer holds an even number of rows
+                    __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(g.ln_stats + 2 * (long)m), WG_LDS_PTR(biasbuf + par * EPIB + 2048 + u * 1024), 16, 0, 0);
+                }
+            }
+        } else if (g.bias && wave == 0 && lane < 32) {   // the tile's 256 bias values: one 512-byte LDS-DMA
             int n = n0 + lane * 8;
             n = n + 8 <= g.N ? n : 0;             // columns past N are never stored
             __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(g.bias + n), WG_LDS_PTR(biasbuf + par * 512), 16, 0, 0);
@@ -986,7 +1006,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
     int m0, n0;
     tile_of(v, m0, n0);
     set_sources(m0, n0);
-    first_slab(n0, 0);
+    first_slab(m0, n0, 0);
     bool stores_in_flight = false;
     int par = 0;
 
@@ -1067,17 +1087,20 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
         int el = lane, efr = fr, efq = fq;
         asm volatile("" : "+v"(el), "+v"(efr), "+v"(efq));
         float bv[FJ][4];
+        if (!LN) {
 #pragma unroll
-        for (int j = 0; j < FJ; ++j) {
-            bf16x4 b = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-            if (g.bias) b = *(const bf16x4*)(biasbuf + par * 512 + (wn * WTN + j * 16 + efq * 4) * 2);
+            for (int j = 0; j < FJ; ++j) {
+                bf16x4 b = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+                if (g.bias) b = *(const bf16x4*)(biasbuf + par * 512 + (wn * WTN + j * 16 + efq * 4) * 2);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) bv[j][e] = (float)b[e];
+                for (int e = 0; e < 4; ++e) bv[j][e] = (float)b[e];
+            }
         }
+        const char* lnbuf = biasbuf + par * EPIB;
         if (has_next) {
             tile_of(vn, m0, n0);
             set_sources(m0, n0);
-            first_slab(n0, par ^ 1);
+            first_slab(m0, n0, par ^ 1);
         }
         auto finish = [&](auto has_r) __attribute__((always_inline)) {
             constexpr bool HAS_R = decltype(has_r)::value;
@@ -1085,6 +1108,30 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
             if (HAS_R) wg_load_residual<CH, NIT>(rres, rrs, (int)g.ldr, g.res_mod, cm0 + wm * WTM, nbase, el);
 #pragma unroll
             for (int half = 0; half < WTM / 64; ++half) {
+                if (LN) {
+                    // LayerNorm folded into the GEMM: y = LN(x) W^T + b = rstd * (x W'^T - mean * s) + b' with W' = W * gamma (per
+                    // input column), s = row sums of W', b' = b + W beta.  A holds the RAW rows x (statistics: wg_row_stats_bf16).
+                    float lnr[4], lnm[4];   // rstd and mean * rstd of this lane's 4 accumulator rows of this half
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const f32x2 st2 = *(const f32x2*)(lnbuf + 2048 + (wm * WTM + (half * 4 + i) * 16 + efr) * 8);
+                        lnr[i] = st2.y;
+                        lnm[i] = st2.x * st2.y;
+                    }
+                    WG_ACT_SWITCH(g.act,
+                        _Pragma("unroll") for (int j = 0; j < FJ; ++j) {
+                            const f32x4 s4 = *(const f32x4*)(lnbuf + (wn * WTN + j * 16 + efq * 4) * 4);
+                            const f32x4 b4 = *(const f32x4*)(lnbuf + 1024 + (wn * WTN + j * 16 + efq * 4) * 4);
+                            _Pragma("unroll") for (int i = 0; i < 4; ++i) {
+                                const float r = lnr[i]; const float mr = lnm[i];
+                                const f32x4 a4 = acc[half * 4 + i][j];
+                                f32x2 lo = {a4[0] * r + (b4[0] - mr * s4[0]), a4[1] * r + (b4[1] - mr * s4[1])};
+                                f32x2 hi = {a4[2] * r + (b4[2] - mr * s4[2]), a4[3] * r + (b4[3] - mr * s4[3])};
+                                lo = wg_act2<ACT>(lo); hi = wg_act2<ACT>(hi);
+                                *(bf16x4*)(stg + (i * 16 + efr) * SROW + (j * 16 + efq * 4) * 2) = (bf16x4){(bf16)lo.x, (bf16)lo.y, (bf16)hi.x, (bf16)hi.y};
+                            }
+                        })
+                } else
                 WG_ACT_SWITCH(g.act,
                     _Pragma("unroll") for (int i = 0; i < 4; ++i) {
                         _Pragma("unroll") for (int j = 0; j < FJ; ++j)
@@ -1140,15 +1187,18 @@ static int launch_pp_persist(GemmArgs& g, hipStream_t st) {
         g.col_block = (wbytes > (3L << 20) && cb >= 2 && cb < g.tiles_n) ? cb : 0;
     }
     constexpr int stage = 512 * 128, slab = 64 * (64 * 2 + 16);
-    constexpr int lds = 2 * stage + (8 - stage / slab) * slab + 2 * 512;   // + the double-buffered bias row
+    const int lds = 2 * stage + (8 - stage / slab) * slab + (g.ln_stats ? 2 * 4096 : 2 * 512);   // + the double-buffered bias row
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        constexpr int base = 2 * stage + (8 - stage / slab) * slab;
+        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, base + 2 * 512);
+        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, base + 2 * 4096);
         attr_done = true;
     }
     const int nwg = g.tiles_m * g.tiles_n;
     const int grid = nwg < 256 ? nwg : 256;   // one resident workgroup per CU; a multiple of 8 keeps a workgroup's tiles on one XCD
-    hipLaunchKernelGGL(wg_gemm_pp_persist_kernel, dim3(grid), dim3(512), lds, st, g);
+    if (g.ln_stats) hipLaunchKernelGGL(wg_gemm_pp_persist_kernel<true>, dim3(grid), dim3(512), lds, st, g);
+    else hipLaunchKernelGGL(wg_gemm_pp_persist_kernel<false>, dim3(grid), dim3(512), lds, st, g);
     return wg_check_launch("wg_gemm_bias_act_bf16(ping-pong persistent)");
 }
 
@@ -1202,9 +1252,36 @@ extern "C" int wg_gemm_pick_tile_ex(int M, int N, int allow_tail) {
 
 extern "C" int wg_gemm_pick_tile(int M, int N) { return wg_gemm_pick_tile_ex(M, N, 0); }
 
+static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const void* bias, const void* residual, long ldr,
+                            int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32, int tile_hint,
+                            const float* ln_stats, const float* ln_s, const float* ln_b, void* stream);
+
 extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, const void* bias,
                                      const void* residual, long ldr, int res_row_mod, void* C, long ldc, int M, int N,
                                      int K, int act, int out_f32, int tile_hint, void* stream) {
+    return wg_gemm_dispatch(A, lda, W, ldw, bias, residual, ldr, res_row_mod, C, ldc, M, N, K, act, out_f32, tile_hint, nullptr, nullptr,
+                            nullptr, stream);
+}
+
+// C = act(LayerNorm(A) . W^T + b) with the LayerNorm folded in: A = the raw rows, Wg = W * gamma (bf16), colsum[n] = sum_k Wg[n,k],
+// bias_f32[n] = b[n] + sum_k W[n,k] beta[k], stats[m] = {mean, rstd} of row m of A (wg_row_stats_bf16; the buffer must hold
+// M rounded up to an even number of rows, 16-byte aligned: rows travel to LDS in pairs).  Runs on the persistent
+// 256x256 kernel only: wg_gemm_ln_supported() tells the caller whether this shape / alignment qualifies.
+extern "C" int wg_gemm_ln_supported(int M, int N, int K, long lda, long ldw, long ldc) {
+    return (wg_gemm_pick_tile(M, N) == 16 && K % 64 == 0 && N % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 &&
+            (long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31) && ((long)(M - 1) * ldc + N) * 2 < (1L << 31)) ? 1 : 0;
+}
+extern "C" int wg_gemm_ln_bias_act_bf16(const void* A, long lda, const void* Wg, long ldw, const float* bias_f32, const float* colsum,
+                                        const float* stats, void* C, long ldc, int M, int N, int K, int act, void* stream) {
+    WG_REQUIRE(bias_f32 && colsum && stats, "gemm_ln: null operand");
+    WG_REQUIRE((((uintptr_t)bias_f32 | (uintptr_t)colsum) & 15) == 0 && ((uintptr_t)stats & 15) == 0, "gemm_ln: misaligned operand");
+    WG_REQUIRE(wg_gemm_ln_supported(M, N, K, lda, ldw, ldc) && ((uintptr_t)C & 15) == 0, "gemm_ln: shape M=%d N=%d K=%d does not run on the persistent 256x256 kernel", M, N, K);
+    return wg_gemm_dispatch(A, lda, Wg, ldw, nullptr, nullptr, 0, 0, C, ldc, M, N, K, act, 0, 16, stats, colsum, bias_f32, stream);
+}
+
+static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const void* bias, const void* residual, long ldr,
+                            int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32, int tile_hint,
+                            const float* ln_stats, const float* ln_s, const float* ln_b, void* stream) {
     WG_REQUIRE(A && W && C, "gemm: null operand");
     WG_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
     WG_REQUIRE(act >= 0 && act <= 3, "gemm: bad activation %d", act);
@@ -1216,6 +1293,7 @@ extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, lon
     g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.act = act; g.out_f32 = out_f32;
     g.tiles_m = g.tiles_n = 0;
     g.col_block = 0;
+    g.ln_stats = ln_stats; g.ln_s = ln_s; g.ln_b = ln_b;
     {   // byte extents for the staged epilogue's buffer descriptors (it addresses C and R with 32-bit byte offsets)
         const long cb = ((long)(M - 1) * ldc + N) * 2;
         const long rrows = res_row_mod > 0 ? (res_row_mod < M ? res_row_mod : M) : M;

@@ -134,3 +134,50 @@ extern "C" int wg_layernorm_rows(const void* x, long ldx, const void* gamma, con
     else hipLaunchKernelGGL(wg_layernorm_kernel<16>, grid, block, 0, st, a);
     return wg_check_launch("wg_layernorm_rows");
 }
+
+// Row statistics only (mean, 1/sqrt(var + eps)) -> stats[m] = {mean, rstd} fp32: the LayerNorm whose affine map is folded into
+// the consuming GEMM (wg_gemm_ln_bias_act_bf16) needs nothing else -- half the HBM traffic of a full LayerNorm pass.
+template <int MAXC>
+__global__ __launch_bounds__(256) void wg_row_stats_kernel(const bf16* x, long ldx, float* stats, int M, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const bf16* p = x + (long)m * ldx;
+    float v[MAXC][8];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int d = c * 512 + lane * 8;
+        if (d < D) {
+            const bf16x8 t = *(const bf16x8*)(p + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[c][e] = (float)t[e]; s += v[c][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+        }
+    }
+    const float mean = wg_wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+        const int d = c * 512 + lane * 8;
+        if (d < D) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float t = v[c][e] - mean; q += t * t; }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wg_wave_sum(q) / (float)D + eps);
+    if (lane == 0) { stats[2 * (long)m] = mean; stats[2 * (long)m + 1] = rstd; }
+}
+
+extern "C" int wg_row_stats_bf16(const void* x, long ldx, float* stats, int M, int D, float eps, void* stream) {
+    WG_REQUIRE(x && stats && M > 0 && D > 0 && D % 8 == 0 && D <= 8192 && ldx % 8 == 0 && ldx >= D, "row_stats: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((M + 3) / 4), block(256);
+    if (D <= 1024) hipLaunchKernelGGL(wg_row_stats_kernel<2>, grid, block, 0, st, (const bf16*)x, ldx, stats, M, D, eps);
+    else if (D <= 2048) hipLaunchKernelGGL(wg_row_stats_kernel<4>, grid, block, 0, st, (const bf16*)x, ldx, stats, M, D, eps);
+    else if (D <= 4096) hipLaunchKernelGGL(wg_row_stats_kernel<8>, grid, block, 0, st, (const bf16*)x, ldx, stats, M, D, eps);
+    else hipLaunchKernelGGL(wg_row_stats_kernel<16>, grid, block, 0, st, (const bf16*)x, ldx, stats, M, D, eps);
+    return wg_check_launch("wg_row_stats_bf16");
+}

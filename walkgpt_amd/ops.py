@@ -96,6 +96,54 @@ def layernorm(x, gamma, beta, eps, act=ACT_NONE, out=None):
     return out
 
 
+LN_FUSE = _os.environ.get("WG_LN_FUSE", "1") != "0"  # experiments: 0 = always run LayerNorm and GEMM as two kernels
+
+
+def fold_layernorm(gamma, beta, weight, bias):
+    """Operands of ln_linear: the LayerNorm's affine map folded into the linear layer that consumes it.
+    y = LN(x) W^T + b = rstd (x Wg^T - mean s) + b'  with  Wg = bf16(W gamma), s = row sums of Wg (fp32, of the ROUNDED
+    Wg, so the mean term cancels exactly what the MFMA accumulates), b' = b + W beta (fp32)."""
+    wf = weight.float()
+    wg = (wf * gamma.float()[None, :]).to(_BF16).contiguous()
+    b = wf @ beta.float()
+    if bias is not None:
+        b = b + bias.float()
+    return {"wg": wg, "colsum": wg.float().sum(1).contiguous(), "bias_f32": b.contiguous(),
+            "gamma": gamma, "beta": beta, "weight": weight, "bias": bias}
+
+
+def row_stats(x, eps):
+    """(mean, 1/sqrt(var + eps)) per row of x [..., D] bf16 -> fp32 [rows rounded up to even, 2]."""
+    _need_gpu(x)
+    M, D, ldx = _rows(x)
+    st = torch.empty((M + 1) // 2 * 2, 2, device=x.device, dtype=torch.float32)
+    _lib.check(_lib.lib().wg_row_stats_bf16(x.data_ptr(), ldx, st.data_ptr(), M, D, float(eps), _stream()), "wg_row_stats_bf16")
+    return st
+
+
+def ln_linear(x, fold, eps, act=ACT_NONE):
+    """act(LayerNorm(x) @ W.T + b) with `fold` from fold_layernorm.  Shapes the persistent 256x256 GEMM takes run as a
+    row-statistics pass + one GEMM on the raw rows (the normalised rows never reach HBM); the rest as LayerNorm + GEMM."""
+    _need_gpu(x)
+    assert x.dtype == _BF16
+    M, K, lda = _rows(x)
+    N = fold["wg"].shape[0]
+    L = _lib.lib()
+    if not (LN_FUSE and not _FORCE_TILE and L.wg_gemm_ln_supported(M, N, K, lda, K, N)):
+        return linear(layernorm(x, fold["gamma"], fold["beta"], eps), fold["weight"], fold["bias"], act=act)
+    st = row_stats(x, eps)
+    out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=_BF16)
+    ev = GEMM_EVENT_HOOK(M, N, K, 16) if GEMM_EVENT_HOOK is not None else None
+    if ev is not None:
+        ev[0].record()
+    rc = L.wg_gemm_ln_bias_act_bf16(x.data_ptr(), lda, fold["wg"].data_ptr(), K, fold["bias_f32"].data_ptr(),
+                                    fold["colsum"].data_ptr(), st.data_ptr(), out.data_ptr(), N, M, N, K, act, _stream())
+    if ev is not None:
+        ev[1].record()
+    _lib.check(rc, "wg_gemm_ln_bias_act_bf16")
+    return out
+
+
 def _rows_per_batch(t):
     """[B, L, D] (contiguous rows, possibly a column slice of a wider buffer) -> (B, L, ld, rows per batch)."""
     assert t.dim() == 3 and t.stride(2) == 1

@@ -94,8 +94,8 @@ class Attention(nn.Module):
             self.rel_pos_w = nn.Parameter(torch.zeros(2 * input_size[1] - 1, head_dim))
 
 
-class Block(nn.Module):
-    """image_encoder.py:130-193."""
+class Block(nn.Module, _Prepared):
+    """image_encoder.py:130-193.  norm1 / norm2 are folded into the qkv / lin1 GEMMs behind them (ops.ln_linear)."""
 
     def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=True, norm_layer=nn.LayerNorm, act_layer=nn.GELU,
                  use_rel_pos=False, rel_pos_zero_init=True, window_size=0, input_size=None):
@@ -113,13 +113,18 @@ class Block(nn.Module):
         a = self.attn
         if not a.use_rel_pos or a.qkv.bias is None:
             raise NotImplementedError("the HIP SAM attention is built for use_rel_pos=True, qkv_bias=True (build_sam.py:56-108)")
-        y = ops.layernorm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        qkv = ops.linear(y, a.qkv.weight, a.qkv.bias)
+        p = self._prep_get(self._build)
+        qkv = ops.ln_linear(x, p["qkv"], self.norm1.eps)
         window = self.window_size if self.window_size > 0 else grid
         o = ops.sam_attention(qkv, a.qkv.bias, a.rel_pos_h, a.rel_pos_w, B, grid, window, a.num_heads)
         x = ops.linear(o, a.proj.weight, a.proj.bias, residual=x)
-        y = ops.layernorm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
-        return self.mlp.rows(y, residual=x)
+        h = ops.ln_linear(x, p["lin1"], self.norm2.eps, act=self.mlp._act_code)
+        return ops.linear(h, self.mlp.lin2.weight, self.mlp.lin2.bias, residual=x)
+
+    def _build(self):
+        a, m = self.attn, self.mlp
+        return {"qkv": ops.fold_layernorm(self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias),
+                "lin1": ops.fold_layernorm(self.norm2.weight, self.norm2.bias, m.lin1.weight, m.lin1.bias)}
 
 
 class ImageEncoderViT(nn.Module, _Prepared):
