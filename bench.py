@@ -304,7 +304,7 @@ def main():
     n_l, fl, sec, byt = per_tile[dom]
     achieved_tf = fl / sec / 1e12
     gf_step = B * (GF_CLIP_L_448 + GF_SAM[args.sam] + (GF_MSQP if args.with_msqp else 0.0) + T * (GF_DECODE_PER_TOKEN + GF_CTP_PER_TOKEN))
-    roofline = {"bound": "mfma", "kernel": "wg_gemm_pp_persist_kernel (256x256 tiles, ping-pong, persistent)" if dom == 16 else "wg_gemm_kernel<%s>" % {1: "128,128,64,2,2,2", 2: "256,256,64,2,2,4", 8: "256,256,64,2,2,4,pipe", 11: "persist 128,128,2,2", 12: "tail 128,128 (+16 rows)", 14: "256,256,64,2,2,4,ping-pong", 3: "rowwave"}.get(dom, str(dom)),
+    roofline = {"bound": "mfma", "kernel": "wg_gemm_pp_persist_kernel<%s> (256x256 tiles, ping-pong, persistent%s)" % (("true", ", LayerNorm folded in") if dom == 17 else ("false", "")) if dom in (16, 17) else "wg_gemm_kernel<%s>" % {1: "128,128,64,2,2,2", 2: "256,256,64,2,2,4", 8: "256,256,64,2,2,4,pipe", 11: "persist 128,128,2,2", 12: "tail 128,128 (+16 rows)", 14: "256,256,64,2,2,4,ping-pong", 3: "rowwave"}.get(dom, str(dom)),
                 "achieved": round(achieved_tf, 1), "peak": MFMA_BF16_DENSE_PEAK_TF, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / MFMA_BF16_DENSE_PEAK_TF, 4), "traffic": None,
                 "launches_per_step": n_l, "avg_launch_us": round(sec / n_l * 1e6, 1),
@@ -317,7 +317,7 @@ def main():
     try:  # HBM traffic of the dominant kernel from the committed PMC passes of this same command (profiles/)
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             pmc = json.load(f)["kernels"]
-        key = [k for k in pmc if k.startswith("wg_gemm_pp_persist_kernel" if dom == 16 else "wg_gemm_kernel<%s" % ("256, 256" if dom in (2, 14) else "128, 128"))]
+        key = [k for k in pmc if k.startswith("wg_gemm_pp_persist_kernel<true>" if dom == 17 else "wg_gemm_pp_persist_kernel<false>" if dom == 16 else "wg_gemm_kernel<%s" % ("256, 256" if dom in (2, 14) else "128, 128"))]
         if key:
             roofline["traffic"] = pmc[key[0]]["hbm_bytes_per_launch"]
             roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"

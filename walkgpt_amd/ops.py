@@ -133,7 +133,7 @@ def ln_linear(x, fold, eps, act=ACT_NONE):
         return linear(layernorm(x, fold["gamma"], fold["beta"], eps), fold["weight"], fold["bias"], act=act)
     st = row_stats(x, eps)
     out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=_BF16)
-    ev = GEMM_EVENT_HOOK(M, N, K, 16) if GEMM_EVENT_HOOK is not None else None
+    ev = GEMM_EVENT_HOOK(M, N, K, 17) if GEMM_EVENT_HOOK is not None else None  # 17: the LN instance of kernel 16
     if ev is not None:
         ev[0].record()
     rc = L.wg_gemm_ln_bias_act_bf16(x.data_ptr(), lda, fold["wg"].data_ptr(), K, fold["bias_f32"].data_ptr(),
