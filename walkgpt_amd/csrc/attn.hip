@@ -172,6 +172,21 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         for (int s = 0; s < KSTEPS; ++s) qf[s] = *(const bf16x8*)(qp + 16 * s);
     }
 
+    // Window-sized tables (2S-1 <= 32 rows): the rel-pos rows of BOTH passes below are requested here, together with the query,
+    // so that the prologue waits for global memory once instead of three times (query, width rows, height rows) -- with four key
+    // tiles per window the prologue is as long as the loop.
+    constexpr int NJB = GRID ? (2 * S - 1 + 31) / 32 : 1;
+    constexpr bool REL_EARLY = GRID && NJB == 1;
+    bf16x8 rel_early[REL_EARLY ? 2 : 1][KSTEPS];
+    if constexpr (REL_EARLY) {
+        const int j = ql_lane < 2 * S - 1 ? ql_lane : 2 * S - 2;
+#pragma unroll
+        for (int which = 0; which < 2; ++which)
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s)
+                rel_early[which][s] = *(const bf16x8*)((which == 0 ? a.rel_w : a.rel_h) + (long)j * HD + 16 * s + 8 * hi);
+    }
+
     // ---- K/V staging (LDS-DMA, swizzle on the source address) -----------------------------------------------
     // Piece i of this wave (1 KiB = 64 lanes x 16 bytes) covers fixed key slots of every tile, so its source is a running
     // per-lane pointer that advances by one tile of rows per call (softmax at head_dim 64 is VALU-bound: the general index
@@ -266,8 +281,8 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     float relw_reg[NRW];
     float* mytab = tab + wave * 32 * SP;
     if constexpr (GRID) {
-        constexpr int NJB = (2 * S - 1 + 31) / 32;
         // pass 0: width table -> registers; pass 1: height table -> stays in LDS (same slot)
+#pragma unroll
         for (int which = 0; which < 2; ++which) {
             const bf16* rel = which == 0 ? a.rel_w : a.rel_h;
             const int qpos = which == 0 ? qw : qh;
@@ -281,7 +296,9 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
                 for (int s = 0; s < KSTEPS; ++s) {
-                    const bf16x8 rf = *(const bf16x8*)(rel + (long)j * HD + 16 * s + 8 * hi);
+                    bf16x8 rf;
+                    if constexpr (REL_EARLY) rf = rel_early[which][s];
+                    else rf = *(const bf16x8*)(rel + (long)j * HD + 16 * s + 8 * hi);
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf, qf[s], acc, 0, 0, 0);
                 }
 #pragma unroll
