@@ -114,7 +114,7 @@ def test_layernorm_rows(dev, M, D, eps):
 
 
 @pytest.mark.parametrize("M,N,K", [(8200, 3072, 1024), (8200, 4096, 1024), (32768, 2304, 768), (4096, 3072, 768),
-                                   (1025, 3072, 1024), (300, 512, 256), (5125, 1280, 320)])
+                                   (1025, 3072, 1024), (300, 512, 256), (5125, 1280, 320), (4096, 3840, 1280), (2050, 5120, 1280)])
 @pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_GELU, ops.ACT_QUICK_GELU])
 def test_ln_linear_folded(dev, M, N, K, act):
     """LayerNorm folded into the GEMM (row statistics + persistent kernel epilogue) against fp32 LayerNorm -> linear; rows carry
