@@ -137,47 +137,57 @@ extern "C" int wg_layernorm_rows(const void* x, long ldx, const void* gamma, con
 
 // Row statistics only (mean, 1/sqrt(var + eps)) -> stats[m] = {mean, rstd} fp32: the LayerNorm whose affine map is folded into
 // the consuming GEMM (wg_gemm_ln_bias_act_bf16) needs nothing else -- half the HBM traffic of a full LayerNorm pass.
-template <int MAXC>
+template <int MAXC, int R>   // R rows per wave, their loads all in flight before the first reduction (the kernel is latency-bound)
 __global__ __launch_bounds__(256) void wg_row_stats_kernel(const bf16* x, long ldx, float* stats, int M, int D, float eps) {
     const int lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (m >= M) return;
-    const bf16* p = x + (long)m * ldx;
-    float v[MAXC][8];
-    float s = 0.f;
+    const int m0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (m0 >= M) return;
+    float v[R][MAXC][8];
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        const int d = c * 512 + lane * 8;
-        if (d < D) {
-            const bf16x8 t = *(const bf16x8*)(p + d);
+    for (int r = 0; r < R; ++r) {
+        const int m = m0 + r < M ? m0 + r : M - 1;
+        const bf16* p = x + (long)m * ldx;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { v[c][e] = (float)t[e]; s += v[c][e]; }
-        } else {
+        for (int c = 0; c < MAXC; ++c) {
+            const int d = c * 512 + lane * 8;
+            bf16x8 t = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+            if (d < D) t = *(const bf16x8*)(p + d);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[c][e] = 0.f;
+            for (int e = 0; e < 8; ++e) v[r][c][e] = (float)t[e];
         }
     }
-    const float mean = wg_wave_sum(s) / (float)D;
-    float q = 0.f;
 #pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-        const int d = c * 512 + lane * 8;
-        if (d < D) {
+    for (int r = 0; r < R; ++r) {
+        float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float t = v[c][e] - mean; q += t * t; }
+        for (int c = 0; c < MAXC; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[r][c][e];
+        const float mean = wg_wave_sum(s) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+            if (c * 512 + lane * 8 < D) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float t = v[r][c][e] - mean; q += t * t; }
+            }
         }
+        const float rstd = 1.0f / sqrtf(wg_wave_sum(q) / (float)D + eps);
+        if (lane == 0 && m0 + r < M) { stats[2 * (long)(m0 + r)] = mean; stats[2 * (long)(m0 + r) + 1] = rstd; }
     }
-    const float rstd = 1.0f / sqrtf(wg_wave_sum(q) / (float)D + eps);
-    if (lane == 0) { stats[2 * (long)m] = mean; stats[2 * (long)m + 1] = rstd; }
 }
 
 extern "C" int wg_row_stats_bf16(const void* x, long ldx, float* stats, int M, int D, float eps, void* stream) {
     WG_REQUIRE(x && stats && M > 0 && D > 0 && D % 8 == 0 && D <= 8192 && ldx % 8 == 0 && ldx >= D, "row_stats: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((M + 3) / 4), block(256);
-    if (D <= 1024) hipLaunchKernelGGL(wg_row_stats_kernel<2>, grid, block, 0, st, (const bf16*)x, ldx, stats, M, D, eps);
-    else if (D <= 2048) hipLaunchKernelGGL(wg_row_stats_kernel<4>, grid, block, 0, st, (const bf16*)x, ldx, stats, M, D, eps);
-    else if (D <= 4096) hipLaunchKernelGGL(wg_row_stats_kernel<8>, grid, block, 0, st, (const bf16*)x, ldx, stats, M, D, eps);
-    else hipLaunchKernelGGL(wg_row_stats_kernel<16>, grid, block, 0, st, (const bf16*)x, ldx, stats, M, D, eps);
+    dim3 block(256);
+    const int R = (D <= 2048 && M >= 4096) ? 2 : 1;
+    dim3 grid((M + 4 * R - 1) / (4 * R));
+    if (D <= 1024 && R == 2) hipLaunchKernelGGL((wg_row_stats_kernel<2, 2>), grid, block, 0, st, (const bf16*)x, ldx, stats, M, D, eps);
+    else if (D <= 1024) hipLaunchKernelGGL((wg_row_stats_kernel<2, 1>), grid, block, 0, st, (const bf16*)x, ldx, stats, M, D, eps);
+    else if (D <= 2048 && R == 2) hipLaunchKernelGGL((wg_row_stats_kernel<4, 2>), grid, block, 0, st, (const bf16*)x, ldx, stats, M, D, eps);
+    else if (D <= 2048) hipLaunchKernelGGL((wg_row_stats_kernel<4, 1>), grid, block, 0, st, (const bf16*)x, ldx, stats, M, D, eps);
+    else if (D <= 4096) hipLaunchKernelGGL((wg_row_stats_kernel<8, 1>), grid, block, 0, st, (const bf16*)x, ldx, stats, M, D, eps);
+    else hipLaunchKernelGGL((wg_row_stats_kernel<16, 1>), grid, block, 0, st, (const bf16*)x, ldx, stats, M, D, eps);
     return wg_check_launch("wg_row_stats_bf16");
 }
