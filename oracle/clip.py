@@ -12,10 +12,12 @@ The reference's own additions are restated from its call sites:
   patch-mask construction  model/llava_walkgpt/model/llava_arch.py:160-193
   layer selection          clip_encoder.py:61-69  (hidden_states[select_layer][:,1:], [hidden_states[-11][:,1:]])
 
-PARITY PIN: the reference has no tests or fixtures at this boundary and its own wrapper cannot be imported here
-(transformers 5.15 removed the class it subclasses).  tests/golden/clip_*.npz pins the block arithmetic against
-transformers 5.15 CLIPVisionModel (eager attention, quick_gelu) as a stand-in; the wrapper quirks are pinned only
-by this restatement => "parity unpinned" for those three call sites.
+PARITY PIN: the reference has no tests or fixtures at this boundary and its package does not import here (transformers 5.15
+removed the class its wrapper subclasses).  tests/golden/clip_*.npz pins the block arithmetic against transformers 5.15
+CLIPVisionModel (eager attention, quick_gelu) as a stand-in for the pinned 4.31.  The reference's own additions ARE pinned to its
+source: tests/golden/clipwrap_*.npz holds the outputs of its encode_images (patch mask for the tower, token mask for the LLM),
+_expand_mask (additive key mask) and CLIPVisionTower.load_model (position-table resize) run on synthetic inputs, each module loaded
+outside its package (tests/golden/make_golden.py:make_clipwrap); tests/test_oracle_golden.py holds this file to them bit for bit.
 
 Weight names follow transformers' CLIPVisionModel state_dict (`vision_model.*`).
 """
@@ -53,6 +55,15 @@ def patch_key_mask(batch, image_hw, clip_resize_list, patch=14):
     pn = w // patch
     m = F.interpolate(m[:, None], size=(pn, pn), mode="nearest")[:, 0]
     return torch.cat([torch.ones(batch, 1), m.flatten(1)], 1)
+
+
+def llm_token_mask(key_mask, side=16):
+    """llava_arch.py:176-179: the patch mask (class column dropped) nearest-resampled to the side x side grid of the image tokens
+    the LLM sees; spliced into the attention mask by prepare_inputs_labels_for_multimodal.  [B, 1 + P*P] -> [B, side*side]."""
+    B = key_mask.shape[0]
+    pn = int(round((key_mask.shape[1] - 1) ** 0.5))
+    m = key_mask[:, 1:].reshape(B, 1, pn, pn)
+    return F.interpolate(m, size=(side, side), mode="nearest")[:, 0].flatten(1)
 
 
 def clip_hidden_states(w, images, key_mask, heads=16, layers=24, patch=14, prefix="vision_model"):

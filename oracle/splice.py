@@ -5,9 +5,12 @@
                                           the same sequence, :330-378)
   seg_token_mask()                        /root/reference/model/walkgpt.py:293-306
 
-PARITY UNPINNED: llava_arch.py cannot be imported in this container (its package imports transformers' CLIPVisionTransformer,
-removed in the installed 5.x), and the reference has no test or fixture for it.  The restatement follows the source line by line
-(per-row torch.cat of the same slices); tests check it against hand-built cases and invariants.
+Pinned by tests/golden/splice_{r3,vit_mask}.npz: outputs of the reference's own method on synthetic rows (placeholder first / mid-row /
+near the end, a masked text position, labels, a ViT patch mask).  llava_arch.py is loaded for that on its own, outside its package
+(whose __init__ chain does not import under the installed transformers 5.x); how is written down in tests/golden/make_golden.py:make_splice.
+The restatement follows the source line by line (per-row torch.cat of the same slices) and is bit-exact against those vectors
+(tests/test_oracle_golden.py:test_splice_oracle_vs_reference); seg_token_mask has no reference fixture (walkgpt.py does not import here)
+and is checked on a hand-built case.
 """
 import torch
 

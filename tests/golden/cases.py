@@ -279,3 +279,43 @@ def prep_frame(c):
     yy, xx = np.mgrid[0:c["h"], 0:c["w"]]
     smooth = 0.5 + 0.5 * np.sin(yy[..., None] / 7.0 + xx[..., None] / 5.0 + np.arange(3))
     return np.clip((0.6 * smooth + 0.4 * u) * 255.0, 0, 255).astype(np.uint8)
+
+
+# ---- LLM-side splice (llava_arch.py:213-518, the branch WalkGPT takes) -------------------------------------------------------
+SPLICES = {
+    "r3": dict(rows=3, L=11, hidden=32, vocab=50, image_pos=[2, 0, 9], seed=101),   # placeholder mid-row, first and near the end
+    "vit_mask": dict(rows=2, L=8, hidden=16, vocab=40, image_pos=[3, 5], seed=102, vit_mask=True, no_labels=True),
+}
+
+
+def splice_inputs(c):
+    """input_ids [rows, L] (one -200 placeholder per row), attention_mask (last position of row 0 masked), labels, image features
+    [rows, 36, hidden] as the projector hands them over, embedding table [vocab, hidden], optional ViT patch mask [rows, 256]."""
+    rows, L, H = c["rows"], c["L"], c["hidden"]
+    ids = (synth.uniform01(c["seed"], "input.ids", rows * L) * (c["vocab"] - 1)).astype(np.int64).reshape(rows, L) + 1
+    for r, pos in enumerate(c["image_pos"]):
+        ids[r, pos] = -200
+    ids = torch.from_numpy(ids)
+    mask = torch.ones(rows, L, dtype=torch.bool)
+    mask[0, L - 1] = False
+    labels = None
+    if not c.get("no_labels"):
+        labels = ids.clone()
+        labels[:, :2] = -100
+    feats = torch.from_numpy(synth.normal(c["seed"], "input.image_features", (rows, 36, H)))
+    table = torch.from_numpy(synth.normal(c["seed"], "embed_tokens.weight", (c["vocab"], H)))
+    vit = None
+    if c.get("vit_mask"):
+        vit = torch.from_numpy((synth.uniform01(c["seed"], "input.vit_mask", rows * 256) > 0.3).astype(np.float32)).reshape(rows, 256)
+    return ids, mask, labels, feats, table, vit
+
+
+# ---- the reference's CLIP-wrapper additions (clip_encoder.py:38-55, custom_clip.py:27-38, llava_arch.py:160-193) --------------
+CLIPWRAPS = {
+    "w56": dict(image=56, sizes=[(56, 56), (30, 44), (14, 56), (41, 13)], old_side=4, new_side=6, dim=8, seed=111),
+    "w448": dict(image=448, sizes=[(448, 448), (448, 300), (299, 448)], old_side=24, new_side=32, dim=8, seed=112),
+}
+
+
+def clipwrap_table(c):
+    return torch.from_numpy(synth.normal(c["seed"], "position_embedding.weight", (c["old_side"] ** 2 + 1, c["dim"])))

@@ -220,6 +220,106 @@ def make_prep(name):
     np.savez_compressed(os.path.join(HERE, "prep_%s.npz" % name), resized=resized, image=x.numpy())
 
 
+def make_splice(name):
+    """LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal of the reference (llava_arch.py:213-518), run unmodified.
+    Its package does not import here (`custom_clip.py:2` wants transformers' CLIPVisionTransformer, gone from the
+    installed 5.x, and `llava_llama.py:176` re-registers the "llava" config name that 5.x already owns), so llava_arch.py is
+    loaded on its own: as a module of a synthetic package whose search path is the reference's `model/llava_walkgpt/model/`
+    directory (its relative imports then resolve to the reference's own files), with an empty placeholder class standing where
+    the removed transformers name was -- the splice never touches the vision tower's classes.  `self` is a small harness that
+    supplies what the method reads: `encode_images` (returns the case's projector output), `get_model().embed_tokens`,
+    `get_vision_tower()`, `config`, `device`."""
+    arch = _load_ref_llava_module("llava_arch")
+    c = cases.SPLICES[name]
+    ids, mask, labels, feats, table, vit = cases.splice_inputs(c)
+
+    class Harness:
+        device = torch.device("cpu")
+        config = types.SimpleNamespace(mm_use_im_start_end=False, tune_mm_mlp_adapter=False)
+
+        def __init__(self):
+            self._model = types.SimpleNamespace(embed_tokens=torch.nn.Embedding.from_pretrained(table, freeze=True))
+
+        def get_vision_tower(self):
+            return object()
+
+        def get_model(self):
+            return self._model
+
+        def encode_images(self, images, clip_resize_list):
+            return feats, vit, []
+
+    with torch.no_grad():
+        out = arch.LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal(
+            Harness(), ids, mask, None, labels, torch.zeros(c["rows"], 3, 4, 4), None)
+    feats_out, none_ids, attn, _pkv, embeds, new_labels = out
+    assert none_ids is None and feats_out[0] is feats
+    save = dict(attention_mask=attn.numpy(), inputs_embeds=embeds.numpy())
+    if new_labels is not None:
+        save["labels"] = new_labels.numpy()
+    np.savez_compressed(os.path.join(HERE, "splice_%s.npz" % name), **save)
+
+
+def _load_ref_llava_module(name):
+    """A module of the reference's model/llava_walkgpt/model/ directory, loaded outside its package (see make_splice)."""
+    import importlib
+    import transformers.models.clip.modeling_clip as mc
+    if not hasattr(mc, "CLIPVisionTransformer"):
+        mc.CLIPVisionTransformer = type("CLIPVisionTransformer", (torch.nn.Module,), {})
+    if "_ref_llava_model" not in sys.modules:
+        pkg = types.ModuleType("_ref_llava_model")
+        pkg.__path__ = [os.path.join(REF, "model", "llava_walkgpt", "model")]
+        sys.modules["_ref_llava_model"] = pkg
+    return importlib.import_module("_ref_llava_model." + name)
+
+
+def make_clipwrap(name):
+    """What the reference adds around transformers' CLIP, run from its own source on synthetic inputs:
+      * patch-mask construction: LlavaMetaForCausalLM.encode_images (llava_arch.py:133-210, pixel path) with a harness tower that
+        records the `attention_mask` it is called with -> `tower_mask` [B, 1 + P*P] and the returned `llm_mask` [B, 256];
+      * key-padding mask: custom_clip._expand_mask (custom_clip.py:27-38) on that tower mask -> additive [B, 1, L, L] (row 0 kept);
+      * position-table resize: CLIPVisionTower.load_model (clip_encoder.py:23-59) with `from_pretrained` of the two transformers
+        names it calls replaced by a synthetic tower (no network, no checkpoint): lines 38-55 run unmodified on a synthetic table."""
+    arch = _load_ref_llava_module("llava_arch")
+    cc = _load_ref_llava_module("multimodal_encoder.custom_clip")
+    ce = _load_ref_llava_module("multimodal_encoder.clip_encoder")
+    c = cases.CLIPWRAPS[name]
+    B, S = len(c["sizes"]), c["image"]
+    seen = {}
+
+    class Tower:
+        vision_tower = object.__new__(cc._CLIPVisionModel)   # isinstance() only: never initialised, never called
+
+        def __call__(self, images, attention_mask=None):
+            seen["mask"] = attention_mask
+            return torch.zeros(images.shape[0], 1, 1), []
+
+    tower = Tower()
+
+    class Harness:
+        def get_model(self):
+            return types.SimpleNamespace(get_vision_tower=lambda: tower)
+
+    _f, llm_mask, _p = arch.LlavaMetaForCausalLM.encode_images(Harness(), torch.zeros(B, 3, S, S), [tuple(s) for s in c["sizes"]])
+    key = cc._expand_mask(seen["mask"], torch.float32, seen["mask"].shape[1])
+
+    table = cases.clipwrap_table(c)
+    emb = torch.nn.Module()
+    emb.num_patches, emb.embed_dim, emb.patch_size, emb.image_size = c["old_side"] ** 2, c["dim"], 14, c["old_side"] * 14
+    emb.position_embedding = torch.nn.Embedding.from_pretrained(table.clone(), freeze=True)
+    fake = torch.nn.Module()
+    fake.vision_model = torch.nn.Module()
+    fake.vision_model.embeddings = emb
+    ce.CLIPImageProcessor = types.SimpleNamespace(from_pretrained=lambda *a, **k: None)
+    ce.CLIPVisionModel = types.SimpleNamespace(from_pretrained=lambda *a, **k: fake)
+    args = types.SimpleNamespace(mm_vision_select_layer=-2, resize_vision_tower=True, resize_vision_tower_size=c["new_side"] * 14)
+    with torch.no_grad():
+        vt = ce.CLIPVisionTower("synthetic", args, delay_load=False)
+    new_table = vt.vision_tower.vision_model.embeddings.position_embedding.weight.detach()
+    np.savez_compressed(os.path.join(HERE, "clipwrap_%s.npz" % name), tower_mask=seen["mask"].numpy(), llm_mask=llm_mask.numpy(),
+                        key_mask_row0=key[:, 0, 0, :].numpy(), table=new_table.numpy())
+
+
 def make_state_dict_shapes(_name):
     """Key -> shape tables of the reference modules (data, not source): the de-facto checkpoint ABI."""
     import json
@@ -241,6 +341,8 @@ ALL = {
     "nce": (make_nce, cases.NCES),
     "match": (make_match, cases.MATCHES),
     "prep": (make_prep, cases.PREPS),
+    "splice": (make_splice, cases.SPLICES),
+    "clipwrap": (make_clipwrap, cases.CLIPWRAPS),
     "sam_encoder": (make_sam_encoder, cases.SAM_ENCODERS),
     "decoder": (make_decoder, cases.DECODERS),
     "projectors": (make_projectors, cases.PROJECTORS),

@@ -1,4 +1,5 @@
 """GPU parity of the layout / elementwise kernels against torch fp32 (exact where the op is data movement)."""
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -218,6 +219,45 @@ def test_preprocess_full_size_vs_oracle(dev):
         ref = op.resize_longest_side(frame, target)
         assert np.array_equal(resized[0].cpu().numpy(), ref)
         assert np.array_equal(img[0].cpu().numpy(), op.preprocess(ref, target, (97.17, 105.73, 108.16), (53.05, 56.40, 61.93)))
+
+
+@pytest.mark.parametrize("name", ["w56", "w448"])
+def test_clip_position_table_resize_vs_reference_golden(dev, name):
+    """clip_encoder.resize_position_table (HIP bilinear on bf16 rows) against the reference's CLIPVisionTower.load_model run on the
+    same synthetic table (tests/golden/clipwrap_*.npz): within bf16 rounding; the carried-over last row exactly."""
+    from tests.golden import cases
+    from walkgpt_amd.clip_encoder import resize_position_table
+    c = cases.CLIPWRAPS[name]
+    gold = torch.from_numpy(cases.load("clipwrap_" + name)["table"])
+    table = cases.clipwrap_table(c).bfloat16()
+    out = resize_position_table(table.to(dev), c["new_side"]).float().cpu()
+    assert out.shape == gold.shape
+    assert torch.equal(out[-1], table[-1].float())
+    assert (out - gold).abs().max().item() <= 0.03 * max(1.0, gold.abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["r3", "vit_mask"])
+def test_multimodal_splice_vs_reference_golden(dev, name):
+    """The HIP resample + splice against the reference's own prepare_inputs_labels_for_multimodal (tests/golden/splice_*.npz):
+    mask and labels bit-exact, text rows bit-exact after the bf16 cast, image rows within bf16 rounding of the fp32 resample."""
+    from tests.golden import cases
+    from walkgpt_amd import ops
+    from walkgpt_amd.llava_splice import prepare_inputs_labels_for_multimodal
+    c = cases.SPLICES[name]
+    gold = cases.load("splice_" + name)
+    ids, mask, labels, feats, table, vit = cases.splice_inputs(c)
+    img = ops.resample_tokens(feats.bfloat16().to(dev).contiguous(), 16)
+    m, e, l, _ = prepare_inputs_labels_for_multimodal(ids.to(dev), mask.to(dev), None if labels is None else labels.to(dev), img,
+                                                      table.bfloat16().to(dev), None if vit is None else (vit > 0.5).to(dev))
+    assert np.array_equal(m.cpu().numpy(), gold["attention_mask"])
+    if labels is not None:
+        assert np.array_equal(l.cpu().numpy(), gold["labels"])
+    ge = torch.from_numpy(gold["inputs_embeds"])
+    e = e.float().cpu()
+    for r, s0 in enumerate(c["image_pos"]):
+        text = [i for i in range(ge.shape[1]) if i < s0 or i >= s0 + 256]
+        assert torch.equal(e[r, text], ge[r, text].bfloat16().float())
+        assert (e[r, s0:s0 + 256] - ge[r, s0:s0 + 256]).abs().max().item() <= 0.03
 
 
 def test_multimodal_splice_vs_oracle(dev):

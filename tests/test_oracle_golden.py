@@ -177,8 +177,48 @@ def test_preprocess_matches_reference_and_pillow(name):
         assert ks == ks2 and all(b[i, 0] == lo and list(k[i, :len(kk)]) == kk for i, (lo, kk) in enumerate(co))
 
 
+@pytest.mark.parametrize("name", sorted(cases.CLIPWRAPS))
+def test_clip_wrapper_additions_vs_reference(name):
+    """What the reference adds around transformers' CLIP -- patch mask for the tower, token mask for the LLM, additive key mask,
+    position-table resize -- against the outputs of its own source (tests/golden/make_golden.py:make_clipwrap); the oracle and the
+    product's host-side mirrors (walkgpt_amd/clip_encoder.py) both, bit for bit."""
+    from walkgpt_amd import clip_encoder as pce
+    c = cases.CLIPWRAPS[name]
+    gold = cases.load("clipwrap_" + name)
+    B, S = len(c["sizes"]), c["image"]
+    km = oclip.patch_key_mask(B, (S, S), c["sizes"])
+    assert np.array_equal(km.numpy(), gold["tower_mask"])
+    assert np.array_equal(oclip.llm_token_mask(km).numpy(), gold["llm_mask"])
+    assert np.array_equal(((1.0 - km) * torch.finfo(torch.float32).min).numpy(), gold["key_mask_row0"])   # as clip_hidden_states applies it
+    assert np.array_equal(oclip.resize_position_table(cases.clipwrap_table(c), c["new_side"]).numpy(), gold["table"])
+    pk = pce.patch_key_mask(torch.zeros(B, 3, S, S), c["sizes"])
+    assert np.array_equal(pk.numpy(), gold["tower_mask"]) and np.array_equal(pce.llm_token_mask(pk).numpy(), gold["llm_mask"])
+    # the additive key bias the HIP attention receives (clip_encoder.py forward)
+    kb = torch.where(pk > 0.5, 0.0, torch.finfo(torch.float32).min).float()
+    assert np.array_equal(kb.numpy(), gold["key_mask_row0"])
+
+
+@pytest.mark.parametrize("name", sorted(cases.SPLICES))
+def test_splice_oracle_vs_reference(name):
+    """oracle/splice.py (+ the 6x6 -> 16x16 token resample of oracle/projectors.py) against the reference's own
+    prepare_inputs_labels_for_multimodal run on the same rows (tests/golden/make_golden.py:make_splice): embeddings, the spliced
+    attention mask (ViT patch mask included) and the labels, bit for bit."""
+    from oracle import projectors as oproj
+    from oracle import splice as osp
+    c = cases.SPLICES[name]
+    gold = cases.load("splice_" + name)
+    ids, mask, labels, feats, table, vit = cases.splice_inputs(c)
+    m, e, l = osp.prepare_inputs_labels_for_multimodal(ids, mask, labels, oproj.resample_tokens(feats), table, vit)
+    assert np.array_equal(e.numpy(), gold["inputs_embeds"])
+    assert np.array_equal(m.numpy(), gold["attention_mask"])
+    if labels is None:
+        assert l is None and "labels" not in gold
+    else:
+        assert np.array_equal(l.numpy(), gold["labels"])
+
+
 def test_splice_oracle_hand_case():
-    """oracle/splice.py is parity-unpinned (llava_arch.py does not import here): a hand-built row checks the restatement."""
+    """A hand-built row: the splice positions and the [SEG] bookkeeping of walkgpt.py:293-306 in numbers one can check by eye."""
     from oracle import splice as osp
     ids = torch.tensor([[7, -200, 3, 9, 4]])
     table = torch.arange(10, dtype=torch.float32)[:, None].repeat(1, 2)

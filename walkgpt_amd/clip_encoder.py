@@ -233,6 +233,15 @@ class CLIPVisionTower(nn.Module):
         return (self.config.image_size // self.config.patch_size) ** 2
 
 
+def llm_token_mask(key_mask, side=16):
+    """llava_arch.py:176-179 (host side): the patch mask without its class column, nearest-resampled to the side x side grid of
+    the image tokens the LLM sees -> [B, side*side]; the `vit_attention_mask` of llava_splice.prepare_inputs_labels_for_multimodal."""
+    B = key_mask.shape[0]
+    pn = int(round((key_mask.shape[1] - 1) ** 0.5))
+    m = key_mask[:, 1:].reshape(B, 1, pn, pn).float()
+    return torch.nn.functional.interpolate(m, size=(side, side), mode="nearest")[:, 0].flatten(1)
+
+
 def patch_key_mask(images, clip_resize_list=None, patch_size=14):
     """llava_arch.py:160-193 (mask bookkeeping, host side): [B, 1 + P*P] float, 1 = real patch / class token."""
     B = images.shape[0]
