@@ -1,0 +1,62 @@
+"""BASELINE config C2 at its full sizes (bs = 8, SAM ViT-B @ 1024, CLIP ViT-L/14 @ 448) through properties that do not need a full-size
+reference run per image: an image's result must not depend on its batch (the bs = 8 launches take the persistent LayerNorm-folded GEMM
+on M = 32768 / 8200 rows; one image alone tiles differently and, for CLIP, takes the unfused 128x128 path), two runs are bit-identical,
+and ONE full-size CLIP image is held against the fp32 oracle (the full-size SAM image against the reference is test_gpu_modules'
+`vit_b` case)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.golden import cases
+from tests.test_gpu_modules import build_encoder, load_into, rel_err
+from walkgpt_amd.clip_encoder import CLIP_VIT_L_14, CLIPVisionTower, patch_key_mask
+from walkgpt_amd import synth
+
+
+def test_sam_vit_b_full_size_batch_of_8(dev):
+    c = dict(cases.SAM_ENCODERS["vit_b"])
+    enc = build_encoder(c, dev)
+    x = torch.from_numpy(synth.normal(7, "input.images8", (8, 3, 1024, 1024))).to(dev, torch.bfloat16)
+    with torch.no_grad():
+        out8 = enc(x)
+        again = enc(x)
+        one = [enc(x[i:i + 1]) for i in (0, 5)]
+    assert out8.shape == (8, 256, 64, 64) and torch.isfinite(out8.float()).all()
+    assert torch.equal(out8, again)
+    for o, i in zip(one, (0, 5)):
+        e = rel_err(out8[i].float().cpu().numpy(), o[0].float().cpu().numpy())
+        assert e < 0.01, (i, e)
+    # distinct images give distinct embeddings (a batch-index mix-up in the window / global addressing would not)
+    assert rel_err(out8[0].float().cpu().numpy(), out8[5].float().cpu().numpy()) > 0.1
+
+
+def test_clip_vit_l_448_full_size_batch_of_8(dev):
+    from types import SimpleNamespace
+    from oracle import clip as oclip
+    cfg = dict(CLIP_VIT_L_14, image_size=448)
+    c = dict(dim=1024, heads=16, layers=24, img=448, seed=43)
+    args = SimpleNamespace(mm_vision_select_layer=-2, pad_train_clip_images=True, resize_vision_tower=True, resize_vision_tower_size=448)
+    tower = CLIPVisionTower("synthetic", args, config=cfg)
+    w = cases.clip_weights(c)
+    load_into(tower.vision_tower, w, "", dev)
+    x = torch.from_numpy(synth.normal(8, "input.images_clip8", (8, 3, 448, 448)))
+    sizes = [(448, 448)] * 8
+    sizes[3] = (300, 448)   # one padded image: its key mask rides along in the batch
+    sizes[6] = (448, 210)
+    xd = x.to(dev, torch.bfloat16)
+    km = patch_key_mask(xd, sizes)
+    with torch.no_grad():
+        sel8, pre8 = tower(xd, attention_mask=km)
+        sel8b, _ = tower(xd, attention_mask=km)
+        sel1, pre1 = tower(xd[3:4], attention_mask=km[3:4])
+    assert sel8.shape == (8, 1024, 1024) and torch.equal(sel8, sel8b)
+    assert rel_err(sel8[3].float().cpu().numpy(), sel1[0].float().cpu().numpy()) < 0.02
+    assert rel_err(pre8[0][3].float().cpu().numpy(), pre1[0][0].float().cpu().numpy()) < 0.02
+    # the same image through the fp32 oracle (bf16-rounded weights and input, as the HIP tower holds them)
+    wq = {k: v.bfloat16().float() for k, v in w.items()}
+    with torch.no_grad():
+        ref_sel, ref_pre = oclip.clip_tower(wq, x[3:4].bfloat16().float(), oclip.patch_key_mask(1, (448, 448), [sizes[3]]))
+    assert rel_err(sel8[3].float().cpu().numpy(), ref_sel[0].numpy()) < 0.03
+    assert rel_err(pre8[0][3].float().cpu().numpy(), ref_pre[0][0].numpy()) < 0.03
