@@ -43,7 +43,7 @@ struct AttnArgs {
 
 template <int HD> __device__ __forceinline__ int swzK(int row) {
     if (HD == 16) return (row >> 2) & 3;   // stored as 64-byte rows like head_dim 32
-    if (HD == 80) return 0;   // 192-byte padded rows (SAM ViT-H): unswizzled for now (4-way conflicts on the K reads)
+    if (HD == 80) return 0;   // 208-byte padded rows (SAM ViT-H): the row pitch itself spreads the banks
     if (HD == 128) return row & 15;
     if (HD == 64) return (row >> 1) & 7;
     return (row >> 2) & 3;  // HD == 32
@@ -94,8 +94,11 @@ extern "C" int wg_debug_attn_stamps(unsigned* buf) {
 template <int HD, int S, int NW, bool KB>
 __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     constexpr int HDP = (HD == 80) ? 96 : (HD == 16 ? 32 : HD);  // head dim padded to a multiple of 32 inside LDS
-    constexpr int CPR = HDP / 8;           // 16-byte chunks per K/V row
-    constexpr int ROWB = HDP * 2;          // bytes per row
+    // head_dim 80: rows padded once more to 13 chunks = 52 dwords, a pitch that sends 16 consecutive rows to 16 different bank
+    // quads (the K fragment reads of 192-byte rows were 4-way conflicted: rows r and r + 4 shared their banks); the 13th chunk of
+    // a row is never read
+    constexpr int ROWB = (HD == 80) ? 208 : HDP * 2;   // bytes per row
+    constexpr int CPR = ROWB / 16;                     // 16-byte chunks per K/V row
     constexpr int TILE = 64 * ROWB;        // bytes per K (or V) tile
     constexpr int KSTEPS = HD / 16;        // QK^T runs over the real head dim only
     constexpr int DB = HDP / 32;           // PV d-blocks; columns >= HD hold don't-care data and are never stored
@@ -568,7 +571,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
 
 template <int HD, int S, int NW, bool KB>
 static int launch_attn_impl(const AttnArgs& a, int groups, hipStream_t st) {
-    constexpr int TILE = 64 * ((HD == 80) ? 96 : (HD == 16 ? 32 : HD)) * 2;
+    constexpr int TILE = 64 * ((HD == 80) ? 104 : (HD == 16 ? 32 : HD)) * 2;
     constexpr int RP = S <= 16 ? 16 : (S <= 32 ? 32 : 64);
     constexpr int RPT = 64 / RP;
     constexpr int SP = S > 0 ? ((S + RPT - 1) / RPT) * RPT + 1 : 1;
