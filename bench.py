@@ -1,66 +1,133 @@
 #!/usr/bin/env python3
 """bench.py -- images/sec of WalkGPT's grounded-segmentation forward path on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch of synthetic input on each GPU (config C2 of SURVEY.md §8d):
-  bs=8 source images of 448x448  ->  images_clip [8,3,448,448] and SAM input [8,3,1024,1024] (bf16, resident in HBM)
-  CLIP ViT-L/14 tower (24 layers, 1025 tokens, key-padding mask)  +  SAM ViT-B image encoder
-  + CTP on T [SEG] hidden states per image + prompt encoder + two-way mask decoder + fused postprocess to 448x448
+One "step" = one pass of the hot path over one batch of synthetic input on each GPU:
+  bs images/GPU of 448x448  ->  images_clip [bs,3,448,448] and SAM input [bs,3,1024,1024] (bf16, resident in HBM)
+  CLIP ViT-L/14 tower (24 layers, 1025 tokens)  +  SAM image encoder (+ MSQP for C3/C5)
+  + CTP on T [SEG] hidden states per image + prompt encoder + two-way mask decoder + fused postprocess
   (+ one RCCL all-gather of the mask logits when world_size > 1).
-The language model between MSQP and CTP is not part of config C2 and is not run.
+Configs (--config sets the defaults, explicit flags override, the label is derived from what actually ran):
+  C2 (default)  bs=8/GPU, SAM ViT-B, T=1              -- the configuration the BASELINE metric is quoted on
+  C3            bs=32/GPU, SAM ViT-H + MSQP, T=14     -- (the LLM between MSQP and CTP is stock PyTorch and is not run)
+  C4            bs=32/GPU on 8 GPUs (global 256), model of C2, RCCL all-gather of the mask logits
+  C5            bs=8/GPU, SAM ViT-H + MSQP, T=14, 1024x1024 originals (fp8 GEMMs: --dtype fp8)
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 8            # spawns the 8 ranks itself (torch.distributed.run on 127.0.0.1) before touching a GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      the dominant kernel (the 256x256-tile bf16 MFMA GEMM): algorithmic FLOPs of all its launches in one step
-                / the sum of their durations, timed with HIP events on the launch stream in an instrumented, serialised
-                (single-stream) step that runs right after the timed region (same process, same buffers);
-                rocprofv3's average for the same kernel: profiles/r01_single_stream_summary.md.  e2e_* = whole step.
-  cpu_baseline  the CPU oracle (oracle/, fp32 PyTorch restatement pinned to the reference) timed on the host cores on
-                a bounded sample (one image of the batch), rank 0 at N=1 only.
+  roofline      the dominant kernel (most GEMM time in a step): algorithmic FLOPs of all its launches in one step / the sum of
+                their durations, timed with HIP events on the launch stream in an instrumented, serialised (single-stream) step
+                that runs right after the timed region (same process, same buffers).  e2e_* = whole step.
+  cpu_baseline  the CPU oracle (oracle/, fp32 PyTorch restatement pinned to the reference) timed on the host cores on a bounded
+                sample (one image of the batch: 1 warm-up + 3 timed runs), rank 0 at N=1 only.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-# algorithmic FLOPs per image (2*MAC, matmul/conv only) -- BASELINE.md §2, counted on the reference modules
+# algorithmic FLOPs per image (2*MAC, matmul/conv only) -- BASELINE.md section 2, counted on the reference modules
 GF_CLIP_L_448 = 723.6
-GF_SAM_B = 972.1
 GF_DECODE_PER_TOKEN = 3.61
 GF_CTP_PER_TOKEN = 0.00446
 GF_MSQP = 50.8
 GF_SAM = {"vit_b": 972.1, "vit_l": 2985.7, "vit_h": 5961.1}
-MFMA_BF16_DENSE_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: ~2.5 PF dense bf16
+PEAK_TF = {"bf16": 2500.0, "fp8": 5000.0}  # MI355X_MICROARCH.md: ~2.5 PF dense bf16, ~5 PF dense fp8 (block-scaled MFMA)
+
+CONFIGS = {
+    "C2": dict(batch=8, sam="vit_b", seg_tokens=1, with_msqp=False, original=448),
+    "C3": dict(batch=32, sam="vit_h", seg_tokens=14, with_msqp=True, original=448),
+    "C4": dict(batch=32, sam="vit_b", seg_tokens=1, with_msqp=False, original=448),
+    "C5": dict(batch=8, sam="vit_h", seg_tokens=14, with_msqp=True, original=1024),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
-    ap.add_argument("--seg-tokens", type=int, default=1, help="[SEG] tokens per image (reference default --seg_token_num=1)")
-    ap.add_argument("--sam", default="vit_b")
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step")
+    ap.add_argument("--seg-tokens", type=int, default=None, help="[SEG] tokens per image (reference default --seg_token_num=1)")
+    ap.add_argument("--sam", default=None, choices=sorted(GF_SAM))
+    ap.add_argument("--original", type=int, default=None, help="side of the original image the masks are resampled to")
     ap.add_argument("--llm-hidden", type=int, default=4096)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="GEMM operand type of the encoder blocks")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--with-msqp", action="store_true", help="also run the Multi-Scale Query Projector on the SAM tokens (config C3's projector)")
+    ap.add_argument("--cpu-baseline-b8", action="store_true", help="also time the CPU oracle on a batch of 8 (about a minute more)")
+    ap.add_argument("--with-msqp", action="store_true", default=None, help="also run the Multi-Scale Query Projector on the SAM tokens")
     ap.add_argument("--tail-tiles", action="store_true", help="allow the tail-absorbing 128x128 GEMM tiles (wins with --single-stream)")
-    ap.add_argument("--sam-split", type=int, default=1, help="experiment: run the SAM encoder in this many batch chunks on separate streams")
     ap.add_argument("--side-priority", type=int, default=0, help="HIP priority of the CLIP stream (-1 = high)")
     ap.add_argument("--single-stream", action="store_true", help="run the CLIP tower and the SAM branch back to back")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-decode-graph", action="store_true", help="launch the decode chain eagerly instead of replaying its captured HIP graph")
-    return ap.parse_args()
+    ap.add_argument("--probe-launch", action="store_true", help="self-test of the rank launch only: gloo rendezvous, no GPU work (tests/test_bench_launch.py)")
+    args = ap.parse_args(argv)
+    preset = CONFIGS[args.config]
+    for k, v in preset.items():
+        if getattr(args, k) is None:
+            setattr(args, k, v)
+    return args
+
+
+def config_name(args, world):
+    """Name of what ran, derived from the arguments (never a fixed prefix)."""
+    match = [k for k, p in CONFIGS.items() if all(getattr(args, f) == v for f, v in p.items())]
+    if "C4" in match:
+        return "C4" if world == 8 else "custom (C4's per-GPU share on %d GPU)" % world
+    if "C5" in match:
+        return "C5" if args.dtype == "fp8" else "C5 geometry with bf16 GEMMs"
+    if match and args.dtype == "bf16":
+        return match[0]
+    return "custom"
+
+
+def workload_label(args, world):
+    return ("%s: bs=%d/GPU x %d GPU, 448x448 source images (CLIP input 448^2, SAM input 1024^2), CLIP ViT-L/14 + SAM %s encoder%s + CTP + "
+            "prompt encoder + mask decoder + postprocess to %dx%d, T=%d [SEG]/image, %s GEMMs, random-init weights"
+            % (config_name(args, world), args.batch, world, args.sam, " + MSQP" if args.with_msqp else "", args.original, args.original,
+               args.seg_tokens, args.dtype))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """--gpus N without a torchrun environment: start N fresh rank processes (one per GPU) through torch.distributed.run on
+    127.0.0.1 and relay rank 0's JSON line.  Runs BEFORE anything in this process touches the GPU (no exec of a GPU process)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode if proc.returncode != 0 or line is not None else 1
 
 
 def build_model(args, dev):
+    import torch
     from walkgpt_amd.walkgpt import WalkGPTGrounding
     torch.manual_seed(1234)
     model = WalkGPTGrounding(sam=args.sam, llm_hidden=args.llm_hidden, with_clip=True, with_projectors=True)
@@ -73,26 +140,42 @@ def build_model(args, dev):
     model.to(dev).bfloat16().eval()
     pe = model.visual_model.prompt_encoder.pe_layer
     pe.positional_encoding_gaussian_matrix.data = pe.positional_encoding_gaussian_matrix.data.float()
+    if args.dtype == "fp8":
+        model.set_gemm_dtype("fp8")
     return model
 
 
 def make_inputs(args, dev, rank):
+    import torch
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     B, T = args.batch, args.seg_tokens
     images = torch.randn(B, 3, 1024, 1024, generator=g).to(dev, torch.bfloat16)
     images_clip = torch.randn(B, 3, 448, 448, generator=g).to(dev, torch.bfloat16)
     seg_hidden = [torch.randn(T, args.llm_hidden, generator=g).to(dev, torch.bfloat16) for _ in range(B)]
     return dict(images=images, images_clip=images_clip, seg_hidden=seg_hidden, resize_list=[(1024, 1024)] * B,
-                original_size_list=[(448, 448)] * B, clip_resize_list=[(448, 448)] * B)
+                original_size_list=[(args.original, args.original)] * B, clip_resize_list=[(448, 448)] * B)
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(args):
-    """The oracle's own forward for ONE image of the workload, fp32, on the host cores."""
+    """The oracle's own forward on the host cores, fp32 (SURVEY.md 8d protocol: all cores the process may use, 1 warm-up + 3 timed
+    runs at B=1; B=8 only with --cpu-baseline-b8, it alone takes about a minute)."""
+    import torch
     from oracle import clip as oclip
     from oracle import projectors as oproj
     from oracle import sam as osam
     from tests.golden import cases
-    threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))  # 16 = the CPU share of a one-GPU box
+    threads = args.cpu_threads or len(os.sched_getaffinity(0))
     torch.set_num_threads(threads)
     gen = torch.Generator().manual_seed(7)
 
@@ -110,39 +193,58 @@ def cpu_baseline(args):
         return out
 
     c = dict(cases.SAM_ENCODERS["vit_b"])
+    if args.sam != "vit_b":
+        c.update({"vit_l": dict(embed_dim=1024, depth=24, heads=16, global_idx=(5, 11, 17, 23)),
+                  "vit_h": dict(embed_dim=1280, depth=32, heads=16, global_idx=(7, 15, 23, 31))}[args.sam])
     w = rnd({k: tuple(v.shape) for k, v in _shape_only_encoder(c).items()})
     w.update(rnd(cases.decoder_weight_shapes()))
     clip_c = dict(dim=1024, heads=16, layers=24, img=448)
     wc = rnd(cases.clip_weight_shapes(clip_c))
     wt = rnd(cases.ctp_weight_shapes(args.llm_hidden))
     wt["text_type"] = wt["text_type"].reshape(1, 1, -1)
-    x = torch.randn(1, 3, 1024, 1024, generator=gen)
-    xc = torch.randn(1, 3, 448, 448, generator=gen)
-    hid = torch.randn(args.seg_tokens, args.llm_hidden, generator=gen)
     cfg = dict(patch=16, depth=c["depth"], heads=c["heads"], global_idx=c["global_idx"], window=14)
-    with torch.no_grad():
-        t0 = time.perf_counter()
-        key_mask = oclip.patch_key_mask(1, (448, 448), [(448, 448)])
-        oclip.clip_tower(wc, xc, key_mask, -2)
-        t1 = time.perf_counter()
-        emb = osam.image_encoder(w, x, cfg)
-        t2 = time.perf_counter()
-        pe = oproj.ctp(wt, hid).reshape(-1, 1, 256)
-        dpe = osam.dense_pe(w, (64, 64))
-        sparse, dense = osam.prompt_encoder_text(w, pe, (64, 64))
-        masks, _ = osam.mask_decoder(w, emb, dpe, sparse, dense)
-        post = osam.postprocess_masks(masks, 1024, (1024, 1024), (448, 448))
-        osam.mask_score(post[:, 0])
-        t3 = time.perf_counter()
-    total = t3 - t0
-    return {"value": round(1.0 / total, 4), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": "1 image of the batch (CLIP ViT-L@448 %.1fs + SAM ViT-B@1024 %.1fs + decode T=%d %.2fs), fp32 oracle, torch CPU"
-                      % (t1 - t0, t2 - t1, args.seg_tokens, t3 - t2),
-            "mask_decode_ms": round((t3 - t2) * 1e3, 1)}
+    T = args.seg_tokens
+
+    def run(B):
+        x = torch.randn(B, 3, 1024, 1024, generator=gen)
+        xc = torch.randn(B, 3, 448, 448, generator=gen)
+        hid = torch.randn(B * T, args.llm_hidden, generator=gen)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            key_mask = oclip.patch_key_mask(B, (448, 448), [(448, 448)] * B)
+            oclip.clip_tower(wc, xc, key_mask, -2)
+            t1 = time.perf_counter()
+            emb = osam.image_encoder(w, x, cfg)
+            t2 = time.perf_counter()
+            pe = oproj.ctp(wt, hid).reshape(B, T, 1, 256)
+            dpe = osam.dense_pe(w, (64, 64))
+            for i in range(B):   # the reference decodes image by image (model/walkgpt.py:716-737)
+                sparse, dense = osam.prompt_encoder_text(w, pe[i], (64, 64))
+                masks, _ = osam.mask_decoder(w, emb[i:i + 1], dpe, sparse, dense)
+                post = osam.postprocess_masks(masks, 1024, (1024, 1024), (args.original, args.original))
+                osam.mask_score(post[:, 0])
+            t3 = time.perf_counter()
+        return t1 - t0, t2 - t1, t3 - t2
+
+    run(1)                                   # warm-up (thread pool, allocator, oneDNN primitive caches)
+    runs = [run(1) for _ in range(3)]
+    tot = sorted(sum(r) for r in runs)
+    med = tot[1]
+    best = min(runs, key=sum)
+    out = {"value": round(1.0 / med, 4), "unit": "images/s", "cores": threads, "kind": "port", "cpu": cpu_model_name(),
+           "sample": "B=1 (one image of the batch), 1 warm-up + 3 timed runs, median %.2f s (min %.2f, max %.2f): CLIP ViT-L@448 %.2fs + SAM %s@1024 "
+                     "%.2fs + decode T=%d %.2fs; fp32 oracle, torch CPU, %d threads"
+                     % (med, tot[0], tot[2], best[0], args.sam, best[1], T, best[2], threads),
+           "mask_decode_ms": round(sorted(r[2] for r in runs)[1] * 1e3, 1)}
+    if args.cpu_baseline_b8:
+        r8 = run(8)
+        out["b8"] = {"value": round(8.0 / sum(r8), 4), "unit": "images/s", "sample": "B=8, 1 run of %.1f s" % sum(r8)}
+    return out
 
 
 def _shape_only_encoder(c):
-    """Key -> zero tensor of the right shape for a SAM encoder config (values are drawn by the caller)."""
+    """Key -> meta tensor of the right shape for a SAM encoder config (values are drawn by the caller)."""
+    import torch
     D, p, g = c["embed_dim"], c["patch"], c["img"] // c["patch"]
     hd = D // c["heads"]
     pre = "image_encoder."
@@ -160,11 +262,44 @@ def _shape_only_encoder(c):
     return {pre + k: torch.empty(v, device="meta") for k, v in s.items()}
 
 
+def probe_launch(args, rank, local_rank, world):
+    """What the launcher hands each rank, checked without a GPU: env of a one-node torchrun job, a gloo rendezvous on 127.0.0.1 and
+    one all-reduce; rank 0 prints a line shaped like the bench line."""
+    import torch
+    import torch.distributed as dist
+    ok = world == args.gpus and 0 <= rank < world and local_rank == rank and os.environ.get("MASTER_ADDR") == "127.0.0.1"
+    dist.init_process_group("gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    ok = ok and float(t.item()) == world * (world + 1) / 2
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"metric": "launch-probe", "n_gpus": dist.get_world_size(), "ok": bool(flag.item()),
+                          "config": {"workload": workload_label(args, world)}}), flush=True)
+    dist.destroy_process_group()
+    return 0 if flag.item() else 1
+
+
+KERNEL_NAMES = {1: "wg_gemm_kernel<128,128,64,2,2,2>", 2: "wg_gemm_kernel<256,256,64,2,2,4>", 3: "wg_gemm_rowwave_kernel",
+                11: "wg_gemm_persist_kernel<128,128,2,2>", 12: "wg_gemm_kernel<128,128 tail (+16 rows)>",
+                14: "wg_gemm_kernel<256,256,64,2,2,4,ping-pong>",
+                16: "wg_gemm_pp_persist_kernel<false> (256x256 tiles, ping-pong, persistent)",
+                17: "wg_gemm_pp_persist_kernel<true> (256x256 tiles, ping-pong, persistent, LayerNorm folded in)",
+                20: "wg_gemm_fp8_kernel (256x256 tiles, block-scaled fp8 MFMA)"}
+PMC_PREFIX = {16: "wg_gemm_pp_persist_kernel<false>", 17: "wg_gemm_pp_persist_kernel<true>", 20: "wg_gemm_fp8_kernel"}
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    import torch
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.probe_launch:
+        return probe_launch(args, rank, local_rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -181,50 +316,34 @@ def main():
     if dist is not None:
         dist.barrier()
     from walkgpt_amd import ops
-    ops.ALLOW_TAIL_TILES = bool(args.tail_tiles)
     model = build_model(args, dev)
     inp = make_inputs(args, dev, rank)
-    B, T = args.batch, args.seg_tokens
+    B, T, O = args.batch, args.seg_tokens, args.original
     gathered = None
     if dist is not None:
-        gathered = torch.empty(world * B * T, 448, 448, device=dev, dtype=torch.float32)
+        gathered = torch.empty(world * B * T, O, O, device=dev, dtype=torch.float32)
 
     decode_ev = []
-
     side = torch.cuda.Stream(priority=args.side_priority) if not args.single_stream else None
     dec = torch.cuda.Stream() if not args.single_stream else None
-    sam_streams = [torch.cuda.Stream() for _ in range(args.sam_split)] if args.sam_split > 1 else []
+    dec_fn = model.decode_from_hidden if args.no_decode_graph else model.decode_from_hidden_graphed
 
     def step(record_decode=False, serial=False):
         """One pass over one batch.  Three HIP streams in steady state: the CLIP tower (side), the SAM encoder (main) and
-        the prompt-encoder / mask-decoder / postprocess chain (dec).  The decode chain is ~75 small latency-bound
-        launches at low occupancy; on its own stream it runs under the NEXT step's encoders instead of in front of them.
+        the prompt-encoder / mask-decoder / postprocess chain (dec).  The decode chain is latency-bound at low occupancy; on its
+        own stream it runs under the NEXT step's encoders instead of in front of them.
         All work of every step is inside the timed region (the closing fence synchronises the device)."""
         with torch.no_grad():
             cur = torch.cuda.current_stream()
             use_side = side is not None and not serial
+            tails = bool(args.tail_tiles)
             if use_side:
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
-                    feats, _pre = model.encode_images_clip(inp["images_clip"], inp["clip_resize_list"])
+                    feats, _pre = model.encode_images_clip(inp["images_clip"], inp["clip_resize_list"], tail_tiles=tails)
             else:
-                feats, _pre = model.encode_images_clip(inp["images_clip"], inp["clip_resize_list"])
-            if args.sam_split > 1 and use_side:
-                # experiment: the SAM batch in `sam_split` chunks on separate streams (MFMA-bound GEMMs of one chunk
-                # next to the VALU-bound attention of another)
-                chunks = list(torch.chunk(inp["images"], args.sam_split, 0))
-                parts = [None] * len(chunks)
-                for i, ch in enumerate(chunks):
-                    st = sam_streams[i]
-                    st.wait_stream(cur)
-                    with torch.cuda.stream(st):
-                        parts[i] = model.get_visual_emb_tokens(ch.contiguous())
-                for i, st in enumerate(sam_streams[:len(chunks)]):
-                    cur.wait_stream(st)
-                    parts[i].record_stream(cur)
-                emb = torch.cat(parts, 0)
-            else:
-                emb = model.get_visual_emb_tokens(inp["images"])
+                feats, _pre = model.encode_images_clip(inp["images_clip"], inp["clip_resize_list"], tail_tiles=tails)
+            emb = model.get_visual_emb_tokens(inp["images"])
             if args.with_msqp:
                 model.project_visual_tokens(emb)
 
@@ -233,8 +352,6 @@ def main():
                     e0 = torch.cuda.Event(enable_timing=True)
                     e1 = torch.cuda.Event(enable_timing=True)
                     e0.record()
-                # the ~75 small launches of the chain are replayed from one captured HIP graph (same kernels, same arguments)
-                dec_fn = model.decode_from_hidden if args.no_decode_graph else model.decode_from_hidden_graphed
                 masks, scores = dec_fn(emb, inp["seg_hidden"], inp["resize_list"], inp["original_size_list"])
                 if record_decode:
                     e1.record()
@@ -252,7 +369,7 @@ def main():
                 cur.wait_stream(side)         # keep at most one CLIP pass in flight per step
             else:
                 masks, scores = decode_part()
-        return feats, masks, scores
+        return feats, masks, scores, emb
 
     def fence():
         torch.cuda.synchronize()
@@ -275,64 +392,80 @@ def main():
         elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     images_per_s = world * B * args.steps / elapsed
-    decode_ms = sum(a.elapsed_time(b) for a, b in decode_ev) / max(1, len(decode_ev)) / B
+    decode_batch_ms = sum(a.elapsed_time(b) for a, b in decode_ev) / max(1, len(decode_ev))
 
-    # ---- instrumented step: per-launch HIP-event timing of every GEMM, grouped by the tile kernel that ran ---------
-    records = []
-
-    def hook(M, N, K, tile):
-        e0 = torch.cuda.Event(enable_timing=True)
-        e1 = torch.cuda.Event(enable_timing=True)
-        records.append((tile, 2.0 * M * N * K, e0, e1, 2.0 * (M * K + N * K + M * N)))
-        return e0, e1
-
-    # serialised (one stream): the events then bracket each launch running alone on the chip, which is what a kernel
-    # roofline describes; in the timed region above the streams overlap and per-launch times are not separable
+    # ---- mask-decode latency of ONE image (its T prompts) on an otherwise idle GPU: what BASELINE's "mask-decode ms" names --------
+    _f, _m, _s, emb = step(serial=True)
     torch.cuda.synchronize()
-    ops.GEMM_EVENT_HOOK = hook
-    step(serial=True)
+    one = (emb[:1].contiguous(), inp["seg_hidden"][:1], inp["resize_list"][:1], inp["original_size_list"][:1])
+    lat = {}
+    with torch.no_grad():
+        for name, fn in (("graph", model.decode_from_hidden_graphed), ("eager", model.decode_from_hidden)):
+            for _ in range(3):
+                fn(*one)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                fn(*one)
+            e1.record()
+            torch.cuda.synchronize()
+            lat[name] = e0.elapsed_time(e1) / 10
+
+    # ---- instrumented step: per-launch HIP-event timing of every GEMM, grouped by the kernel that ran ---------------------------
+    # serialised (one stream): the events then bracket each launch running alone on the chip, which is what a kernel roofline
+    # describes; in the timed region above the streams overlap and per-launch times are not separable
     torch.cuda.synchronize()
-    ops.GEMM_EVENT_HOOK = None
-    per_tile = {}
-    for tile, fl, e0, e1, nbytes in records:
-        d = per_tile.setdefault(tile, [0, 0.0, 0.0, 0.0])
+    with ops.time_gemms() as records:
+        step(serial=True)
+    torch.cuda.synchronize()
+    per_kernel = {}
+    for kid, M, N, K, e0, e1 in records:
+        d = per_kernel.setdefault(kid, [0, 0.0, 0.0, 0.0])
         d[0] += 1
-        d[1] += fl
+        d[1] += 2.0 * M * N * K
         d[2] += e0.elapsed_time(e1) * 1e-3
-        d[3] += nbytes
-    dom = max(per_tile, key=lambda k: per_tile[k][2])
-    n_l, fl, sec, byt = per_tile[dom]
+        d[3] += (1.0 if kid == 20 else 2.0) * (M * K + N * K) + 2.0 * M * N   # operands (1 B fp8 / 2 B bf16) + bf16 output
+    dom = max(per_kernel, key=lambda k: per_kernel[k][2])
+    n_l, fl, sec, byt = per_kernel[dom]
     achieved_tf = fl / sec / 1e12
+    peak = PEAK_TF["fp8" if dom == 20 else "bf16"]
     gf_step = B * (GF_CLIP_L_448 + GF_SAM[args.sam] + (GF_MSQP if args.with_msqp else 0.0) + T * (GF_DECODE_PER_TOKEN + GF_CTP_PER_TOKEN))
-    roofline = {"bound": "mfma", "kernel": "wg_gemm_pp_persist_kernel<%s> (256x256 tiles, ping-pong, persistent%s)" % (("true", ", LayerNorm folded in") if dom == 17 else ("false", "")) if dom in (16, 17) else "wg_gemm_kernel<%s>" % {1: "128,128,64,2,2,2", 2: "256,256,64,2,2,4", 8: "256,256,64,2,2,4,pipe", 11: "persist 128,128,2,2", 12: "tail 128,128 (+16 rows)", 14: "256,256,64,2,2,4,ping-pong", 3: "rowwave"}.get(dom, str(dom)),
-                "achieved": round(achieved_tf, 1), "peak": MFMA_BF16_DENSE_PEAK_TF, "unit": "TFLOP/s",
-                "frac": round(achieved_tf / MFMA_BF16_DENSE_PEAK_TF, 4), "traffic": None,
+    roofline = {"bound": "mfma", "kernel": KERNEL_NAMES.get(dom, str(dom)),
+                "achieved": round(achieved_tf, 1), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved_tf / peak, 4), "traffic": None,
                 "launches_per_step": n_l, "avg_launch_us": round(sec / n_l * 1e6, 1),
                 "measured": "HIP events around every launch of this kernel in one serialised (single-stream) step run right after the timed region",
-                "all_gemm_ms_serial": round(sum(v[2] for v in per_tile.values()) * 1e3, 3),
+                "all_gemm_ms_serial": round(sum(v[2] for v in per_kernel.values()) * 1e3, 3),
                 "e2e_algorithmic_gflop_per_step": round(gf_step, 1),
                 "e2e_achieved": round(gf_step / ms_per_step, 1),  # GFLOP/ms == TFLOP/s
-                "e2e_frac": round(gf_step / ms_per_step / MFMA_BF16_DENSE_PEAK_TF, 4)}
-
-    try:  # HBM traffic of the dominant kernel from the committed PMC passes of this same command (profiles/)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            pmc = json.load(f)["kernels"]
-        key = [k for k in pmc if k.startswith("wg_gemm_pp_persist_kernel<true>" if dom == 17 else "wg_gemm_pp_persist_kernel<false>" if dom == 16 else "wg_gemm_kernel<%s" % ("256, 256" if dom in (2, 14) else "128, 128"))]
-        if key:
-            roofline["traffic"] = pmc[key[0]]["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r01_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, avg per launch)"
+                "e2e_peak": PEAK_TF["bf16"], "e2e_frac": round(gf_step / ms_per_step / PEAK_TF["bf16"], 4),
+                "algorithmic_bytes_per_launch": round(byt / n_l)}
+    # HBM traffic of the dominant kernel from the committed PMC passes -- only when they profiled THIS configuration
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        same = pmc.get("config") == {"batch": B, "sam": args.sam, "seg_tokens": T, "with_msqp": bool(args.with_msqp), "dtype": args.dtype,
+                                     "world": 1}
+        key = [k for k in pmc["kernels"] if dom in PMC_PREFIX and k.startswith(PMC_PREFIX[dom])]
+        if same and key:
+            roofline["traffic"] = pmc["kernels"][key[0]]["hbm_bytes_per_launch"]
+            roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes of this command, avg per launch)"
     except (OSError, KeyError, ValueError):
         pass
-    roofline["algorithmic_bytes_per_launch"] = round(byt / n_l)
 
     out = {"metric": "images/sec", "value": round(images_per_s, 2), "unit": "images/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "mask_decode_ms": round(decode_ms, 3), "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
-           "config": {"workload": "C2: bs=%d/GPU 448x448 source images (CLIP input 448^2, SAM input 1024^2), CLIP ViT-L/14 + SAM %s "
-                                  "encoder%s + CTP + prompt encoder + mask decoder + postprocess, T=%d [SEG]/image, random-init weights"
-                                  % (B, args.sam, " + MSQP" if args.with_msqp else "", T),
-                      "global_batch": world * B, "batch_per_gpu": B, "seg_tokens_per_image": T,
+           "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+           "mask_decode_ms": round(lat["graph"], 3),
+           "mask_decode": {"one_image_latency_ms": round(lat["graph"], 3), "one_image_latency_eager_ms": round(lat["eager"], 3),
+                           "amortised_ms_per_image": round(decode_batch_ms / B, 3), "batch_ms_overlapped": round(decode_batch_ms, 3),
+                           "prompts_per_image": T,
+                           "note": "latency: prompt encoder + mask decoder + postprocess of one image's T prompts alone on the GPU (CTP included); "
+                                   "amortised: the batch's decode chain as timed inside the step, overlapped with the next step's encoders, / images"},
+           "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
+           "rccl_ranks": world if dist is not None else 0,
+           "config": {"workload": workload_label(args, world), "global_batch": world * B, "batch_per_gpu": B, "seg_tokens_per_image": T,
                       "parallelism": "dp%d (images sharded, RCCL all-gather of mask logits)" % world if world > 1 else "single GPU"},
            "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -344,4 +477,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -75,17 +75,18 @@ class _EncoderLayer(nn.Module, _Prepared):
         return {"qkv": ops.fold_layernorm(n1.weight, n1.bias, w, b),
                 "fc1": ops.fold_layernorm(n2.weight, n2.bias, m.fc1.weight, m.fc1.bias)}
 
-    def run(self, x, key_bias):
+    def run(self, x, key_bias, tail_tiles=False):
         """HF CLIPEncoderLayer: pre-LN attention + pre-LN quick-GELU MLP, both residual.  x [B, L, D].
-        Both LayerNorms are folded into the GEMM behind them (ops.ln_linear)."""
+        Both LayerNorms are folded into the GEMM behind them (ops.ln_linear).  tail_tiles: let the M = B*1025 GEMMs use the
+        tail-absorbing tiles (faster when nothing else shares the GPU, slower under stream overlap)."""
         a = self.self_attn
         p = self._prep_get(self._build)
         D = x.shape[-1]
-        qkv = ops.ln_linear(x, p["qkv"], self.layer_norm1.eps)
+        qkv = ops.ln_linear(x, p["qkv"], self.layer_norm1.eps, tail_tiles=tail_tiles)
         o = ops.mha(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], a.num_heads, a.scale, key_bias, small=False)
-        x = ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=x)
-        h = ops.ln_linear(x, p["fc1"], self.layer_norm2.eps, act=ops.ACT_QUICK_GELU)
-        return ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x)
+        x = ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=x, tail_tiles=tail_tiles)
+        h = ops.ln_linear(x, p["fc1"], self.layer_norm2.eps, act=ops.ACT_QUICK_GELU, tail_tiles=tail_tiles)
+        return ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x, tail_tiles=tail_tiles)
 
 
 class _Encoder(nn.Module):
@@ -111,7 +112,7 @@ class _CLIPVisionTransformer(nn.Module, _Prepared):
         w[:, :K] = e.patch_embedding.weight.reshape(e.embed_dim, K)
         return {"patch_w": w, "kpad": kpad}
 
-    def hidden_states(self, pixel_values, attention_mask, want, run_all_layers=True):
+    def hidden_states(self, pixel_values, attention_mask, want, run_all_layers=True, tail_tiles=False):
         """{index: hidden state [B, 1+P, D]} for the (python-style, possibly negative) indices in `want`;
         hidden_states[0] is the pre_layrnorm output (custom_clip.py:74-92)."""
         _check_bf16_gpu(pixel_values, "images_clip")
@@ -138,7 +139,7 @@ class _CLIPVisionTransformer(nn.Module, _Prepared):
         keep = {0: x} if 0 in idx else {}
         last = n if run_all_layers else max(idx)
         for i in range(last):
-            x = self.encoder.layers[i].run(x, key_bias)
+            x = self.encoder.layers[i].run(x, key_bias, tail_tiles)
             if i + 1 in idx:
                 keep[i + 1] = x
         return {w_: keep[w_ if w_ >= 0 else n + 1 + w_] for w_ in want}
@@ -201,11 +202,11 @@ class CLIPVisionTower(nn.Module):
         return feats, [states[-11][:, 1:]]
 
     @torch.no_grad()
-    def forward(self, images, attention_mask=None):
+    def forward(self, images, attention_mask=None, tail_tiles=False):
         if type(images) is list:
             raise NotImplementedError("list-of-images input is not on the WalkGPT path (llava_arch.py:236-243 asserts it away)")
         states = self.vision_tower.vision_model.hidden_states(images, attention_mask, [self.select_layer, -11],
-                                                              self.run_all_layers)
+                                                              self.run_all_layers, tail_tiles)
         return self.feature_select(states)
 
     @property

@@ -23,6 +23,7 @@
 //            registers and relh costs one LDS read per tile.
 // LDS swizzles (source-side, undone on the read): K rows for ds_read_b128, V rows for the transposed read.
 #include "wg_common.h"
+#include <stdlib.h>
 
 #define LOG2E 1.4426950408889634f
 #define NEG_BIG (-1.0e30f)
@@ -281,46 +282,52 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     stage(0, 0, true);
 
     // ---- rel-pos tables (grid) / key bias row (plain) -----------------------------------------------------------
-    float relw_reg[NRW];
+    // Width term of the rel-pos bias, laid out as the S^T accumulator of a key block (element r of block kb belongs to padded-row
+    // column slot (16*kb + r) % NRW) and pre-divided by scale*log2(e): it is the C operand of the first S^T MFMA of every tile,
+    // so the matrix pipe adds it and the scores leave the MFMAs as (q.k + relw / sc2).
+    constexpr int NC = (GRID && RP == 64) ? 2 : 1;
+    f32x16 relw_c[NC];
     float* mytab = tab + wave * 32 * SP;
-    if constexpr (GRID) {
-        // pass 0: width table -> registers; pass 1: height table -> stays in LDS (same slot)
+    // T^T = Rel . Q^T for one of the two tables, scattered to key space: mytab[q][kpos]
+    auto rel_pass = [&](int which) __attribute__((always_inline)) {
+        const bf16* rel = which == 0 ? a.rel_w : a.rel_h;
+        const int qpos = which == 0 ? qw : qh;
+        for (int k = S + hi; k < SP; k += 2) mytab[ql_lane * SP + k] = NEG_BIG;   // rows / columns beyond the window
 #pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const bf16* rel = which == 0 ? a.rel_w : a.rel_h;
-            const int qpos = which == 0 ? qw : qh;
-            for (int k = S + hi; k < SP; k += 2) mytab[ql_lane * SP + k] = NEG_BIG;   // rows / columns beyond the window
+        for (int jb = 0; jb < NJB; ++jb) {
+            int j = jb * 32 + ql_lane;
+            j = j < 2 * S - 1 ? j : 2 * S - 2;
+            f32x16 acc;
 #pragma unroll
-            for (int jb = 0; jb < NJB; ++jb) {
-                int j = jb * 32 + ql_lane;
-                j = j < 2 * S - 1 ? j : 2 * S - 2;
-                f32x16 acc;
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-                for (int s = 0; s < KSTEPS; ++s) {
-                    bf16x8 rf;
-                    if constexpr (REL_EARLY) rf = rel_early[which][s];
-                    else rf = *(const bf16x8*)(rel + (long)j * HD + 16 * s + 8 * hi);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf, qf[s], acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int jj = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // table row held in acc[r]
-                    const int kpos = qpos + S - 1 - jj;                        // key coordinate it belongs to
-                    if (jj < 2 * S - 1 && kpos >= 0 && kpos < S) mytab[ql_lane * SP + kpos] = acc[r] * LOG2E;
-                }
+            for (int s = 0; s < KSTEPS; ++s) {
+                bf16x8 rf;
+                if constexpr (REL_EARLY) rf = rel_early[which][s];
+                else rf = *(const bf16x8*)(rel + (long)j * HD + 16 * s + 8 * hi);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf, qf[s], acc, 0, 0, 0);
             }
-            if (which == 0) {
-                __syncthreads();
 #pragma unroll
-                for (int j = 0; j < NRW; ++j) {
-                    const int kw = (j & 3) + 8 * (j >> 2) + 4 * hi;   // this lane's j-th column slot inside a padded row
-                    relw_reg[j] = kw < S ? mytab[ql_lane * SP + kw] : NEG_BIG;
-                }
-                __syncthreads();
+            for (int r = 0; r < 16; ++r) {
+                const int jj = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;  // table row held in acc[r]
+                const int kpos = qpos + S - 1 - jj;                        // key coordinate it belongs to
+                if (jj < 2 * S - 1 && kpos >= 0 && kpos < S) mytab[ql_lane * SP + kpos] = acc[r] * LOG2E;
             }
         }
+    };
+    if constexpr (GRID) {
+        // width table -> registers (through the LDS scatter); height table -> stays in LDS (same slot)
+        const float inv_sc2 = 1.0f / (a.scale * LOG2E);
+        rel_pass(0);
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 16 * NC; ++e) {
+            const int j = e % NRW;
+            const int kw = (j & 3) + 8 * (j >> 2) + 4 * hi;   // this lane's j-th column slot inside a padded row
+            relw_c[e >> 4][e & 15] = (kw < S ? mytab[ql_lane * SP + kw] : NEG_BIG) * inv_sc2;
+        }
+        __syncthreads();
+        rel_pass(1);
     } else {
         if (KB) {
             for (int k = tid; k < nt * 64; k += NW * 64) {
@@ -351,7 +358,9 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     // latency chain in an in-order pipeline (matrix pipe 35 %, VALU 46 % busy, 18 % of the time together), not a throughput
     // problem of either unit.
     constexpr float RESCALE_THR = 6.0f;
-    constexpr bool RAW = !GRID && !KB;           // no additive bias: scores stay unscaled, p = exp2(s*sc2 - off)
+    // RAW: no per-element bias is left to add on the VALU (none at all, or -- grid mode with one key row per tile -- the width term
+    // comes out of the MFMAs and the height term is one value per tile): scores stay unscaled, p = exp2(s*sc2 - off)
+    constexpr bool RAW = (!GRID && !KB) || (GRID && RPT == 1);
     constexpr int NQK = 2 * KSTEPS;              // S^T MFMAs per tile
     constexpr int NPV = 4 * DB;                  // P.V MFMAs per tile
     f32x16 sa[2];                                // scores of the tile
@@ -383,8 +392,12 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         return;
 #endif
         if (s == 0) {
-            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g], qf[s], z, 0, 0, 0);
+            if constexpr (GRID) {
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g], qf[s], relw_c[kb % NC], 0, 0, 0);
+            } else {
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g], qf[s], z, 0, 0, 0);
+            }
         } else {
             st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g], qf[s], st[kb], 0, 0, 0);
         }
@@ -408,17 +421,14 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         for (int e = e0; e < e1; ++e) {
             const int kb = e >> 4, r = e & 15;
             float v = st[kb][r];
-            if constexpr (GRID) {
+            if constexpr (GRID && RPT > 1) {
                 const int sl0 = 32 * kb + (r & 3) + 8 * (r >> 2);        // slot in tile without the lane-half bit
-                const int slr = sl0 % RP;                                  // slot in its padded row
-                const int j = (slr & 3) + 4 * (slr >> 3);                  // which of this lane's column registers
-                v = v * sc2 + relw_reg[j];
-                if constexpr (RPT > 1) v += rh[sl0 / RP];
+                v = v * sc2 + rh[sl0 / RP];                                // (the width term is already in v: C operand of the MFMA)
             } else if constexpr (KB) {
                 v = v * sc2 + kbv[kb][r >> 2][r & 3];
             }
             if (mask_tail && t * 64 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi >= Lk) v = NEG_BIG;
-            st[kb][r] = v;
+            if (!RAW || mask_tail) st[kb][r] = v;
             mt = fmaxf(mt, v);
         }
     };
@@ -671,6 +681,10 @@ extern "C" int wg_sam_attn_relpos_bf16(const void* qkv, const void* qkv_bias, co
         return launch_attn<HD_, S_, NW_>(a, groups, st);           \
     }
     WG_SAM_CASE(64, 14, 4)   // two 4-wave workgroups per window (one idle query slot in eight) measured 5 % faster than one of 7 waves
+    {   // experiments: WG_SAM_GLOBAL_NW=4 runs the global kernel as two four-wave workgroups per CU
+        static const int nw_env = getenv("WG_SAM_GLOBAL_NW") ? atoi(getenv("WG_SAM_GLOBAL_NW")) : 8;
+        if (nw_env == 4) { WG_SAM_CASE(64, 64, 4) }
+    }
     WG_SAM_CASE(64, 64, 8)
     WG_SAM_CASE(64, 32, 8)
     WG_SAM_CASE(32, 14, 7)

@@ -33,25 +33,49 @@ def _rows(t):
     return t.numel() // t.shape[-1], t.shape[-1], t.shape[-1]
 
 
+import contextlib as _contextlib
 import os as _os
+import threading as _threading
 
 _FORCE_TILE = int(_os.environ.get("WG_GEMM_TILE", "0"))  # experiments only: force one GEMM tile variant
-ALLOW_TAIL_TILES = False  # single-stream callers set this: see wg_gemm_pick_tile_ex in csrc/gemm.hip
-GEMM_EVENT_HOOK = None  # bench.py: callable(M, N, K, tile) -> (start_event, end_event) recorded around the launch
+_tls = _threading.local()  # per-thread measurement state (no module-level mutable switches: two models / threads never interact)
 
 
-def gemm_tile_for(M, N, K, lda, ldw, ldc, ldr):
+@_contextlib.contextmanager
+def time_gemms():
+    """Measurement only (bench.py): inside the block every GEMM launch of THIS thread is bracketed by a pair of HIP events on its
+    launch stream.  Yields the list that collects (kernel id, M, N, K, start_event, end_event); 17 = the LayerNorm-folded instance."""
+    records = []
+    prev = getattr(_tls, "gemm_records", None)
+    _tls.gemm_records = records
+    try:
+        yield records
+    finally:
+        _tls.gemm_records = prev
+
+
+def _timed(kid, M, N, K):
+    rec = getattr(_tls, "gemm_records", None)
+    if rec is None:
+        return None
+    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+    rec.append((kid, M, N, K, ev[0], ev[1]))
+    return ev
+
+
+def gemm_tile_for(M, N, K, lda, ldw, ldc, ldr, tail_tiles=False):
     """Which kernel wg_gemm_bias_act_bf16 runs for this shape: 1 = 128x128 tiles, 2 = 256x256 tiles,
-    3 = row-wave (asks the library's own selector, so host-side accounting and the library agree)."""
+    3 = row-wave (asks the library's own selector, so host-side accounting and the library agree).
+    tail_tiles: also consider the tail-absorbing 128x128 kernel (wg_gemm_pick_tile_ex in csrc/gemm.hip; single-stream callers)."""
     ok = K % 64 == 0 and N % 4 == 0 and N >= 16 and lda % 8 == 0 and ldw % 8 == 0 and ldc % 4 == 0 and ldr % 4 == 0
     if not ok:
         return 3
     if _FORCE_TILE:
         return _FORCE_TILE
-    return _lib.lib().wg_gemm_pick_tile_ex(M, N, 1 if ALLOW_TAIL_TILES else 0)
+    return _lib.lib().wg_gemm_pick_tile_ex(M, N, 1 if tail_tiles else 0)
 
 
-def linear(x, weight, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out=None, out_f32=False, tile=0):
+def linear(x, weight, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out=None, out_f32=False, tile=0, tail_tiles=False):
     """y = act(x @ weight.T + bias) (+ residual).  x [..., K] bf16, weight [N, K] bf16."""
     _need_gpu(x, weight, bias, residual, out)
     assert x.dtype == _BF16 and weight.dtype == _BF16
@@ -70,8 +94,8 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out
     if bias is not None:
         assert bias.dtype == _BF16 and bias.numel() == N
     if tile == 0:
-        tile = gemm_tile_for(M, N, K, lda, weight.stride(0), ldc, ldr)
-    ev = GEMM_EVENT_HOOK(M, N, K, tile) if GEMM_EVENT_HOOK is not None else None
+        tile = gemm_tile_for(M, N, K, lda, weight.stride(0), ldc, ldr, tail_tiles)
+    ev = _timed(tile, M, N, K)
     if ev is not None:
         ev[0].record()
     rc = _lib.lib().wg_gemm_bias_act_bf16(x.data_ptr(), lda, weight.data_ptr(), weight.stride(0), _ptr(bias),
@@ -121,7 +145,7 @@ def row_stats(x, eps):
     return st
 
 
-def ln_linear(x, fold, eps, act=ACT_NONE):
+def ln_linear(x, fold, eps, act=ACT_NONE, tail_tiles=False):
     """act(LayerNorm(x) @ W.T + b) with `fold` from fold_layernorm.  Shapes the persistent 256x256 GEMM takes run as a
     row-statistics pass + one GEMM on the raw rows (the normalised rows never reach HBM); the rest as LayerNorm + GEMM."""
     _need_gpu(x)
@@ -130,10 +154,10 @@ def ln_linear(x, fold, eps, act=ACT_NONE):
     N = fold["wg"].shape[0]
     L = _lib.lib()
     if not (LN_FUSE and not _FORCE_TILE and L.wg_gemm_ln_supported(M, N, K, lda, K, N)):
-        return linear(layernorm(x, fold["gamma"], fold["beta"], eps), fold["weight"], fold["bias"], act=act)
+        return linear(layernorm(x, fold["gamma"], fold["beta"], eps), fold["weight"], fold["bias"], act=act, tail_tiles=tail_tiles)
     st = row_stats(x, eps)
     out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=_BF16)
-    ev = GEMM_EVENT_HOOK(M, N, K, 17) if GEMM_EVENT_HOOK is not None else None  # 17: the LN instance of kernel 16
+    ev = _timed(17, M, N, K)  # 17: the LayerNorm-folded instance of kernel 16
     if ev is not None:
         ev[0].record()
     rc = L.wg_gemm_ln_bias_act_bf16(x.data_ptr(), lda, fold["wg"].data_ptr(), K, fold["bias_f32"].data_ptr(),

@@ -25,8 +25,12 @@ BF16 = torch.bfloat16
 class _Prepared:
     """Derived (re-laid / concatenated / bf16) kernel operands, rebuilt after any parameter change."""
 
-    def _prep_get(self, build):
-        key = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in self.parameters(recurse=True))
+    def _prep_get(self, build, deps=None):
+        """deps: the tensors `build` reads (default: every parameter below this module -- pass them explicitly where the module
+        tree is large, the key is recomputed on every forward)."""
+        if deps is None:
+            deps = self.parameters(recurse=True)
+        key = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in deps if p is not None)
         if getattr(self, "_prep_key", None) != key:
             object.__setattr__(self, "_prep_val", build())
             object.__setattr__(self, "_prep_key", key)
@@ -113,7 +117,8 @@ class Block(nn.Module, _Prepared):
         a = self.attn
         if not a.use_rel_pos or a.qkv.bias is None:
             raise NotImplementedError("the HIP SAM attention is built for use_rel_pos=True, qkv_bias=True (build_sam.py:56-108)")
-        p = self._prep_get(self._build)
+        p = self._prep_get(self._build, (self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, self.norm2.weight,
+                                         self.norm2.bias, self.mlp.lin1.weight, self.mlp.lin1.bias))
         qkv = ops.ln_linear(x, p["qkv"], self.norm1.eps)
         window = self.window_size if self.window_size > 0 else grid
         o = ops.sam_attention(qkv, a.qkv.bias, a.rel_pos_h, a.rel_pos_w, B, grid, window, a.num_heads)
@@ -175,7 +180,7 @@ class ImageEncoderViT(nn.Module, _Prepared):
         g = x.shape[-1] // self.patch_size
         if x.shape[-2] != x.shape[-1] or g != self.img_size // self.patch_size:
             raise RuntimeError("image encoder expects %dx%d inputs" % (self.img_size, self.img_size))
-        p = self._prep_get(self._build_prepared)
+        p = self._prep_get(self._build_prepared, (self.patch_embed.proj.weight, self.neck[0].weight, self.neck[2].weight, self.pos_embed))
         rows = ops.patchify(x.contiguous(), self.patch_size)
         t = ops.linear(rows, p["patch_w"], self.patch_embed.proj.bias, residual=p["pos"], res_row_mod=g * g if p["pos"] is not None else 0)
         for blk in self.blocks:

@@ -58,14 +58,14 @@ class WalkGPTGrounding(nn.Module):
         return t.view(pixel_values.shape[0], -1, t.shape[-1])
 
     # -- llava_arch.py:160-193 + clip_encoder.py:71-98 ---------------------------------------------------------------------
-    def encode_images_clip(self, images_clip, clip_resize_list=None):
+    def encode_images_clip(self, images_clip, clip_resize_list=None, tail_tiles=False):
         h, w = images_clip.shape[-2:]
         if clip_resize_list is None or all(tuple(s) == (h, w) for s in clip_resize_list):
             # nothing is padded: the key mask is all ones and its additive bias all zeros, so it is not passed at all
             # (decided from the python size list; no device sync)
-            return self.vision_tower(images_clip, attention_mask=None)
+            return self.vision_tower(images_clip, attention_mask=None, tail_tiles=tail_tiles)
         mask = patch_key_mask(images_clip, clip_resize_list)
-        return self.vision_tower(images_clip, attention_mask=mask)
+        return self.vision_tower(images_clip, attention_mask=mask, tail_tiles=tail_tiles)
 
     # -- walkgpt.py:316-318 / 364-378 (batched instead of one call per image) --------------------------------------------------
     def project_visual_tokens(self, emb_tokens):
@@ -136,10 +136,19 @@ class WalkGPTGrounding(nn.Module):
         launch gaps (1.4 -> 0.8 ms per batch of 8 prompts).  One graph per (shapes, sizes) signature; inputs are copied into
         the graph's static buffers, and the returned tensors are the graph's output buffers -- valid until the next call with
         the same signature (clone them to keep them)."""
+        # The captured graph bakes in the addresses of the weights AND of every derived operand the modules cache (re-laid ConvT
+        # weights, PE-folded K/V tables, the dense-PE rows): its key therefore carries the identity and version of every parameter
+        # and buffer the chain reads, so load_state_dict / .to() / an in-place edit after the first call re-captures instead of
+        # replaying stale (or freed) memory.
+        vm = self.visual_model
+        mods = [vm.prompt_encoder, vm.mask_decoder] + (list(self.text_hidden_fcs) if hasattr(self, "text_hidden_fcs") else [])
+        wkey = tuple((t.data_ptr(), t._version, t.dtype) for m in mods for t in list(m.parameters()) + list(m.buffers()))
         key = (tuple(emb_tokens.shape), tuple(tuple(h.shape) for h in seg_hidden), tuple(map(tuple, resize_list)),
-               tuple(map(tuple, original_size_list)), str(emb_tokens.device))
+               tuple(map(tuple, original_size_list)), str(emb_tokens.device), seg_hidden[0].dtype if seg_hidden else None)
         graphs = self.__dict__.setdefault("_decode_graphs", {})
         ent = graphs.get(key)
+        if ent is not None and ent[4] != wkey:
+            ent = None          # weights changed since capture: drop the stale graph (its buffers are released with it)
         if ent is None:
             s_emb = torch.empty_like(emb_tokens)
             s_hid = [torch.empty_like(h) for h in seg_hidden]
@@ -155,8 +164,8 @@ class WalkGPTGrounding(nn.Module):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), torch.no_grad():
                 out = self.decode_from_hidden(s_emb, s_hid, resize_list, original_size_list)
-            ent = graphs[key] = (g, s_emb, s_hid, out)
-        g, s_emb, s_hid, out = ent
+            ent = graphs[key] = (g, s_emb, s_hid, out, wkey)
+        g, s_emb, s_hid, out, _ = ent
         s_emb.copy_(emb_tokens)
         for d, h in zip(s_hid, seg_hidden):
             d.copy_(h)
@@ -186,7 +195,6 @@ class WalkGPTGrounding(nn.Module):
         streams so each one's partially filled launches (M = B*1025 rows never tile evenly) use the other's idle CUs."""
         out = {}
         side = None
-        ops.ALLOW_TAIL_TILES = not overlap_streams
         if hasattr(self, "vision_tower") and images_clip is not None:
             cur = torch.cuda.current_stream()
             if overlap_streams:
@@ -196,8 +204,8 @@ class WalkGPTGrounding(nn.Module):
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     out["clip_features"], out["clip_pre_features"] = self.encode_images_clip(images_clip, clip_resize_list)
-            else:
-                out["clip_features"], out["clip_pre_features"] = self.encode_images_clip(images_clip, clip_resize_list)
+            else:   # nothing shares the GPU with the tower: its M = B*1025 GEMMs may use the tail-absorbing tiles
+                out["clip_features"], out["clip_pre_features"] = self.encode_images_clip(images_clip, clip_resize_list, tail_tiles=True)
         emb_tokens = self.get_visual_emb_tokens(images)
         if hasattr(self, "out_mm_projector"):
             out["visual_tokens"] = self.project_visual_tokens(emb_tokens)
