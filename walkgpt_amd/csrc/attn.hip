@@ -23,7 +23,6 @@
 //            registers and relh costs one LDS read per tile.
 // LDS swizzles (source-side, undone on the read): K rows for ds_read_b128, V rows for the transposed read.
 #include "wg_common.h"
-#include <stdlib.h>
 
 #define LOG2E 1.4426950408889634f
 #define NEG_BIG (-1.0e30f)
@@ -681,10 +680,6 @@ extern "C" int wg_sam_attn_relpos_bf16(const void* qkv, const void* qkv_bias, co
         return launch_attn<HD_, S_, NW_>(a, groups, st);           \
     }
     WG_SAM_CASE(64, 14, 4)   // two 4-wave workgroups per window (one idle query slot in eight) measured 5 % faster than one of 7 waves
-    {   // experiments: WG_SAM_GLOBAL_NW=4 runs the global kernel as two four-wave workgroups per CU
-        static const int nw_env = getenv("WG_SAM_GLOBAL_NW") ? atoi(getenv("WG_SAM_GLOBAL_NW")) : 8;
-        if (nw_env == 4) { WG_SAM_CASE(64, 64, 4) }
-    }
     WG_SAM_CASE(64, 64, 8)
     WG_SAM_CASE(64, 32, 8)
     WG_SAM_CASE(32, 14, 7)
