@@ -119,6 +119,31 @@ int wg_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
 int wg_hyper_mask_dot(const void* up, const void* hyper, float* masks, int T, int h, int w, int channels, int nmask_total,
                       int first_mask, int num_masks, void* stream);
 
+/* mask_decoder.py:140-160 fused: `upscaled = output_upscaling(src)` (ConvT k2 s2 -> LayerNorm2d -> GELU -> ConvT k2 s2 -> GELU) and
+ * `masks = hyper_in @ upscaled` in one launch; every step is local to an image token.  x [P*h*w, 256] bf16 token rows; w1 [(dy,dx,64),
+ * 256], w2 [(dy,dx,32), 64]: the transposed convolutions re-laid as GEMM weights; hyper [P, nmask_total, 32] fp32;
+ * out [P, num_masks, 4h, 4w] fp32.  fp32 inside (the 64-channel intermediate feeds the second MFMA as a bf16 hi + lo pair). */
+int wg_upscale_mask_bf16(const void* x, long ldx, const void* w1, const void* b1, const void* ln_g, const void* ln_b, float eps,
+                         const void* w2, const void* b2, const float* hyper, float* out, int P, int h, int w, int nmask_total,
+                         int first_mask, int num_masks, void* stream);
+
+/* Token side of SAM's two-way transformer, one launch per block, one workgroup per prompt, fp32 token state in LDS.
+ * mode 0 = one TwoWayAttentionBlock (transformer.py:151-182): [self-attention (+query_pe unless skip_pe), norm1, token->image
+ *          cross attention over the hw projected image tokens, norm2, MLP(ReLU), norm3, k / v of the image->token attention];
+ * mode 1 = final_attn_token_to_image + norm_final_attn (transformer.py:96-106) + the four hypernetwork MLPs and the IoU head
+ *          (mask_decoder.py:146-160).
+ * queries [P,6,256] fp32 in/out (token order [iou, mask0..3, prompt], mask_decoder.py:125-132); query_pe [P,6,256] fp32;
+ * weights: host array of n_weights bf16 device pointers (weight, bias / gamma, beta pairs) --
+ *   mode 0 (26): self_attn q,k,v,out | norm1 | cross_attn_token_to_image q,out | norm2 | mlp lin1,lin2 | norm3 |
+ *                cross_attn_image_to_token k,v;
+ *   mode 1 (36): final attn q,out | norm_final_attn | output_hypernetworks_mlps[0..3].layers[0..2] | iou_prediction_head.layers[0..2];
+ * Kimg / Vimg: projected image tokens (k_proj(keys + key_pe), v_proj(keys)) as bf16 rows [P or 1][hw][128] with row stride ld_img;
+ * img_rows_per_prompt = 0 when all prompts share one image.  Outputs: mode 0 k_i2t / v_i2t [P,6,128] bf16; mode 1 hyper_out
+ * [P,4,32] fp32 and iou_out [P,4] fp32. */
+int wg_dec_tokens_f32(int mode, int skip_pe, float* queries, const float* query_pe, const void* const* weights, int n_weights,
+                      const void* Kimg, const void* Vimg, long ld_img, long img_rows_per_prompt, int hw, void* k_i2t, void* v_i2t,
+                      float* hyper_out, float* iou_out, int P, float eps, void* stream);
+
 /* Sam.postprocess_masks (sam.py:137-172): bilinear to img_size^2, crop [:in_h,:in_w], bilinear to (out_h,out_w), one pass. */
 int wg_postprocess_masks_f32(const float* low_res, float* out, int N, int low_h, int low_w, int img_size, int in_h,
                              int in_w, int out_h, int out_w, void* stream);

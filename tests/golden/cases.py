@@ -58,18 +58,65 @@ def tap_embedding(out):
 
 
 # --- prompt encoder + mask decoder + postprocess -----------------------------------------------------------------
+# "g32" / "g64": white-noise embedding, fp32 weights (every pixel of the mask is a boundary pixel: the hardest case for thresholded
+# agreement; kept from round 1, now with the reference's own bf16 run stored next to its fp32 run as the calibration of "just bf16").
+# "conf_g64": the confident-mask case.  The embedding is piecewise constant over nine regions (+2 % noise), as the embedding of an
+# image of a few objects is, and the two transposed convolutions use the same weights for their 2x2 sub-pixels (a trained upscaler
+# is coherent across sub-pixels; independent random ones paint a 4x4 texture whose amplitude exceeds the differences between regions),
+# so the reference's logits are piecewise constant: four regions at >= +0.19, five at <= -0.19, 0.011 of spread inside a region (the
+# seed was searched for that margin with the reference itself).  Weights and inputs are bf16-representable (the deployed checkpoint
+# IS bf16: evaluation_walkgpt.py:908-910 casts the model), so the only difference between the reference's fp32 run and the HIP path
+# is the arithmetic in between.
 DECODERS = {
     "g32": dict(grid=32, tokens=3, seed=21, input_size=(384, 512), original_size=(75, 111)),
     "g64": dict(grid=64, tokens=2, seed=22, input_size=(1024, 683), original_size=(448, 299)),
+    "conf_g64": dict(grid=64, tokens=3, seed=50, input_size=(1024, 1024), original_size=(448, 448), style="regions", regions=9,
+                     bf16_weights=True, coherent_upscaler=True),
 }
+
+
+def _bf16_round(t):
+    return t.to(torch.bfloat16).float()
 
 
 def decoder_inputs(c):
     g = c["grid"]
-    emb = torch.from_numpy(synth.normal(c["seed"], "input.image_embedding", (1, 256, g, g)))
+    if c.get("style") == "regions":
+        R = c["regions"]
+        u = synth.uniform01(c["seed"], "input.region_sites", 2 * R).reshape(R, 2) * g
+        yy, xx = np.mgrid[0:g, 0:g]
+        d = (yy[None] + 0.5 - u[:, 0, None, None]) ** 2 + (xx[None] + 0.5 - u[:, 1, None, None]) ** 2
+        region = torch.from_numpy(d.argmin(0))                                     # [g, g] nearest site
+        vals = torch.from_numpy(synth.normal(c["seed"], "input.region_values", (R, 256)))
+        emb = vals[region].permute(2, 0, 1)[None].contiguous()
+        emb = emb + 0.02 * torch.from_numpy(synth.normal(c["seed"], "input.image_embedding", (1, 256, g, g)))
+    else:
+        emb = torch.from_numpy(synth.normal(c["seed"], "input.image_embedding", (1, 256, g, g)))
     text = torch.from_numpy(synth.normal(c["seed"], "input.text_embeds", (c["tokens"], 1, 256)))
     text = torch.nn.functional.normalize(text, dim=-1)
+    if c.get("bf16_weights"):
+        emb, text = _bf16_round(emb), _bf16_round(text)
     return emb, text
+
+
+def decoder_case_weights(c):
+    w = decoder_weights(c["seed"])
+    if c.get("coherent_upscaler"):
+        for k in ("mask_decoder.output_upscaling.0.weight", "mask_decoder.output_upscaling.3.weight"):
+            w[k] = w[k][:, :, :1, :1].expand_as(w[k]).contiguous()
+    if c.get("bf16_weights"):
+        w = {k: (v if "gaussian_matrix" in k else _bf16_round(v)) for k, v in w.items()}   # the PE buffer stays fp32 in the build
+    return w
+
+
+def tap_keys(keys, g):
+    """[T, g*g, C] image-token stream -> strided slice (the fixtures stay small)."""
+    return keys.reshape(keys.shape[0], g, g, -1)[:, ::8, ::8, ::4].contiguous()
+
+
+def tap_upscaled(up):
+    """[T, 32, 4g, 4g] upscaled embedding -> strided slice."""
+    return up[:, :, ::16, ::16].contiguous()
 
 
 def _mlp3_shapes(prefix, din, dh, dout):

@@ -74,30 +74,75 @@ def make_sam_encoder(name):
 
 
 def make_decoder(name):
+    """Prompt encoder (text branch) + mask decoder + Sam.postprocess_masks of the reference, three ways:
+      * fp32 (the parity target), with stage taps: queries / keys after each TwoWayAttentionBlock and after the final attention,
+        the upscaled embedding, hyper_in;
+      * the same modules cast with .bfloat16() and run on CPU in bf16 -- the precision the reference's own callers use
+        (evaluation_walkgpt.py:908-910) -- stored as `*_bf16`: the calibration of how far "bf16 storage" alone moves the masks."""
     sam_modeling, _ = _import_reference()
     c = cases.DECODERS[name]
     g = c["grid"]
-    pe = sam_modeling.PromptEncoder(embed_dim=256, image_embedding_size=(g, g), input_image_size=(g * 16, g * 16),
-                                    mask_in_chans=16)
-    dec = sam_modeling.MaskDecoder(num_multimask_outputs=3, transformer=sam_modeling.TwoWayTransformer(
-        depth=2, embedding_dim=256, mlp_dim=2048, num_heads=8), transformer_dim=256, iou_head_depth=3,
-        iou_head_hidden_dim=256)
-    _load(pe, c["seed"], "prompt_encoder.")
-    _load(dec, c["seed"], "mask_decoder.")
+
+    def build():
+        pe = sam_modeling.PromptEncoder(embed_dim=256, image_embedding_size=(g, g), input_image_size=(g * 16, g * 16), mask_in_chans=16)
+        dec = sam_modeling.MaskDecoder(num_multimask_outputs=3, transformer=sam_modeling.TwoWayTransformer(
+            depth=2, embedding_dim=256, mlp_dim=2048, num_heads=8), transformer_dim=256, iou_head_depth=3, iou_head_hidden_dim=256)
+        w = cases.decoder_case_weights(c)
+        for mod, prefix in ((pe, "prompt_encoder."), (dec, "mask_decoder.")):
+            sd = mod.state_dict()
+            new = {k: (w[prefix + k] if prefix + k in w else torch.from_numpy(synth.param(c["seed"], prefix + k, tuple(v.shape))))
+                   for k, v in sd.items()}
+            mod.load_state_dict(new, strict=True)
+            mod.eval()
+        return pe, dec
+
+    holder = types.SimpleNamespace(image_encoder=types.SimpleNamespace(img_size=g * 16))
     emb, text = cases.decoder_inputs(c)
     out = {}
+    pe, dec = build()
+    taps = {}
+    hooks = []
+    for i, layer in enumerate(dec.transformer.layers):
+        hooks.append(layer.register_forward_hook(lambda m, a, o, i=i: taps.__setitem__("layer%d" % i, o)))
+    hooks.append(dec.transformer.register_forward_hook(lambda m, a, o: taps.__setitem__("final", o)))
+    hooks.append(dec.output_upscaling.register_forward_hook(lambda m, a, o: taps.__setitem__("up", o)))
     with torch.no_grad():
         sparse, dense = pe(points=None, boxes=None, masks=None, text_embeds=text)
         dpe = pe.get_dense_pe()
         masks, iou = dec(image_embeddings=emb, image_pe=dpe, sparse_prompt_embeddings=sparse,
                          dense_prompt_embeddings=dense, multimask_output=False)
         # Sam.postprocess_masks (sam.py:137-172) needs a whole Sam object only for image_encoder.img_size
-        holder = types.SimpleNamespace(image_encoder=types.SimpleNamespace(img_size=g * 16))
         post = sam_modeling.Sam.postprocess_masks(holder, masks, input_size=c["input_size"], original_size=c["original_size"])
+        hs = taps["final"][0]
+        hyper = torch.stack([dec.output_hypernetworks_mlps[i](hs[:, 1 + i]) for i in range(4)], 1)
+    for h in hooks:
+        h.remove()
     out["dense_pe"] = dpe[0, ::8].numpy()
     out["masks"] = masks.numpy()
     out["iou"] = iou.numpy()
     out["post"] = post.numpy()
+    for i in range(2):
+        out["queries%d" % i] = taps["layer%d" % i][0].numpy()
+        out["keys%d" % i] = cases.tap_keys(taps["layer%d" % i][1], g).numpy()
+    out["queries_final"] = hs.numpy()
+    out["upscaled"] = cases.tap_upscaled(taps["up"]).numpy()
+    out["hyper_in"] = hyper.numpy()
+    # the reference's own bf16 run
+    pe16, dec16 = build()
+    pe16.bfloat16()
+    dec16.bfloat16()
+    with torch.no_grad():
+        sparse, dense = pe16(points=None, boxes=None, masks=None, text_embeds=text.bfloat16())
+        sparse = sparse.to(torch.bfloat16)   # model/walkgpt.py:521: `sparse_embeddings.to(pred_embeddings[i].dtype)`
+        masks16, _ = dec16(image_embeddings=emb.bfloat16(), image_pe=pe16.get_dense_pe(), sparse_prompt_embeddings=sparse,
+                           dense_prompt_embeddings=dense, multimask_output=False)
+        post16 = sam_modeling.Sam.postprocess_masks(holder, masks16, input_size=c["input_size"], original_size=c["original_size"])
+    out["masks_bf16"] = masks16.float().numpy()
+    out["post_bf16"] = post16.float().numpy()
+    a, b = post.numpy() > 0, post16.float().numpy() > 0
+    print("  %s: reference bf16 vs fp32: mask rel L2 %.4f, pixel IoU %.5f, positive fraction %.3f" % (
+        name, float(np.linalg.norm(masks16.float().numpy() - masks.numpy()) / np.linalg.norm(masks.numpy())),
+        (a & b).sum() / max(1, (a | b).sum()), a.mean()))
     np.savez_compressed(os.path.join(HERE, "decoder_%s.npz" % name), **out)
 
 

@@ -62,13 +62,22 @@ def test_sam_encoder_vs_reference_golden(dev, name, tol):
                 assert rel_err(tap, gold["block%d" % i]) < tol, ("block", i)
 
 
-@pytest.mark.parametrize("name", ["g32", "g64"])
+def pixel_iou(a, b):
+    a, b = np.asarray(a) > 0, np.asarray(b) > 0
+    return float((a & b).sum()) / max(1, int((a | b).sum()))
+
+
+@pytest.mark.parametrize("name", ["g32", "g64", "conf_g64"])
 def test_decoder_and_postprocess_vs_reference_golden(dev, name):
+    """Prompt encoder + mask decoder + postprocess against the reference's fp32 run, calibrated by the reference's own bf16 run
+    (both in the fixture).  north_star's bar -- masks within 1e-3 mIoU of the reference PyTorch CPU path -- is asserted on the
+    confident-mask case; on the white-noise cases (every pixel a boundary pixel) the HIP path must be at least as close to the fp32
+    reference as the reference is to itself when its callers run it in bf16 (evaluation_walkgpt.py:908-910)."""
     c = cases.DECODERS[name]
     gold = cases.load("decoder_" + name)
     g = c["grid"]
     sam = M._build_sam(128, 1, 2, [0], image_size=g * 16)   # encoder unused here
-    w = cases.decoder_weights(c["seed"])
+    w = cases.decoder_case_weights(c)
     res = load_into(sam.prompt_encoder, w, "prompt_encoder.", dev, strict=False)
     assert all(("point_embeddings" in k or "not_a_point" in k or "mask_downscaling" in k) for k in res.missing_keys)
     load_into(sam.mask_decoder, w, "mask_decoder.", dev)
@@ -84,17 +93,49 @@ def test_decoder_and_postprocess_vs_reference_golden(dev, name):
         masks, iou = sam.mask_decoder(image_embeddings=emb, image_pe=dpe, sparse_prompt_embeddings=sparse,
                                       dense_prompt_embeddings=dense, multimask_output=False)
         post = sam.postprocess_masks(masks, input_size=c["input_size"], original_size=c["original_size"])
+        # stage taps of the two-way transformer (same code path, block by block)
+        md = sam.mask_decoder
+        p = md._prep_get(md._build_prepared)
+        P = text.shape[0]
+        src = ops.add_rows(ops.nchw_to_tokens(emb.contiguous()), sam.prompt_encoder.no_mask_embed.weight.reshape(1, -1))
+        pe_tok = sam.prompt_encoder.dense_pe_tokens().unsqueeze(0)
+        tokens = torch.cat([p["out_tokens_f32"].unsqueeze(0).expand(P, -1, -1), sparse.float()], 1).contiguous()
+        q, keys = tokens.clone(), src
+        taps = {}
+        for i, layer in enumerate(md.transformer.layers):
+            q, keys = layer.run(q, keys, tokens, pe_tok, P)
+            taps["queries%d" % i] = q.clone().cpu().numpy()
+            taps["keys%d" % i] = cases.tap_keys(keys.float().cpu(), g).numpy()
     assert masks.shape == gold["masks"].shape and post.shape == gold["post"].shape
-    a, b = post.cpu().numpy() > 0, gold["post"] > 0
-    iou_px = (a & b).sum() / max(1, (a | b).sum())
-    print("decoder %s: rel_err masks %.4f iou %.4f post %.4f | pixel IoU vs reference %.4f" % (
-        name, rel_err(masks.cpu().numpy(), gold["masks"]), rel_err(iou.cpu().numpy(), gold["iou"]),
-        rel_err(post.cpu().numpy(), gold["post"]), iou_px))
-    assert rel_err(masks.cpu().numpy(), gold["masks"]) < 0.03
-    assert rel_err(iou.cpu().numpy(), gold["iou"]) < 0.03
-    assert rel_err(post.cpu().numpy(), gold["post"]) < 0.03
-    # thresholded masks: IoU with the reference's masks (the quantity WalkGPT reports)
-    assert iou_px > 0.98, iou_px
+    e_masks, e_post = rel_err(masks.cpu().numpy(), gold["masks"]), rel_err(post.cpu().numpy(), gold["post"])
+    ref16_masks = rel_err(gold["masks_bf16"], gold["masks"])
+    iou_hip, iou_ref16 = pixel_iou(post.cpu().numpy(), gold["post"]), pixel_iou(gold["post_bf16"], gold["post"])
+    print("decoder %s: rel_err masks %.4f (reference bf16 run: %.4f) iou-head %.4f post %.4f | pixel IoU vs reference %.5f (reference bf16 run: %.5f)"
+          % (name, e_masks, ref16_masks, rel_err(iou.cpu().numpy(), gold["iou"]), e_post, iou_hip, iou_ref16))
+    for k, v in taps.items():
+        print("   tap %-9s rel_err %.5f" % (k, rel_err(v, gold[k])))
+    exact_weights = bool(c.get("bf16_weights"))
+    # token stream is fp32 end to end: with bf16-representable weights it tracks the reference to fp32-rounding-of-inputs level
+    for i in range(2):
+        assert rel_err(taps["queries%d" % i], gold["queries%d" % i]) < (0.004 if exact_weights else 0.02), i
+        assert rel_err(taps["keys%d" % i], gold["keys%d" % i]) < (0.004 if exact_weights else 0.02), i
+    assert e_masks < (0.01 if exact_weights else 0.02), e_masks
+    assert rel_err(iou.cpu().numpy(), gold["iou"]) < (0.004 if exact_weights else 0.02)
+    assert e_post < (0.01 if exact_weights else 0.02), e_post
+    # never further from the fp32 reference than the reference's own bf16 run
+    assert e_masks <= ref16_masks, (e_masks, ref16_masks)
+    assert iou_hip >= iou_ref16 - 2e-4, (iou_hip, iou_ref16)
+    if name.startswith("conf"):
+        # north_star: masks within 1e-3 mIoU of the reference.  (a) the thresholded masks themselves agree to 1e-3; (b) against a
+        # ground truth (the reference's mask with a band flipped) both score the same IoU to 1e-3, per mask and on average
+        assert iou_hip >= 1.0 - 1e-3, iou_hip
+        ref_post = torch.from_numpy(gold["post"][:, 0]).to(dev)
+        gt = (ref_post > 0).float()
+        gt[:, 100:140, :] = 1.0 - gt[:, 100:140, :]
+        i_h, u_h, _ = ops.mask_iou(post[:, 0].contiguous(), gt.contiguous())
+        i_r, u_r, _ = ops.mask_iou(ref_post.contiguous(), gt.contiguous())
+        iou_h, iou_r = (i_h[:, 1] / u_h[:, 1]).cpu().numpy(), (i_r[:, 1] / u_r[:, 1]).cpu().numpy()
+        assert np.abs(iou_h - iou_r).max() <= 1e-3 and abs(iou_h.mean() - iou_r.mean()) <= 1e-3, (iou_h, iou_r)
 
 
 def test_projectors_vs_reference_golden(dev):

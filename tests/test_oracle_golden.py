@@ -53,11 +53,11 @@ def test_sam_encoder_matches_reference(name):
     assert np.allclose(stats, gold["out_stats"], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("name", ["g32", "g64"])
+@pytest.mark.parametrize("name", ["g32", "g64", "conf_g64"])
 def test_prompt_decoder_postprocess_match_reference(name):
     c = cases.DECODERS[name]
     gold = cases.load("decoder_" + name)
-    w = cases.decoder_weights(c["seed"])
+    w = cases.decoder_case_weights(c)
     emb, text = cases.decoder_inputs(c)
     g = c["grid"]
     with torch.no_grad():

@@ -308,6 +308,43 @@ def hyper_mask_dot(up, hyper, T, h, w, first_mask, num_masks):
     return masks
 
 
+def dec_tokens(mode, skip_pe, queries, query_pe, weights, k_img, v_img, hw, k_i2t=None, v_i2t=None, hyper_out=None, iou_out=None, eps=1e-5):
+    """Token side of one TwoWayAttentionBlock (mode 0) or of the transformer's tail + hypernetwork / IoU heads (mode 1) in one launch
+    (csrc/decoder.hip: wg_dec_tokens_f32).  queries / query_pe [P, 6, 256] fp32 (queries updated in place); weights: list of bf16
+    tensors in the order the C-ABI documents; k_img / v_img [1 | P, hw, 128] bf16 column slices of the projected image tokens."""
+    import ctypes
+    _need_gpu(queries, query_pe, k_img, v_img, k_i2t, v_i2t, hyper_out, iou_out, *weights)
+    P = queries.shape[0]
+    assert queries.dtype == torch.float32 and queries.is_contiguous() and queries.shape == (P, 6, 256)
+    assert query_pe.dtype == torch.float32 and query_pe.is_contiguous() and query_pe.shape == (P, 6, 256)
+    assert all(w.dtype == _BF16 and w.is_contiguous() for w in weights)
+    assert k_img.dtype == _BF16 and v_img.dtype == _BF16 and k_img.shape[-1] == 128 and k_img.stride(-1) == 1 and v_img.stride(-1) == 1
+    assert k_img.shape[1] == hw and k_img.stride(1) == v_img.stride(1) and k_img.shape[0] in (1, P)
+    img_bs = 0 if k_img.shape[0] == 1 and P > 1 else (k_img.stride(0) // k_img.stride(1) if k_img.shape[0] > 1 else hw)
+    table = (ctypes.c_void_p * len(weights))(*[w.data_ptr() for w in weights])
+    rc = _lib.lib().wg_dec_tokens_f32(mode, 1 if skip_pe else 0, queries.data_ptr(), query_pe.data_ptr(), table, len(weights),
+                                      k_img.data_ptr(), v_img.data_ptr(), k_img.stride(1), img_bs, hw, _ptr(k_i2t), _ptr(v_i2t),
+                                      _ptr(hyper_out), _ptr(iou_out), P, float(eps), _stream())
+    _lib.check(rc, "wg_dec_tokens_f32")
+    return queries
+
+
+def upscale_mask(keys, up1_w, up1_b, ln_g, ln_b, eps, up2_w, up2_b, hyper, h, w, first_mask, num_masks):
+    """mask_decoder.py:140-160 in one launch.  keys [P, h*w, 256] bf16 image tokens; up1_w [(dy,dx,64), 256], up2_w [(dy,dx,32), 64]
+    (re-laid ConvTranspose2d weights); hyper [P, nmask, 32] fp32 -> fp32 [P, num_masks, 4h, 4w]."""
+    _need_gpu(keys, up1_w, up1_b, ln_g, ln_b, up2_w, up2_b, hyper)
+    P = keys.shape[0]
+    assert keys.dtype == _BF16 and keys.is_contiguous() and keys.shape[1:] == (h * w, 256)
+    assert up1_w.shape == (256, 256) and up2_w.shape == (128, 64) and up1_w.is_contiguous() and up2_w.is_contiguous()
+    assert hyper.dtype == torch.float32 and hyper.is_contiguous() and hyper.shape[0] == P and hyper.shape[2] == 32
+    masks = torch.empty(P, num_masks, 4 * h, 4 * w, device=keys.device, dtype=torch.float32)
+    rc = _lib.lib().wg_upscale_mask_bf16(keys.data_ptr(), 256, up1_w.data_ptr(), up1_b.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(),
+                                         float(eps), up2_w.data_ptr(), up2_b.data_ptr(), hyper.data_ptr(), masks.data_ptr(), P, h, w,
+                                         hyper.shape[1], first_mask, num_masks, _stream())
+    _lib.check(rc, "wg_upscale_mask_bf16")
+    return masks
+
+
 def postprocess_masks(low_res, img_size, input_size, original_size):
     """fp32 [N, C, lh, lw] -> fp32 [N, C, H0, W0] (Sam.postprocess_masks, both resamples + crop in one pass)."""
     _need_gpu(low_res)

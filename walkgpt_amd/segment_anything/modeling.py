@@ -315,6 +315,10 @@ def _pe_folded_projection(pe_rows, parts):
     return torch.cat(ws, 0).contiguous(), torch.cat(rs, 1).contiguous()
 
 
+def _lin_pair(lin):
+    return [lin.weight, lin.bias]
+
+
 class TwoWayAttentionBlock(nn.Module):
     def __init__(self, embedding_dim, num_heads, mlp_dim=2048, activation=nn.ReLU, attention_downsample_rate=2,
                  skip_first_layer_pe=False):
@@ -341,35 +345,34 @@ class TwoWayAttentionBlock(nn.Module):
             self._img_key = key
         return self._img_val
 
+    def token_weights(self):
+        """Pointer-table order of wg_dec_tokens_f32, mode 0 (include/walkgpt_hip.h)."""
+        sa, t2i, i2t, m = self.self_attn, self.cross_attn_token_to_image, self.cross_attn_image_to_token, self.mlp
+        w = []
+        for lin in (sa.q_proj, sa.k_proj, sa.v_proj, sa.out_proj):
+            w += _lin_pair(lin)
+        w += [self.norm1.weight, self.norm1.bias] + _lin_pair(t2i.q_proj) + _lin_pair(t2i.out_proj) + [self.norm2.weight, self.norm2.bias]
+        w += _lin_pair(m.lin1) + _lin_pair(m.lin2) + [self.norm3.weight, self.norm3.bias] + _lin_pair(i2t.k_proj) + _lin_pair(i2t.v_proj)
+        return w
+
     def run(self, queries, keys, query_pe, key_pe, P):
-        """transformer.py:151-182.  queries/query_pe [P,N,C]; keys [1|P, hw, C]; key_pe [1, hw, C].
-        The three projections that read `keys` in this layer (k and v of token->image, q of image->token: the reference
-        recomputes keys + key_pe for two of them) are one fused GEMM with the positional term folded into an additive
-        table; `keys + key_pe` is never materialised."""
-        ln = lambda x, n: ops.layernorm(x, n.weight, n.bias, n.eps)
+        """transformer.py:151-182.  queries / query_pe [P,6,C] fp32 (queries updated in place); keys [1|P, hw, C] bf16; key_pe [1, hw, C].
+        Image side: the three projections that read `keys` (k and v of token->image, q of image->token; the reference recomputes
+        keys + key_pe for two of them) are one fused GEMM with the positional term folded into an additive table.  Token side: one
+        launch (ops.dec_tokens) for self-attention .. norm3 and the k / v projections of the image->token attention."""
         hw = keys.shape[1]
         t2i, i2t = self.cross_attn_token_to_image, self.cross_attn_image_to_token
         d = t2i.internal_dim
-        if self.skip_first_layer_pe:
-            queries = self.self_attn.run(queries, queries, queries, P)
-        else:
-            q = ops.add_rows(queries, query_pe)
-            queries = self.self_attn.run(q, q, queries, P, residual=queries)
-        queries = ln(queries, self.norm1)
+        if self.norm1.eps != self.norm2.eps or self.norm1.eps != self.norm3.eps or self.mlp._act_code != ops.ACT_RELU:
+            raise NotImplementedError("the fused token kernel is built for SAM's decoder block (one LayerNorm eps, ReLU MLP)")
         wcat, rtab = self._image_side(key_pe)
         proj = ops.linear(keys, wcat, residual=rtab, res_row_mod=hw)          # [1|P, hw, 3d]
-        kp, vp, qi = proj[..., :d], proj[..., d:2 * d], proj[..., 2 * d:]
-        q = ops.add_rows(queries, query_pe)
-        qp = ops.linear(q, t2i.q_proj.weight, t2i.q_proj.bias)
-        queries = t2i.run_projected(qp, kp, vp, P, residual=queries)
-        queries = ln(queries, self.norm2)
-        queries = self.mlp.rows(queries, residual=queries)
-        queries = ln(queries, self.norm3)
-        q = ops.add_rows(queries, query_pe)
-        kq = ops.linear(q, i2t.k_proj.weight, i2t.k_proj.bias)
-        vq = ops.linear(queries, i2t.v_proj.weight, i2t.v_proj.bias)
-        keys = i2t.run_projected(qi, kq, vq, P, residual=keys, res_row_mod=hw if keys.shape[0] == 1 and P > 1 else 0)
-        keys = ln(keys, self.norm4)
+        kq = torch.empty(P, queries.shape[1], d, device=keys.device, dtype=BF16)
+        vq = torch.empty_like(kq)
+        ops.dec_tokens(0, self.skip_first_layer_pe, queries, query_pe, self.token_weights(), proj[..., :d], proj[..., d:2 * d], hw,
+                       k_i2t=kq, v_i2t=vq, eps=self.norm1.eps)
+        keys = i2t.run_projected(proj[..., 2 * d:], kq, vq, P, residual=keys, res_row_mod=hw if keys.shape[0] == 1 and P > 1 else 0)
+        keys = ops.layernorm(keys, self.norm4.weight, self.norm4.bias, self.norm4.eps)
         return queries, keys
 
 
@@ -391,13 +394,20 @@ class TwoWayTransformer(nn.Module):
         self.final_attn_token_to_image = DecoderAttention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
         self.norm_final_attn = nn.LayerNorm(embedding_dim)
 
-    def run(self, src_tokens, pe_tokens, point_embedding):
-        """src_tokens [1|P, hw, C] rows, pe_tokens [1, hw, C], point_embedding [P, N, C] -> (queries, keys [P, hw, C])."""
-        P = point_embedding.shape[0]
-        queries, keys = point_embedding, src_tokens
+    def run_blocks(self, src_tokens, pe_tokens, queries, query_pe):
+        """The depth TwoWayAttentionBlocks.  src_tokens [1|P, hw, C] bf16, pe_tokens [1, hw, C] bf16, queries / query_pe [P, N, C] fp32
+        -> (queries fp32, updated in place; keys [P, hw, C] bf16)."""
+        if self.embedding_dim != 256 or self.num_heads != 8 or queries.shape[1] != 6 or self.mlp_dim != 2048:
+            raise NotImplementedError("the fused token kernel is built for SAM's decoder geometry (256 channels, 8 heads, 6 tokens, "
+                                      "MLP 2048); got %d / %d / %d / %d" % (self.embedding_dim, self.num_heads, queries.shape[1], self.mlp_dim))
+        P = queries.shape[0]
+        keys = src_tokens
         for layer in self.layers:
-            queries, keys = layer.run(queries, keys, point_embedding, pe_tokens, P)
-        q = ops.add_rows(queries, point_embedding)
+            queries, keys = layer.run(queries, keys, query_pe, pe_tokens, P)
+        return queries, keys
+
+    def final_image_side(self, keys, pe_tokens):
+        """[K | V] of the final token->image attention (positional term folded into the additive table)."""
         fa = self.final_attn_token_to_image
         key = (pe_tokens.data_ptr(), pe_tokens._version) + tuple((p.data_ptr(), p._version) for p in
                                                                  (fa.k_proj.weight, fa.v_proj.weight, fa.k_proj.bias, fa.v_proj.bias))
@@ -405,18 +415,10 @@ class TwoWayTransformer(nn.Module):
             self._fin_val = _pe_folded_projection(pe_tokens.reshape(-1, pe_tokens.shape[-1]), [(fa.k_proj, True), (fa.v_proj, False)])
             self._fin_key = key
         wcat, rtab = self._fin_val
-        proj = ops.linear(keys, wcat, residual=rtab, res_row_mod=keys.shape[1])
-        d = fa.internal_dim
-        qp = ops.linear(q, fa.q_proj.weight, fa.q_proj.bias)
-        queries = fa.run_projected(qp, proj[..., :d], proj[..., d:], P, residual=queries)
-        queries = ops.layernorm(queries, self.norm_final_attn.weight, self.norm_final_attn.bias, self.norm_final_attn.eps)
-        return queries, keys
+        return ops.linear(keys, wcat, residual=rtab, res_row_mod=keys.shape[1])
 
     def forward(self, image_embedding, image_pe, point_embedding):
-        bs, c, h, w = image_embedding.shape
-        src = ops.nchw_to_tokens(image_embedding.contiguous())
-        pe = ops.nchw_to_tokens(image_pe.to(BF16).contiguous())[:1]
-        return self.run(src, pe, point_embedding)
+        raise NotImplementedError("TwoWayTransformer is driven by MaskDecoder.predict_masks_tokens on the WalkGPT path")
 
 
 class MLP(nn.Module):
@@ -467,30 +469,45 @@ class MaskDecoder(nn.Module, _Prepared):
         # -> [(dy, dx, Cout), Cin]; the bias repeats over the four sub-pixels.
         return {
             "up1_w": c1.weight.permute(2, 3, 1, 0).reshape(-1, c1.weight.shape[0]).contiguous(),
-            "up1_b": c1.bias.repeat(4).contiguous(),
             "up2_w": c3.weight.permute(2, 3, 1, 0).reshape(-1, c3.weight.shape[0]).contiguous(),
-            "up2_b": c3.bias.repeat(4).contiguous(),
-            "out_tokens": torch.cat([self.iou_token.weight, self.mask_tokens.weight], 0).contiguous(),
+            "out_tokens_f32": torch.cat([self.iou_token.weight, self.mask_tokens.weight], 0).float().contiguous(),
         }
+
+    def head_weights(self):
+        """Pointer-table order of wg_dec_tokens_f32, mode 1 (include/walkgpt_hip.h)."""
+        tr = self.transformer
+        fa = tr.final_attn_token_to_image
+        w = _lin_pair(fa.q_proj) + _lin_pair(fa.out_proj) + [tr.norm_final_attn.weight, tr.norm_final_attn.bias]
+        for mlp in list(self.output_hypernetworks_mlps) + [self.iou_prediction_head]:
+            if mlp.num_layers != 3 or mlp.sigmoid_output:
+                raise NotImplementedError("the fused head kernel is built for SAM's 3-layer hypernetwork / IoU MLPs")
+            for layer in mlp.layers:
+                w += _lin_pair(layer)
+        return w
 
     def predict_masks_tokens(self, src_tokens, pe_tokens, sparse, h, w, mask_slice):
         """src_tokens [1|P, hw, C] (image embedding + dense prompt, channels-last rows), pe_tokens [1, hw, C],
-        sparse [P, n, C] -> (masks fp32 [P, k, 4h, 4w], iou fp32 [P, k])."""
-        p = self._prep_get(self._build_prepared)
+        sparse [P, n, C] -> (masks fp32 [P, k, 4h, 4w], iou fp32 [P, k]).
+        Launches: per block one image-side GEMM, one token kernel, the image->token attention + out_proj + norm4; then one GEMM and
+        one token kernel for the final attention and the heads, and one kernel for upscaling + the hypernetwork product."""
+        p = self._prep_get(self._build_prepared, (self.output_upscaling[0].weight, self.output_upscaling[3].weight, self.iou_token.weight,
+                                                  self.mask_tokens.weight))
         P = sparse.shape[0]
-        C = self.transformer_dim
-        tokens = torch.cat([p["out_tokens"].unsqueeze(0).expand(P, -1, -1), sparse.to(BF16)], dim=1).contiguous()
-        hs, keys = self.transformer.run(src_tokens, pe_tokens, tokens)
+        tr = self.transformer
+        if self.num_mask_tokens != 4 or sparse.shape[1] != 1:
+            raise NotImplementedError("the fused decoder kernels are built for 4 mask tokens + one text prompt per query (mask_decoder.py:125-132)")
+        tokens = torch.cat([p["out_tokens_f32"].unsqueeze(0).expand(P, -1, -1), sparse.float()], dim=1).contiguous()   # [P, 6, C] fp32
+        queries, keys = tr.run_blocks(src_tokens, pe_tokens, tokens.clone(), tokens)
+        proj = tr.final_image_side(keys, pe_tokens)
+        d = tr.final_attn_token_to_image.internal_dim
+        hyper = torch.empty(P, self.num_mask_tokens, self.transformer_dim // 8, device=keys.device, dtype=torch.float32)
+        iou = torch.empty(P, self.num_mask_tokens, device=keys.device, dtype=torch.float32)
+        ops.dec_tokens(1, False, queries, tokens, self.head_weights(), proj[..., :d], proj[..., d:], h * w, hyper_out=hyper, iou_out=iou,
+                       eps=tr.norm_final_attn.eps)
         ln1 = self.output_upscaling[1]
-        u = ops.linear(keys.reshape(P * h * w, C), p["up1_w"], p["up1_b"])               # [P*hw, 4*C/4]
-        u = ops.layernorm(u.view(P * h * w * 4, C // 4), ln1.weight, ln1.bias, ln1.eps, act=ops.ACT_GELU)
-        u = ops.linear(u, p["up2_w"], p["up2_b"], act=ops.ACT_GELU)                       # [P*hw*4, 4*C/8]
-        hyper = torch.empty(P, self.num_mask_tokens, C // 8, device=u.device, dtype=BF16)
-        for i in range(self.num_mask_tokens):
-            hyper[:, i] = self.output_hypernetworks_mlps[i].rows(hs[:, 1 + i].contiguous())
         k0, nk = mask_slice
-        masks = ops.hyper_mask_dot(u, hyper, P, h, w, k0, nk)
-        iou = self.iou_prediction_head.rows(hs[:, 0].contiguous(), out_f32=True)
+        masks = ops.upscale_mask(keys, p["up1_w"], self.output_upscaling[0].bias, ln1.weight, ln1.bias, ln1.eps, p["up2_w"],
+                                 self.output_upscaling[3].bias, hyper, h, w, k0, nk)
         return masks, iou[:, k0:k0 + nk]
 
     def forward(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output):
