@@ -156,6 +156,30 @@ def make_inputs(args, dev, rank):
                 original_size_list=[(args.original, args.original)] * B, clip_resize_list=[(448, 448)] * B)
 
 
+def usable_cpus():
+    """Cores this process may actually use: the affinity mask capped by the cgroup CPU quota (a container on a big host sees every
+    host core in its mask; running that many threads on its 16-core share is slower than 16 threads by an order of magnitude)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(-(-int(quota) // int(period)))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = int(f.read()), int(g.read())
+            if q > 0:
+                n = min(n, max(1, -(-q // per)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+def note(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
 def cpu_model_name():
     try:
         with open("/proc/cpuinfo") as f:
@@ -175,7 +199,7 @@ def cpu_baseline(args):
     from oracle import projectors as oproj
     from oracle import sam as osam
     from tests.golden import cases
-    threads = args.cpu_threads or len(os.sched_getaffinity(0))
+    threads = args.cpu_threads or usable_cpus()
     torch.set_num_threads(threads)
     gen = torch.Generator().manual_seed(7)
 
@@ -227,7 +251,10 @@ def cpu_baseline(args):
         return t1 - t0, t2 - t1, t3 - t2
 
     run(1)                                   # warm-up (thread pool, allocator, oneDNN primitive caches)
-    runs = [run(1) for _ in range(3)]
+    runs = []
+    for i in range(3):
+        runs.append(run(1))
+        note("cpu baseline run %d: %.2f s" % (i + 1, sum(runs[-1])))
     tot = sorted(sum(r) for r in runs)
     med = tot[1]
     best = min(runs, key=sum)
@@ -377,9 +404,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    note("model built; warm-up")
     for _ in range(args.warmup):
         step()
     fence()
+    note("timed region: %d steps" % args.steps)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(record_decode=True)
@@ -395,6 +424,7 @@ def main():
     decode_batch_ms = sum(a.elapsed_time(b) for a, b in decode_ev) / max(1, len(decode_ev))
 
     # ---- mask-decode latency of ONE image (its T prompts) on an otherwise idle GPU: what BASELINE's "mask-decode ms" names --------
+    note("%.2f images/s; single-image decode latency" % images_per_s)
     _f, _m, _s, emb = step(serial=True)
     torch.cuda.synchronize()
     one = (emb[:1].contiguous(), inp["seg_hidden"][:1], inp["resize_list"][:1], inp["original_size_list"][:1])
@@ -416,6 +446,7 @@ def main():
     # serialised (one stream): the events then bracket each launch running alone on the chip, which is what a kernel roofline
     # describes; in the timed region above the streams overlap and per-launch times are not separable
     torch.cuda.synchronize()
+    note("instrumented step")
     with ops.time_gemms() as records:
         step(serial=True)
     torch.cuda.synchronize()
@@ -469,6 +500,7 @@ def main():
                       "parallelism": "dp%d (images sharded, RCCL all-gather of mask logits)" % world if world > 1 else "single GPU"},
            "roofline": roofline}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        note("cpu baseline (oracle on %d host threads)" % (args.cpu_threads or usable_cpus()))
         out["cpu_baseline"] = cpu_baseline(args)
     if rank == 0:
         print(json.dumps(out), flush=True)

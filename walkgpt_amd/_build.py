@@ -19,9 +19,9 @@ def _digest(paths):
     h = hashlib.sha256()
     for p in sorted(paths):
         with open(p, "rb") as f:
-            h.update(p.encode())
+            h.update(os.path.basename(p).encode())   # names, not paths: the tree is built here and loaded from another directory on the GPU box
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(f for f in FLAGS if f != CSRC).encode())
     return h.hexdigest()
 
 
@@ -47,7 +47,7 @@ def build_library(force=False, verbose=True):
             return obj
         cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
         if verbose:
-            print("[walkgpt_amd build]", " ".join(cmd), flush=True)
+            print("[walkgpt_amd build]", " ".join(cmd), file=sys.stderr, flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, r.stdout, r.stderr))
