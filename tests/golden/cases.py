@@ -22,6 +22,10 @@ SAM_ENCODERS = {
                  batch=1, seed=14, tap_blocks=(0, 1)),
     "vit_b": dict(img=1024, patch=16, embed_dim=768, depth=12, heads=12, global_idx=(2, 5, 8, 11), window=14,
                   out=256, batch=1, seed=13, tap_blocks=(0, 2, 11)),
+    # SAM ViT-H's real width (the reference's default encoder, model/walkgpt.py:128, build_sam.py:15-24): D = 1280, 16 heads of 80, the
+    # 64x64 grid; three of its 32 blocks (two windowed, one global) -- what the CPU affords for a reference run
+    "vit_h3": dict(img=1024, patch=16, embed_dim=1280, depth=3, heads=16, global_idx=(2,), window=14, out=256, batch=1, seed=15,
+                   tap_blocks=(1, 2)),
 }
 
 

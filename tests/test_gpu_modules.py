@@ -39,7 +39,7 @@ def build_encoder(c, dev):
     return enc
 
 
-@pytest.mark.parametrize("name,tol", [("tiny", 0.02), ("tiny_hd32", 0.02), ("hd80", 0.02), ("vit_b", 0.03)])
+@pytest.mark.parametrize("name,tol", [("tiny", 0.02), ("tiny_hd32", 0.02), ("hd80", 0.02), ("vit_b", 0.03), ("vit_h3", 0.02)])
 def test_sam_encoder_vs_reference_golden(dev, name, tol):
     c = cases.SAM_ENCODERS[name]
     gold = cases.load("sam_encoder_" + name)

@@ -36,7 +36,7 @@ def _run_encoder_with_taps(w, x, c):
     return taps
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_hd32", "hd80", "vit_b"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_hd32", "hd80", "vit_b", "vit_h3"])
 def test_sam_encoder_matches_reference(name):
     c = cases.SAM_ENCODERS[name]
     gold = cases.load("sam_encoder_" + name)

@@ -1,0 +1,208 @@
+"""Top-level surface (walkgptForCausalLM adapter, model/ and utils/ alias packages): the reference's import lines resolve, and
+model_forward / evaluate take the reference's arguments and return its structures, checked against the oracle composition on a
+synthetic collate dict (ragged [SEG] counts, offsets, the -200 image placeholder)."""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from tests.golden import cases
+
+SEG, EOS, V, H = 60, 2, 64, 64
+
+
+def test_reference_import_lines_resolve():
+    from model.walkgpt import walkgptForCausalLM                      # train_walkgpt.py:19, evaluation_walkgpt.py:18
+    from model.segment_anything import build_sam_vit_h, sam_model_registry   # model/walkgpt.py:15 of the reference
+    from utils.utils_walkgpt import CalibratedTextProjector, MultiScaleQFormerProjector, dice_loss, infonce_loss, sigmoid_ce_loss
+    from utils.matcher import match_pred
+    import walkgpt_amd.causal_lm as cl
+    assert walkgptForCausalLM is cl.walkgptForCausalLM and callable(build_sam_vit_h) and "vit_h" in sam_model_registry
+    for name in ("forward", "model_forward", "evaluate", "get_visual_embs", "get_model", "get_vision_tower", "from_pretrained"):
+        assert hasattr(walkgptForCausalLM, name), name
+    import inspect
+    sig = inspect.signature(walkgptForCausalLM.model_forward)
+    for arg in ("images", "images_clip", "input_ids", "labels", "attention_masks", "offset", "masks_list", "label_list", "resize_list",
+                "inference", "clip_resize_list"):                  # the collate_fn dict of utils/dataset.py:180-197
+        assert arg in sig.parameters, arg
+    assert list(inspect.signature(walkgptForCausalLM.evaluate).parameters)[1:] == [
+        "images_clip", "images", "input_ids", "resize_list", "clip_resize_list", "original_size_list", "max_new_tokens", "tokenizer"]
+    with pytest.raises(RuntimeError):
+        walkgptForCausalLM.from_pretrained("some/checkpoint")         # the language model is injected, never built here
+
+
+class TinyLM(nn.Module):
+    """Stand-in for the injected causal LM (transformers protocol): two causal self-attention layers; `script` adds a large bias
+    towards a fixed token at every position so that greedy decoding is reproducible across precisions."""
+
+    def __init__(self, script=None):
+        super().__init__()
+        g = torch.Generator().manual_seed(5)
+        self.embed = nn.Embedding(V, H)
+        self.wq = nn.ParameterList([nn.Parameter(torch.randn(H, H, generator=g) / 8) for _ in range(2)])
+        self.wv = nn.ParameterList([nn.Parameter(torch.randn(H, H, generator=g) / 8) for _ in range(2)])
+        self.head = nn.Linear(H, V, bias=False)
+        with torch.no_grad():
+            self.embed.weight.copy_(torch.randn(V, H, generator=g))
+            self.head.weight.copy_(torch.randn(V, H, generator=g) / 8)
+        self.script = script or {}
+        self.config = SimpleNamespace(eos_token_id=EOS)
+
+    def get_input_embeddings(self):
+        return self.embed
+
+    def forward(self, inputs_embeds=None, attention_mask=None, labels=None, past_key_values=None, use_cache=False,
+                output_hidden_states=False, **kw):
+        x_new = inputs_embeds.float()
+        x = torch.cat([past_key_values, x_new], 1) if past_key_values is not None else x_new
+        L = x.shape[1]
+        keep = torch.ones(x.shape[0], L, dtype=torch.bool, device=x.device) if attention_mask is None else attention_mask.bool()
+        causal = torch.tril(torch.ones(L, L, dtype=torch.bool, device=x.device))[None] & keep[:, None, :]
+        h = x
+        for wq, wv in zip(self.wq, self.wv):
+            a = (h @ wq.float()) @ h.transpose(1, 2) / math.sqrt(H)
+            a = a.masked_fill(~causal, -1e30).softmax(-1)
+            h = h + torch.tanh(a @ (h @ wv.float()))
+        logits = h @ self.head.weight.float().t()
+        for pos, tok in self.script.items():
+            if pos < L:
+                logits[:, pos, tok] += 1e4
+        n = x_new.shape[1]
+        loss = None
+        if labels is not None:
+            loss = F.cross_entropy(logits[:, :-1].reshape(-1, V), labels[:, 1:].reshape(-1), ignore_index=-100)
+        return SimpleNamespace(logits=logits[:, -n:], loss=loss, hidden_states=(h[:, -n:],), past_key_values=x)
+
+
+def _build(dev, script=None):
+    from walkgpt_amd.causal_lm import walkgptForCausalLM
+    from walkgpt_amd.walkgpt import WalkGPTGrounding
+    c = cases.SAM_ENCODERS["tiny"]
+    g = WalkGPTGrounding(sam=dict(embed_dim=c["embed_dim"], depth=c["depth"], heads=c["heads"], global_idx=c["global_idx"], img=c["img"]),
+                         llm_hidden=H, with_clip=False)
+    w_enc, w_dec = cases.sam_encoder_weights(c), cases.decoder_weights(5)
+    wm, wt = cases.projector_weights(dict(cases.PROJECTORS["h64"]))
+
+    def load(mod, weights, prefix, strict=True):
+        mod.load_state_dict({k[len(prefix):]: v for k, v in weights.items() if k.startswith(prefix)}, strict=strict)
+
+    load(g.visual_model.image_encoder, w_enc, "image_encoder.")
+    load(g.visual_model.prompt_encoder, w_dec, "prompt_encoder.", strict=False)
+    load(g.visual_model.mask_decoder, w_dec, "mask_decoder.")
+    load(g.out_mm_projector, {"x." + k: v for k, v in wm.items()}, "x.")
+    load(g.text_hidden_fcs[0], {"x." + k: v for k, v in wt.items()}, "x.")
+    g.to(dev).bfloat16()
+    g.visual_model.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix.data = \
+        w_dec["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].to(dev)
+    lm = TinyLM(script).to(dev)
+    lm.embed.weight.data = lm.embed.weight.data.to(torch.bfloat16)     # the splice reads embed_tokens.weight as bf16
+    m = walkgptForCausalLM(lm, grounding=g, seg_token_idx=SEG, seg_token_num=1, eos_token_id=EOS)
+    weights = dict(w_enc=w_enc, w_dec=w_dec, wm=wm, wt=wt, c=c)
+    return m, lm, weights
+
+
+def _oracle_masks(weights, lm, x, ids_rows, row_img, hidden_fn, resize, orig):
+    """Oracle composition: SAM encoder -> MSQP -> resample -> splice -> TinyLM (fp32, CPU) -> CTP at the [SEG]-1 positions -> decode."""
+    from oracle import projectors as oproj
+    from oracle import sam as osam
+    from oracle import splice as osplice
+    c = weights["c"]
+    g = c["img"] // c["patch"]
+    w_all = dict(weights["w_enc"])
+    w_all.update(weights["w_dec"])
+    lm32 = TinyLM(lm.script)
+    lm32.load_state_dict({k: v.float().cpu() for k, v in lm.state_dict().items()})
+    with torch.no_grad():
+        emb = osam.image_encoder(w_all, x, dict(patch=c["patch"], depth=c["depth"], heads=c["heads"], global_idx=c["global_idx"], window=c["window"]))
+        vis = oproj.msqp(weights["wm"], emb.flatten(2).transpose(1, 2))
+        feats = oproj.resample_tokens(vis)[row_img]
+        _, embeds, _ = osplice.prepare_inputs_labels_for_multimodal(ids_rows, None, None, feats, lm32.embed.weight.float())
+        hidden = lm32(inputs_embeds=embeds, output_hidden_states=True).hidden_states[-1]
+        mask = hidden_fn(ids_rows)
+        dpe = osam.dense_pe(w_all, (g, g))
+        out = []
+        for i in sorted(set(row_img.tolist())):
+            rows = [r for r in range(len(row_img)) if int(row_img[r]) == i]
+            hs = torch.cat([hidden[r][mask[r]] for r in rows], 0)
+            if hs.shape[0] == 0:
+                out.append(torch.zeros(0, *orig[i]))
+                continue
+            pe = oproj.ctp(weights["wt"], hs)
+            sparse, dense = osam.prompt_encoder_text(w_all, pe.reshape(-1, 1, 256), (g, g))
+            masks, _ = osam.mask_decoder(w_all, emb[i:i + 1], dpe, sparse, dense)
+            out.append(osam.postprocess_masks(masks, c["img"], resize[i], orig[i])[:, 0])
+    return out
+
+
+def _iou(a, b):
+    a, b = a > 0, b > 0
+    return float((a & b).sum()) / max(1, int((a | b).sum()))
+
+
+@pytest.mark.gpu
+def test_model_forward_collate_dict_vs_oracle(dev):
+    from oracle import splice as osplice
+    m, lm, weights = _build(dev)
+    c = weights["c"]
+    x = cases.sam_encoder_input(c)                                   # two images
+    L = 12
+    ids = torch.randint(3, 50, (3, L), generator=torch.Generator().manual_seed(9))
+    ids[:, 1] = -200                                                 # the image placeholder of every row
+    ids[0, 5] = SEG; ids[0, 9] = SEG                                 # image 0: rows 0, 1 -> 2 + 1 prompts
+    ids[1, 7] = SEG
+    ids[2, 4] = SEG; ids[2, 6] = SEG; ids[2, 10] = SEG               # image 1: row 2 -> 3 prompts
+    offset = torch.tensor([0, 2, 3])
+    resize, orig = [(512, 384), (400, 512)], [(200, 150), (75, 96)]
+    batch = dict(images=x.to(dev, torch.bfloat16), images_clip=torch.zeros(2, 3, 28, 28, device=dev, dtype=torch.bfloat16),
+                 input_ids=ids.to(dev), labels=ids.to(dev), attention_masks=torch.ones(3, L, dtype=torch.bool, device=dev), offset=offset.to(dev),
+                 masks_list=[torch.zeros(3, *orig[0], device=dev), torch.zeros(3, *orig[1], device=dev)],
+                 label_list=[torch.zeros(orig[0], device=dev), torch.zeros(orig[1], device=dev)], resize_list=resize,
+                 clip_resize_list=[(28, 28)] * 2, inference=False, image_paths=["a", "b"], questions_list=None)   # extra keys are absorbed
+    out = m(**batch)
+    assert set(out) == {"loss", "ce_loss", "mask_bce_loss", "mask_dice_loss", "nce_loss", "mask_loss"}      # walkgpt.py:598-605
+    assert all(torch.isfinite(v).all() for v in out.values())
+    # the same forward in inference layout returns the reference's inference dict (one image, its rows)
+    inf = dict(batch, images=batch["images"][:1], images_clip=batch["images_clip"][:1], input_ids=ids[:2].to(dev), labels=ids[:2].to(dev),
+               attention_masks=batch["attention_masks"][:2], offset=torch.tensor([0, 2], device=dev), masks_list=batch["masks_list"][:1],
+               label_list=batch["label_list"][:1], resize_list=resize[:1], clip_resize_list=[(28, 28)], inference=True)
+    res = m(**inf)
+    assert set(res) == {"pred_masks", "gt_masks", "batch_seg_token_counts", "mask_scores"}                   # walkgpt.py:549-555
+    assert res["batch_seg_token_counts"] == [3] and res["pred_masks"][0].shape == (3,) + orig[0]
+    ref = _oracle_masks(weights, lm, x[:1], ids[:2], torch.tensor([0, 0]), lambda r: osplice.seg_token_mask(r, [SEG]), resize[:1], orig[:1])
+    got = res["pred_masks"][0].float().cpu()
+    e = float((got - ref[0]).norm() / ref[0].norm())
+    assert e < 0.06 and _iou(got.numpy(), ref[0].numpy()) > 0.97, e
+    # released behaviour: empty lists (walkgpt.py:541-555)
+    assert m(**dict(inf, decode_masks=False))["pred_masks"] == []
+
+
+@pytest.mark.gpu
+def test_evaluate_signature_and_masks_vs_oracle(dev):
+    from oracle import splice as osplice
+    L0 = 8
+    # the scripted continuation: positions are in the spliced sequence (L0 + 255 prompt positions), greedy picks script[pos] for pos+1
+    script = {L0 + 254: 7, L0 + 255: SEG, L0 + 256: 9, L0 + 257: SEG, L0 + 258: EOS}
+    m, lm, weights = _build(dev, script)
+    c = weights["c"]
+    x = cases.sam_encoder_input(c)[:1]
+    ids = torch.randint(3, 50, (1, L0 + 3), generator=torch.Generator().manual_seed(11))
+    ids[0, 1] = -200
+    ids[0, L0:] = 0                                                  # right padding that evaluate() strips (:621-625)
+    resize, orig = [(512, 384)], [(200, 150)]
+    all_ids, pred_masks, counts, scores = m.evaluate(torch.zeros(1, 3, 28, 28, device=dev, dtype=torch.bfloat16), x.to(dev, torch.bfloat16),
+                                                     ids.to(dev), resize, [(28, 28)], orig, max_new_tokens=16)
+    assert len(all_ids) == 1 and all_ids[0][0, L0:].tolist() == [7, SEG, 9, SEG, EOS]
+    assert counts[0].tolist() == [2] and pred_masks[0].shape == (2,) + orig[0] and scores[0].shape == (2,)
+
+    def ev_mask(r):                                                   # evaluate()'s mask has no right pad (:651-659) and the last
+        return osplice.seg_token_mask(r, [SEG])[:, :-1]              # generated token is never fed back: one position fewer
+
+    out_ids = all_ids[0].cpu()
+    ref = _oracle_masks(weights, lm, x, out_ids[:, :-1], torch.tensor([0]), lambda r: ev_mask(out_ids)[:, : r.shape[1] + 255], resize, orig)
+    got = pred_masks[0].float().cpu()
+    e = float((got - ref[0]).norm() / ref[0].norm())
+    assert e < 0.06 and _iou(got.numpy(), ref[0].numpy()) > 0.97, e
