@@ -119,6 +119,18 @@ int wg_cast_f32_to_bf16(const float* x, void* y, long n, void* stream);
 int wg_hyper_mask_dot(const void* up, const void* hyper, float* masks, int T, int h, int w, int channels, int nmask_total,
                       int first_mask, int num_masks, void* stream);
 
+/* ---- fp8 (OCP e4m3) GEMM path, BASELINE config C5 (qkv / proj / MLP GEMMs in fp8, attention and LayerNorm statistics
+ * stay bf16 / fp32).  Not in the reference (it runs bf16): the operation replaced is still `nn.Linear` (image_encoder.py:177-193). ----
+ * wg_quantize_rows_fp8:       q[m][:] = e4m3(x[m][:] / scale[m]), scale[m] = max|x[m][:]| / 448.  x [M,K] bf16, q [M,K] bytes.
+ * wg_layernorm_quantize_fp8:  the same on LayerNorm(x) (norm1 / norm2 of a block, fp32 statistics), one pass.
+ * wg_gemm_fp8_bias_act:       C[M,N] bf16 = act(scale_a[m] scale_w[n] sum_k Aq[m,k] Wq[n,k] + bias[n]) (+ residual[m % res_row_mod]);
+ *                             block-scaled MFMA 16x16x128 on the 256x256 ping-pong tile; K % 128 == 0, lda / ldw % 16 == 0. */
+int wg_quantize_rows_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int M, int K, void* stream);
+int wg_layernorm_quantize_fp8(const void* x, long ldx, const void* gamma, const void* beta, float eps, void* q, long ldq, float* scale,
+                              int M, int K, void* stream);
+int wg_gemm_fp8_bias_act(const void* Aq, long lda, const float* scale_a, const void* Wq, long ldw, const float* scale_w, const void* bias,
+                         const void* residual, long ldr, int res_row_mod, void* C, long ldc, int M, int N, int K, int act, void* stream);
+
 /* mask_decoder.py:140-160 fused: `upscaled = output_upscaling(src)` (ConvT k2 s2 -> LayerNorm2d -> GELU -> ConvT k2 s2 -> GELU) and
  * `masks = hyper_in @ upscaled` in one launch; every step is local to an image token.  x [P*h*w, 256] bf16 token rows; w1 [(dy,dx,64),
  * 256], w2 [(dy,dx,32), 64]: the transposed convolutions re-laid as GEMM weights; hyper [P, nmask_total, 32] fp32;

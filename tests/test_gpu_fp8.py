@@ -1,0 +1,102 @@
+"""fp8 (OCP e4m3) GEMM path of BASELINE config C5: operand layout of the block-scaled MFMA on exact integer data, the row quantiser
+against torch's float8_e4m3fn, the GEMM against fp32 on the dequantised operands, and what the path costs in parity: encoder output and
+thresholded masks against the same references as the bf16 path, with the measured deltas printed."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from tests.golden import cases
+from tests.test_gpu_modules import build_encoder, rel_err
+from walkgpt_amd import ops
+
+F8 = torch.float8_e4m3fn
+
+
+def _q(t):
+    return t.to(F8).view(torch.uint8).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 264, 384), (1000, 520, 1280)])
+def test_fp8_gemm_exact_on_small_integers(dev, M, N, K):
+    """Integers in [-3, 3] are exact in e4m3 and their products sum exactly in fp32: any error in the fragment layout (which 32 bytes of
+    a row belong to which lane of v_mfma_scale_f32_16x16x128_f8f6f4) shows up as a wrong integer.  Asymmetric operands."""
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float()
+    w[:, ::7] = 0.0
+    sa = (torch.arange(M) % 5 + 1).float()                 # per-row / per-channel scales that are exact too
+    sw = (torch.arange(N) % 3 + 1).float() * 0.5
+    bias = torch.randint(-8, 9, (N,), generator=g).float()
+    out = ops.linear_fp8(_q(a).to(dev), sa.to(dev), _q(w).to(dev), sw.to(dev), bias=bias.to(dev, torch.bfloat16))
+    ref = (a @ w.t()) * sa[:, None] * sw[None, :] + bias
+    got = out.float().cpu()
+    exact = ref.to(torch.bfloat16).float()                 # the only rounding left is the bf16 output
+    assert torch.equal(got, exact), float((got - exact).abs().max())
+
+
+def test_quantize_rows_matches_float8_e4m3fn(dev):
+    x = (torch.randn(77, 1280, generator=torch.Generator().manual_seed(3)) * 3).to(torch.bfloat16)
+    x[5] = 0
+    q, s = ops.quantize_rows_fp8(x.to(dev))
+    amax = x.float().abs().amax(1)
+    s_ref = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+    assert torch.allclose(s.cpu(), s_ref, rtol=1e-6)
+    q_ref = _q(x.float() / s_ref[:, None])
+    same = (q.cpu() == q_ref).float().mean().item()
+    assert same > 0.995, same                              # (ties of the two divisions may round differently: reciprocal-multiply here)
+    deq = q.cpu().view(F8).float() * s.cpu()[:, None]
+    assert rel_err(deq.numpy(), x.float().numpy()) < 0.04
+    # LayerNorm fused in front: against torch's LayerNorm followed by the same quantisation
+    g_ = torch.randn(1280, generator=torch.Generator().manual_seed(4)).to(torch.bfloat16)
+    b_ = torch.randn(1280, generator=torch.Generator().manual_seed(5)).to(torch.bfloat16)
+    q2, s2 = ops.quantize_rows_fp8(x.to(dev), ln=(g_.to(dev), b_.to(dev)), eps=1e-6)
+    y = torch.nn.functional.layer_norm(x.float(), (1280,), g_.float(), b_.float(), 1e-6)
+    y[5] = b_.float()
+    deq2 = q2.cpu().view(F8).float() * s2.cpu()[:, None]
+    assert rel_err(deq2.numpy(), y.numpy()) < 0.04
+    assert torch.allclose(s2.cpu(), y.abs().amax(1) / 448.0, rtol=2e-3)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(4096, 768, 768, 0), (1025, 3072, 768, 1), (8200, 1024, 4096, 0)])
+def test_fp8_linear_vs_fp32_on_dequantised_operands(dev, M, N, K, act):
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16)
+    r = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    xq, xs = ops.quantize_rows_fp8(x.to(dev))
+    wq, ws = ops.quantize_weight_fp8(w.to(dev))
+    out = ops.linear_fp8(xq, xs, wq, ws, bias=b.to(dev), act=act, residual=r.to(dev))
+    xd = xq.cpu().view(F8).float() * xs.cpu()[:, None]
+    wd = wq.cpu().view(F8).float() * ws.cpu()[:, None]
+    y = xd @ wd.t() + b.float()
+    if act == 1:
+        y = torch.nn.functional.gelu(y)
+    y = y + r.float()
+    assert rel_err(out.float().cpu().numpy(), y.numpy()) < 4e-3          # same operands: only accumulation order + the bf16 output
+    full = x.float() @ w.float().t() + b.float()
+    if act == 1:
+        full = torch.nn.functional.gelu(full)
+    full = full + r.float()
+    e = rel_err(out.float().cpu().numpy(), full.numpy())
+    print("fp8 linear M=%d N=%d K=%d: rel err vs unquantised fp32 %.4f" % (M, N, K, e))
+    assert e < 0.05
+
+
+@pytest.mark.parametrize("name", ["tiny", "vit_h3"])
+def test_sam_encoder_fp8_vs_reference_golden(dev, name):
+    """The encoder with its qkv / proj / MLP GEMMs in fp8 against the reference's fp32 output: the measured cost of config C5's operand
+    type next to the bf16 path's error on the same golden."""
+    c = cases.SAM_ENCODERS[name]
+    gold = cases.load("sam_encoder_" + name)
+    enc = build_encoder(c, dev)
+    x = cases.sam_encoder_input(c).to(dev, torch.bfloat16)
+    with torch.no_grad():
+        e16 = rel_err(cases.tap_embedding(enc(x).float().cpu()).numpy(), gold["out"])
+        for blk in enc.blocks:
+            blk.gemm_dtype = "fp8"
+        e8 = rel_err(cases.tap_embedding(enc(x).float().cpu()).numpy(), gold["out"])
+    print("encoder %s: rel err vs reference fp32: bf16 GEMMs %.4f, fp8 GEMMs %.4f" % (name, e16, e8))
+    assert e8 < 0.12 and e8 < 15 * e16 + 0.02

@@ -60,3 +60,22 @@ def test_clip_vit_l_448_full_size_batch_of_8(dev):
         ref_sel, ref_pre = oclip.clip_tower(wq, x[3:4].bfloat16().float(), oclip.patch_key_mask(1, (448, 448), [sizes[3]]))
     assert rel_err(sel8[3].float().cpu().numpy(), ref_sel[0].numpy()) < 0.03
     assert rel_err(pre8[0][3].float().cpu().numpy(), ref_pre[0][0].numpy()) < 0.03
+
+
+def test_sam_vit_h_full_geometry_batch_of_4(dev):
+    """Config C3's encoder at its full geometry (the reference's default, model/walkgpt.py:128: D = 1280, 32 blocks, 16 heads of 80,
+    global attention at 7/15/23/31) on a batch of four: finite, deterministic, batch-independent, image-dependent.  The arithmetic of
+    its blocks against the reference is the `vit_h3` golden (test_gpu_modules); this test is about the full depth and the batch."""
+    c = dict(cases.SAM_ENCODERS["vit_b"])
+    c.update(embed_dim=1280, depth=32, heads=16, global_idx=(7, 15, 23, 31), seed=16)
+    enc = build_encoder(c, dev)
+    x = torch.from_numpy(synth.normal(8, "input.images4", (4, 3, 1024, 1024))).to(dev, torch.bfloat16)
+    with torch.no_grad():
+        out4 = enc(x)
+        again = enc(x)
+        one = enc(x[2:3])
+    assert out4.shape == (4, 256, 64, 64) and torch.isfinite(out4.float()).all()
+    assert torch.equal(out4, again)
+    e = rel_err(out4[2].float().cpu().numpy(), one[0].float().cpu().numpy())
+    assert e < 0.02, e
+    assert rel_err(out4[0].float().cpu().numpy(), out4[2].float().cpu().numpy()) > 0.1

@@ -34,6 +34,10 @@ SIGNATURES = {
     "wg_dense_pe_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "wg_cast_f32_to_bf16": [c_void_p, c_void_p, c_long, c_void_p],
     "wg_hyper_mask_dot": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "wg_quantize_rows_fp8": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p],
+    "wg_layernorm_quantize_fp8": [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p],
+    "wg_gemm_fp8_bias_act": [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_long,
+                             c_int, c_int, c_int, c_int, c_void_p],
     "wg_upscale_mask_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_dec_tokens_f32": [c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_long, c_long, c_int, c_void_p, c_void_p,

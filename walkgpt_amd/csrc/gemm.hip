@@ -34,6 +34,8 @@ struct GemmArgs {
     const float* ln_s;           //   [N] column sums of the (gamma-scaled, bf16) weight rows,
     const float* ln_b;           //   [N] folded bias  b + W beta:   C = rstd * (A W'^T - mean * s) + b'
     unsigned c_bytes, r_bytes;   // extents of C and R for the staged epilogue's buffer descriptors (0: not addressable in 32 bits)
+    const float* scale_a;        // fp8 operands (wg_gemm_fp8_bias_act): per-row scale of A [M] and per-output-channel scale of W [N];
+    const float* scale_w;        //   A, W then point at e4m3 bytes and lda / ldw / K count PAIRS of bytes (see the entry point)
 };
 
 // Linear tile index -> (tile row, tile column).  With col_block = c > 0 the grid is walked in blocks of c tile columns, row-major
@@ -142,9 +144,17 @@ __device__ __forceinline__ void wg_load_residual(u32x4* rres, __amdgpu_buffer_rs
     }
 }
 
-template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, int PIPE>
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+// FP8 = true: the same kernel on e4m3 (OCP) operands.  A K slab is still 128 bytes per row -- 128 fp8 values instead of 64 bf16 -- so
+// staging, swizzle, barriers and the ping-pong schedule are unchanged; a fragment is the 32 contiguous bytes k = 32*fq .. 32*fq+31
+// of its row (two 16-byte chunks) and ONE block-scaled MFMA 16x16x128 (v_mfma_scale_f32_16x16x128_f8f6f4, both block scales 1.0 =
+// E8M0 127) replaces the two bf16 16x16x32 steps of a slab at the same matrix-pipe time for twice the K.  Per-row (A) and
+// per-output-channel (W) fp32 scales are applied to the accumulators before the epilogue.
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, int PIPE, bool FP8 = false>
 __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 : 2)) void wg_gemm_kernel(GemmArgs g) {
     static_assert(PIPE == 0 || (PIPE == 2 && BK == 64 && STAGES == 2), "the ping-pong schedule is written for two 64-deep slabs");
+    static_assert(!FP8 || PIPE == 2, "fp8 operands run on the ping-pong schedule only");
     static_assert((BM / WM) % 64 == 0, "the staged epilogue walks the wave tile 64 rows at a time");
     static_assert(BK == 32 || BK == 64, "K slab depth");
     constexpr int NT = WM * WN * 64;
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const int r = wm * WTM + (4 * ci + i) * 16 + fr;
-                    af[i][ks] = *(const bf16x8*)(ldsA + r * ROWB + (((ks * 4 + fq) ^ wg_swz<BK>(r)) << 4));
+                    af[i][ks] = *(const bf16x8*)(ldsA + r * ROWB + ((((FP8 ? 2 * fq + ks : ks * 4 + fq)) ^ wg_swz<BK>(r)) << 4));
                 }
         };
         auto read_w = [&](const char* ldsW, int cj) {
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const int r = wn * WTN + (2 * cj + j) * 16 + fr;
-                    wf2[cj][j][ks] = *(const bf16x8*)(ldsW + r * ROWB + (((ks * 4 + fq) ^ wg_swz<BK>(r)) << 4));
+                    wf2[cj][j][ks] = *(const bf16x8*)(ldsW + r * ROWB + ((((FP8 ? 2 * fq + ks : ks * 4 + fq)) ^ wg_swz<BK>(r)) << 4));
                 }
         };
         auto piece = [&](int kt, int which) {   // which: 0,1 = W round pairs; 2 = A rounds 0,2 (early); 3 = A rounds 1,3 (late)
@@ -301,6 +311,19 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
                 WG_GSTAMP(2);
                 // ---- C half-phase: 64 rows x 64 columns x K 64
                 __builtin_amdgcn_s_setprio(1);
+                if constexpr (FP8) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32x4 a0 = __builtin_bit_cast(u32x4, af[i][0]), a1 = __builtin_bit_cast(u32x4, af[i][1]);
+                        const i32x8 a8 = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const u32x4 w0 = __builtin_bit_cast(u32x4, wf2[j >> 1][j & 1][0]), w1 = __builtin_bit_cast(u32x4, wf2[j >> 1][j & 1][1]);
+                            const i32x8 w8 = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+                            acc[4 * sc + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8, a8, acc[4 * sc + i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -308,6 +331,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             acc[4 * sc + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[j >> 1][j & 1][ks], af[i][ks], acc[4 * sc + i][j], 0, 0, 0);
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 WG_GSTAMP(3);
@@ -370,6 +394,26 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
     // ---- epilogue -------------------------------------------------------------------------------------------------------
     // acc[i][j][e]: output row m = .. + i*16 + (lane&15), column n = .. + j*16 + (lane>>4)*4 + e.
     const int nbase = n0 + wn * WTN;
+    if constexpr (FP8) {
+        // dequantise: C[m][n] = scale_a[m] * scale_w[n] * sum_k Aq[m][k] Wq[n][k]
+        float sw[FJ][4];
+#pragma unroll
+        for (int j = 0; j < FJ; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = nbase + j * 16 + fq * 4 + e;
+                sw[j][e] = g.scale_w[n < g.N ? n : g.N - 1];
+            }
+#pragma unroll
+        for (int i = 0; i < FI; ++i) {
+            const int m = m0 + wm * WTM + i * 16 + fr;
+            const float sa = g.scale_a[m < g.M ? m : g.M - 1];
+#pragma unroll
+            for (int j = 0; j < FJ; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] *= sa * sw[j][e];
+        }
+    }
     if (STAGED) {
         // bf16 output: bias + activation in registers, then the wave's sub-tile goes through a private LDS slab
         // (64 rows at a time, rows padded by 16 bytes) so that residual loads and output stores are whole 128-byte
@@ -854,7 +898,7 @@ __global__ __launch_bounds__(256) void wg_gemm_rowwave_kernel(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, int PIPE>
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, int PIPE, bool FP8 = false>
 static int launch_tile_impl(GemmArgs& g, hipStream_t st) {
     g.tiles_m = (g.M + BM - 1) / BM;
     g.tiles_n = (g.N + BN - 1) / BN;
@@ -875,11 +919,11 @@ static int launch_tile_impl(GemmArgs& g, hipStream_t st) {
 #endif
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wg_gemm_kernel<BM, BN, BK, STAGES, WM, WN, STAGED, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)wg_gemm_kernel<BM, BN, BK, STAGES, WM, WN, STAGED, PIPE, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((wg_gemm_kernel<BM, BN, BK, STAGES, WM, WN, STAGED, PIPE>), dim3(g.tiles_m * g.tiles_n), dim3(WM * WN * 64), lds, st, g);
-    return wg_check_launch("wg_gemm_bias_act_bf16");
+    hipLaunchKernelGGL((wg_gemm_kernel<BM, BN, BK, STAGES, WM, WN, STAGED, PIPE, FP8>), dim3(g.tiles_m * g.tiles_n), dim3(WM * WN * 64), lds, st, g);
+    return wg_check_launch(FP8 ? "wg_gemm_fp8_bias_act" : "wg_gemm_bias_act_bf16");
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -917,6 +961,7 @@ static int launch_persist(GemmArgs& g, hipStream_t st) {
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool LN>
 __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) {
+    constexpr bool FP8 = false;   // (the fp8 operands of wg_gemm_kernel<..., FP8 = true> share this loop's source; bf16 only here)
     constexpr int BM = 256, BN = 256, BK = 64, WN = 4;
     constexpr int WTM = 128, WTN = 64, FJ = 4;
     constexpr int ROWB = 128, STAGE = (BM + BN) * ROWB, RPI = 8, RPR = 64;   // RPR: rows per LDS-DMA round of the 8 waves
@@ -1024,7 +1069,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const int r = wm * WTM + (4 * ci + i) * 16 + fr;
-                    af[i][ks] = *(const bf16x8*)(ldsA + r * ROWB + (((ks * 4 + fq) ^ wg_swz<BK>(r)) << 4));
+                    af[i][ks] = *(const bf16x8*)(ldsA + r * ROWB + ((((FP8 ? 2 * fq + ks : ks * 4 + fq)) ^ wg_swz<BK>(r)) << 4));
                 }
         };
         auto read_w = [&](const char* ldsW, int cj) {
@@ -1033,7 +1078,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const int r = wn * WTN + (2 * cj + j) * 16 + fr;
-                    wf2[cj][j][ks] = *(const bf16x8*)(ldsW + r * ROWB + (((ks * 4 + fq) ^ wg_swz<BK>(r)) << 4));
+                    wf2[cj][j][ks] = *(const bf16x8*)(ldsW + r * ROWB + ((((FP8 ? 2 * fq + ks : ks * 4 + fq)) ^ wg_swz<BK>(r)) << 4));
                 }
         };
         // the whole first slab (older than the previous tile's stores) has landed; those stores may still be draining
@@ -1064,6 +1109,19 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_s_setprio(1);
+                if constexpr (FP8) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const u32x4 a0 = __builtin_bit_cast(u32x4, af[i][0]), a1 = __builtin_bit_cast(u32x4, af[i][1]);
+                        const i32x8 a8 = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const u32x4 w0 = __builtin_bit_cast(u32x4, wf2[j >> 1][j & 1][0]), w1 = __builtin_bit_cast(u32x4, wf2[j >> 1][j & 1][1]);
+                            const i32x8 w8 = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
+                            acc[4 * sc + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8, a8, acc[4 * sc + i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
+                        }
+                    }
+                } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -1071,6 +1129,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             acc[4 * sc + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[j >> 1][j & 1][ks], af[i][ks], acc[4 * sc + i][j], 0, 0, 0);
+                }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
@@ -1294,6 +1353,7 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
     g.tiles_m = g.tiles_n = 0;
     g.col_block = 0;
     g.ln_stats = ln_stats; g.ln_s = ln_s; g.ln_b = ln_b;
+    g.scale_a = g.scale_w = nullptr;
     {   // byte extents for the staged epilogue's buffer descriptors (it addresses C and R with 32-bit byte offsets)
         const long cb = ((long)(M - 1) * ldc + N) * 2;
         const long rrows = res_row_mod > 0 ? (res_row_mod < M ? res_row_mod : M) : M;
@@ -1327,4 +1387,40 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
         case 16: return launch_pp_persist(g, st);                      // the same loop, persistent tiles (first slab / store drain hidden)
         default: return launch_tile<128, 128, 64, 2, 2, 2>(g, st);  //  64 KiB LDS, 4 waves, 2 workgroups / CU
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) GEMM with per-row / per-output-channel scales (BASELINE config C5):
+//     C[M,N] (bf16) = act( scale_a[m] scale_w[n] sum_k Aq[m,k] Wq[n,k] + bias[n] ) (+ R)
+// Aq [M,K] and Wq [N,K] are e4m3 bytes, K-contiguous, produced by wg_quantize_rows_fp8 (activations: per call; weights: once).
+// Runs the 256x256 ping-pong kernel with block-scaled MFMAs (see wg_gemm_kernel<..., FP8 = true>); K % 128 == 0 (one 128-byte slab),
+// leading dimensions multiples of 16 bytes.
+extern "C" int wg_gemm_fp8_bias_act(const void* Aq, long lda, const float* scale_a, const void* Wq, long ldw, const float* scale_w,
+                                    const void* bias, const void* residual, long ldr, int res_row_mod, void* C, long ldc, int M, int N,
+                                    int K, int act, void* stream) {
+    WG_REQUIRE(Aq && Wq && C && scale_a && scale_w, "gemm_fp8: null operand");
+    WG_REQUIRE(M > 0 && N > 0 && K > 0 && K % 128 == 0, "gemm_fp8: K = %d must be a positive multiple of 128", K);
+    WG_REQUIRE(act >= 0 && act <= 3, "gemm_fp8: bad activation %d", act);
+    WG_REQUIRE(lda >= K && ldw >= K && ldc >= N && lda % 16 == 0 && ldw % 16 == 0, "gemm_fp8: leading dimensions must cover the row and be multiples of 16");
+    WG_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && (!residual || (ldr >= N && ldr % 8 == 0)), "gemm_fp8: N, ldc, ldr must be multiples of 8");
+    WG_REQUIRE((((uintptr_t)Aq | (uintptr_t)Wq | (uintptr_t)C) & 15) == 0 && (!bias || ((uintptr_t)bias & 7) == 0) &&
+                   (!residual || ((uintptr_t)residual & 15) == 0), "gemm_fp8: misaligned operand");
+    WG_REQUIRE((long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31), "gemm_fp8: operand larger than 2 GiB");
+    GemmArgs g;
+    // the kernel's address arithmetic counts 2-byte elements: hand it byte PAIRS (a 128-byte slab = "64 elements")
+    g.A = (const bf16*)Aq; g.lda = lda / 2; g.W = (const bf16*)Wq; g.ldw = ldw / 2;
+    g.bias = (const bf16*)bias; g.R = (const bf16*)residual; g.ldr = ldr; g.res_mod = res_row_mod;
+    g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K / 2; g.act = act; g.out_f32 = 0;
+    g.tiles_m = g.tiles_n = 0;
+    g.col_block = 0;
+    g.ln_stats = nullptr; g.ln_s = nullptr; g.ln_b = nullptr;
+    g.scale_a = scale_a; g.scale_w = scale_w;
+    const long cb = ((long)(M - 1) * ldc + N) * 2;
+    const long rrows = res_row_mod > 0 ? (res_row_mod < M ? res_row_mod : M) : M;
+    const long rb = residual ? ((rrows - 1) * ldr + N) * 2 : 0;
+    WG_REQUIRE(cb < (1L << 31) && rb < (1L << 31), "gemm_fp8: output larger than 2 GiB");
+    g.c_bytes = (unsigned)cb;
+    g.r_bytes = (unsigned)rb;
+    return launch_tile_impl<256, 256, 64, 2, 2, 4, true, 2, true>(g, (hipStream_t)stream);
 }

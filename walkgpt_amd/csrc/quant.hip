@@ -1,0 +1,111 @@
+// Row quantisation to OCP e4m3 for the fp8 GEMM (gemm.hip: wg_gemm_fp8_bias_act; BASELINE config C5).
+//   wg_quantize_rows_fp8        q[m][:] = e4m3(x[m][:] / s[m]),  s[m] = max|x[m][:]| / 448   (activations per call, weights once)
+//   wg_layernorm_quantize_fp8   the same on LayerNorm(x) -- the pre-LN of a transformer block and the quantisation of its output
+//                               are one pass over the row (statistics in fp32, as SURVEY.md 8d C5 asks)
+// One wave per row, the row held in registers (K <= 5120), 16-byte loads, 8-byte stores.  HBM-bound: 3 bytes per element.
+#include "wg_common.h"
+
+namespace {
+
+constexpr int QMAXIT = 10;          // 10 x 64 lanes x 8 values = 5120 columns
+constexpr float E4M3_MAX = 448.0f;
+
+template <bool LN>
+__global__ __launch_bounds__(256) void wg_quantize_rows_kernel(const bf16* x, long ldx, const bf16* gamma, const bf16* beta, float eps,
+                                                               unsigned char* q, long ldq, float* scale, int M, int K) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16* xr = x + (long)row * ldx;
+    float v[QMAXIT][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int it = 0; it < QMAXIT; ++it) {
+        const int c = it * 512 + lane * 8;
+        if (c < K) {
+            const bf16x8 t = *(const bf16x8*)(xr + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[it][e] = (float)t[e];
+                sum += v[it][e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[it][e] = 0.f;
+        }
+    }
+    if (LN) {
+        const float mean = wg_wave_sum(sum) / (float)K;
+        float sq = 0.f;
+#pragma unroll
+        for (int it = 0; it < QMAXIT; ++it) {
+            const int c = it * 512 + lane * 8;
+            if (c < K) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[it][e] -= mean;
+                    sq += v[it][e] * v[it][e];
+                }
+            }
+        }
+        const float rstd = 1.0f / sqrtf(wg_wave_sum(sq) / (float)K + eps);
+#pragma unroll
+        for (int it = 0; it < QMAXIT; ++it) {
+            const int c = it * 512 + lane * 8;
+            if (c < K) {
+                const bf16x8 gm = *(const bf16x8*)(gamma + c), bt = *(const bf16x8*)(beta + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[it][e] = v[it][e] * rstd * (float)gm[e] + (float)bt[e];
+            }
+        }
+    }
+    float amax = 0.f;
+#pragma unroll
+    for (int it = 0; it < QMAXIT; ++it)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) amax = fmaxf(amax, fabsf(v[it][e]));
+    amax = wg_wave_max(amax);
+    const float s = amax > 0.f ? amax * (1.0f / E4M3_MAX) : 1.0f;
+    const float inv = 1.0f / s;
+    if (lane == 0) scale[row] = s;
+    unsigned char* qr = q + (long)row * ldq;
+#pragma unroll
+    for (int it = 0; it < QMAXIT; ++it) {
+        const int c = it * 512 + lane * 8;
+        if (c < K) {
+            int lo = 0, hi = 0;
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[it][0] * inv, v[it][1] * inv, lo, false);
+            lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[it][2] * inv, v[it][3] * inv, lo, true);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[it][4] * inv, v[it][5] * inv, hi, false);
+            hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[it][6] * inv, v[it][7] * inv, hi, true);
+            *(u32x2*)(qr + c) = (u32x2){(unsigned)lo, (unsigned)hi};
+        }
+    }
+}
+
+int launch(bool ln, const void* x, long ldx, const void* gamma, const void* beta, float eps, void* q, long ldq, float* scale, int M,
+           int K, void* stream) {
+    WG_REQUIRE(x && q && scale && (!ln || (gamma && beta)), "quantize_rows: null operand");
+    WG_REQUIRE(M > 0 && K > 0 && K % 8 == 0 && K <= QMAXIT * 512, "quantize_rows: K = %d must be a multiple of 8, at most %d", K, QMAXIT * 512);
+    WG_REQUIRE(ldx % 8 == 0 && ldq % 8 == 0 && ldx >= K && ldq >= K, "quantize_rows: leading dimensions must be multiples of 8 covering the row");
+    WG_REQUIRE((((uintptr_t)x & 15) | ((uintptr_t)q & 7)) == 0, "quantize_rows: misaligned operand");
+    const dim3 grid((unsigned)((M + 3) / 4)), block(256);
+    if (ln)
+        hipLaunchKernelGGL(wg_quantize_rows_kernel<true>, grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx, (const bf16*)gamma,
+                           (const bf16*)beta, eps, (unsigned char*)q, ldq, scale, M, K);
+    else
+        hipLaunchKernelGGL(wg_quantize_rows_kernel<false>, grid, block, 0, (hipStream_t)stream, (const bf16*)x, ldx, nullptr, nullptr, 0.f,
+                           (unsigned char*)q, ldq, scale, M, K);
+    return wg_check_launch("wg_quantize_rows_fp8");
+}
+
+}  // namespace
+
+extern "C" int wg_quantize_rows_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int M, int K, void* stream) {
+    return launch(false, x, ldx, nullptr, nullptr, 0.f, q, ldq, scale, M, K, stream);
+}
+
+extern "C" int wg_layernorm_quantize_fp8(const void* x, long ldx, const void* gamma, const void* beta, float eps, void* q, long ldq,
+                                         float* scale, int M, int K, void* stream) {
+    return launch(true, x, ldx, gamma, beta, eps, q, ldq, scale, M, K, stream);
+}

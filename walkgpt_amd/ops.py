@@ -308,6 +308,55 @@ def hyper_mask_dot(up, hyper, T, h, w, first_mask, num_masks):
     return masks
 
 
+def quantize_rows_fp8(x, ln=None, eps=0.0):
+    """Per-row e4m3 quantisation of x [..., K] bf16 (of LayerNorm(x) when ln = (gamma, beta)) -> (q uint8 [..., K], scale fp32 [rows])."""
+    _need_gpu(x)
+    assert x.dtype == _BF16
+    M, K, ldx = _rows(x)
+    q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    scale = torch.empty(M, device=x.device, dtype=torch.float32)
+    L = _lib.lib()
+    if ln is None:
+        rc = L.wg_quantize_rows_fp8(x.data_ptr(), ldx, q.data_ptr(), K, scale.data_ptr(), M, K, _stream())
+    else:
+        g, b = ln
+        _need_gpu(g, b)
+        rc = L.wg_layernorm_quantize_fp8(x.data_ptr(), ldx, g.data_ptr(), b.data_ptr(), float(eps), q.data_ptr(), K, scale.data_ptr(), M, K, _stream())
+    _lib.check(rc, "wg_quantize_rows_fp8")
+    return q, scale
+
+
+def quantize_weight_fp8(weight):
+    """nn.Linear weight [N, K] bf16 -> (e4m3 bytes [N, K], per-output-channel scale fp32 [N]); once per weight set."""
+    return quantize_rows_fp8(weight.contiguous())
+
+
+def linear_fp8(xq, x_scale, wq, w_scale, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out=None):
+    """act(dequant(xq) @ dequant(wq).T + bias) (+ residual) -> bf16.  xq [..., K] uint8 (e4m3) with per-row scales, wq [N, K]."""
+    _need_gpu(xq, x_scale, wq, w_scale, bias, residual, out)
+    assert xq.dtype == torch.uint8 and wq.dtype == torch.uint8 and xq.is_contiguous() and wq.is_contiguous()
+    K = xq.shape[-1]
+    M = xq.numel() // K
+    N = wq.shape[0]
+    assert wq.shape[1] == K and x_scale.numel() == M and w_scale.numel() == N
+    if out is None:
+        out = torch.empty(xq.shape[:-1] + (N,), device=xq.device, dtype=_BF16)
+    _, _, ldc = _rows(out)
+    ldr = 0
+    if residual is not None:
+        assert residual.dtype == _BF16
+        _, _, ldr = _rows(residual)
+    ev = _timed(20, M, N, K)
+    if ev is not None:
+        ev[0].record()
+    rc = _lib.lib().wg_gemm_fp8_bias_act(xq.data_ptr(), K, x_scale.data_ptr(), wq.data_ptr(), K, w_scale.data_ptr(), _ptr(bias),
+                                         _ptr(residual), ldr, res_row_mod, out.data_ptr(), ldc, M, N, K, act, _stream())
+    if ev is not None:
+        ev[1].record()
+    _lib.check(rc, "wg_gemm_fp8_bias_act")
+    return out
+
+
 def dec_tokens(mode, skip_pe, queries, query_pe, weights, k_img, v_img, hw, k_i2t=None, v_i2t=None, hyper_out=None, iou_out=None, eps=1e-5):
     """Token side of one TwoWayAttentionBlock (mode 0) or of the transformer's tail + hypernetwork / IoU heads (mode 1) in one launch
     (csrc/decoder.hip: wg_dec_tokens_f32).  queries / query_pe [P, 6, 256] fp32 (queries updated in place); weights: list of bf16

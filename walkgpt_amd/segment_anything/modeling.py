@@ -112,11 +112,40 @@ class Block(nn.Module, _Prepared):
         self.mlp = MLPBlock(embedding_dim=dim, mlp_dim=int(dim * mlp_ratio), act=act_layer)
         self.window_size = window_size
 
+    gemm_dtype = "bf16"   # "fp8": qkv / proj / lin1 / lin2 on e4m3 operands (BASELINE config C5); set through WalkGPTGrounding.set_gemm_dtype
+
+    def _build_fp8(self):
+        a, m = self.attn, self.mlp
+        return {k: ops.quantize_weight_fp8(w) for k, w in (("qkv", a.qkv.weight), ("proj", a.proj.weight), ("lin1", m.lin1.weight),
+                                                           ("lin2", m.lin2.weight))}
+
+    def rows_fp8(self, x, B, grid):
+        """The block on the fp8 GEMM path: both LayerNorms are fused with the per-row quantisation of their output; attention, the
+        residual stream and every statistic stay bf16 / fp32."""
+        a, m = self.attn, self.mlp
+        w = self.__dict__.get("_fp8_val")
+        key = tuple((p.data_ptr(), p._version) for p in (a.qkv.weight, a.proj.weight, m.lin1.weight, m.lin2.weight))
+        if w is None or self.__dict__.get("_fp8_key") != key:
+            w = self._build_fp8()
+            self.__dict__["_fp8_val"], self.__dict__["_fp8_key"] = w, key
+        q, s = ops.quantize_rows_fp8(x, ln=(self.norm1.weight, self.norm1.bias), eps=self.norm1.eps)
+        qkv = ops.linear_fp8(q, s, *w["qkv"], bias=a.qkv.bias)
+        window = self.window_size if self.window_size > 0 else grid
+        o = ops.sam_attention(qkv, a.qkv.bias, a.rel_pos_h, a.rel_pos_w, B, grid, window, a.num_heads)
+        q, s = ops.quantize_rows_fp8(o)
+        x = ops.linear_fp8(q, s, *w["proj"], bias=a.proj.bias, residual=x)
+        q, s = ops.quantize_rows_fp8(x, ln=(self.norm2.weight, self.norm2.bias), eps=self.norm2.eps)
+        h = ops.linear_fp8(q, s, *w["lin1"], bias=m.lin1.bias, act=m._act_code)
+        q, s = ops.quantize_rows_fp8(h)
+        return ops.linear_fp8(q, s, *w["lin2"], bias=m.lin2.bias, residual=x)
+
     def rows(self, x, B, grid):
         """x [B*grid*grid, D] -> same.  window partition / unpartition live inside the attention kernel."""
         a = self.attn
         if not a.use_rel_pos or a.qkv.bias is None:
             raise NotImplementedError("the HIP SAM attention is built for use_rel_pos=True, qkv_bias=True (build_sam.py:56-108)")
+        if self.gemm_dtype == "fp8":
+            return self.rows_fp8(x, B, grid)
         p = self._prep_get(self._build, (self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, self.norm2.weight,
                                          self.norm2.bias, self.mlp.lin1.weight, self.mlp.lin1.bias))
         qkv = ops.ln_linear(x, p["qkv"], self.norm1.eps)

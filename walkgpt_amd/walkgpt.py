@@ -48,6 +48,14 @@ class WalkGPTGrounding(nn.Module):
             self.vision_tower = CLIPVisionTower("openai/clip-vit-large-patch14-336", args, config=clip_config)
         self.eval()
 
+    def set_gemm_dtype(self, dtype):
+        """"bf16" (default) or "fp8": operand type of the qkv / proj / MLP GEMMs of the SAM encoder blocks (BASELINE config C5; needs
+        block widths that are multiples of 128: ViT-B / L / H are).  Attention, LayerNorm statistics and the residual stream stay bf16 / fp32."""
+        if dtype not in ("bf16", "fp8"):
+            raise ValueError("gemm dtype must be 'bf16' or 'fp8'")
+        for blk in self.visual_model.image_encoder.blocks:
+            blk.gemm_dtype = dtype
+
     # -- walkgpt.py:241-258 -----------------------------------------------------------------------------------------
     def get_visual_embs(self, pixel_values):
         return self.visual_model.image_encoder(pixel_values)
