@@ -87,10 +87,10 @@ def test_weight_relayouts_are_the_right_permutations():
     t = torch.randn(1, 16, 3, 3, generator=g)
     c1 = dec.output_upscaling[0]
     ref = F.conv_transpose2d(t, c1.weight, c1.bias, stride=2)  # [1,4,6,6]
-    out = t.permute(0, 2, 3, 1).reshape(9, 16) @ p["up1_w"].t() + p["up1_b"]  # rows (y,x), cols (dy,dx,co)
+    out = t.permute(0, 2, 3, 1).reshape(9, 16) @ p["up1_w"].t() + c1.bias.repeat(4)  # rows (y,x), cols (dy,dx,co); the bias repeats per sub-pixel
     out = out.reshape(3, 3, 2, 2, 4).permute(4, 0, 2, 1, 3).reshape(4, 6, 6)
     assert torch.allclose(out, ref[0], atol=1e-5)
-    assert p["out_tokens"].shape == (5, 16)
+    assert p["out_tokens_f32"].shape == (5, 16) and p["out_tokens_f32"].dtype == torch.float32
 
 
 def test_synth_is_deterministic_and_scaled():
@@ -135,3 +135,26 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.WalkgptHipError, match="not built"):
         _lib.lib()
+
+
+def test_clip_tower_resizes_a_stock_position_table_on_load():
+    """clip_encoder.py:38-55: the stock checkpoint carries the 577-row (24x24 + class) table of 336 px; the tower runs at 448 px
+    (32x32 + class).  load_state_dict must take the stock table and resize it the reference's way (quirk included: rows [:-1] are
+    the grid, the last row is carried over), as pinned by tests/golden/clipwrap_*.npz."""
+    import numpy as np
+    import torch
+    from types import SimpleNamespace
+    from tests.golden import cases
+    from walkgpt_amd.clip_encoder import CLIPVisionTower
+    c = cases.CLIPWRAPS["w56"]
+    gold = cases.load("clipwrap_w56")
+    cfg = dict(hidden_size=c["dim"], intermediate_size=4 * c["dim"], num_hidden_layers=1, num_attention_heads=1,
+               image_size=c["old_side"] * 14, patch_size=14, layer_norm_eps=1e-5)
+    args = SimpleNamespace(mm_vision_select_layer=-1, resize_vision_tower=True, resize_vision_tower_size=c["new_side"] * 14)
+    tower = CLIPVisionTower("synthetic", args, config=cfg)
+    sd = tower.vision_tower.state_dict()
+    assert sd["vision_model.embeddings.position_embedding.weight"].shape[0] == c["new_side"] ** 2 + 1
+    sd["vision_model.embeddings.position_embedding.weight"] = cases.clipwrap_table(c)          # the stock-size table
+    tower.vision_tower.load_state_dict(sd, strict=True)
+    got = tower.vision_tower.vision_model.embeddings.position_embedding.weight.detach().numpy()
+    assert np.allclose(got, gold["table"], atol=1e-6)

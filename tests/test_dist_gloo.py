@@ -47,6 +47,10 @@ def _worker(rank, world, port, q):
         for r in range(world):
             want = _masks_for(r)
             ok = ok and len(got[r]) == len(want) and all(torch.equal(a, b) for a, b in zip(got[r], want))
+        # a rank without a single mask (a shard with no [SEG] token) still joins the collectives
+        mine = [] if rank == 1 else [torch.full((2, 4, 3), 7.0)]
+        got2 = all_gather_masks(mine)
+        ok = ok and len(got2[1]) == 0 and len(got2[0]) == 1 and bool((got2[0][0] == 7.0).all()) and got2[0][0].shape == (2, 4, 3)
         u = all_gather_masks_uniform(torch.full((2, 3, 3), float(rank)))
         ok = ok and u.shape == (4, 3, 3) and bool((u[:2] == 0).all()) and bool((u[2:] == 1).all())
         # images sharded by rank cover the batch exactly once

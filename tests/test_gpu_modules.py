@@ -289,3 +289,15 @@ def test_grounding_pipeline_end_to_end_vs_oracle(dev):
         gm, gs = model.decode_from_hidden_graphed(emb_t, hid, resize, orig)
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(em, gm)) and all(torch.equal(a, b) for a, b in zip(es, gs))
+    # new weights after the capture (load_state_dict copies in place; .to() / re-assignment would move the storage): the graph key
+    # carries the identity and version of every parameter and buffer of the chain, so the stale graph is dropped and re-captured
+    md = model.visual_model.mask_decoder
+    sd = {k: v * 1.25 if "output_hypernetworks_mlps.0.layers.2" in k or "output_upscaling.0.weight" in k else v for k, v in md.state_dict().items()}
+    md.load_state_dict(sd)
+    ctp = model.text_hidden_fcs[0]
+    ctp.load_state_dict({k: (v * 0.5 if k == "net.3.weight" else v) for k, v in ctp.state_dict().items()})
+    em2, _ = model.decode_from_hidden(emb_t, hid, resize, orig)
+    gm2, _ = model.decode_from_hidden_graphed(emb_t, hid, resize, orig)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(em2, gm2))
+    assert not any(torch.equal(a, b) for a, b in zip(em2, em))

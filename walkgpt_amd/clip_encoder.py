@@ -191,7 +191,28 @@ class CLIPVisionTower(nn.Module):
             cfg["image_size"] = self.resize_vision_tower_size  # the table is created at the run size (clip_encoder.py:38-55)
         self.vision_tower = _CLIPVisionModel(SimpleNamespace(**cfg))
         self.vision_tower.requires_grad_(False)
+        if self.resize_vision_tower:
+            self.vision_tower._register_load_state_dict_pre_hook(self._resize_loaded_position_table)
         self.is_loaded = True
+
+    def _resize_loaded_position_table(self, state_dict, prefix, *args):
+        """The reference loads the stock checkpoint (577-row table at 336 px) and THEN resizes it (clip_encoder.py:38-55); here the module
+        is created at the run size, so a checkpoint that still carries the stock table is resized on its way in -- with the
+        reference's own arithmetic (rows [:-1] taken as the grid, last row carried over; resize_position_table)."""
+        key = prefix + "vision_model.embeddings.position_embedding.weight"
+        t = state_dict.get(key)
+        want = self.vision_tower.vision_model.embeddings.position_embedding.weight.shape[0]
+        if t is None or t.shape[0] == want:
+            return
+        side = int(round((want - 1) ** 0.5))
+        if t.is_cuda:
+            state_dict[key] = resize_position_table(t.to(BF16), side).to(t.dtype)
+        else:   # a checkpoint still on the host: same arithmetic in torch (fp32 bilinear, align_corners=False), no HIP call without a GPU
+            n, D = t.shape
+            old = int(round((n - 1) ** 0.5))
+            grid = t[:-1].float().reshape(1, old, old, D).permute(0, 3, 1, 2)
+            new = torch.nn.functional.interpolate(grid, size=(side, side), mode="bilinear", align_corners=False)
+            state_dict[key] = torch.cat([new.permute(0, 2, 3, 1).reshape(side * side, D), t[-1:].float()], 0).to(t.dtype)
 
     def feature_select(self, states):
         feats = states[self.select_layer]

@@ -21,12 +21,23 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
     return start, start + base + (1 if rank < extra else 0)
 
 
-def all_gather_masks(masks: Sequence[torch.Tensor], group=None) -> List[List[torch.Tensor]]:
+def _collective_device(group=None) -> torch.device:
+    """Where a rank without any local tensor must put its collective buffers: RCCL (backend "nccl") only takes tensors of the
+    rank's GPU, gloo takes CPU tensors."""
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def all_gather_masks(masks: Sequence[torch.Tensor], group=None, device=None, dtype=None) -> List[List[torch.Tensor]]:
     """masks[i]: [T_i, H_i, W_i] float tensors of this rank's images.  Returns, on every rank, a list over ranks of
-    lists over that rank's images.  Collectives: one all_gather of the int64 header, one all_gather of the payload."""
+    lists over that rank's images.  Collectives: one all_gather of the int64 header, one all_gather of the payload.
+    A rank may hold NO masks (fewer images than ranks, or a shard without any [SEG]): it still has to join both collectives with
+    buffers on the right device and of the payload dtype the other ranks use -- pass `device` / `dtype` (default: the backend's
+    device, float32, which is what Sam.postprocess_masks returns)."""
     world = dist.get_world_size(group)
-    dev = masks[0].device if len(masks) else torch.device("cpu")
-    dtype = masks[0].dtype if len(masks) else torch.float32
+    dev = masks[0].device if len(masks) else (torch.device(device) if device is not None else _collective_device(group))
+    dtype = masks[0].dtype if len(masks) else (dtype or torch.float32)
     shapes = torch.tensor([list(m.shape) for m in masks], dtype=torch.int64, device=dev).reshape(-1, 3)
     # header 1: images per rank and payload elements per rank
     local = torch.tensor([shapes.shape[0], int(sum(m.numel() for m in masks))], dtype=torch.int64, device=dev)
