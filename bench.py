@@ -70,6 +70,7 @@ def parse(argv=None):
     ap.add_argument("--single-stream", action="store_true", help="run the CLIP tower and the SAM branch back to back")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-decode-graph", action="store_true", help="launch the decode chain eagerly instead of replaying its captured HIP graph")
+    ap.add_argument("--steps-only", action="store_true", help="profiling runs: warm-up + timed steps only (no latency / instrumented / CPU passes)")
     ap.add_argument("--probe-launch", action="store_true", help="self-test of the rank launch only: gloo rendezvous, no GPU work (tests/test_bench_launch.py)")
     args = ap.parse_args(argv)
     preset = CONFIGS[args.config]
@@ -422,6 +423,15 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     images_per_s = world * B * args.steps / elapsed
     decode_batch_ms = sum(a.elapsed_time(b) for a, b in decode_ev) / max(1, len(decode_ev))
+
+    if args.steps_only:
+        if rank == 0:
+            print(json.dumps({"metric": "images/sec", "value": round(images_per_s, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                              "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "dtype": args.dtype, "steps_only": True,
+                              "config": {"workload": workload_label(args, world)}}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return 0
 
     # ---- mask-decode latency of ONE image (its T prompts) on an otherwise idle GPU: what BASELINE's "mask-decode ms" names --------
     note("%.2f images/s; single-image decode latency" % images_per_s)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# The rocprofv3 passes behind profiles/r02_* (run on the GPU box from the repo root; outputs under gpurun_out/).
+set -e
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+P="rocprofv3 --output-format csv"
+$P --kernel-trace --stats -d gpurun_out/p2_stats -o s -- python3 bench.py --steps 3 --warmup 2 --steps-only > gpurun_out/p2_stats.log 2>&1
+echo stats done
+$P --kernel-trace --pmc FETCH_SIZE -d gpurun_out/p2_fetch -o s -- python3 bench.py --steps 1 --warmup 1 --steps-only > gpurun_out/p2_fetch.log 2>&1
+$P --kernel-trace --pmc WRITE_SIZE -d gpurun_out/p2_write -o s -- python3 bench.py --steps 1 --warmup 1 --steps-only > gpurun_out/p2_write.log 2>&1
+echo traffic done
+$P --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY -d gpurun_out/p2_sq -o s -- python3 bench.py --steps 1 --warmup 1 --steps-only --single-stream > gpurun_out/p2_sq.log 2>&1
+echo sq done
+$P --kernel-trace --stats -d gpurun_out/p2_ss -o s -- python3 bench.py --steps 3 --warmup 2 --steps-only --single-stream > gpurun_out/p2_ss.log 2>&1
+$P --kernel-trace --stats -d gpurun_out/p2_c3 -o s -- python3 bench.py --config C3 --steps 2 --warmup 1 --steps-only > gpurun_out/p2_c3.log 2>&1
+echo c3 done
+$P --kernel-trace --stats -d gpurun_out/p2_c5 -o s -- python3 bench.py --config C5 --dtype fp8 --steps 2 --warmup 1 --steps-only > gpurun_out/p2_c5.log 2>&1
+$P --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY -d gpurun_out/p2_c5sq -o s -- python3 bench.py --config C5 --dtype fp8 --steps 1 --warmup 1 --steps-only --single-stream > gpurun_out/p2_c5sq.log 2>&1
+echo c5 done
+tail -2 gpurun_out/p2_stats.log gpurun_out/p2_c3.log gpurun_out/p2_c5.log
