@@ -233,31 +233,46 @@ __device__ void tok_linear(const float* x, int ldx, int rows, LinW W, int N, flo
     const int lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kg = lane >> 4;
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int nb = wave; nb * 16 < N; nb += TK_THREADS / 64) {
-        const int n = nb * 16 + l16;
-        const bf16* wp = W.w + (long)(n < N ? n : N - 1) * K + 8 * kg;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // two column blocks of 16 per pass: 16 independent 1-KiB weight fragments in flight per wave (the loop is a chain of L2 / HBM round
+    // trips, not of MFMAs)
+    constexpr int NWAVES = TK_THREADS / 64;
+    const bool live = l16 < rows;
+    const int arow = live ? l16 : 0;
+    for (int nb0 = wave; nb0 * 16 < N; nb0 += 2 * NWAVES) {
+        const int n_a = nb0 * 16 + l16, n_b = (nb0 + NWAVES) * 16 + l16;
+        const bf16* wpa = W.w + (long)(n_a < N ? n_a : N - 1) * K + 8 * kg;
+        const bf16* wpb = W.w + (long)(n_b < N ? n_b : N - 1) * K + 8 * kg;
+        f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
         for (int ks = 0; ks < K / 32; ++ks) {
-            const bf16x8 bfrag = *(const bf16x8*)(wp + 32 * ks);
-            bf16x8 ah = zero, al = zero;
-            if (l16 < rows) {
-                ah = *(const bf16x8*)(sh + l16 * PITCH + 32 * ks + 8 * kg);
-                al = *(const bf16x8*)(sl + l16 * PITCH + 32 * ks + 8 * kg);
-            }
-            acc = mfma16(ah, bfrag, acc);
-            acc = mfma16(al, bfrag, acc);
+            const bf16x8 fa = *(const bf16x8*)(wpa + 32 * ks);
+            const bf16x8 fb = *(const bf16x8*)(wpb + 32 * ks);
+            // rows >= `rows` of the 16-row A operand are zero: read a valid row and select (no branch inside the loop -- at a
+            // control-flow join hipcc waits for every weight load in flight)
+            bf16x8 ah = *(const bf16x8*)(sh + arow * PITCH + 32 * ks + 8 * kg);
+            bf16x8 al = *(const bf16x8*)(sl + arow * PITCH + 32 * ks + 8 * kg);
+            ah = live ? ah : zero;
+            al = live ? al : zero;
+            acc_a = mfma16(ah, fa, acc_a);
+            acc_a = mfma16(al, fa, acc_a);
+            acc_b = mfma16(ah, fb, acc_b);
+            acc_b = mfma16(al, fb, acc_b);
         }
-        if (n < N) {
-            const float bias = W.b ? (float)W.b[n] : 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 4 * kg + i;
-                if (r < rows) {
-                    float v = acc[i] + bias;
-                    if (act == WG_ACT_RELU) v = fmaxf(v, 0.f);
-                    if (res) v += res[r * ldres + n];
-                    y[r * ldy + n] = v;
+        for (int u = 0; u < 2; ++u) {
+            const int n = u == 0 ? n_a : n_b;
+            const f32x4 acc = u == 0 ? acc_a : acc_b;
+            if (n < N) {
+                const float bias = W.b ? (float)W.b[n] : 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * kg + i;
+                    if (r < rows) {
+                        float v = acc[i] + bias;
+                        if (act == WG_ACT_RELU) v = fmaxf(v, 0.f);
+                        if (res) v += res[r * ldres + n];
+                        y[r * ldy + n] = v;
+                    }
                 }
             }
         }
@@ -329,13 +344,12 @@ __device__ void tok_self_attention(const float* q, const float* k, const float* 
 
 // token -> image attention: q [6][128] LDS fp32 (8 heads x 16, unscaled), K / V image rows [hw][ld] bf16 in global memory.
 // wave = head; a lane owns keys lane, lane + 64, ...; online softmax per lane, merged across the wave at the end.  o [6][128] LDS fp32.
-__device__ void tok_image_attention(const float* q, const bf16* Kp, const bf16* Vp, long ld, int hw, float* o) {
+__device__ void tok_image_attention(float* q, const bf16* Kp, const bf16* Vp, long ld, int hw, float* o) {
     const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
-    float qr[TK_N][16];
-#pragma unroll
-    for (int t = 0; t < TK_N; ++t)
-#pragma unroll
-        for (int d = 0; d < 16; ++d) qr[t][d] = q[t * 128 + h * 16 + d] * 0.25f;   // 1 / sqrt(16)
+    // the six query rows are wave-uniform: they stay in LDS (scaled once; q is scratch of the caller) and are re-read per key as
+    // broadcast 16-byte reads, which frees 96 registers for keeping the next pass's keys in flight
+    for (int i = threadIdx.x; i < TK_N * 128; i += TK_THREADS) q[i] *= 0.25f;   // 1 / sqrt(16)
+    __syncthreads();
     float m[TK_N], l[TK_N], acc[TK_N][16];
 #pragma unroll
     for (int t = 0; t < TK_N; ++t) {
@@ -344,9 +358,19 @@ __device__ void tok_image_attention(const float* q, const bf16* Kp, const bf16* 
 #pragma unroll
         for (int d = 0; d < 16; ++d) acc[t][d] = 0.f;
     }
+    // the keys of the next pass are requested before the current pass is computed (the loop was a chain of strided-read round trips)
+    auto ldk = [&](int j, bf16x8* kk, bf16x8* vv) __attribute__((always_inline)) {
+        const int jj = j < hw ? j : hw - 1;
+        kk[0] = *(const bf16x8*)(Kp + (long)jj * ld + h * 16); kk[1] = *(const bf16x8*)(Kp + (long)jj * ld + h * 16 + 8);
+        vv[0] = *(const bf16x8*)(Vp + (long)jj * ld + h * 16); vv[1] = *(const bf16x8*)(Vp + (long)jj * ld + h * 16 + 8);
+    };
+    bf16x8 kn[2], vn[2];
+    ldk(lane, kn, vn);
     for (int j = lane; j < hw; j += 64) {
-        const bf16x8 k0 = *(const bf16x8*)(Kp + (long)j * ld + h * 16), k1 = *(const bf16x8*)(Kp + (long)j * ld + h * 16 + 8);
-        const bf16x8 v0 = *(const bf16x8*)(Vp + (long)j * ld + h * 16), v1 = *(const bf16x8*)(Vp + (long)j * ld + h * 16 + 8);
+        const bf16x8 k0 = kn[0], k1 = kn[1], v0 = vn[0], v1 = vn[1];
+        ldk(j + 64, kn, vn);
+        int qo = h * 16;
+        asm volatile("" : "+v"(qo));   // keeps the (loop-invariant) query reads inside the loop: hoisted they are 96 registers again
         float kf[16], vf[16];
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
@@ -357,7 +381,10 @@ __device__ void tok_image_attention(const float* q, const bf16* Kp, const bf16* 
         for (int t = 0; t < TK_N; ++t) {
             float s = 0.f;
 #pragma unroll
-            for (int d = 0; d < 16; ++d) s += qr[t][d] * kf[d];
+            for (int d4 = 0; d4 < 4; ++d4) {
+                const f32x4 qv = *(const f32x4*)(q + t * 128 + qo + 4 * d4);
+                s += qv[0] * kf[4 * d4] + qv[1] * kf[4 * d4 + 1] + qv[2] * kf[4 * d4 + 2] + qv[3] * kf[4 * d4 + 3];
+            }
             if (s > m[t]) {                       // rare after the first few keys: rescale the running state
                 const float a = __expf(m[t] - s);
                 l[t] *= a;
