@@ -97,9 +97,14 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     // head_dim 80: rows padded once more to 13 chunks = 52 dwords, a pitch that sends 16 consecutive rows to 16 different bank
     // quads (the K fragment reads of 192-byte rows were 4-way conflicted: rows r and r + 4 shared their banks); the 13th chunk of
     // a row is never read
-    constexpr int ROWB = (HD == 80) ? 208 : HDP * 2;   // bytes per row
-    constexpr int CPR = ROWB / 16;                     // 16-byte chunks per K/V row
-    constexpr int TILE = 64 * ROWB;        // bytes per K (or V) tile
+    constexpr int ROWB = (HD == 80) ? 208 : HDP * 2;   // bytes per K row
+    // V rows of head_dim 80 keep the natural 192-byte pitch (12 chunks): four consecutive rows x 16 dwords then fall on disjoint bank
+    // ranges for the transposed reads (pitch 48 dwords: 0, 48, 32, 16 mod 64), which the 208-byte pitch of the K rows (0, 52, 40, 28: rows
+    // r and r + 1 overlap by four banks, a 2-way conflict) does not give; K keeps 208 for its ds_read_b128 pattern
+    constexpr int ROWBV = (HD == 80) ? 192 : ROWB;     // bytes per V row
+    constexpr int TILE = 64 * ROWB;        // bytes per K tile
+    constexpr int TILEV = 64 * ROWBV;      // bytes per V tile
+    constexpr int TILE2 = TILE + TILEV;    // one buffer = K tile | V tile
     constexpr int KSTEPS = HD / 16;        // QK^T runs over the real head dim only
     constexpr int DB = HDP / 32;           // PV d-blocks; columns >= HD hold don't-care data and are never stored
     constexpr bool GRID = (S > 0);
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     constexpr int NRW = GRID ? RP / 2 : 1;                // width-bias registers per lane
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* kv = smem;                                  // [2 buffers][K tile | V tile]
-    float* tab = (float*)(smem + 4 * TILE);           // grid: per-wave rel table; plain: key bias row
+    float* tab = (float*)(smem + 2 * TILE2);          // grid: per-wave rel table; plain: key bias row
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -197,8 +202,8 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     // as much as the exponentials).  Slots that do not exist in a tile (keys beyond Lk; window rows beyond the window or the
     // image) read the substitute row instead: the last key (plain) or the qkv-bias row that stands for zero padding (grid);
     // slots beyond the window width do so in every tile and keep a stride of 0.  Their scores are masked by the bias tables.
-    constexpr int NINST = TILE / 1024;               // wave-instructions per K (or V) tile
-    constexpr int NPW = (NINST + NW - 1) / NW;       // ... per wave
+    constexpr int NINSTK = TILE / 1024, NINSTV = TILEV / 1024;   // wave-instructions per K / V tile
+    constexpr int NPW = (NINSTK + NW - 1) / NW;                    // ... per wave (NINSTV <= NINSTK)
     const bf16* altK = GRID ? a.padK + hcol : a.K + ((long)b * a.k_bs + (a.Lk - 1)) * a.ldk + hcol;
     const bf16* altV = GRID ? a.padV + hcol : a.V + ((long)b * a.k_bs + (a.Lk - 1)) * a.ldv + hcol;
     const int klim0 = GRID ? (S < a.Hg - wy * S ? S : a.Hg - wy * S) : a.Lk;   // rows (grid) / keys (plain) that exist
@@ -206,56 +211,59 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     constexpr int NRP = RUNP ? NPW : 1;
     const bf16* runp[2][NRP];
     unsigned coff[2][NRP];
-    int kslot[NRP];
-    bool padx[NRP];
+    int kslot[2][NRP];
+    bool padx[2][NRP];
     if constexpr (RUNP) {
 #pragma unroll
-        for (int i = 0; i < NPW; ++i) {
-            const int ii = wave + i * NW < NINST ? wave + i * NW : NINST - 1;
-            const int ci = ii * 64 + lane;
-            const int row = ci / CPR, cs = ci % CPR;        // key slot inside the tile, 16-byte chunk inside the row
-            int cK = cs ^ swzK<HD>(row), cV = cs ^ swzV<HD>(row);
-            if (HDP != HD && cK * 8 >= HD) cK = HD / 8 - 1;   // pad columns: any readable bytes will do
-            if (HDP != HD && cV * 8 >= HD) cV = HD / 8 - 1;
-            coff[0][i] = cK * 8;
-            coff[1][i] = cV * 8;
-            long r;
-            if (GRID) {
-                int kw = row % RP;
-                kw = kw < S ? kw : S - 1;
-                kslot[i] = row / RP;
-                padx[i] = wx * S + kw >= a.Hg;
-                r = (long)b * a.Hg * a.Hg + (long)(wy * S + kslot[i]) * a.Hg + wx * S + kw;
-            } else {
-                kslot[i] = row;
-                padx[i] = false;
-                r = (long)b * a.k_bs + row;
+        for (int o = 0; o < 2; ++o) {
+            const int cpr = (o ? ROWBV : ROWB) / 16, ninst = o ? NINSTV : NINSTK;
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) {
+                const int ii = wave + i * NW < ninst ? wave + i * NW : ninst - 1;
+                const int ci = ii * 64 + lane;
+                const int row = ci / cpr, cs = ci % cpr;        // key slot inside the tile, 16-byte chunk inside the row
+                int c = cs ^ (o ? swzV<HD>(row) : swzK<HD>(row));
+                if (HDP != HD && c * 8 >= HD) c = HD / 8 - 1;   // pad columns: any readable bytes will do
+                coff[o][i] = c * 8;
+                long r;
+                if (GRID) {
+                    int kw = row % RP;
+                    kw = kw < S ? kw : S - 1;
+                    kslot[o][i] = row / RP;
+                    padx[o][i] = wx * S + kw >= a.Hg;
+                    r = (long)b * a.Hg * a.Hg + (long)(wy * S + kslot[o][i]) * a.Hg + wx * S + kw;
+                } else {
+                    kslot[o][i] = row;
+                    padx[o][i] = false;
+                    r = (long)b * a.k_bs + row;
+                }
+                if (o == 0) runp[0][i] = padx[0][i] ? altK + coff[0][i] : a.K + r * a.ldk + hcol + coff[0][i];
+                else runp[1][i] = padx[1][i] ? altV + coff[1][i] : a.V + r * a.ldv + hcol + coff[1][i];
             }
-            runp[0][i] = padx[i] ? altK + coff[0][i] : a.K + r * a.ldk + hcol + coff[0][i];
-            runp[1][i] = padx[i] ? altV + coff[1][i] : a.V + r * a.ldv + hcol + coff[1][i];
         }
     }
     const unsigned strideK = (unsigned)((GRID ? (long)RPT * a.Hg : 64L) * a.ldk);
     const unsigned strideV = (unsigned)((GRID ? (long)RPT * a.Hg : 64L) * a.ldv);
     // tile t of K (or V) -> buffer `buf`; per operand the tiles must be staged in order 0, 1, 2, ... (running pointers)
     auto stage = [&](int t, int buf, bool isV) __attribute__((always_inline)) {
-        char* dst = kv + buf * 2 * TILE + (isV ? TILE : 0);
+        char* dst = kv + buf * TILE2 + (isV ? TILE : 0);
         const int lim = klim0 - t * (GRID ? RPT : 64);
         const int o = isV ? 1 : 0;
+        const int cpr = (isV ? ROWBV : ROWB) / 16, ninst = isV ? NINSTV : NINSTK;
         if constexpr (RUNP) {
 #pragma unroll
             for (int i = 0; i < NPW; ++i) {
                 const int ii = wave + i * NW;
-                if (ii < NINST) {
-                    const bf16* src = kslot[i] < lim ? runp[o][i] : (isV ? altV : altK) + coff[o][i];
+                if (ii < ninst) {
+                    const bf16* src = kslot[o][i] < lim ? runp[o][i] : (isV ? altV : altK) + coff[o][i];
                     __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(src), WG_LDS_PTR(dst + ii * 1024), 16, 0, 0);
                 }
-                runp[o][i] += padx[i] ? 0u : (isV ? strideV : strideK);
+                runp[o][i] += padx[o][i] ? 0u : (isV ? strideV : strideK);
             }
         } else {
-            for (int ii = wave; ii < NINST; ii += NW) {
+            for (int ii = wave; ii < ninst; ii += NW) {
                 const int ci = ii * 64 + lane;
-                const int row = ci / CPR, cs = ci % CPR;
+                const int row = ci / cpr, cs = ci % cpr;
                 int c = cs ^ (isV ? swzV<HD>(row) : swzK<HD>(row));
                 if (HDP != HD && c * 8 >= HD) c = HD / 8 - 1;
                 const bf16* src = (isV ? altV : altK) + c * 8;
@@ -463,22 +471,22 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
             const int col = 32 * d + 16 * (g & 1) + 4 * cp;
             const int chunk = col >> 3;
             // swzV depends on the key only through its low bits, which 16*ks and +8 leave untouched
-            vt_ad[d] = vbase + (4 * hi + rq) * ROWB + ((chunk ^ swzV<HD>(4 * hi + rq)) << 4) + (col & 7) * 2;
+            vt_ad[d] = vbase + (4 * hi + rq) * ROWBV + ((chunk ^ swzV<HD>(4 * hi + rq)) << 4) + (col & 7) * 2;
         }
     }
     // the two transposed reads that feed P.V MFMA g = ks*DB + d (the offset must be an immediate: switch on the unrolled ks)
     auto vt_pair = [&](int g, int buf) __attribute__((always_inline)) {
         const int ks = g / DB, d = g % DB;
-        const unsigned ad = vt_ad[d] + (unsigned)(buf * 2 * TILE);
+        const unsigned ad = vt_ad[d] + (unsigned)(buf * TILE2);
 #if defined(WG_ATTN_ABL) && WG_ATTN_ABL == 7
         vt[ks][d][0] = (u32x2){ad, ad}; vt[ks][d][1] = (u32x2){ad, ad};   // ablation build: no V^T reads
         return;
 #endif
         switch (ks) {
-            case 0: vt[0][d][0] = wg_ds_read_tr<0 * 16 * ROWB>(ad); vt[0][d][1] = wg_ds_read_tr<0 * 16 * ROWB + 8 * ROWB>(ad); break;
-            case 1: vt[1][d][0] = wg_ds_read_tr<1 * 16 * ROWB>(ad); vt[1][d][1] = wg_ds_read_tr<1 * 16 * ROWB + 8 * ROWB>(ad); break;
-            case 2: vt[2][d][0] = wg_ds_read_tr<2 * 16 * ROWB>(ad); vt[2][d][1] = wg_ds_read_tr<2 * 16 * ROWB + 8 * ROWB>(ad); break;
-            default: vt[3][d][0] = wg_ds_read_tr<3 * 16 * ROWB>(ad); vt[3][d][1] = wg_ds_read_tr<3 * 16 * ROWB + 8 * ROWB>(ad); break;
+            case 0: vt[0][d][0] = wg_ds_read_tr<0 * 16 * ROWBV>(ad); vt[0][d][1] = wg_ds_read_tr<0 * 16 * ROWBV + 8 * ROWBV>(ad); break;
+            case 1: vt[1][d][0] = wg_ds_read_tr<1 * 16 * ROWBV>(ad); vt[1][d][1] = wg_ds_read_tr<1 * 16 * ROWBV + 8 * ROWBV>(ad); break;
+            case 2: vt[2][d][0] = wg_ds_read_tr<2 * 16 * ROWBV>(ad); vt[2][d][1] = wg_ds_read_tr<2 * 16 * ROWBV + 8 * ROWBV>(ad); break;
+            default: vt[3][d][0] = wg_ds_read_tr<3 * 16 * ROWBV>(ad); vt[3][d][1] = wg_ds_read_tr<3 * 16 * ROWBV + 8 * ROWBV>(ad); break;
         }
     };
     // exponentials, row sum and bf16 packing of score elements [e0, e1)
@@ -511,7 +519,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         }
         bias_begin(t);
 #pragma unroll
-        for (int g = 0; g < NQK; ++g) qk_read(kv + buf * 2 * TILE, g);
+        for (int g = 0; g < NQK; ++g) qk_read(kv + buf * TILE2, g);
 #pragma unroll
         for (int g = 0; g < NQK; ++g) qk_one(sa, g);
         // V^T fragments: inline-asm reads (invisible to hipcc's wait insertion), issued as early as the registers allow so that
@@ -580,11 +588,11 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
 
 template <int HD, int S, int NW, bool KB>
 static int launch_attn_impl(const AttnArgs& a, int groups, hipStream_t st) {
-    constexpr int TILE = 64 * ((HD == 80) ? 104 : (HD == 16 ? 32 : HD)) * 2;
+    constexpr int TILE = 64 * ((HD == 80) ? 208 + 192 : 4 * (HD == 16 ? 32 : HD));   // bytes of a K tile + a V tile (head_dim 80: 208- and 192-byte rows)
     constexpr int RP = S <= 16 ? 16 : (S <= 32 ? 32 : 64);
     constexpr int RPT = 64 / RP;
     constexpr int SP = S > 0 ? ((S + RPT - 1) / RPT) * RPT + 1 : 1;
-    size_t lds = 4 * TILE;
+    size_t lds = 2 * TILE;
     if (S > 0) lds += (size_t)NW * 32 * SP * 4;
     else lds += (size_t)((a.Lk + 63) / 64) * 64 * 4;
     if (lds > 160 * 1024) {
