@@ -100,3 +100,50 @@ def test_sam_encoder_fp8_vs_reference_golden(dev, name):
         e8 = rel_err(cases.tap_embedding(enc(x).float().cpu()).numpy(), gold["out"])
     print("encoder %s: rel err vs reference fp32: bf16 GEMMs %.4f, fp8 GEMMs %.4f" % (name, e16, e8))
     assert e8 < 0.12 and e8 < 15 * e16 + 0.02
+
+
+def test_masks_with_fp8_encoder_vs_oracle(dev):
+    """What config C5's operand type costs at the OUTPUT of the path: tiny SAM encoder (fp8 qkv / proj / MLP GEMMs) -> CTP -> prompt
+    encoder -> mask decoder -> postprocess against the fp32 oracle, next to the bf16 path on the same inputs.  The stated, measured
+    mIoU delta of the fp8 path (white-noise embedding: every pixel is a boundary pixel, the worst case for thresholded agreement)."""
+    from oracle import projectors as oproj
+    from oracle import sam as osam
+    from tests.test_gpu_modules import load_into, pixel_iou
+    from walkgpt_amd.walkgpt import WalkGPTGrounding
+    c = cases.SAM_ENCODERS["tiny"]
+    g = c["img"] // c["patch"]
+    model = WalkGPTGrounding(sam=dict(embed_dim=c["embed_dim"], depth=c["depth"], heads=c["heads"], global_idx=c["global_idx"], img=c["img"]),
+                             llm_hidden=64, with_clip=False)
+    w_enc, w_dec = cases.sam_encoder_weights(c), cases.decoder_weights(5)
+    wm, wt = cases.projector_weights(dict(cases.PROJECTORS["h64"]))
+    load_into(model.visual_model.image_encoder, w_enc, "image_encoder.", dev)
+    load_into(model.visual_model.prompt_encoder, w_dec, "prompt_encoder.", dev, strict=False)
+    load_into(model.visual_model.mask_decoder, w_dec, "mask_decoder.", dev)
+    load_into(model.out_mm_projector, {"x." + k: v for k, v in wm.items()}, "x.", dev)
+    load_into(model.text_hidden_fcs[0], {"x." + k: v for k, v in wt.items()}, "x.", dev)
+    model.visual_model.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix.data = \
+        w_dec["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].to(dev)
+    x = cases.sam_encoder_input(c)
+    hidden = [torch.randn(2, 64, generator=torch.Generator().manual_seed(3)), torch.randn(3, 64, generator=torch.Generator().manual_seed(4))]
+    resize, orig = [(512, 384), (400, 512)], [(200, 150), (75, 96)]
+    hid = [h.to(dev, torch.bfloat16) for h in hidden]
+    out16 = model(x.to(dev, torch.bfloat16), None, hid, resize, orig)
+    m16 = [m.clone() for m in out16["pred_masks"]]
+    model.set_gemm_dtype("fp8")
+    out8 = model(x.to(dev, torch.bfloat16), None, hid, resize, orig)
+    w_all = dict(w_enc)
+    w_all.update(w_dec)
+    with torch.no_grad():
+        emb = osam.image_encoder(w_all, x, dict(patch=c["patch"], depth=c["depth"], heads=c["heads"], global_idx=c["global_idx"], window=c["window"]))
+        dpe = osam.dense_pe(w_all, (g, g))
+        i16, i8 = [], []
+        for i in range(2):
+            pe = oproj.ctp(wt, hidden[i].to(torch.bfloat16).float())
+            sparse, dense = osam.prompt_encoder_text(w_all, pe.reshape(-1, 1, 256), (g, g))
+            masks, _ = osam.mask_decoder(w_all, emb[i:i + 1], dpe, sparse, dense)
+            ref = osam.postprocess_masks(masks, c["img"], resize[i], orig[i])[:, 0].numpy()
+            i16.append(pixel_iou(m16[i].cpu().numpy(), ref))
+            i8.append(pixel_iou(out8["pred_masks"][i].cpu().numpy(), ref))
+    print("thresholded masks vs the fp32 oracle (pixel IoU per image): bf16 GEMMs %s, fp8 GEMMs %s; mean delta %.4f"
+          % (["%.4f" % v for v in i16], ["%.4f" % v for v in i8], float(np.mean(i16) - np.mean(i8))))
+    assert min(i8) > 0.93 and np.mean(i16) - np.mean(i8) < 0.06
