@@ -309,7 +309,7 @@ def probe_launch(args, rank, local_rank, world):
     return 0 if flag.item() else 1
 
 
-KERNEL_NAMES = {1: "wg_gemm_kernel<128,128,64,2,2,2>", 2: "wg_gemm_kernel<256,256,64,2,2,4>", 3: "wg_gemm_rowwave_kernel",
+KERNEL_NAMES = {1: "wg_gemm_kernel<128,128,64,2,2,2>", 2: "wg_gemm_kernel<256,256,64,2,2,4>", 3: "wg_gemm_rowwave_kernel", 5: "wg_gemm_skinny_kernel",
                 11: "wg_gemm_persist_kernel<128,128,2,2>", 12: "wg_gemm_kernel<128,128 tail (+16 rows)>",
                 14: "wg_gemm_kernel<256,256,64,2,2,4,ping-pong>",
                 16: "wg_gemm_pp_persist_kernel<false> (256x256 tiles, ping-pong, persistent)",

@@ -139,22 +139,35 @@ int wg_upscale_mask_bf16(const void* x, long ldx, const void* w1, const void* b1
                          const void* w2, const void* b2, const float* hyper, float* out, int P, int h, int w, int nmask_total,
                          int first_mask, int num_masks, void* stream);
 
-/* Token side of SAM's two-way transformer, one launch per block, one workgroup per prompt, fp32 token state in LDS.
- * mode 0 = one TwoWayAttentionBlock (transformer.py:151-182): [self-attention (+query_pe unless skip_pe), norm1, token->image
- *          cross attention over the hw projected image tokens, norm2, MLP(ReLU), norm3, k / v of the image->token attention];
- * mode 1 = final_attn_token_to_image + norm_final_attn (transformer.py:96-106) + the four hypernetwork MLPs and the IoU head
- *          (mask_decoder.py:146-160).
- * queries [P,6,256] fp32 in/out (token order [iou, mask0..3, prompt], mask_decoder.py:125-132); query_pe [P,6,256] fp32;
- * weights: host array of n_weights bf16 device pointers (weight, bias / gamma, beta pairs) --
- *   mode 0 (26): self_attn q,k,v,out | norm1 | cross_attn_token_to_image q,out | norm2 | mlp lin1,lin2 | norm3 |
- *                cross_attn_image_to_token k,v;
- *   mode 1 (36): final attn q,out | norm_final_attn | output_hypernetworks_mlps[0..3].layers[0..2] | iou_prediction_head.layers[0..2];
- * Kimg / Vimg: projected image tokens (k_proj(keys + key_pe), v_proj(keys)) as bf16 rows [P or 1][hw][128] with row stride ld_img;
- * img_rows_per_prompt = 0 when all prompts share one image.  Outputs: mode 0 k_i2t / v_i2t [P,6,128] bf16; mode 1 hyper_out
- * [P,4,32] fp32 and iou_out [P,4] fp32. */
-int wg_dec_tokens_f32(int mode, int skip_pe, float* queries, const float* query_pe, const void* const* weights, int n_weights,
-                      const void* Kimg, const void* Vimg, long ld_img, long img_rows_per_prompt, int hw, void* k_i2t, void* v_i2t,
-                      float* hyper_out, float* iou_out, int P, float eps, void* stream);
+/* Token side of SAM's two-way transformer (transformer.py:62-182) and the decoder heads (mask_decoder.py:146-160): the six tokens of a
+ * prompt ([iou, mask0..3, prompt], mask_decoder.py:125-132) stay fp32; the two heavy pieces (token->image attention over the hw image
+ * tokens, the 2048-wide MLP) are spread over the chip and hand fp32 partials across kernel boundaries.
+ *
+ * wg_dec_tokens_f32: one workgroup per prompt runs the stages named by the bit mask `stages`, in this order:
+ *   1 SUM_MLP  x += mlp.lin2.bias + sum of the 8 MLP partials (:169-171); norm3; k / v of the image->token attention (:173-176)
+ *              -> k_i2t / v_i2t [P,6,128] bf16
+ *   2 SELF     self attention (+ query_pe unless skip_pe) and norm1 (:153-160)
+ *   4 Q_T2I    q_proj(x + query_pe) of the token->image attention (:162-165; tail :96-99) -> q_t2i [P,6,128] fp32
+ *   8 COMBINE  merge the attention partials; out_proj + residual; norm2 / norm_final_attn (:165-167; tail :100-101)
+ *  16 INIT     (modifier of the first launch) queries = query_pe = cat(init_tokens [5,256] fp32, init_prompt [P,256] bf16)
+ *              (mask_decoder.py:125-132: cat(iou_token, mask_tokens) | sparse prompt); both buffers are written
+ *   queries [P,6,256] fp32 in / out; query_pe [P,6,256] fp32; weights: 24 bf16 device pointers (weight, bias / gamma, beta; slots of
+ *   stages not requested may be null, so one launch can close block i (SUM_MLP) and open block i+1 (SELF, Q_T2I)):
+ *   self_attn q,k,v,out [0..7] | norm1 [8,9] | token->image q,out [10..13] | norm2 or norm_final_attn [14,15] | mlp.lin2.bias [16] |
+ *   unused [17] | norm3 [18,19] | image->token k,v [20..23].
+ * wg_dec_attn_partial_f32: softmax(q k^T / 4) v per (prompt, head, split of 1024 keys), a wave per 256 keys.  Kimg / Vimg: the projected image
+ *   tokens (k_proj(keys + key_pe), v_proj(keys)) as bf16 rows [P or 1][hw][128] with row stride ld_img (img_rows_per_prompt = 0 when all
+ *   prompts share one image); partials [P, 8, n_splits, 108] fp32 = {running max[6], sum[6], o[6][16]}, n_splits = ceil(hw / 1024).
+ * wg_dec_mlp_partial_f32: slice s of 8 of mlp(x): relu(x lin1[256 s .. +255]^T + b1) lin2[:, 256 s .. +255]^T -> partials [P,8,6,256].
+ * wg_dec_heads_f32: output_hypernetworks_mlps[i](x[:, 1 + i]) -> hyper_out [P,4,32]; iou_prediction_head(x[:, 0]) -> iou_out [P,4];
+ *   weights: 30 bf16 pointers = (hypernetwork 0..3, IoU head) x layers[0..2] x (weight, bias). */
+int wg_dec_tokens_f32(int stages, int skip_pe, float* queries, float* query_pe, const float* init_tokens, const void* init_prompt,
+                      const void* const* weights, int n_weights, float* q_t2i, const float* attn_partials, int n_splits, const float* mlp_partials, void* k_i2t, void* v_i2t, int P,
+                      float eps, void* stream);
+int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const void* Vimg, long ld_img, long img_rows_per_prompt, int hw,
+                            float* partials, int n_splits, int P, void* stream);
+int wg_dec_mlp_partial_f32(const float* x, const void* lin1_w, const void* lin1_b, const void* lin2_w, float* partials, int P, void* stream);
+int wg_dec_heads_f32(const float* x, const void* const* weights, int n_weights, float* hyper_out, float* iou_out, int P, void* stream);
 
 /* Sam.postprocess_masks (sam.py:137-172): bilinear to img_size^2, crop [:in_h,:in_w], bilinear to (out_h,out_w), one pass. */
 int wg_postprocess_masks_f32(const float* low_res, float* out, int N, int low_h, int low_w, int img_size, int in_h,

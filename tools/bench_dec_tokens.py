@@ -1,4 +1,4 @@
-"""wg_dec_tokens_f32 alone: how its time splits between the token-side Linear chain and the token->image attention (hw keys)."""
+"""Token-side kernels of the mask decoder on their own: per-launch time of each stage at P prompts and hw image tokens."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,7 +8,7 @@ dev = torch.device("cuda:0")
 torch.manual_seed(0)
 sam = M.build_sam_vit_b().to(dev).bfloat16()
 md = sam.mask_decoder
-layer = md.transformer.layers[1]
+l0, l1 = md.transformer.layers
 def t(fn, n=20):
     for _ in range(3): fn()
     torch.cuda.synchronize()
@@ -23,8 +23,15 @@ for P in (1, 8, 112):
         pe = torch.randn(P, 6, 256, device=dev)
         proj = torch.randn(P, hw, 384, device=dev).to(torch.bfloat16)
         kq = torch.empty(P, 6, 128, device=dev, dtype=torch.bfloat16); vq = torch.empty_like(kq)
-        w0 = layer.token_weights(); w1 = md.head_weights()
-        hy = torch.empty(P, 4, 32, device=dev); io = torch.empty(P, 4, device=dev)
-        a = t(lambda: ops.dec_tokens(0, False, q, pe, w0, proj[..., :128], proj[..., 128:256], hw, k_i2t=kq, v_i2t=vq))
-        b = t(lambda: ops.dec_tokens(1, False, q, pe, w1, proj[..., :128], proj[..., 128:256], hw, hyper_out=hy, iou_out=io))
-        print("P=%3d hw=%4d: block kernel %.1f us, tail+heads kernel %.1f us" % (P, hw, a, b), flush=True)
+        qt = torch.empty(P, 6, 128, device=dev)
+        tab = M.token_stage_table(self_blk=l1, t2i=l1.cross_attn_token_to_image, norm=l1.norm2, sum_blk=l0)
+        part = ops.dec_attn_partial(qt, proj[..., :128], proj[..., 128:256])
+        mp = l1.mlp_partials(q)
+        r = {
+            "sum|self|q": t(lambda: ops.dec_tokens(7, False, q, pe, tab, q_t2i=qt, mlp_partials=mp, k_i2t=kq, v_i2t=vq)),
+            "attn": t(lambda: ops.dec_attn_partial(qt, proj[..., :128], proj[..., 128:256])),
+            "combine": t(lambda: ops.dec_tokens(8, False, q, pe, tab, attn_partials=part)),
+            "mlp": t(lambda: l1.mlp_partials(q)),
+            "heads": t(lambda: ops.dec_heads(q, md.head_weights())),
+        }
+        print("P=%3d hw=%4d: " % (P, hw) + "  ".join("%s %.1f us" % kv for kv in r.items()), flush=True)

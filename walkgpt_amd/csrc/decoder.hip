@@ -179,50 +179,67 @@ extern "C" int wg_upscale_mask_bf16(const void* x, long ldx, const void* w1, con
 }
 
 // =====================================================================================================================================
-//   wg_dec_tokens_f32      the token side of one TwoWayAttentionBlock (transformer.py:151-182) -- self attention, norm1, token->image
-//                          cross attention over all image tokens, norm2, MLP, norm3, and the k / v projections that the image->token
-//                          attention of the same block reads -- or of the tail of the transformer (final token->image attention,
-//                          norm_final_attn: transformer.py:96-106) plus the hypernetwork MLPs and the IoU head (mask_decoder.py:146-160)
-//                          in ONE launch, one workgroup per prompt.  The six tokens of a prompt live in LDS as fp32 for the whole
-//                          kernel; Linear layers run on the matrix pipe with the tokens as a 16-row A operand (rows 6..15 zero) split
-//                          into a bf16 hi + lo pair, weights (bf16, the checkpoint's precision) streamed from L2 as B fragments.
+// Token side of SAM's two-way transformer (transformer.py:62-182) and the decoder heads (mask_decoder.py:146-160).
+//
+// The six tokens of a prompt are tiny (6 x 256 fp32) but every Linear that touches them streams its weights: 2.8 MB per block, and ONE
+// compute unit ingests ~30 GB/s with plain loads (in-kernel stamps of the one-kernel-per-block version: 183 us = 83 us walking the 4096
+// image keys + 63 us streaming the MLP's 2 MB + 37 us for everything else).  So the two heavy pieces run as kernels of their own, spread over
+// the chip, and hand small fp32 partials across a kernel boundary (the cheapest grid-wide synchronisation there is):
+//
+//   wg_dec_tokens_f32        one workgroup per prompt, the tokens in LDS as fp32; executes the stages named by a bit mask:
+//                              SUM_MLP  x = x + lin2 bias + sum of the MLP partials; norm3; k / v of the image->token attention
+//                              SELF     self attention of the six tokens (+ query_pe unless skip_pe), norm1
+//                              Q_T2I    q of the token->image attention -> q_t2i [P,6,128]
+//                              COMBINE  merge the attention partials; out_proj + residual; norm2 (or norm_final_attn)
+//                              INIT     (with the first SELF) build the tokens from the output-token table and the prompt rows
+//   wg_dec_attn_partial_f32  token->image attention: grid (prompt, head, split of 1024 keys), a wave per 256 keys, online softmax per lane
+//                            merged across the wave, then across the four waves in LDS -> {m[6], l[6], o[6][16]} per (prompt, head, split)
+//   wg_dec_mlp_partial_f32   the MLP (256 -> 2048 -> ReLU -> 256): grid (prompt, 8 slices of 256 hidden units) -> partial [6][256] each
+//   wg_dec_heads_f32         the four hypernetwork MLPs and the IoU head: grid (prompt, 5), one 3-layer MLP each
+//
+// Linear layers run on the matrix pipe with the tokens as a 16-row A operand (rows 6..15 zero) split into a bf16 hi + lo pair (~16
+// significant bits); weights are bf16 (the checkpoint's precision), streamed from L2 as B fragments.
 // =====================================================================================================================================
 namespace {
 
 constexpr int TK_THREADS = 512;
 constexpr int TK_N = 6;          // tokens per prompt: iou + 4 mask tokens + 1 text prompt (mask_decoder.py:125-132)
 constexpr int TK_C = 256;        // transformer_dim
-constexpr int TK_KMAX = 2048;    // widest Linear input (mlp.lin2)
+constexpr int TK_HID = 2048;     // MLP width
+constexpr int TK_SLICES = 8;     // MLP slices (256 hidden units each)
+constexpr int TK_PART = TK_N * 18;   // floats of one attention partial: m[6] | l[6] | o[6][16]
 
 struct LinW { const bf16* w; const bf16* b; };
 struct NormW { const bf16* g; const bf16* b; };
 struct AttnW { LinW q, k, v, o; };
 
+enum { ST_SUM_MLP = 1, ST_SELF = 2, ST_Q_T2I = 4, ST_COMBINE = 8, ST_INIT = 16 };
+
 struct TokArgs {
-    // mode 0: one TwoWayAttentionBlock; mode 1: final attention + heads
-    int mode, skip_pe, P, hw;
+    int stages, skip_pe, P, n_splits;
     float* queries;            // [P, 6, 256] fp32 in / out
-    const float* pe;           // [P, 6, 256] fp32: the prompt tokens as they entered the transformer (query_pe)
+    float* pe;                 // [P, 6, 256] fp32: the prompt tokens as they entered the transformer (query_pe); written by INIT
+    const float* init_tokens;  // INIT: [5, 256] fp32 = cat(iou_token.weight, mask_tokens.weight)   (mask_decoder.py:125-128)
+    const bf16* init_prompt;   //       [P, 256] bf16 = the sparse prompt embedding of each query  (:129-132)
     AttnW self_attn; NormW norm1;
-    LinW t2i_q, t2i_o; NormW norm2;          // (mode 1: final_attn_token_to_image q / out, norm_final_attn)
-    LinW lin1, lin2; NormW norm3;
+    LinW t2i_q, t2i_o; NormW norm2;          // (tail: final_attn_token_to_image q / out, norm_final_attn)
+    const bf16* lin2_b; NormW norm3;         // SUM_MLP: bias of mlp.lin2, norm3
     LinW i2t_k, i2t_v;
-    const bf16* Kimg; const bf16* Vimg; long ld_img, img_bs;   // projected image tokens: [P | 1, hw, ld_img] (img_bs = 0: shared by all prompts)
-    bf16* k_i2t; bf16* v_i2t;                // out (mode 0): [P, 6, 128] bf16 keys / values of the image->token attention
-    LinW hyper[4][3]; LinW iou[3];           // mode 1
-    float* hyper_out;                        // [P, 4, 32] fp32
-    float* iou_out;                          // [P, 4] fp32
+    float* q_t2i;                            // [P, 6, 128] fp32: out of Q_T2I
+    const float* attn_part;                  // [P, 8, n_splits, TK_PART]: in of COMBINE
+    const float* mlp_part;                   // [P, TK_SLICES, 6, 256]: in of SUM_MLP
+    bf16* k_i2t; bf16* v_i2t;                // out of SUM_MLP: [P, 6, 128] bf16 keys / values of the image->token attention
     float eps;
 };
 
-// y[r][n] = act(x[r][:] . W[n][:] + b[n]) (+ res[r][n]) for r < rows (<= 6), n < N.  x, y, res: LDS fp32.  sh / sl: LDS staging of the
-// bf16 hi / lo split of x, [8][K + 8].  Every thread of the workgroup calls it; the result is visible to all on return.
-template <int K>
-__device__ void tok_linear(const float* x, int ldx, int rows, LinW W, int N, float* y, int ldy, int act, const float* res, int ldres,
+// y[r][n] = act(x[r][:] . W[n][:] + b[n]) (+ res[r][n]) for r < rows (<= 6), n < N; W rows are ldw elements apart.  x, y, res: LDS fp32.
+// sh / sl: LDS staging of the bf16 hi / lo split of x, [8][K + 8].  Every thread of the workgroup calls it; visible to all on return.
+template <int K, int THREADS = TK_THREADS>
+__device__ void tok_linear(const float* x, int ldx, int rows, LinW W, long ldw, int N, float* y, int ldy, int act, const float* res, int ldres,
                            bf16* sh, bf16* sl) {
     constexpr int PITCH = K + 8;
     const int tid = threadIdx.x;
-    for (int i = tid; i < rows * K; i += TK_THREADS) {
+    for (int i = tid; i < rows * K; i += THREADS) {
         const int r = i / K, c = i % K;
         const float v = x[r * ldx + c];
         const bf16 hi = (bf16)v;
@@ -235,13 +252,13 @@ __device__ void tok_linear(const float* x, int ldx, int rows, LinW W, int N, flo
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     // two column blocks of 16 per pass: 16 independent 1-KiB weight fragments in flight per wave (the loop is a chain of L2 / HBM round
     // trips, not of MFMAs)
-    constexpr int NWAVES = TK_THREADS / 64;
+    constexpr int NWAVES = THREADS / 64;
     const bool live = l16 < rows;
     const int arow = live ? l16 : 0;
     for (int nb0 = wave; nb0 * 16 < N; nb0 += 2 * NWAVES) {
         const int n_a = nb0 * 16 + l16, n_b = (nb0 + NWAVES) * 16 + l16;
-        const bf16* wpa = W.w + (long)(n_a < N ? n_a : N - 1) * K + 8 * kg;
-        const bf16* wpb = W.w + (long)(n_b < N ? n_b : N - 1) * K + 8 * kg;
+        const bf16* wpa = W.w + (long)(n_a < N ? n_a : N - 1) * ldw + 8 * kg;
+        const bf16* wpb = W.w + (long)(n_b < N ? n_b : N - 1) * ldw + 8 * kg;
         f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
         for (int ks = 0; ks < K / 32; ++ks) {
@@ -313,7 +330,7 @@ __device__ void tok_add(float* out, const float* a, const float* b) {
 // softmax(q k^T / sqrt(32)) v over the six tokens themselves: q, k, v [6][256] LDS fp32 (8 heads x 32) -> o [6][256]
 __device__ void tok_self_attention(const float* q, const float* k, const float* v, float* o) {
     const int tid = threadIdx.x;
-    if (tid < 8 * TK_N * 8) {               // (head, query, quarter of the head's 32 output dims)
+    if (tid < 8 * TK_N * 8) {               // (head, query, eighth of the head's 32 output dims)
         const int hq = tid >> 3, part = tid & 7;
         const int h = hq / TK_N, t = hq % TK_N;
         float s[TK_N], m = -1e30f;
@@ -342,14 +359,118 @@ __device__ void tok_self_attention(const float* q, const float* k, const float* 
     __syncthreads();
 }
 
-// token -> image attention: q [6][128] LDS fp32 (8 heads x 16, unscaled), K / V image rows [hw][ld] bf16 in global memory.
-// wave = head; a lane owns keys lane, lane + 64, ...; online softmax per lane, merged across the wave at the end.  o [6][128] LDS fp32.
-__device__ void tok_image_attention(float* q, const bf16* Kp, const bf16* Vp, long ld, int hw, float* o) {
-    const int lane = threadIdx.x & 63, h = threadIdx.x >> 6;
-    // the six query rows are wave-uniform: they stay in LDS (scaled once; q is scratch of the caller) and are re-read per key as
-    // broadcast 16-byte reads, which frees 96 registers for keeping the next pass's keys in flight
-    for (int i = threadIdx.x; i < TK_N * 128; i += TK_THREADS) q[i] *= 0.25f;   // 1 / sqrt(16)
+__global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
+    __shared__ float qs[TK_N * TK_C], pes[TK_N * TK_C], t0[TK_N * TK_C], t1[TK_N * TK_C], t2[TK_N * TK_C], t3[TK_N * TK_C];
+    __shared__ __attribute__((aligned(16))) bf16 sh[8 * (TK_C + 8)], sl[8 * (TK_C + 8)];
+    const int p = blockIdx.x;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < TK_N * TK_C; i += TK_THREADS) {
+        float v, pv;
+        if (a.stages & ST_INIT) {         // tokens = cat(output tokens, prompt) (mask_decoder.py:125-132) = queries = query_pe of the first block
+            v = pv = i < 5 * TK_C ? a.init_tokens[i] : (float)a.init_prompt[(long)p * TK_C + i - 5 * TK_C];
+            a.pe[(long)p * TK_N * TK_C + i] = pv;
+        } else {
+            v = a.queries[(long)p * TK_N * TK_C + i];
+            pv = a.pe[(long)p * TK_N * TK_C + i];
+        }
+        if (a.stages & ST_SUM_MLP) {      // x + mlp(x) (transformer.py:169-171): the eight slices' partial sums and the bias of lin2
+            v += (float)a.lin2_b[i % TK_C];
+            const float* mp = a.mlp_part + (long)p * TK_SLICES * TK_N * TK_C + i;
+#pragma unroll
+            for (int sl_ = 0; sl_ < TK_SLICES; ++sl_) v += mp[sl_ * TK_N * TK_C];
+        }
+        qs[i] = v;
+        pes[i] = pv;
+    }
     __syncthreads();
+    if (a.stages & ST_SUM_MLP) {
+        // ---- norm3, then k / v of the image -> token attention (:172-178) ----------------------------------------------------------------
+        tok_layernorm(qs, TK_N, a.norm3, a.eps);
+        tok_add(t3, qs, pes);
+        tok_linear<TK_C>(t3, TK_C, TK_N, a.i2t_k, TK_C, 128, t0, 128, 0, nullptr, 0, sh, sl);
+        tok_linear<TK_C>(qs, TK_C, TK_N, a.i2t_v, TK_C, 128, t1, 128, 0, nullptr, 0, sh, sl);
+        for (int i = tid; i < TK_N * 128; i += TK_THREADS) {
+            a.k_i2t[(long)p * TK_N * 128 + i] = (bf16)t0[i];
+            a.v_i2t[(long)p * TK_N * 128 + i] = (bf16)t1[i];
+        }
+        __syncthreads();
+    }
+    if (a.stages & ST_SELF) {
+        // ---- self attention (:153-160): layer 0 replaces the queries and skips the positional term --------------------------------------
+        if (a.skip_pe) {
+            tok_linear<TK_C>(qs, TK_C, TK_N, a.self_attn.q, TK_C, TK_C, t0, TK_C, 0, nullptr, 0, sh, sl);
+            tok_linear<TK_C>(qs, TK_C, TK_N, a.self_attn.k, TK_C, TK_C, t1, TK_C, 0, nullptr, 0, sh, sl);
+        } else {
+            tok_add(t3, qs, pes);
+            tok_linear<TK_C>(t3, TK_C, TK_N, a.self_attn.q, TK_C, TK_C, t0, TK_C, 0, nullptr, 0, sh, sl);
+            tok_linear<TK_C>(t3, TK_C, TK_N, a.self_attn.k, TK_C, TK_C, t1, TK_C, 0, nullptr, 0, sh, sl);
+        }
+        tok_linear<TK_C>(qs, TK_C, TK_N, a.self_attn.v, TK_C, TK_C, t2, TK_C, 0, nullptr, 0, sh, sl);
+        tok_self_attention(t0, t1, t2, t3);
+        tok_linear<TK_C>(t3, TK_C, TK_N, a.self_attn.o, TK_C, TK_C, qs, TK_C, 0, a.skip_pe ? nullptr : qs, TK_C, sh, sl);
+        tok_layernorm(qs, TK_N, a.norm1, a.eps);
+    }
+    if (a.stages & ST_Q_T2I) {
+        // ---- q of the token -> image attention (:162-165; tail: :96-101), internal width 128 ------------------------------------------------
+        tok_add(t3, qs, pes);
+        tok_linear<TK_C>(t3, TK_C, TK_N, a.t2i_q, TK_C, 128, t0, 128, 0, nullptr, 0, sh, sl);
+        for (int i = tid; i < TK_N * 128; i += TK_THREADS) a.q_t2i[(long)p * TK_N * 128 + i] = t0[i];
+        __syncthreads();
+    }
+    if (a.stages & ST_COMBINE) {
+        // ---- merge the key splits of every (head, query): o = sum_s o_s e^(m_s - M) / sum_s l_s e^(m_s - M) -----------------------------------
+        for (int i = tid; i < 8 * TK_N * 16; i += TK_THREADS) {
+            const int d = i & 15, t = (i >> 4) % TK_N, h = i / (16 * TK_N);
+            const float* pp = a.attn_part + ((long)p * 8 + h) * a.n_splits * TK_PART;
+            float M = -1e30f, L = 0.f, o = 0.f;
+            for (int s0 = 0; s0 < a.n_splits; s0 += 4) {        // four splits' loads in flight at a time
+                float mm[4], ll[4], oo[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const bool in = s0 + u < a.n_splits;
+                    const float* q_ = pp + (in ? s0 + u : s0) * TK_PART;
+                    mm[u] = in ? q_[t] : -1e30f;
+                    ll[u] = in ? q_[TK_N + t] : 0.f;
+                    oo[u] = in ? q_[2 * TK_N + t * 16 + d] : 0.f;
+                }
+                const float Mn = fmaxf(fmaxf(fmaxf(mm[0], mm[1]), fmaxf(mm[2], mm[3])), M);
+                const float sc = __expf(M - Mn);
+                L *= sc;
+                o *= sc;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const float w = __expf(mm[u] - Mn);
+                    L += ll[u] * w;
+                    o += oo[u] * w;
+                }
+                M = Mn;
+            }
+            t1[t * 128 + h * 16 + d] = o / L;
+        }
+        __syncthreads();
+        tok_linear<128>(t1, 128, TK_N, a.t2i_o, 128, TK_C, qs, TK_C, 0, qs, TK_C, sh, sl);
+        tok_layernorm(qs, TK_N, a.norm2, a.eps);
+    }
+    for (int i = tid; i < TK_N * TK_C; i += TK_THREADS) a.queries[(long)p * TK_N * TK_C + i] = qs[i];
+}
+
+// token -> image attention, one workgroup of four waves per (prompt, head, split of 1024 keys), a wave per 256 keys; the waves' online-softmax
+// states are merged in LDS.  q [P,6,128] fp32 (unscaled); K / V image rows [hw][ld] bf16.
+constexpr int AT_WAVES = 4;
+constexpr int AT_KEYS = 256 * AT_WAVES;    // keys per workgroup
+struct AttnPartArgs {
+    const float* q; const bf16* K; const bf16* V; long ld, img_bs; int hw, n_splits; float* part;
+};
+__global__ __launch_bounds__(64 * AT_WAVES) void wg_dec_attn_partial_kernel(AttnPartArgs a) {
+    __shared__ __attribute__((aligned(16))) float qsh[TK_N * 16];
+    __shared__ float wpart[AT_WAVES][TK_PART];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int split = blockIdx.x % a.n_splits, h = (blockIdx.x / a.n_splits) & 7, p = blockIdx.x / (a.n_splits * 8);
+    for (int i = threadIdx.x; i < TK_N * 16; i += 64 * AT_WAVES)
+        qsh[i] = a.q[((long)p * TK_N + i / 16) * 128 + h * 16 + (i & 15)] * 0.25f;   // 1 / sqrt(16)
+    __syncthreads();
+    const bf16* Kp = a.K + (long)p * a.img_bs * a.ld + h * 16;
+    const bf16* Vp = a.V + (long)p * a.img_bs * a.ld + h * 16;
     float m[TK_N], l[TK_N], acc[TK_N][16];
 #pragma unroll
     for (int t = 0; t < TK_N; ++t) {
@@ -358,175 +479,176 @@ __device__ void tok_image_attention(float* q, const bf16* Kp, const bf16* Vp, lo
 #pragma unroll
         for (int d = 0; d < 16; ++d) acc[t][d] = 0.f;
     }
-    // the keys of the next pass are requested before the current pass is computed (the loop was a chain of strided-read round trips)
-    auto ldk = [&](int j, bf16x8* kk, bf16x8* vv) __attribute__((always_inline)) {
-        const int jj = j < hw ? j : hw - 1;
-        kk[0] = *(const bf16x8*)(Kp + (long)jj * ld + h * 16); kk[1] = *(const bf16x8*)(Kp + (long)jj * ld + h * 16 + 8);
-        vv[0] = *(const bf16x8*)(Vp + (long)jj * ld + h * 16); vv[1] = *(const bf16x8*)(Vp + (long)jj * ld + h * 16 + 8);
-    };
-    bf16x8 kn[2], vn[2];
-    ldk(lane, kn, vn);
-    for (int j = lane; j < hw; j += 64) {
-        const bf16x8 k0 = kn[0], k1 = kn[1], v0 = vn[0], v1 = vn[1];
-        ldk(j + 64, kn, vn);
-        int qo = h * 16;
-        asm volatile("" : "+v"(qo));   // keeps the (loop-invariant) query reads inside the loop: hoisted they are 96 registers again
+    const int j0 = split * AT_KEYS + wave * 256;
+    // all of this lane's four keys are requested before the first one is used
+    bf16x8 kk[4][2], vv[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u * 64 + lane;
+        const long jj = j < a.hw ? j : a.hw - 1;
+        kk[u][0] = *(const bf16x8*)(Kp + jj * a.ld); kk[u][1] = *(const bf16x8*)(Kp + jj * a.ld + 8);
+        vv[u][0] = *(const bf16x8*)(Vp + jj * a.ld); vv[u][1] = *(const bf16x8*)(Vp + jj * a.ld + 8);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool valid = j0 + u * 64 + lane < a.hw;
         float kf[16], vf[16];
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
-            kf[d] = (float)k0[d]; kf[8 + d] = (float)k1[d];
-            vf[d] = (float)v0[d]; vf[8 + d] = (float)v1[d];
+            kf[d] = (float)kk[u][0][d]; kf[8 + d] = (float)kk[u][1][d];
+            vf[d] = (float)vv[u][0][d]; vf[8 + d] = (float)vv[u][1][d];
         }
 #pragma unroll
         for (int t = 0; t < TK_N; ++t) {
             float s = 0.f;
 #pragma unroll
             for (int d4 = 0; d4 < 4; ++d4) {
-                const f32x4 qv = *(const f32x4*)(q + t * 128 + qo + 4 * d4);
+                const f32x4 qv = *(const f32x4*)(qsh + t * 16 + 4 * d4);
                 s += qv[0] * kf[4 * d4] + qv[1] * kf[4 * d4 + 1] + qv[2] * kf[4 * d4 + 2] + qv[3] * kf[4 * d4 + 3];
             }
-            if (s > m[t]) {                       // rare after the first few keys: rescale the running state
-                const float a = __expf(m[t] - s);
-                l[t] *= a;
+            s = valid ? s : -1e30f;
+            const float mn = fmaxf(m[t], s);
+            const float al = __expf(m[t] - mn), pr = valid ? __expf(s - mn) : 0.f;
+            m[t] = mn;
+            l[t] = l[t] * al + pr;
 #pragma unroll
-                for (int d = 0; d < 16; ++d) acc[t][d] *= a;
-                m[t] = s;
-            }
-            const float p = __expf(s - m[t]);
-            l[t] += p;
-#pragma unroll
-            for (int d = 0; d < 16; ++d) acc[t][d] += p * vf[d];
+            for (int d = 0; d < 16; ++d) acc[t][d] = acc[t][d] * al + pr * vf[d];
         }
     }
+    // lanes -> wave
 #pragma unroll
     for (int t = 0; t < TK_N; ++t) {
         const float M = wg_wave_max(m[t]);
-        const float a = __expf(m[t] - M);
-        const float L = wg_wave_sum(l[t] * a);
-        const float inv = 1.0f / L;
+        const float w = __expf(m[t] - M);
+        const float L = wg_wave_sum(l[t] * w);
+        if (lane == 0) { wpart[wave][t] = M; wpart[wave][TK_N + t] = L; }
 #pragma unroll
         for (int d = 0; d < 16; ++d) {
-            const float s = wg_wave_sum(acc[t][d] * a);
-            if (lane == d) o[t * 128 + h * 16 + d] = s * inv;
+            const float sv = wg_wave_sum(acc[t][d] * w);
+            if (lane == d) wpart[wave][2 * TK_N + t * 16 + d] = sv;
         }
     }
     __syncthreads();
+    // waves -> workgroup
+    float* out = a.part + (((long)p * 8 + h) * a.n_splits + split) * TK_PART;
+    if (threadIdx.x < TK_N * 16) {
+        const int t = threadIdx.x >> 4, d = threadIdx.x & 15;
+        float M = -1e30f;
+#pragma unroll
+        for (int w_ = 0; w_ < AT_WAVES; ++w_) M = fmaxf(M, wpart[w_][t]);
+        float L = 0.f, o = 0.f;
+#pragma unroll
+        for (int w_ = 0; w_ < AT_WAVES; ++w_) {
+            const float w = __expf(wpart[w_][t] - M);
+            L += wpart[w_][TK_N + t] * w;
+            o += wpart[w_][2 * TK_N + t * 16 + d] * w;
+        }
+        out[2 * TK_N + t * 16 + d] = o;
+        if (d == 0) { out[t] = M; out[TK_N + t] = L; }
+    }
 }
 
-__global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* qs = (float*)smem;                 // [6][256] queries
-    float* pes = qs + TK_N * TK_C;            // [6][256] query_pe
-    float* t0 = pes + TK_N * TK_C;            // [6][256] scratch
-    float* t1 = t0 + TK_N * TK_C;
-    float* t2 = t1 + TK_N * TK_C;
-    float* t3 = t2 + TK_N * TK_C;
-    float* hid = t3 + TK_N * TK_C;            // [6][2048] MLP hidden
-    bf16* sh = (bf16*)(hid + TK_N * TK_KMAX); // [8][2048 + 8] hi
-    bf16* sl = sh + 8 * (TK_KMAX + 8);        // [8][2048 + 8] lo
-    const int p = blockIdx.x;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < TK_N * TK_C; i += TK_THREADS) {
-        qs[i] = a.queries[(long)p * TK_N * TK_C + i];
-        pes[i] = a.pe[(long)p * TK_N * TK_C + i];
-    }
+// one slice (256 hidden units) of the MLP of a prompt's six tokens: part[p][slice] = relu(x lin1_s^T + b1_s) lin2[:, slice]^T
+struct MlpArgs { const float* x; LinW lin1; const bf16* lin2_w; float* part; };
+__global__ __launch_bounds__(TK_THREADS) void wg_dec_mlp_partial_kernel(MlpArgs a) {
+    __shared__ float xs[TK_N * TK_C], hs[TK_N * TK_C], ys[TK_N * TK_C];
+    __shared__ __attribute__((aligned(16))) bf16 sh[8 * (TK_C + 8)], sl[8 * (TK_C + 8)];
+    const int slice = blockIdx.x % TK_SLICES, p = blockIdx.x / TK_SLICES;
+    for (int i = threadIdx.x; i < TK_N * TK_C; i += TK_THREADS) xs[i] = a.x[(long)p * TK_N * TK_C + i];
     __syncthreads();
-    const bf16* Kp = a.Kimg + (long)p * a.img_bs * a.ld_img;
-    const bf16* Vp = a.Vimg + (long)p * a.img_bs * a.ld_img;
-
-    if (a.mode == 0) {
-        // ---- self attention (transformer.py:153-160): layer 0 replaces the queries and skips the positional term ---------------------
-        if (a.skip_pe) {
-            tok_linear<TK_C>(qs, TK_C, TK_N, a.self_attn.q, TK_C, t0, TK_C, 0, nullptr, 0, sh, sl);
-            tok_linear<TK_C>(qs, TK_C, TK_N, a.self_attn.k, TK_C, t1, TK_C, 0, nullptr, 0, sh, sl);
-        } else {
-            tok_add(t3, qs, pes);
-            tok_linear<TK_C>(t3, TK_C, TK_N, a.self_attn.q, TK_C, t0, TK_C, 0, nullptr, 0, sh, sl);
-            tok_linear<TK_C>(t3, TK_C, TK_N, a.self_attn.k, TK_C, t1, TK_C, 0, nullptr, 0, sh, sl);
-        }
-        tok_linear<TK_C>(qs, TK_C, TK_N, a.self_attn.v, TK_C, t2, TK_C, 0, nullptr, 0, sh, sl);
-        tok_self_attention(t0, t1, t2, t3);
-        tok_linear<TK_C>(t3, TK_C, TK_N, a.self_attn.o, TK_C, qs, TK_C, 0, a.skip_pe ? nullptr : qs, TK_C, sh, sl);
-        tok_layernorm(qs, TK_N, a.norm1, a.eps);
-    }
-    // ---- token -> image attention (:162-167; mode 1: :96-106), internal width 128 ---------------------------------------------------------
-    tok_add(t3, qs, pes);
-    tok_linear<TK_C>(t3, TK_C, TK_N, a.t2i_q, 128, t0, 128, 0, nullptr, 0, sh, sl);
-    tok_image_attention(t0, Kp, Vp, a.ld_img, a.hw, t1);
-    tok_linear<128>(t1, 128, TK_N, a.t2i_o, TK_C, qs, TK_C, 0, qs, TK_C, sh, sl);
-    tok_layernorm(qs, TK_N, a.norm2, a.eps);
-    if (a.mode == 0) {
-        // ---- MLP (:169-172), norm3, then k / v of the image -> token attention (:174-178) ---------------------------------------------------
-        tok_linear<TK_C>(qs, TK_C, TK_N, a.lin1, TK_KMAX, hid, TK_KMAX, WG_ACT_RELU, nullptr, 0, sh, sl);
-        tok_linear<TK_KMAX>(hid, TK_KMAX, TK_N, a.lin2, TK_C, qs, TK_C, 0, qs, TK_C, sh, sl);
-        tok_layernorm(qs, TK_N, a.norm3, a.eps);
-        tok_add(t3, qs, pes);
-        tok_linear<TK_C>(t3, TK_C, TK_N, a.i2t_k, 128, t0, 128, 0, nullptr, 0, sh, sl);
-        tok_linear<TK_C>(qs, TK_C, TK_N, a.i2t_v, 128, t1, 128, 0, nullptr, 0, sh, sl);
-        for (int i = tid; i < TK_N * 128; i += TK_THREADS) {
-            a.k_i2t[(long)p * TK_N * 128 + i] = (bf16)t0[i];
-            a.v_i2t[(long)p * TK_N * 128 + i] = (bf16)t1[i];
-        }
-    } else {
-        // ---- hypernetwork MLPs on the mask tokens (rows 1..4), IoU head on row 0 (mask_decoder.py:146-160) -------------------------------
-        for (int i = 0; i < 5; ++i) {
-            const LinW* mlp = i < 4 ? a.hyper[i] : a.iou;
-            const float* x = qs + (i < 4 ? 1 + i : 0) * TK_C;
-            tok_linear<TK_C>(x, TK_C, 1, mlp[0], TK_C, t0, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
-            tok_linear<TK_C>(t0, TK_C, 1, mlp[1], TK_C, t1, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
-            tok_linear<TK_C>(t1, TK_C, 1, mlp[2], i < 4 ? 32 : 4, t2, TK_C, 0, nullptr, 0, sh, sl);
-            if (i < 4) {
-                if (tid < 32) a.hyper_out[((long)p * 4 + i) * 32 + tid] = t2[tid];
-            } else if (tid < 4) {
-                a.iou_out[(long)p * 4 + tid] = t2[tid];
-            }
-            __syncthreads();
-        }
-    }
-    for (int i = tid; i < TK_N * TK_C; i += TK_THREADS) a.queries[(long)p * TK_N * TK_C + i] = qs[i];
+    const LinW l1{a.lin1.w + (long)slice * 256 * TK_C, a.lin1.b + slice * 256};
+    tok_linear<TK_C>(xs, TK_C, TK_N, l1, TK_C, 256, hs, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
+    const LinW l2{a.lin2_w + slice * 256, nullptr};                  // columns slice*256 .. +255 of lin2.weight [256, 2048]
+    tok_linear<TK_C>(hs, TK_C, TK_N, l2, TK_HID, TK_C, ys, TK_C, 0, nullptr, 0, sh, sl);
+    float* out = a.part + ((long)p * TK_SLICES + slice) * TK_N * TK_C;
+    for (int i = threadIdx.x; i < TK_N * TK_C; i += TK_THREADS) out[i] = ys[i];
 }
 
-constexpr size_t TK_LDS = (size_t)(6 * TK_N * TK_C + TK_N * TK_KMAX) * 4 + (size_t)2 * 8 * (TK_KMAX + 8) * 2;
+// hypernetwork MLPs on the mask tokens (rows 1..4), IoU head on row 0 (mask_decoder.py:146-160): one (prompt, head) pair per workgroup
+struct HeadArgs { const float* x; LinW mlp[5][3]; float* hyper_out; float* iou_out; };
+__global__ __launch_bounds__(256) void wg_dec_heads_kernel(HeadArgs a) {
+    __shared__ float x0[TK_C], x1[TK_C], x2[TK_C];
+    __shared__ __attribute__((aligned(16))) bf16 sh[8 * (TK_C + 8)], sl[8 * (TK_C + 8)];
+    const int i = blockIdx.x % 5, p = blockIdx.x / 5;
+    const float* x = a.x + ((long)p * TK_N + (i < 4 ? 1 + i : 0)) * TK_C;
+    for (int c = threadIdx.x; c < TK_C; c += 256) x0[c] = x[c];
+    __syncthreads();
+    tok_linear<TK_C, 256>(x0, TK_C, 1, a.mlp[i][0], TK_C, TK_C, x1, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
+    tok_linear<TK_C, 256>(x1, TK_C, 1, a.mlp[i][1], TK_C, TK_C, x2, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
+    tok_linear<TK_C, 256>(x2, TK_C, 1, a.mlp[i][2], TK_C, i < 4 ? 32 : 4, x0, TK_C, 0, nullptr, 0, sh, sl);
+    if (i < 4) {
+        if (threadIdx.x < 32) a.hyper_out[((long)p * 4 + i) * 32 + threadIdx.x] = x0[threadIdx.x];
+    } else if (threadIdx.x < 4) {
+        a.iou_out[(long)p * 4 + threadIdx.x] = x0[threadIdx.x];
+    }
+}
 
 }  // namespace
 
-// Flat pointer table of wg_dec_tokens_f32 (all bf16 device pointers, weight then bias / gamma then beta):
-//   mode 0 (a TwoWayAttentionBlock, transformer.py:151-182), 26 entries:
-//     self_attn q,k,v,out (8) | norm1 (2) | cross_attn_token_to_image q,out (4) | norm2 (2) | mlp lin1,lin2 (4) | norm3 (2) |
-//     cross_attn_image_to_token k,v (4)
-//   mode 1 (final_attn_token_to_image + norm_final_attn + output_hypernetworks_mlps + iou_prediction_head), 36 entries:
-//     final attn q,out (4) | norm_final_attn (2) | 4 x 3 hypernetwork layers (24) | 3 IoU-head layers (6)
-extern "C" int wg_dec_tokens_f32(int mode, int skip_pe, float* queries, const float* query_pe, const void* const* weights, int n_weights,
-                                 const void* Kimg, const void* Vimg, long ld_img, long img_rows_per_prompt, int hw, void* k_i2t,
-                                 void* v_i2t, float* hyper_out, float* iou_out, int P, float eps, void* stream) {
-    WG_REQUIRE(queries && query_pe && weights && Kimg && Vimg, "dec_tokens: null operand");
-    WG_REQUIRE(P > 0 && hw > 0 && ld_img % 8 == 0, "dec_tokens: bad shape");
-    WG_REQUIRE((((uintptr_t)Kimg | (uintptr_t)Vimg) & 15) == 0, "dec_tokens: misaligned image projections");
-    WG_REQUIRE((mode == 0 && n_weights == 26 && k_i2t && v_i2t) || (mode == 1 && n_weights == 36 && hyper_out && iou_out),
-               "dec_tokens: mode %d needs %d weight pointers and its outputs", mode, mode == 0 ? 26 : 36);
-    for (int i = 0; i < n_weights; ++i) WG_REQUIRE(weights[i] && ((uintptr_t)weights[i] & 15) == 0, "dec_tokens: weight %d null or misaligned", i);
+// Flat pointer table of wg_dec_tokens_f32 (bf16 device pointers, weight then bias / gamma then beta; entries of stages that are not
+// requested may be null), 24 entries:
+//   self_attn q,k,v,out (8) | norm1 (2) | token->image attention q,out (4) | norm2 or norm_final_attn (2) | mlp.lin2 bias (1) + unused (1) |
+//   norm3 (2) | image->token attention k,v (4)
+extern "C" int wg_dec_tokens_f32(int stages, int skip_pe, float* queries, float* query_pe, const float* init_tokens, const void* init_prompt,
+                                 const void* const* weights, int n_weights, float* q_t2i, const float* attn_partials, int n_splits, const float* mlp_partials, void* k_i2t, void* v_i2t,
+                                 int P, float eps, void* stream) {
+    WG_REQUIRE(queries && query_pe && weights && n_weights == 24 && P > 0, "dec_tokens: bad arguments");
+    WG_REQUIRE(stages > 0 && stages < 32, "dec_tokens: bad stage mask %d", stages);
+    WG_REQUIRE(!(stages & ST_INIT) || (init_tokens && init_prompt && !(stages & ST_SUM_MLP)), "dec_tokens: INIT needs the output tokens and the prompt rows (and cannot follow an MLP)");
     TokArgs a{};
-    a.mode = mode; a.skip_pe = skip_pe; a.P = P; a.hw = hw; a.queries = queries; a.pe = query_pe; a.eps = eps;
-    a.Kimg = (const bf16*)Kimg; a.Vimg = (const bf16*)Vimg; a.ld_img = ld_img; a.img_bs = img_rows_per_prompt;
-    a.k_i2t = (bf16*)k_i2t; a.v_i2t = (bf16*)v_i2t; a.hyper_out = hyper_out; a.iou_out = iou_out;
-    int c = 0;
-    auto lin = [&]() { LinW l{(const bf16*)weights[c], (const bf16*)weights[c + 1]}; c += 2; return l; };
-    auto nrm = [&]() { NormW n{(const bf16*)weights[c], (const bf16*)weights[c + 1]}; c += 2; return n; };
-    if (mode == 0) {
-        a.self_attn.q = lin(); a.self_attn.k = lin(); a.self_attn.v = lin(); a.self_attn.o = lin(); a.norm1 = nrm();
-        a.t2i_q = lin(); a.t2i_o = lin(); a.norm2 = nrm();
-        a.lin1 = lin(); a.lin2 = lin(); a.norm3 = nrm();
-        a.i2t_k = lin(); a.i2t_v = lin();
-    } else {
-        a.t2i_q = lin(); a.t2i_o = lin(); a.norm2 = nrm();
-        for (int i = 0; i < 4; ++i) for (int j = 0; j < 3; ++j) a.hyper[i][j] = lin();
-        for (int j = 0; j < 3; ++j) a.iou[j] = lin();
-    }
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wg_dec_tokens_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
-    hipLaunchKernelGGL(wg_dec_tokens_kernel, dim3(P), dim3(TK_THREADS), TK_LDS, (hipStream_t)stream, a);
+    a.stages = stages; a.skip_pe = skip_pe; a.P = P; a.n_splits = n_splits; a.queries = queries; a.pe = query_pe; a.eps = eps;
+    a.init_tokens = init_tokens; a.init_prompt = (const bf16*)init_prompt;
+    a.q_t2i = q_t2i; a.attn_part = attn_partials; a.mlp_part = mlp_partials; a.k_i2t = (bf16*)k_i2t; a.v_i2t = (bf16*)v_i2t;
+    const bf16* const* w = (const bf16* const*)weights;
+    auto need = [&](int lo, int hi) { for (int i = lo; i < hi; ++i) if (!w[i] || ((uintptr_t)w[i] & 15)) return false; return true; };
+    a.self_attn = AttnW{{w[0], w[1]}, {w[2], w[3]}, {w[4], w[5]}, {w[6], w[7]}};
+    a.norm1 = NormW{w[8], w[9]};
+    a.t2i_q = LinW{w[10], w[11]}; a.t2i_o = LinW{w[12], w[13]}; a.norm2 = NormW{w[14], w[15]};
+    a.lin2_b = w[16]; a.norm3 = NormW{w[18], w[19]};
+    a.i2t_k = LinW{w[20], w[21]}; a.i2t_v = LinW{w[22], w[23]};
+    if (stages & ST_SELF) WG_REQUIRE(need(0, 10), "dec_tokens: SELF needs the self-attention and norm1 weights");
+    if (stages & ST_Q_T2I) WG_REQUIRE(need(10, 12) && q_t2i, "dec_tokens: Q_T2I needs the q projection and its output buffer");
+    if (stages & ST_COMBINE) WG_REQUIRE(need(12, 16) && attn_partials && n_splits > 0, "dec_tokens: COMBINE needs out_proj, the norm and the attention partials");
+    if (stages & ST_SUM_MLP) WG_REQUIRE(need(16, 17) && need(18, 24) && mlp_partials && k_i2t && v_i2t, "dec_tokens: SUM_MLP needs lin2 bias, norm3, k / v projections, the MLP partials and its outputs");
+    hipLaunchKernelGGL(wg_dec_tokens_kernel, dim3(P), dim3(TK_THREADS), 0, (hipStream_t)stream, a);
     return wg_check_launch("wg_dec_tokens");
+}
+
+// q [P,6,128] fp32; Kimg / Vimg [P or 1][hw][128] bf16 with row stride ld_img (img_rows_per_prompt = 0: one image shared by all prompts);
+// partials [P, 8, n_splits, 108] fp32 with n_splits = ceil(hw / 1024).
+extern "C" int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const void* Vimg, long ld_img, long img_rows_per_prompt, int hw,
+                                       float* partials, int n_splits, int P, void* stream) {
+    WG_REQUIRE(q && Kimg && Vimg && partials && P > 0 && hw > 0 && ld_img % 8 == 0, "dec_attn_partial: bad arguments");
+    WG_REQUIRE(n_splits == (hw + AT_KEYS - 1) / AT_KEYS, "dec_attn_partial: n_splits must be ceil(hw / 1024)");
+    WG_REQUIRE((((uintptr_t)Kimg | (uintptr_t)Vimg) & 15) == 0, "dec_attn_partial: misaligned image projections");
+    AttnPartArgs a{q, (const bf16*)Kimg, (const bf16*)Vimg, ld_img, img_rows_per_prompt, hw, n_splits, partials};
+    hipLaunchKernelGGL(wg_dec_attn_partial_kernel, dim3((unsigned)(P * 8 * n_splits)), dim3(64 * AT_WAVES), 0, (hipStream_t)stream, a);
+    return wg_check_launch("wg_dec_attn_partial");
+}
+
+// x [P,6,256] fp32 (the tokens after norm2); lin1 [2048,256] + bias, lin2 weight [256,2048] (bias added by the SUM_MLP stage);
+// partials [P, 8, 6, 256] fp32.
+extern "C" int wg_dec_mlp_partial_f32(const float* x, const void* lin1_w, const void* lin1_b, const void* lin2_w, float* partials, int P,
+                                      void* stream) {
+    WG_REQUIRE(x && lin1_w && lin1_b && lin2_w && partials && P > 0, "dec_mlp_partial: bad arguments");
+    WG_REQUIRE((((uintptr_t)lin1_w | (uintptr_t)lin2_w) & 15) == 0, "dec_mlp_partial: misaligned weights");
+    MlpArgs a{x, LinW{(const bf16*)lin1_w, (const bf16*)lin1_b}, (const bf16*)lin2_w, partials};
+    hipLaunchKernelGGL(wg_dec_mlp_partial_kernel, dim3((unsigned)(P * TK_SLICES)), dim3(TK_THREADS), 0, (hipStream_t)stream, a);
+    return wg_check_launch("wg_dec_mlp_partial");
+}
+
+// x [P,6,256] fp32 (the tokens after norm_final_attn); weights: 30 bf16 pointers = 5 MLPs (hypernetwork 0..3, IoU head) x 3 layers x
+// (weight, bias) -> hyper_out [P,4,32], iou_out [P,4] fp32.
+extern "C" int wg_dec_heads_f32(const float* x, const void* const* weights, int n_weights, float* hyper_out, float* iou_out, int P, void* stream) {
+    WG_REQUIRE(x && weights && n_weights == 30 && hyper_out && iou_out && P > 0, "dec_heads: bad arguments");
+    HeadArgs a{};
+    a.x = x; a.hyper_out = hyper_out; a.iou_out = iou_out;
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 3; ++j) {
+            const void* wp = weights[(i * 3 + j) * 2];
+            WG_REQUIRE(wp && ((uintptr_t)wp & 15) == 0 && weights[(i * 3 + j) * 2 + 1], "dec_heads: weight %d null or misaligned", i * 3 + j);
+            a.mlp[i][j] = LinW{(const bf16*)wp, (const bf16*)weights[(i * 3 + j) * 2 + 1]};
+        }
+    hipLaunchKernelGGL(wg_dec_heads_kernel, dim3((unsigned)(P * 5)), dim3(256), 0, (hipStream_t)stream, a);
+    return wg_check_launch("wg_dec_heads");
 }

@@ -898,6 +898,44 @@ __global__ __launch_bounds__(256) void wg_gemm_rowwave_kernel(GemmArgs g) {
     }
 }
 
+// Skinny activations (M <= 16: the [SEG] hidden states through text_hidden_fcs, the MSQP / CTP token rows).  Such a GEMM only streams its
+// weight matrix, and a compute unit ingests ~30 GB/s with plain loads, so a 128-wide tile (32 workgroups for N = 4096) leaves the matrix
+// behind 32 straws: 42 us for the 32 MB of text_hidden_fcs[0].  Here one workgroup owns 16 output columns, its four waves split K,
+// and the rows ride as a 16-row MFMA A operand (rows >= M zero); the partial sums meet in LDS.
+__global__ __launch_bounds__(256) void wg_gemm_skinny_kernel(GemmArgs g) {
+    __shared__ f32x4 red[3][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l16 = lane & 15, kg = lane >> 4;
+    const int n = blockIdx.x * 16 + l16;                 // N % 16 == 0
+    const int kw = g.K / 4;                              // K % 128 == 0: every wave takes whole 32-deep MFMA steps
+    const bool live = l16 < g.M;
+    const bf16* wp = g.W + (long)n * g.ldw + wave * kw + 8 * kg;
+    const bf16* ap = g.A + (long)(live ? l16 : 0) * g.lda + wave * kw + 8 * kg;
+    const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int k = 0; k < kw; k += 32) {
+        const bf16x8 b = *(const bf16x8*)(wp + k);
+        bf16x8 a = *(const bf16x8*)(ap + k);
+        a = live ? a : zero;                             // select, not branch: a join inside the loop would serialise the loads
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+    }
+    if (wave) red[wave - 1][lane] = acc;
+    __syncthreads();
+    if (wave) return;
+    acc += red[0][lane] + red[1][lane] + red[2][lane];
+    const float bias = g.bias ? (float)g.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {                        // accumulator: rows 4*kg + i of column l16
+        const int m = 4 * kg + i;
+        if (m >= g.M) continue;
+        float v = wg_act(acc[i] + bias, g.act);
+        if (g.R) v += (float)g.R[(long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr + n];
+        if (g.out_f32) ((float*)g.C)[(long)m * g.ldc + n] = v;
+        else ((bf16*)g.C)[(long)m * g.ldc + n] = (bf16)v;
+    }
+}
+
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, int PIPE, bool FP8 = false>
 static int launch_tile_impl(GemmArgs& g, hipStream_t st) {
     g.tiles_m = (g.M + BM - 1) / BM;
@@ -1280,6 +1318,7 @@ static int launch_tile(GemmArgs& g, hipStream_t st) {
 // with the other stream's 128 KiB ones, and with the two-stream overlap it measured 3-4 % SLOWER end to end -- so the
 // host only asks for it in single-stream runs.
 extern "C" int wg_gemm_pick_tile_ex(int M, int N, int allow_tail) {
+    if (M <= 16 && N % 16 == 0) return 5;   // a handful of rows: weight streaming spread over N / 16 workgroups (needs K % 128 == 0)
     if (M <= 128) return 1;             // decoder token-side linears: one or two workgroups
     if (allow_tail && M % 128 >= 1 && M % 128 <= 16 && N % 8 == 0) {
         // ragged M just above a multiple of 128 (CLIP: 8 * 1025): fold the leftover rows into the last row tile when that
@@ -1377,9 +1416,13 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
     const bool small_ops = (long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31);
     if (tile == 11 && !(can_stage && small_ops)) tile = 1;
     if (tile == 16 && !(can_stage && small_ops && (!bias || ((uintptr_t)bias % 16 == 0 && N % 8 == 0)))) tile = 14;
-    if (tile != 1 && tile != 2 && tile != 11 && tile != 12 && tile != 14 && tile != 16) tile = 1;
+    if (tile == 5 && !(M <= 16 && N % 16 == 0 && K % 128 == 0)) tile = 1;
+    if (tile != 1 && tile != 2 && tile != 5 && tile != 11 && tile != 12 && tile != 14 && tile != 16) tile = 1;
     if (tile == 12 && !(can_stage && M >= 128 && M % 128 >= 1 && M % 128 <= 16)) tile = 1;
     switch (tile) {
+        case 5:
+            hipLaunchKernelGGL(wg_gemm_skinny_kernel, dim3(N / 16), dim3(256), 0, st, g);
+            return wg_check_launch("wg_gemm_bias_act_bf16(skinny)");
         case 12: return launch_tail(g, st);                            // 128x128 tiles, last row tile absorbs M % 128 <= 16 rows
         case 11: return launch_persist<128, 128, 2, 2>(g, st);         // persistent 128x128 tiles, 2 workgroups / CU
         case 2: return launch_tile<256, 256, 64, 2, 2, 4>(g, st);      // 256x256, plain two-slab loop (best at K >= 8192)

@@ -357,25 +357,98 @@ def linear_fp8(xq, x_scale, wq, w_scale, bias=None, act=ACT_NONE, residual=None,
     return out
 
 
-def dec_tokens(mode, skip_pe, queries, query_pe, weights, k_img, v_img, hw, k_i2t=None, v_i2t=None, hyper_out=None, iou_out=None, eps=1e-5):
-    """Token side of one TwoWayAttentionBlock (mode 0) or of the transformer's tail + hypernetwork / IoU heads (mode 1) in one launch
-    (csrc/decoder.hip: wg_dec_tokens_f32).  queries / query_pe [P, 6, 256] fp32 (queries updated in place); weights: list of bf16
-    tensors in the order the C-ABI documents; k_img / v_img [1 | P, hw, 128] bf16 column slices of the projected image tokens."""
+TOK_SUM_MLP, TOK_SELF, TOK_Q_T2I, TOK_COMBINE, TOK_INIT = 1, 2, 4, 8, 16
+_TOK_PART = 6 * 18          # floats of one attention partial (csrc/decoder.hip)
+
+
+def _f32_tokens(t, P, last):
+    assert t.dtype == torch.float32 and t.is_contiguous() and t.shape == (P, 6, last), (t.dtype, tuple(t.shape))
+
+
+def dec_tokens(stages, skip_pe, queries, query_pe, weights, q_t2i=None, attn_partials=None, mlp_partials=None, k_i2t=None, v_i2t=None,
+               eps=1e-5, init_tokens=None, init_prompt=None):
+    """Per-prompt stages of the token side of SAM's two-way transformer (csrc/decoder.hip: wg_dec_tokens_f32; stage bits TOK_*).
+    queries / query_pe [P, 6, 256] fp32 (queries updated in place); weights: the 24-slot table the C-ABI documents (bf16 tensors or
+    None for the slots of stages that do not run).  TOK_INIT: queries and query_pe are OUTPUTS, both set to
+    cat(init_tokens [5, 256] fp32, init_prompt [P, 256] bf16) before the other stages run."""
     import ctypes
-    _need_gpu(queries, query_pe, k_img, v_img, k_i2t, v_i2t, hyper_out, iou_out, *weights)
+    _need_gpu(queries, query_pe, q_t2i, attn_partials, mlp_partials, k_i2t, v_i2t, init_tokens, init_prompt, *weights)
     P = queries.shape[0]
-    assert queries.dtype == torch.float32 and queries.is_contiguous() and queries.shape == (P, 6, 256)
-    assert query_pe.dtype == torch.float32 and query_pe.is_contiguous() and query_pe.shape == (P, 6, 256)
-    assert all(w.dtype == _BF16 and w.is_contiguous() for w in weights)
-    assert k_img.dtype == _BF16 and v_img.dtype == _BF16 and k_img.shape[-1] == 128 and k_img.stride(-1) == 1 and v_img.stride(-1) == 1
-    assert k_img.shape[1] == hw and k_img.stride(1) == v_img.stride(1) and k_img.shape[0] in (1, P)
-    img_bs = 0 if k_img.shape[0] == 1 and P > 1 else (k_img.stride(0) // k_img.stride(1) if k_img.shape[0] > 1 else hw)
-    table = (ctypes.c_void_p * len(weights))(*[w.data_ptr() for w in weights])
-    rc = _lib.lib().wg_dec_tokens_f32(mode, 1 if skip_pe else 0, queries.data_ptr(), query_pe.data_ptr(), table, len(weights),
-                                      k_img.data_ptr(), v_img.data_ptr(), k_img.stride(1), img_bs, hw, _ptr(k_i2t), _ptr(v_i2t),
-                                      _ptr(hyper_out), _ptr(iou_out), P, float(eps), _stream())
+    _f32_tokens(queries, P, 256)
+    _f32_tokens(query_pe, P, 256)
+    assert len(weights) == 24 and all(w is None or (w.dtype == _BF16 and w.is_contiguous()) for w in weights)
+    n_splits = 0
+    if stages & TOK_INIT:
+        assert init_tokens.dtype == torch.float32 and init_tokens.is_contiguous() and init_tokens.shape == (5, 256)
+        assert init_prompt.dtype == _BF16 and init_prompt.is_contiguous() and init_prompt.numel() == P * 256
+    if stages & TOK_Q_T2I:
+        _f32_tokens(q_t2i, P, 128)
+    if stages & TOK_COMBINE:
+        assert attn_partials.dtype == torch.float32 and attn_partials.is_contiguous() and attn_partials.dim() == 4
+        assert attn_partials.shape[0] == P and attn_partials.shape[1] == 8 and attn_partials.shape[3] == _TOK_PART
+        n_splits = attn_partials.shape[2]
+    if stages & TOK_SUM_MLP:
+        assert mlp_partials.dtype == torch.float32 and mlp_partials.is_contiguous() and mlp_partials.shape == (P, 8, 6, 256)
+        for t in (k_i2t, v_i2t):
+            assert t.dtype == _BF16 and t.is_contiguous() and t.shape == (P, 6, 128)
+    table = (ctypes.c_void_p * 24)(*[None if w is None else w.data_ptr() for w in weights])
+    rc = _lib.lib().wg_dec_tokens_f32(stages, 1 if skip_pe else 0, queries.data_ptr(), query_pe.data_ptr(), _ptr(init_tokens), _ptr(init_prompt),
+                                      table, 24, _ptr(q_t2i),
+                                      _ptr(attn_partials), n_splits, _ptr(mlp_partials), _ptr(k_i2t), _ptr(v_i2t), P, float(eps), _stream())
     _lib.check(rc, "wg_dec_tokens_f32")
     return queries
+
+
+def dec_attn_partial(q_t2i, k_img, v_img):
+    """Token->image attention partials (wg_dec_attn_partial_f32).  q_t2i [P, 6, 128] fp32; k_img / v_img [1 | P, hw, 128] bf16 column
+    slices of the projected image tokens -> fp32 [P, 8, ceil(hw / 1024), 108] for dec_tokens(TOK_COMBINE)."""
+    _need_gpu(q_t2i, k_img, v_img)
+    P = q_t2i.shape[0]
+    _f32_tokens(q_t2i, P, 128)
+    hw = k_img.shape[1]
+    assert k_img.dtype == _BF16 and v_img.dtype == _BF16 and k_img.shape[-1] == 128 and k_img.stride(-1) == 1 and v_img.stride(-1) == 1
+    assert v_img.shape == k_img.shape and k_img.stride(1) == v_img.stride(1) and k_img.shape[0] in (1, P)
+    img_bs = 0 if k_img.shape[0] == 1 and P > 1 else (k_img.stride(0) // k_img.stride(1) if k_img.shape[0] > 1 else hw)
+    n_splits = (hw + 1023) // 1024
+    part = torch.empty(P, 8, n_splits, _TOK_PART, device=q_t2i.device, dtype=torch.float32)
+    rc = _lib.lib().wg_dec_attn_partial_f32(q_t2i.data_ptr(), k_img.data_ptr(), v_img.data_ptr(), k_img.stride(1), img_bs, hw,
+                                            part.data_ptr(), n_splits, P, _stream())
+    _lib.check(rc, "wg_dec_attn_partial_f32")
+    return part
+
+
+def dec_mlp_partial(x, lin1_w, lin1_b, lin2_w, out=None):
+    """The eight 256-unit slices of mlp(x) for x [P, 6, 256] fp32 (wg_dec_mlp_partial_f32) -> fp32 [P, 8, 6, 256]; lin2's bias is added
+    by dec_tokens(TOK_SUM_MLP)."""
+    _need_gpu(x, lin1_w, lin1_b, lin2_w)
+    P = x.shape[0]
+    _f32_tokens(x, P, 256)
+    assert lin1_w.shape == (2048, 256) and lin2_w.shape == (256, 2048) and lin1_b.shape == (2048,)
+    assert all(t.dtype == _BF16 and t.is_contiguous() for t in (lin1_w, lin1_b, lin2_w))
+    if out is None:
+        out = torch.empty(P, 8, 6, 256, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().wg_dec_mlp_partial_f32(x.data_ptr(), lin1_w.data_ptr(), lin1_b.data_ptr(), lin2_w.data_ptr(), out.data_ptr(), P, _stream())
+    _lib.check(rc, "wg_dec_mlp_partial_f32")
+    return out
+
+
+def dec_heads(x, weights):
+    """The four hypernetwork MLPs and the IoU head on x [P, 6, 256] fp32 (wg_dec_heads_f32); weights: 30 bf16 tensors
+    -> (hyper fp32 [P, 4, 32], iou fp32 [P, 4])."""
+    import ctypes
+    _need_gpu(x, *weights)
+    P = x.shape[0]
+    _f32_tokens(x, P, 256)
+    assert len(weights) == 30 and all(w.dtype == _BF16 and w.is_contiguous() for w in weights)
+    for i in range(5):
+        shapes = [tuple(weights[(3 * i + j) * 2].shape) for j in range(3)]
+        assert shapes == [(256, 256), (256, 256), (32 if i < 4 else 4, 256)], shapes
+    hyper = torch.empty(P, 4, 32, device=x.device, dtype=torch.float32)
+    iou = torch.empty(P, 4, device=x.device, dtype=torch.float32)
+    table = (ctypes.c_void_p * 30)(*[w.data_ptr() for w in weights])
+    rc = _lib.lib().wg_dec_heads_f32(x.data_ptr(), table, 30, hyper.data_ptr(), iou.data_ptr(), P, _stream())
+    _lib.check(rc, "wg_dec_heads_f32")
+    return hyper, iou
 
 
 def upscale_mask(keys, up1_w, up1_b, ln_g, ln_b, eps, up2_w, up2_b, hyper, h, w, first_mask, num_masks):

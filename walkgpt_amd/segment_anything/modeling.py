@@ -374,35 +374,63 @@ class TwoWayAttentionBlock(nn.Module):
             self._img_key = key
         return self._img_val
 
-    def token_weights(self):
-        """Pointer-table order of wg_dec_tokens_f32, mode 0 (include/walkgpt_hip.h)."""
-        sa, t2i, i2t, m = self.self_attn, self.cross_attn_token_to_image, self.cross_attn_image_to_token, self.mlp
-        w = []
-        for lin in (sa.q_proj, sa.k_proj, sa.v_proj, sa.out_proj):
-            w += _lin_pair(lin)
-        w += [self.norm1.weight, self.norm1.bias] + _lin_pair(t2i.q_proj) + _lin_pair(t2i.out_proj) + [self.norm2.weight, self.norm2.bias]
-        w += _lin_pair(m.lin1) + _lin_pair(m.lin2) + [self.norm3.weight, self.norm3.bias] + _lin_pair(i2t.k_proj) + _lin_pair(i2t.v_proj)
-        return w
+    def image_side(self, keys, key_pe):
+        """[K_t2i | V_t2i | Q_i2t] of this block's image tokens: the three projections that read `keys` (the reference recomputes
+        keys + key_pe for two of them) as one fused GEMM with the positional term folded into an additive table."""
+        wcat, rtab = self._image_side(key_pe)
+        return ops.linear(keys, wcat, residual=rtab, res_row_mod=keys.shape[1])          # [1|P, hw, 3d]
+
+    def image_to_token(self, proj, keys, kq, vq, P):
+        """transformer.py:173-180: image->token attention on the projected operands, out_proj + residual, norm4."""
+        i2t = self.cross_attn_image_to_token
+        hw = keys.shape[1]
+        keys = i2t.run_projected(proj[..., 2 * i2t.internal_dim:], kq, vq, P, residual=keys,
+                                 res_row_mod=hw if keys.shape[0] == 1 and P > 1 else 0)
+        return ops.layernorm(keys, self.norm4.weight, self.norm4.bias, self.norm4.eps)
+
+    def mlp_partials(self, queries):
+        return ops.dec_mlp_partial(queries, self.mlp.lin1.weight, self.mlp.lin1.bias, self.mlp.lin2.weight)
+
+    def check_fused(self):
+        if self.norm1.eps != self.norm2.eps or self.norm1.eps != self.norm3.eps or self.mlp._act_code != ops.ACT_RELU:
+            raise NotImplementedError("the fused token kernels are built for SAM's decoder block (one LayerNorm eps, ReLU MLP)")
 
     def run(self, queries, keys, query_pe, key_pe, P):
-        """transformer.py:151-182.  queries / query_pe [P,6,C] fp32 (queries updated in place); keys [1|P, hw, C] bf16; key_pe [1, hw, C].
-        Image side: the three projections that read `keys` (k and v of token->image, q of image->token; the reference recomputes
-        keys + key_pe for two of them) are one fused GEMM with the positional term folded into an additive table.  Token side: one
-        launch (ops.dec_tokens) for self-attention .. norm3 and the k / v projections of the image->token attention."""
-        hw = keys.shape[1]
-        t2i, i2t = self.cross_attn_token_to_image, self.cross_attn_image_to_token
+        """transformer.py:151-182, one block on its own (TwoWayTransformer.run_tokens merges the launch that closes a block with the one
+        that opens the next).  queries / query_pe [P,6,C] fp32 (queries updated in place); keys [1|P, hw, C] bf16; key_pe [1, hw, C]."""
+        self.check_fused()
+        t2i = self.cross_attn_token_to_image
         d = t2i.internal_dim
-        if self.norm1.eps != self.norm2.eps or self.norm1.eps != self.norm3.eps or self.mlp._act_code != ops.ACT_RELU:
-            raise NotImplementedError("the fused token kernel is built for SAM's decoder block (one LayerNorm eps, ReLU MLP)")
-        wcat, rtab = self._image_side(key_pe)
-        proj = ops.linear(keys, wcat, residual=rtab, res_row_mod=hw)          # [1|P, hw, 3d]
+        table = token_stage_table(self_blk=self, t2i=t2i, norm=self.norm2, sum_blk=self)
+        q = torch.empty(P, queries.shape[1], d, device=keys.device, dtype=torch.float32)
         kq = torch.empty(P, queries.shape[1], d, device=keys.device, dtype=BF16)
         vq = torch.empty_like(kq)
-        ops.dec_tokens(0, self.skip_first_layer_pe, queries, query_pe, self.token_weights(), proj[..., :d], proj[..., d:2 * d], hw,
-                       k_i2t=kq, v_i2t=vq, eps=self.norm1.eps)
-        keys = i2t.run_projected(proj[..., 2 * d:], kq, vq, P, residual=keys, res_row_mod=hw if keys.shape[0] == 1 and P > 1 else 0)
-        keys = ops.layernorm(keys, self.norm4.weight, self.norm4.bias, self.norm4.eps)
-        return queries, keys
+        ops.dec_tokens(ops.TOK_SELF | ops.TOK_Q_T2I, self.skip_first_layer_pe, queries, query_pe, table, q_t2i=q, eps=self.norm1.eps)
+        proj = self.image_side(keys, key_pe)
+        part = ops.dec_attn_partial(q, proj[..., :d], proj[..., d:2 * d])
+        ops.dec_tokens(ops.TOK_COMBINE, False, queries, query_pe, table, attn_partials=part, eps=self.norm1.eps)
+        ops.dec_tokens(ops.TOK_SUM_MLP, False, queries, query_pe, table, mlp_partials=self.mlp_partials(queries), k_i2t=kq, v_i2t=vq,
+                       eps=self.norm1.eps)
+        return queries, self.image_to_token(proj, keys, kq, vq, P)
+
+
+def token_stage_table(self_blk=None, t2i=None, norm=None, sum_blk=None):
+    """The 24-slot pointer table of wg_dec_tokens_f32 (include/walkgpt_hip.h): SELF from `self_blk`, Q_T2I / COMBINE from the attention
+    module `t2i` and the LayerNorm `norm` that follows it, SUM_MLP from `sum_blk` (possibly the block BEFORE self_blk)."""
+    w = [None] * 24
+    if self_blk is not None:
+        sa = self_blk.self_attn
+        w[0:8] = _lin_pair(sa.q_proj) + _lin_pair(sa.k_proj) + _lin_pair(sa.v_proj) + _lin_pair(sa.out_proj)
+        w[8:10] = [self_blk.norm1.weight, self_blk.norm1.bias]
+    if t2i is not None:
+        w[10:14] = _lin_pair(t2i.q_proj) + _lin_pair(t2i.out_proj)
+        w[14:16] = [norm.weight, norm.bias]
+    if sum_blk is not None:
+        i2t = sum_blk.cross_attn_image_to_token
+        w[16] = sum_blk.mlp.lin2.bias
+        w[18:20] = [sum_blk.norm3.weight, sum_blk.norm3.bias]
+        w[20:24] = _lin_pair(i2t.k_proj) + _lin_pair(i2t.v_proj)
+    return w
 
 
 class TwoWayTransformer(nn.Module):
@@ -423,16 +451,55 @@ class TwoWayTransformer(nn.Module):
         self.final_attn_token_to_image = DecoderAttention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
         self.norm_final_attn = nn.LayerNorm(embedding_dim)
 
-    def run_blocks(self, src_tokens, pe_tokens, queries, query_pe):
-        """The depth TwoWayAttentionBlocks.  src_tokens [1|P, hw, C] bf16, pe_tokens [1, hw, C] bf16, queries / query_pe [P, N, C] fp32
-        -> (queries fp32, updated in place; keys [P, hw, C] bf16)."""
-        if self.embedding_dim != 256 or self.num_heads != 8 or queries.shape[1] != 6 or self.mlp_dim != 2048:
-            raise NotImplementedError("the fused token kernel is built for SAM's decoder geometry (256 channels, 8 heads, 6 tokens, "
-                                      "MLP 2048); got %d / %d / %d / %d" % (self.embedding_dim, self.num_heads, queries.shape[1], self.mlp_dim))
-        P = queries.shape[0]
-        keys = src_tokens
-        for layer in self.layers:
-            queries, keys = layer.run(queries, keys, query_pe, pe_tokens, P)
+    def run_tokens(self, src_tokens, pe_tokens, out_tokens, prompts):
+        """transformer.py:62-106: the depth TwoWayAttentionBlocks and the final token->image attention + norm_final_attn.
+        src_tokens [1|P, hw, C] bf16, pe_tokens [1, hw, C] bf16; out_tokens [5, C] fp32 (iou + mask tokens), prompts [P, 1, C] bf16: the
+        point embedding of prompt p is cat(out_tokens, prompts[p]) (mask_decoder.py:125-132), built by the first launch
+        -> (queries fp32 [P, 6, C]; keys [P, hw, C] bf16).
+        Launch chain per block: tokens[close previous block | self attention | q] -> (previous block's image->token attention, norm4)
+        -> image-side GEMM -> attention partials -> tokens[combine, out_proj, norm2] -> MLP partials."""
+        if self.embedding_dim != 256 or self.num_heads != 8 or out_tokens.shape[0] != 5 or prompts.shape[1] != 1 or self.mlp_dim != 2048:
+            raise NotImplementedError("the fused token kernels are built for SAM's decoder geometry (256 channels, 8 heads, 5 + 1 tokens, "
+                                      "MLP 2048); got %d / %d / %d + %d / %d" % (self.embedding_dim, self.num_heads, out_tokens.shape[0],
+                                                                                prompts.shape[1], self.mlp_dim))
+        P = prompts.shape[0]
+        dev = prompts.device
+        queries = torch.empty(P, 6, self.embedding_dim, device=dev, dtype=torch.float32)
+        query_pe = torch.empty_like(queries)
+        first = True
+        fa = self.final_attn_token_to_image
+        d = fa.internal_dim
+        eps = self.norm_final_attn.eps
+        q = torch.empty(P, 6, d, device=dev, dtype=torch.float32)
+        kq = torch.empty(P, 6, d, device=dev, dtype=BF16)
+        vq = torch.empty_like(kq)
+        keys, prev, prev_proj, mlp_part = src_tokens, None, None, None
+        stages = list(self.layers) + [None]                 # None = the tail
+        for layer in stages:
+            if layer is not None:
+                layer.check_fused()
+                if layer.norm1.eps != eps or layer.cross_attn_token_to_image.internal_dim != d:
+                    raise NotImplementedError("the fused token kernels expect one LayerNorm eps and one attention width in the decoder")
+                t2i, norm, bits = layer.cross_attn_token_to_image, layer.norm2, ops.TOK_SELF | ops.TOK_Q_T2I
+            else:
+                t2i, norm, bits = fa, self.norm_final_attn, ops.TOK_Q_T2I
+            table = token_stage_table(self_blk=layer, t2i=t2i, norm=norm, sum_blk=prev)
+            if prev is not None:
+                bits |= ops.TOK_SUM_MLP
+            if first:
+                bits |= ops.TOK_INIT
+            ops.dec_tokens(bits, layer is not None and layer.skip_first_layer_pe, queries, query_pe, table, q_t2i=q, mlp_partials=mlp_part,
+                           k_i2t=kq, v_i2t=vq, eps=eps, init_tokens=out_tokens if first else None,
+                           init_prompt=prompts.to(BF16).contiguous() if first else None)
+            first = False
+            if prev is not None:
+                keys = prev.image_to_token(prev_proj, keys, kq, vq, P)
+            proj = layer.image_side(keys, pe_tokens) if layer is not None else self.final_image_side(keys, pe_tokens)
+            part = ops.dec_attn_partial(q, proj[..., :d], proj[..., d:2 * d])
+            ops.dec_tokens(ops.TOK_COMBINE, False, queries, query_pe, table, attn_partials=part, eps=eps)
+            if layer is not None:
+                mlp_part = layer.mlp_partials(queries)
+            prev, prev_proj = layer, proj
         return queries, keys
 
     def final_image_side(self, keys, pe_tokens):
@@ -503,10 +570,8 @@ class MaskDecoder(nn.Module, _Prepared):
         }
 
     def head_weights(self):
-        """Pointer-table order of wg_dec_tokens_f32, mode 1 (include/walkgpt_hip.h)."""
-        tr = self.transformer
-        fa = tr.final_attn_token_to_image
-        w = _lin_pair(fa.q_proj) + _lin_pair(fa.out_proj) + [tr.norm_final_attn.weight, tr.norm_final_attn.bias]
+        """Pointer-table order of wg_dec_heads_f32 (include/walkgpt_hip.h)."""
+        w = []
         for mlp in list(self.output_hypernetworks_mlps) + [self.iou_prediction_head]:
             if mlp.num_layers != 3 or mlp.sigmoid_output:
                 raise NotImplementedError("the fused head kernel is built for SAM's 3-layer hypernetwork / IoU MLPs")
@@ -517,22 +582,16 @@ class MaskDecoder(nn.Module, _Prepared):
     def predict_masks_tokens(self, src_tokens, pe_tokens, sparse, h, w, mask_slice):
         """src_tokens [1|P, hw, C] (image embedding + dense prompt, channels-last rows), pe_tokens [1, hw, C],
         sparse [P, n, C] -> (masks fp32 [P, k, 4h, 4w], iou fp32 [P, k]).
-        Launches: per block one image-side GEMM, one token kernel, the image->token attention + out_proj + norm4; then one GEMM and
-        one token kernel for the final attention and the heads, and one kernel for upscaling + the hypernetwork product."""
+        Launches: TwoWayTransformer.run_tokens, then one kernel for the hypernetwork / IoU heads and one for upscaling + the
+        hypernetwork product."""
         p = self._prep_get(self._build_prepared, (self.output_upscaling[0].weight, self.output_upscaling[3].weight, self.iou_token.weight,
                                                   self.mask_tokens.weight))
         P = sparse.shape[0]
         tr = self.transformer
-        if self.num_mask_tokens != 4 or sparse.shape[1] != 1:
+        if self.num_mask_tokens != 4 or sparse.shape[1] != 1 or self.transformer_dim != 256:
             raise NotImplementedError("the fused decoder kernels are built for 4 mask tokens + one text prompt per query (mask_decoder.py:125-132)")
-        tokens = torch.cat([p["out_tokens_f32"].unsqueeze(0).expand(P, -1, -1), sparse.float()], dim=1).contiguous()   # [P, 6, C] fp32
-        queries, keys = tr.run_blocks(src_tokens, pe_tokens, tokens.clone(), tokens)
-        proj = tr.final_image_side(keys, pe_tokens)
-        d = tr.final_attn_token_to_image.internal_dim
-        hyper = torch.empty(P, self.num_mask_tokens, self.transformer_dim // 8, device=keys.device, dtype=torch.float32)
-        iou = torch.empty(P, self.num_mask_tokens, device=keys.device, dtype=torch.float32)
-        ops.dec_tokens(1, False, queries, tokens, self.head_weights(), proj[..., :d], proj[..., d:], h * w, hyper_out=hyper, iou_out=iou,
-                       eps=tr.norm_final_attn.eps)
+        queries, keys = tr.run_tokens(src_tokens, pe_tokens, p["out_tokens_f32"], sparse)
+        hyper, iou = ops.dec_heads(queries, self.head_weights())
         ln1 = self.output_upscaling[1]
         k0, nk = mask_slice
         masks = ops.upscale_mask(keys, p["up1_w"], self.output_upscaling[0].bias, ln1.weight, ln1.bias, ln1.eps, p["up2_w"],

@@ -98,7 +98,7 @@ class WalkGPTGrounding(nn.Module):
         pred_masks = [None] * len(counts)
         mask_scores = [None] * len(counts)
         if P > 0:
-            text = torch.cat([e for e in pred_embeddings if e.shape[0] > 0], 0)
+            text = self._cat_rows(pred_embeddings)
             sparse, _ = vm.prompt_encoder(points=None, boxes=None, masks=None, text_embeds=text.unsqueeze(1))
             if len(counts) == emb_tokens.shape[0] and all(c == 1 for c in counts):
                 src = ops.add_rows(emb_tokens, no_mask)                         # one prompt per image: no gather
@@ -131,6 +131,22 @@ class WalkGPTGrounding(nn.Module):
                 mask_scores[i] = torch.zeros(0, device=dev)
         return pred_masks, mask_scores
 
+    @staticmethod
+    def _cat_rows(parts):
+        """torch.cat(parts, 0) for [T_i, D] row blocks -- without the copy when they already sit back to back in one buffer (the
+        pieces torch.split hands out, the graph path's static input buffer)."""
+        parts = [t for t in parts if t.shape[0] > 0]
+        if len(parts) == 1:
+            return parts[0]
+        first, rows = parts[0], 0
+        for t in parts:
+            if not (t.is_contiguous() and t.dtype == first.dtype and t.device == first.device and t.shape[1:] == first.shape[1:]
+                    and t.untyped_storage().data_ptr() == first.untyped_storage().data_ptr()
+                    and t.storage_offset() == first.storage_offset() + rows * first.stride(0)):
+                return torch.cat(parts, 0)
+            rows += t.shape[0]
+        return first.as_strided((rows,) + tuple(first.shape[1:]), first.stride(), first.storage_offset())
+
     def _prompt_image_index(self, counts, dev):
         """image index of every prompt, cached per count pattern (a host->device copy per call would also forbid graph capture)"""
         cache = self.__dict__.setdefault("_pidx_cache", {})
@@ -159,10 +175,9 @@ class WalkGPTGrounding(nn.Module):
             ent = None          # weights changed since capture: drop the stale graph (its buffers are released with it)
         if ent is None:
             s_emb = torch.empty_like(emb_tokens)
-            s_hid = [torch.empty_like(h) for h in seg_hidden]
+            s_all = torch.cat(list(seg_hidden), 0)        # one buffer for every image's [SEG] rows: one copy per replay, no cat inside
+            s_hid = list(torch.split(s_all, [int(h.shape[0]) for h in seg_hidden], 0))
             s_emb.copy_(emb_tokens)
-            for d, h in zip(s_hid, seg_hidden):
-                d.copy_(h)
             warm = torch.cuda.Stream()
             warm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(warm), torch.no_grad():
@@ -172,11 +187,10 @@ class WalkGPTGrounding(nn.Module):
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), torch.no_grad():
                 out = self.decode_from_hidden(s_emb, s_hid, resize_list, original_size_list)
-            ent = graphs[key] = (g, s_emb, s_hid, out, wkey)
-        g, s_emb, s_hid, out, _ = ent
+            ent = graphs[key] = (g, s_emb, s_all, out, wkey)
+        g, s_emb, s_all, out, _ = ent
         s_emb.copy_(emb_tokens)
-        for d, h in zip(s_hid, seg_hidden):
-            d.copy_(h)
+        torch.cat(list(seg_hidden), 0, out=s_all)
         g.replay()
         return out
 
@@ -190,7 +204,7 @@ class WalkGPTGrounding(nn.Module):
         counts = [int(h.shape[0]) for h in seg_hidden]
         if sum(counts) == 0:
             return [h.new_zeros(0, 256) for h in seg_hidden]
-        pred = self.text_hidden_fcs[0](torch.cat(list(seg_hidden), 0))
+        pred = self.text_hidden_fcs[0](self._cat_rows(seg_hidden))
         return list(torch.split(pred, counts, 0))
 
     @torch.no_grad()
