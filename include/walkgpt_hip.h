@@ -169,6 +169,14 @@ int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const void* Vimg, 
 int wg_dec_mlp_partial_f32(const float* x, const void* lin1_w, const void* lin1_b, const void* lin2_w, float* partials, int P, void* stream);
 int wg_dec_heads_f32(const float* x, const void* const* weights, int n_weights, float* hyper_out, float* iou_out, int P, void* stream);
 
+/* Image side of a TwoWayAttentionBlock after its token stages (transformer.py:173-180), one launch:
+ *   keys = norm4(keys + out_proj(softmax(q k^T / 4) v)),  every image token attending to the six prompt tokens.
+ * q [rows or hw][ldq] bf16: the q columns (128) of the fused image-side projection; kq / vq [P,6,128] bf16 (SUM_MLP stage above);
+ * wo [256,128], bo [256]: cross_attn_image_to_token.out_proj; res: the image tokens themselves (bf16 rows, stride ldr); ln_g / ln_b: norm4;
+ * row_mod = hw when q and res hold ONE image shared by all P prompts, 0 when they hold P*hw rows; out [P*hw, 256] bf16.  hw % 16 == 0. */
+int wg_dec_i2t_rows_bf16(const void* q, long ldq, const void* kq, const void* vq, const void* wo, const void* bo, const void* res, long ldr,
+                         int row_mod, const void* ln_g, const void* ln_b, float eps, void* out, int P, int hw, void* stream);
+
 /* Sam.postprocess_masks (sam.py:137-172): bilinear to img_size^2, crop [:in_h,:in_w], bilinear to (out_h,out_w), one pass. */
 int wg_postprocess_masks_f32(const float* low_res, float* out, int N, int low_h, int low_w, int img_size, int in_h,
                              int in_w, int out_h, int out_w, void* stream);

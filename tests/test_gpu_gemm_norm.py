@@ -100,6 +100,30 @@ def test_gemm_rowwave_fallback(dev, M, N, K):
     assert (out.cpu() - ref).abs().max().item() <= 1e-3
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 4096, 4096), (16, 256, 4096), (3, 256, 256), (14, 1024, 128)])
+def test_gemm_skinny_rows(dev, M, N, K):
+    """M <= 16 (the [SEG] rows through text_hidden_fcs): one workgroup per 16 output columns, four waves splitting K."""
+    assert ops.gemm_tile_for(M, N, K, K, K, N, N) == 5
+    g = torch.Generator().manual_seed(11)
+    # exact part: small integers, asymmetric W -> bit-exact, and rows >= M of the 16-row MFMA operand must not leak in
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-2, 3, (N, K), generator=g).float()
+    w[:, 0] += torch.arange(N).float() % 5
+    out = ops.linear(a.to(dev, torch.bfloat16), w.to(dev, torch.bfloat16), out_f32=True)
+    assert torch.equal(out.cpu(), a @ w.t())
+    # epilogue: bias, activation, residual with a row modulo, bf16 and fp32 outputs, a column-slice A operand
+    a_full = torch.randn(M, 2 * K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16)
+    r = torch.randn(2, N, generator=g).to(torch.bfloat16)
+    ref = _ref_act(a_full[:, K:].float() @ w.float().t() + b.float(), ops.ACT_GELU) + r.float().repeat((M + 1) // 2, 1)[:M]
+    ad = a_full.to(dev)[:, K:]
+    o32 = ops.linear(ad, w.to(dev), b.to(dev), act=ops.ACT_GELU, residual=r.to(dev), res_row_mod=2, out_f32=True)
+    o16 = ops.linear(ad, w.to(dev), b.to(dev), act=ops.ACT_GELU, residual=r.to(dev), res_row_mod=2)
+    assert (o32.cpu() - ref).abs().max().item() <= 2e-3
+    assert (o16.float().cpu() - ref).abs().max().item() <= 3e-2
+
+
 @pytest.mark.parametrize("M,D,eps", [(4100, 768, 1e-6), (1025, 1024, 1e-5), (37, 256, 1e-6), (9, 4096, 1e-5),
                                      (3, 5120, 1e-5), (50, 64, 1e-6), (100003, 64, 1e-6), (77, 32, 1e-5), (1001, 128, 1e-5)])
 def test_layernorm_rows(dev, M, D, eps):

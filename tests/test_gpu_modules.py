@@ -301,3 +301,27 @@ def test_grounding_pipeline_end_to_end_vs_oracle(dev):
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(em2, gm2))
     assert not any(torch.equal(a, b) for a, b in zip(em2, em))
+
+
+@pytest.mark.parametrize("P,hw,shared", [(1, 4096, False), (3, 64, False), (5, 1024, True)])
+def test_decoder_image_to_token_rows_vs_torch(dev, P, hw, shared):
+    """wg_dec_i2t_rows_bf16 (transformer.py:173-180 in one launch) against fp32 torch on the same bf16 operands."""
+    g = torch.Generator().manual_seed(21)
+    rows = 1 if shared else P
+    proj = torch.randn(rows, hw, 384, generator=g).to(torch.bfloat16)
+    keys = torch.randn(rows, hw, 256, generator=g).to(torch.bfloat16)
+    kq, vq = (torch.randn(P, 6, 128, generator=g).to(torch.bfloat16) for _ in range(2))
+    wo = (torch.randn(256, 128, generator=g) / 128 ** 0.5).to(torch.bfloat16)
+    bo, gam, bet = (torch.randn(256, generator=g).to(torch.bfloat16) for _ in range(3))
+    q = proj[..., 256:].float().expand(P, -1, -1).reshape(P, hw, 8, 16).transpose(1, 2)
+    k = kq.float().reshape(P, 6, 8, 16).transpose(1, 2)
+    v = vq.float().reshape(P, 6, 8, 16).transpose(1, 2)
+    att = torch.softmax(q @ k.transpose(-1, -2) / 4.0, -1) @ v
+    x = keys.float().expand(P, -1, -1) + att.transpose(1, 2).reshape(P, hw, 128) @ wo.float().t() + bo.float()
+    ref = torch.nn.functional.layer_norm(x, (256,), gam.float(), bet.float(), 1e-5)
+    pd = proj.to(dev)
+    out = ops.dec_i2t_rows(pd[..., 256:], kq.to(dev), vq.to(dev), wo.to(dev), bo.to(dev), keys.to(dev), gam.to(dev), bet.to(dev), 1e-5, P)
+    assert out.shape == (P, hw, 256)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err <= 0.04, err                      # bf16 output rounding of values up to ~6
+    assert rel_err(out.float().cpu().numpy(), ref.numpy()) < 3e-3

@@ -37,51 +37,70 @@ struct UpArgs {
     float eps;
 };
 
-constexpr int UP_ROWS = 64;            // token rows per workgroup (four waves x 16)
-constexpr int UP_PITCH = 72;           // bf16 elements per LDS row of the 64-channel intermediate (144 B: conflict-free b128 reads)
+constexpr int UP_ROWS = 16;            // token rows per step of a workgroup
+constexpr int UP_PITCH = 72;           // bf16 elements per LDS row of a 64-channel operand (144 B: conflict-free b128 reads)
 
+// Work split: the four waves of a workgroup own the four sub-pixels (dy, dx) of the first transposed convolution.  A wave keeps ITS 64
+// rows of w1 (the 64 channels of its sub-pixel, 32 KB) in registers for the whole kernel and the workgroup walks 16-token-row groups:
+// LayerNorm2d runs over exactly a wave's 64 channels, the second convolution reads only them, so from the x rows to the logits nothing
+// crosses waves.  (First version: a wave per 16 rows doing all four sub-pixels -- every wave re-streamed the 128 KB of w1 from L2, 512 KB
+// per workgroup through one compute unit: 80 us at P = 8.)
 __global__ __launch_bounds__(256) void wg_upscale_mask_kernel(UpArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16 vhi[4][64 * UP_PITCH];
-    __shared__ __attribute__((aligned(16))) bf16 vlo[4][64 * UP_PITCH];
+    __shared__ __attribute__((aligned(16))) bf16 vhi[4][16 * UP_PITCH];
+    __shared__ __attribute__((aligned(16))) bf16 vlo[4][16 * UP_PITCH];
+    __shared__ __attribute__((aligned(16))) bf16 w2s[128 * UP_PITCH];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l16 = lane & 15, kg = lane >> 4;
     const long hw = (long)a.h * a.w;
-    const long total = (long)a.P * hw;
-    const long r0 = (long)blockIdx.x * UP_ROWS + wave * 16;
-    if (r0 >= total) return;            // (whole wave: rows come in multiples of 16, hw % 16 == 0 is checked by the host)
-
-    // ---- GEMM 1: u[16 rows][256] = x[16][256] . w1^T -------------------------------------------------------------------------
-    bf16x8 xa[8];
-    {
-        const bf16* xp = a.x + (r0 + l16) * a.ldx + 8 * kg;
+    const long groups = (long)a.P * hw / UP_ROWS;        // hw % 16 == 0 is checked by the host: a group never straddles two prompts
+    // w2 [(dy2,dx2,32), 64] -> LDS (16 KB, shared by the four waves)
+    for (int i = threadIdx.x; i < 128 * 8; i += 256) *(bf16x8*)(w2s + (i >> 3) * UP_PITCH + 8 * (i & 7)) = *(const bf16x8*)(a.w2 + (long)i * 8);
+    // this wave's rows of w1 as B fragments: column block nb (16 channels) x k step ks
+    bf16x8 wf[4][8];
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) xa[ks] = *(const bf16x8*)(xp + 32 * ks);
-    }
-    f32x4 u[16];
+    for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-    for (int nb = 0; nb < 16; ++nb) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const bf16* wp = a.w1 + (long)(nb * 16 + l16) * 256 + 8 * kg;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) acc = mfma16(xa[ks], *(const bf16x8*)(wp + 32 * ks), acc);
-        u[nb] = acc;
-    }
-    // ---- bias, LayerNorm2d over the 64 channels of each (row, sub-pixel), GELU; -> LDS as bf16 hi + lo, one row per (row, sub-pixel)
-    float b1v[4], g1v[4], be1v[4];
+        for (int ks = 0; ks < 8; ++ks) wf[nb][ks] = *(const bf16x8*)(a.w1 + (long)(wave * 64 + nb * 16 + l16) * 256 + 32 * ks + 8 * kg);
+    float b1v[4], g1v[4], be1v[4], b2v[2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         b1v[j] = (float)a.b1[16 * j + l16];
         g1v[j] = (float)a.g1[16 * j + l16];
         be1v[j] = (float)a.be1[16 * j + l16];
     }
+    b2v[0] = (float)a.b2[l16];
+    b2v[1] = (float)a.b2[16 + l16];
+    __syncthreads();
+    const int H4 = 4 * a.h, W4 = 4 * a.w;
+    bf16x8 xa[8];
+    long grp = blockIdx.x;
+    if (grp < groups) {
+        const bf16* xp = a.x + (grp * UP_ROWS + l16) * a.ldx + 8 * kg;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+        for (int ks = 0; ks < 8; ++ks) xa[ks] = *(const bf16x8*)(xp + 32 * ks);
+    }
+    for (; grp < groups; grp += gridDim.x) {
+        // ---- GEMM 1: u[16 rows][64] = x[16][256] . w1[sub-pixel `wave`]^T ---------------------------------------------------------------
+        f32x4 u[4];
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) acc = mfma16(xa[ks], wf[nb][ks], acc);
+            u[nb] = acc;
+        }
+        if (grp + gridDim.x < groups) {       // the next group's rows travel under the rest of this one
+            const bf16* xp = a.x + ((grp + gridDim.x) * UP_ROWS + l16) * a.ldx + 8 * kg;
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) xa[ks] = *(const bf16x8*)(xp + 32 * ks);
+        }
+        // ---- bias, LayerNorm2d over the 64 channels, GELU -> the wave's LDS slab as a bf16 hi + lo pair (A operand of GEMM 2) ----------------
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float v[4], sum = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[j] = u[4 * s + j][i] + b1v[j];
+                v[j] = u[j][i] + b1v[j];
                 sum += v[j];
             }
             const float mean = row16_sum(sum) * (1.0f / 64.0f);
@@ -92,69 +111,211 @@ __global__ __launch_bounds__(256) void wg_upscale_mask_kernel(UpArgs a) {
                 sq += v[j] * v[j];
             }
             const float rstd = 1.0f / sqrtf(row16_sum(sq) * (1.0f / 64.0f) + a.eps);
-            const int srow = (4 * kg + i) * 4 + s;     // LDS row of (token row 4*kg+i, sub-pixel s)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float y = gelu_erf(v[j] * rstd * g1v[j] + be1v[j]);
                 const bf16 hi = (bf16)y;
-                vhi[wave][srow * UP_PITCH + 16 * j + l16] = hi;
-                vlo[wave][srow * UP_PITCH + 16 * j + l16] = (bf16)(y - (float)hi);
+                vhi[wave][(4 * kg + i) * UP_PITCH + 16 * j + l16] = hi;
+                vlo[wave][(4 * kg + i) * UP_PITCH + 16 * j + l16] = (bf16)(y - (float)hi);
             }
         }
-    }
-    __builtin_amdgcn_wave_barrier();      // the slab is private to the wave and LDS operations of one wave complete in order
-
-    // ---- GEMM 2: z[64 sub-pixel rows][128] = v[64][64] . w2^T (hi + lo), bias, GELU, dot with hyper_in -> 16 logits per token --------
-    bf16x8 wb[8][2];
+        __builtin_amdgcn_wave_barrier();      // the slab is private to the wave and LDS operations of one wave complete in order
+        // ---- GEMM 2: z[16 rows][128] = v[16][64] . w2^T (hi + lo), bias, GELU ----------------------------------------------------------
+        bf16x8 ah[2], al[2];
 #pragma unroll
-    for (int nb = 0; nb < 8; ++nb)
+        for (int ks = 0; ks < 2; ++ks) {
+            ah[ks] = *(const bf16x8*)(&vhi[wave][l16 * UP_PITCH + 32 * ks + 8 * kg]);
+            al[ks] = *(const bf16x8*)(&vlo[wave][l16 * UP_PITCH + 32 * ks + 8 * kg]);
+        }
+        f32x4 gz[8];                          // gelu(z): column block nb = (sub-sub-pixel nb >> 1, channel half nb & 1)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) wb[nb][ks] = *(const bf16x8*)(a.w2 + (long)(nb * 16 + l16) * 64 + 32 * ks + 8 * kg);
-    float b2v[2];
-    b2v[0] = (float)a.b2[l16];
-    b2v[1] = (float)a.b2[16 + l16];
-    const long p = r0 / hw;                 // prompt of this wave's rows (16 | hw: a wave never straddles two prompts)
-    const int t0 = (int)(r0 - p * hw);      // first token of the wave inside its prompt
-    const int H4 = 4 * a.h, W4 = 4 * a.w;
-    for (int mk = 0; mk < a.num_masks; ++mk) {
-        const float* hy = a.hyper + ((long)p * a.nmask_total + a.first_mask + mk) * 32;
-        const float hy0 = hy[l16], hy1 = hy[16 + l16];
-        float* outp = a.out + ((long)p * a.num_masks + mk) * H4 * W4;
-#pragma unroll
-        for (int mb = 0; mb < 4; ++mb) {      // 16 LDS rows = token rows 4*mb .. 4*mb+3 of the wave x 4 sub-pixels
-            bf16x8 ah[2], al[2];
+        for (int nb = 0; nb < 8; ++nb) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                ah[ks] = *(const bf16x8*)(&vhi[wave][(mb * 16 + l16) * UP_PITCH + 32 * ks + 8 * kg]);
-                al[ks] = *(const bf16x8*)(&vlo[wave][(mb * 16 + l16) * UP_PITCH + 32 * ks + 8 * kg]);
+                const bf16x8 wb = *(const bf16x8*)(w2s + (nb * 16 + l16) * UP_PITCH + 32 * ks + 8 * kg);
+                acc = mfma16(ah[ks], wb, acc);
+                acc = mfma16(al[ks], wb, acc);
             }
 #pragma unroll
-            for (int ss = 0; ss < 4; ++ss) {  // sub-sub-pixel (dy2, dx2): columns 32*ss .. 32*ss+31 = N blocks 2*ss, 2*ss+1
-                f32x4 part = {0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < 4; ++i) gz[nb][i] = gelu_erf(acc[i] + b2v[nb & 1]);
+        }
+        __builtin_amdgcn_wave_barrier();      // (the slab is rewritten by the next group)
+        // ---- <hyper_in, .> over the 32 channels: 16 logits per token, this wave's four ------------------------------------------------------
+        const long r0 = grp * UP_ROWS;
+        const long p = r0 / hw;
+        const int t0 = (int)(r0 - p * hw);
+        const int t = t0 + 4 * kg + (l16 & 3);          // lane (kg, l16 = 4*ss + i) stores the logit of token row 4*kg + i, sub-sub-pixel ss
+        const int ty = t / a.w, tx = t % a.w;
+        const int ss_l = l16 >> 2;
+        const long opix = (long)(4 * ty + 2 * (wave >> 1) + (ss_l >> 1)) * W4 + 4 * tx + 2 * (wave & 1) + (ss_l & 1);
+        for (int mk = 0; mk < a.num_masks; ++mk) {
+            const float* hy = a.hyper + ((long)p * a.nmask_total + a.first_mask + mk) * 32;
+            const float hy0 = hy[l16], hy1 = hy[16 + l16];
+            float mine = 0.f;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int nb = 2 * ss + half;
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        acc = mfma16(ah[ks], wb[nb][ks], acc);
-                        acc = mfma16(al[ks], wb[nb][ks], acc);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) part[i] += gelu_erf(acc[i] + b2v[half]) * (half == 0 ? hy0 : hy1);
-                }
+            for (int ss = 0; ss < 4; ++ss)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float logit = row16_sum(part[i]);
-                    // accumulator row 4*kg+i of block mb = LDS row mb*16 + 4*kg + i = (token row 4*mb + kg, sub-pixel i)
-                    if (l16 == 4 * ss + i) {
-                        const int t = t0 + 4 * mb + kg;
-                        const int ty = t / a.w, tx = t % a.w;
-                        const int y = 4 * ty + 2 * (i >> 1) + (ss >> 1), x = 4 * tx + 2 * (i & 1) + (ss & 1);
-                        outp[(long)y * W4 + x] = logit;
-                    }
+                    const float logit = row16_sum(gz[2 * ss][i] * hy0 + gz[2 * ss + 1][i] * hy1);
+                    mine = (l16 == 4 * ss + i) ? logit : mine;
                 }
+            a.out[((long)p * a.num_masks + mk) * H4 * W4 + opix] = mine;
+        }
+    }
+}
+
+// =====================================================================================================================================
+// Image side of a TwoWayAttentionBlock after the token kernel (transformer.py:173-180): every image token attends to the SIX prompt
+// tokens, goes through out_proj, adds itself and is normalised:
+//     keys = norm4(keys + out_proj(softmax(q k^T / 4) v))          q = the [.., 2d:3d] columns of the fused image-side projection
+// One wave per 16 image tokens, nothing leaves the wave: lane (l16 = token, kg) computes the scores of heads kg>>1, 2+(kg>>1), ... and
+// the half (kg & 1) of each head's 16 outputs -- exactly the B fragment (k = 32 ks + 8 kg .. +7) of the transposed product
+// out^T[256][16 tokens] = Wo[256][128] . o^T, whose accumulators hold four CONSECUTIVE channels of one token per lane: residual, LayerNorm
+// statistics (in-lane + two cross-lane steps) and the bf16 store all run on 8-byte pieces.  Wo sits in LDS (shared by the four waves),
+// o is fed as a bf16 hi + lo pair.  Replaces three launches (attention with 6 keys, GEMM + residual, LayerNorm).
+// =====================================================================================================================================
+struct I2tArgs {
+    const bf16* q; long ldq;            // [rows or hw][ldq]: projected image tokens (128 columns used)
+    const bf16* kq; const bf16* vq;     // [P, 6, 128]: projected prompt tokens
+    const bf16* wo; const bf16* bo;     // out_proj [256, 128], [256]
+    const bf16* res; long ldr;          // the image tokens themselves [rows or hw][ldr]
+    int row_mod;                        // hw when q / res are shared by all prompts (one image), 0 otherwise
+    const bf16* g; const bf16* b; float eps;
+    bf16* out;                          // [P * hw, 256]
+    long rows; int hw;
+};
+constexpr int I2_KEYS = 6;             // prompt tokens per query: iou + 4 mask tokens + the text prompt
+constexpr int I2_PITCH = 136;           // bf16 per LDS row of Wo (272 B: conflict-free b128 reads)
+constexpr int I2_LDS = 256 * I2_PITCH * 2 + 3 * 256 * 4 + 4 * 2 * I2_KEYS * 128 * 2;
+
+__device__ __forceinline__ float kg_sum(float v) {      // sum over the four lanes that share l16
+    float x, y;
+    wg_permlane_swap<0>(v, x, y); v = x + y;
+    wg_permlane_swap<1>(v, x, y); return x + y;
+}
+
+__global__ __launch_bounds__(256) void wg_dec_i2t_rows_kernel(I2tArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char i2_smem[];
+    bf16* wos = (bf16*)i2_smem;                                   // [256][I2_PITCH]
+    float* vec = (float*)(i2_smem + 256 * I2_PITCH * 2);           // bias | gamma | beta, fp32 [3][256]
+    bf16* kvs = (bf16*)(vec + 3 * 256);                            // per wave: k [6][128] | v [6][128]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l16 = lane & 15, kg = lane >> 4;
+    for (int i = threadIdx.x; i < 256 * 16; i += 256) *(bf16x8*)(wos + (i >> 4) * I2_PITCH + 8 * (i & 15)) = *(const bf16x8*)(a.wo + (long)i * 8);
+    {
+        const int i = threadIdx.x;
+        vec[i] = (float)a.bo[i];
+        vec[256 + i] = (float)a.g[i];
+        vec[512 + i] = (float)a.b[i];
+    }
+    __syncthreads();
+    bf16* ks_ = kvs + wave * 2 * I2_KEYS * 128;
+    bf16* vs_ = ks_ + I2_KEYS * 128;
+    const long groups = a.rows / 16;
+    for (long grp = (long)blockIdx.x * 4 + wave; grp < groups; grp += (long)gridDim.x * 4) {
+        const long r0 = grp * 16;
+        const long p = r0 / a.hw;                                  // hw % 16 == 0: a group never straddles two prompts
+        const long row = r0 + l16;
+        const long srow = a.row_mod > 0 ? row % a.row_mod : row;   // row of q / res
+        // prompt tokens of this prompt -> the wave's slab
+        for (int i = lane; i < 2 * I2_KEYS * 16; i += 64) {
+            const bf16* src = (i < I2_KEYS * 16 ? a.kq : a.vq) + p * I2_KEYS * 128 + (i % (I2_KEYS * 16)) * 8;
+            *(bf16x8*)(ks_ + i * 8) = *(const bf16x8*)src;
+        }
+        bf16x8 qv[4][2];
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+            const bf16* qp = a.q + srow * a.ldq + (2 * hh + (kg >> 1)) * 16;
+            qv[hh][0] = *(const bf16x8*)qp;
+            qv[hh][1] = *(const bf16x8*)(qp + 8);
+        }
+        bf16x4 rv[16];                                             // residual: channels nb*16 + 4*kg .. +3 of token l16
+#pragma unroll
+        for (int nb = 0; nb < 16; ++nb) rv[nb] = *(const bf16x4*)(a.res + srow * a.ldr + nb * 16 + 4 * kg);
+        __builtin_amdgcn_wave_barrier();
+        // ---- attention over the six prompt tokens: head 2*hh + (kg >> 1), output dims 8*(kg & 1) .. +7 -----------------------------------
+        bf16x8 oh[4], ol[4];
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+            const int hoff = (2 * hh + (kg >> 1)) * 16;
+            float qf[16];
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                qf[d] = (float)qv[hh][0][d] * 0.25f;               // 1 / sqrt(16)
+                qf[8 + d] = (float)qv[hh][1][d] * 0.25f;
             }
+            float sc[I2_KEYS], m = -1e30f;
+#pragma unroll
+            for (int j = 0; j < I2_KEYS; ++j) {
+                const bf16x8 k0 = *(const bf16x8*)(ks_ + j * 128 + hoff), k1 = *(const bf16x8*)(ks_ + j * 128 + hoff + 8);
+                float acc = 0.f;
+#pragma unroll
+                for (int d = 0; d < 8; ++d) acc += qf[d] * (float)k0[d] + qf[8 + d] * (float)k1[d];
+                sc[j] = acc;
+                m = fmaxf(m, acc);
+            }
+            float l = 0.f;
+#pragma unroll
+            for (int j = 0; j < I2_KEYS; ++j) {
+                sc[j] = __expf(sc[j] - m);
+                l += sc[j];
+            }
+            const float inv = 1.0f / l;
+            float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < I2_KEYS; ++j) {
+                const bf16x8 vv = *(const bf16x8*)(vs_ + j * 128 + hoff + 8 * (kg & 1));
+#pragma unroll
+                for (int d = 0; d < 8; ++d) o[d] += sc[j] * (float)vv[d];
+            }
+#pragma unroll
+            for (int d = 0; d < 8; ++d) {
+                const float y = o[d] * inv;
+                const bf16 hi = (bf16)y;
+                oh[hh][d] = hi;
+                ol[hh][d] = (bf16)(y - (float)hi);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                           // (the slab is rewritten by the next group)
+        // ---- out^T = Wo . o^T, + bias + residual; LayerNorm over the 256 channels of each token ------------------------------------------
+        f32x4 acc[16];
+        float sum = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 16; ++nb) {
+            f32x4 c = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 wf = *(const bf16x8*)(wos + (nb * 16 + l16) * I2_PITCH + 32 * ks + 8 * kg);
+                c = mfma16(wf, oh[ks], c);
+                c = mfma16(wf, ol[ks], c);
+            }
+            const f32x4 bias = *(const f32x4*)(vec + nb * 16 + 4 * kg);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                c[i] += bias[i] + (float)rv[nb][i];
+                sum += c[i];
+            }
+            acc[nb] = c;
+        }
+        const float mean = kg_sum(sum) * (1.0f / 256.0f);
+        float sq = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < 16; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[nb][i] -= mean;
+                sq += acc[nb][i] * acc[nb][i];
+            }
+        const float rstd = 1.0f / sqrtf(kg_sum(sq) * (1.0f / 256.0f) + a.eps);
+        bf16* op = a.out + row * 256 + 4 * kg;
+#pragma unroll
+        for (int nb = 0; nb < 16; ++nb) {
+            const f32x4 gm = *(const f32x4*)(vec + 256 + nb * 16 + 4 * kg), bt = *(const f32x4*)(vec + 512 + nb * 16 + 4 * kg);
+            bf16x4 y;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) y[i] = (bf16)(acc[nb][i] * rstd * gm[i] + bt[i]);
+            *(bf16x4*)(op + nb * 16) = y;
         }
     }
 }
@@ -174,7 +335,8 @@ extern "C" int wg_upscale_mask_bf16(const void* x, long ldx, const void* w1, con
     UpArgs a{(const bf16*)x, ldx, (const bf16*)w1, (const bf16*)b1, (const bf16*)ln_g, (const bf16*)ln_b, (const bf16*)w2, (const bf16*)b2,
              hyper, out, P, h, w, nmask_total, first_mask, num_masks, eps};
     const long rows = (long)P * h * w;
-    hipLaunchKernelGGL(wg_upscale_mask_kernel, dim3((unsigned)((rows + UP_ROWS - 1) / UP_ROWS)), dim3(256), 0, (hipStream_t)stream, a);
+    const long groups = rows / UP_ROWS;
+    hipLaunchKernelGGL(wg_upscale_mask_kernel, dim3((unsigned)(groups < 512 ? groups : 512)), dim3(256), 0, (hipStream_t)stream, a);
     return wg_check_launch("wg_upscale_mask");
 }
 
@@ -651,4 +813,26 @@ extern "C" int wg_dec_heads_f32(const float* x, const void* const* weights, int 
         }
     hipLaunchKernelGGL(wg_dec_heads_kernel, dim3((unsigned)(P * 5)), dim3(256), 0, (hipStream_t)stream, a);
     return wg_check_launch("wg_dec_heads");
+}
+
+// transformer.py:173-180 for one block: q [rows | hw][ldq] bf16 (the 128 q columns of the image-side projection), kq / vq [P,6,128] bf16
+// (wg_dec_tokens_f32, SUM_MLP), out_proj [256,128] + bias, res = the image tokens (bf16 rows, stride ldr), norm4 -> out [P*hw, 256] bf16.
+// row_mod = hw when q and res hold ONE image shared by all P prompts, 0 when they have P*hw rows.
+extern "C" int wg_dec_i2t_rows_bf16(const void* q, long ldq, const void* kq, const void* vq, const void* wo, const void* bo, const void* res,
+                                    long ldr, int row_mod, const void* ln_g, const void* ln_b, float eps, void* out, int P, int hw, void* stream) {
+    WG_REQUIRE(q && kq && vq && wo && bo && res && ln_g && ln_b && out, "dec_i2t_rows: null operand");
+    WG_REQUIRE(P > 0 && hw > 0 && hw % 16 == 0 && (row_mod == 0 || row_mod == hw), "dec_i2t_rows: hw must be a positive multiple of 16");
+    WG_REQUIRE(ldq % 8 == 0 && ldr % 4 == 0, "dec_i2t_rows: misaligned leading dimension");
+    WG_REQUIRE((((uintptr_t)q | (uintptr_t)kq | (uintptr_t)vq | (uintptr_t)wo) & 15) == 0 && (((uintptr_t)res | (uintptr_t)out) & 7) == 0,
+               "dec_i2t_rows: misaligned operand");
+    I2tArgs a{(const bf16*)q, ldq, (const bf16*)kq, (const bf16*)vq, (const bf16*)wo, (const bf16*)bo, (const bf16*)res, ldr, row_mod,
+              (const bf16*)ln_g, (const bf16*)ln_b, eps, (bf16*)out, (long)P * hw, hw};
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)wg_dec_i2t_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, I2_LDS);
+        attr_done = true;
+    }
+    const long wgs = (a.rows / 16 + 3) / 4;
+    hipLaunchKernelGGL(wg_dec_i2t_rows_kernel, dim3((unsigned)(wgs < 256 ? wgs : 256)), dim3(256), I2_LDS, (hipStream_t)stream, a);
+    return wg_check_launch("wg_dec_i2t_rows");
 }

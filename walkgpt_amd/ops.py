@@ -451,6 +451,27 @@ def dec_heads(x, weights):
     return hyper, iou
 
 
+def dec_i2t_rows(q_img, k_i2t, v_i2t, out_w, out_b, keys, ln_g, ln_b, eps, P):
+    """transformer.py:173-180 in one launch (wg_dec_i2t_rows_bf16): norm4(keys + out_proj(attention of every image token over the six
+    prompt tokens)).  q_img [1 | P, hw, 128] bf16 (column slice of the image-side projection), k_i2t / v_i2t [P, 6, 128] bf16,
+    keys [1 | P, hw, 256] bf16 -> bf16 [P, hw, 256]."""
+    _need_gpu(q_img, k_i2t, v_i2t, out_w, out_b, keys, ln_g, ln_b)
+    hw = keys.shape[1]
+    assert q_img.dtype == _BF16 and q_img.shape[-1] == 128 and q_img.stride(-1) == 1 and q_img.shape[:2] == keys.shape[:2]
+    assert keys.dtype == _BF16 and keys.shape[-1] == 256 and keys.stride(-1) == 1 and keys.shape[0] in (1, P)
+    assert k_i2t.shape == (P, 6, 128) and v_i2t.shape == (P, 6, 128) and k_i2t.is_contiguous() and v_i2t.is_contiguous()
+    assert out_w.shape == (256, 128) and out_w.is_contiguous() and out_b.numel() == 256 and ln_g.numel() == 256 and ln_b.numel() == 256
+    for t in (q_img, keys):          # rows of all prompts must be evenly spaced
+        assert t.shape[0] == 1 or t.stride(0) == hw * t.stride(1)
+    shared = keys.shape[0] == 1 and P > 1
+    out = torch.empty(P, hw, 256, device=keys.device, dtype=_BF16)
+    rc = _lib.lib().wg_dec_i2t_rows_bf16(q_img.data_ptr(), q_img.stride(1), k_i2t.data_ptr(), v_i2t.data_ptr(), out_w.data_ptr(),
+                                         out_b.data_ptr(), keys.data_ptr(), keys.stride(1), hw if shared else 0, ln_g.data_ptr(),
+                                         ln_b.data_ptr(), float(eps), out.data_ptr(), P, hw, _stream())
+    _lib.check(rc, "wg_dec_i2t_rows_bf16")
+    return out
+
+
 def upscale_mask(keys, up1_w, up1_b, ln_g, ln_b, eps, up2_w, up2_b, hyper, h, w, first_mask, num_masks):
     """mask_decoder.py:140-160 in one launch.  keys [P, h*w, 256] bf16 image tokens; up1_w [(dy,dx,64), 256], up2_w [(dy,dx,32), 64]
     (re-laid ConvTranspose2d weights); hyper [P, nmask, 32] fp32 -> fp32 [P, num_masks, 4h, 4w]."""

@@ -381,11 +381,15 @@ class TwoWayAttentionBlock(nn.Module):
         return ops.linear(keys, wcat, residual=rtab, res_row_mod=keys.shape[1])          # [1|P, hw, 3d]
 
     def image_to_token(self, proj, keys, kq, vq, P):
-        """transformer.py:173-180: image->token attention on the projected operands, out_proj + residual, norm4."""
+        """transformer.py:173-180: image->token attention on the projected operands, out_proj + residual, norm4 -- one launch for SAM's
+        geometry (ops.dec_i2t_rows), three otherwise."""
         i2t = self.cross_attn_image_to_token
         hw = keys.shape[1]
-        keys = i2t.run_projected(proj[..., 2 * i2t.internal_dim:], kq, vq, P, residual=keys,
-                                 res_row_mod=hw if keys.shape[0] == 1 and P > 1 else 0)
+        d = i2t.internal_dim
+        if d == 128 and i2t.num_heads == 8 and keys.shape[-1] == 256 and kq.shape[1] == 6 and hw % 16 == 0:
+            return ops.dec_i2t_rows(proj[..., 2 * d:], kq, vq, i2t.out_proj.weight, i2t.out_proj.bias, keys, self.norm4.weight,
+                                    self.norm4.bias, self.norm4.eps, P)
+        keys = i2t.run_projected(proj[..., 2 * d:], kq, vq, P, residual=keys, res_row_mod=hw if keys.shape[0] == 1 and P > 1 else 0)
         return ops.layernorm(keys, self.norm4.weight, self.norm4.bias, self.norm4.eps)
 
     def mlp_partials(self, queries):
