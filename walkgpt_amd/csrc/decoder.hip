@@ -112,11 +112,14 @@ __global__ __launch_bounds__(256) void wg_upscale_mask_kernel(UpArgs a) {
             }
             const float rstd = 1.0f / sqrtf(row16_sum(sq) * (1.0f / 64.0f) + a.eps);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float y = gelu_erf(v[j] * rstd * g1v[j] + be1v[j]);
-                const bf16 hi = (bf16)y;
-                vhi[wave][(4 * kg + i) * UP_PITCH + 16 * j + l16] = hi;
-                vlo[wave][(4 * kg + i) * UP_PITCH + 16 * j + l16] = (bf16)(y - (float)hi);
+            for (int j = 0; j < 4; j += 2) {      // (pairs: hipcc selects the packed fp32 forms, wg_act2 uses the bare v_exp / v_rcp)
+                const f32x2 y = wg_act2<WG_ACT_GELU_ERF>((f32x2){v[j] * rstd * g1v[j] + be1v[j], v[j + 1] * rstd * g1v[j + 1] + be1v[j + 1]});
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const bf16 hi = (bf16)y[e];
+                    vhi[wave][(4 * kg + i) * UP_PITCH + 16 * (j + e) + l16] = hi;
+                    vlo[wave][(4 * kg + i) * UP_PITCH + 16 * (j + e) + l16] = (bf16)(y[e] - (float)hi);
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();      // the slab is private to the wave and LDS operations of one wave complete in order
@@ -137,8 +140,9 @@ __global__ __launch_bounds__(256) void wg_upscale_mask_kernel(UpArgs a) {
                 acc = mfma16(ah[ks], wb, acc);
                 acc = mfma16(al[ks], wb, acc);
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gz[nb][i] = gelu_erf(acc[i] + b2v[nb & 1]);
+            const f32x2 g01 = wg_act2<WG_ACT_GELU_ERF>((f32x2){acc[0] + b2v[nb & 1], acc[1] + b2v[nb & 1]});
+            const f32x2 g23 = wg_act2<WG_ACT_GELU_ERF>((f32x2){acc[2] + b2v[nb & 1], acc[3] + b2v[nb & 1]});
+            gz[nb] = (f32x4){g01.x, g01.y, g23.x, g23.y};
         }
         __builtin_amdgcn_wave_barrier();      // (the slab is rewritten by the next group)
         // ---- <hyper_in, .> over the 32 channels: 16 logits per token, this wave's four ------------------------------------------------------
@@ -169,7 +173,8 @@ __global__ __launch_bounds__(256) void wg_upscale_mask_kernel(UpArgs a) {
 // Image side of a TwoWayAttentionBlock after the token kernel (transformer.py:173-180): every image token attends to the SIX prompt
 // tokens, goes through out_proj, adds itself and is normalised:
 //     keys = norm4(keys + out_proj(softmax(q k^T / 4) v))          q = the [.., 2d:3d] columns of the fused image-side projection
-// One wave per 16 image tokens, nothing leaves the wave: lane (l16 = token, kg) computes the scores of heads kg>>1, 2+(kg>>1), ... and
+// One wave per 16 image tokens, nothing leaves the wave: lane (l16 = token, kg) computes the scores of heads kg>>1, 2+(kg>>1), ... (three
+// keys each for the two lanes that share a head, swapped with one permlane) and
 // the half (kg & 1) of each head's 16 outputs -- exactly the B fragment (k = 32 ks + 8 kg .. +7) of the transposed product
 // out^T[256][16 tokens] = Wo[256][128] . o^T, whose accumulators hold four CONSECUTIVE channels of one token per lane: residual, LayerNorm
 // statistics (in-lane + two cross-lane steps) and the bf16 store all run on 8-byte pieces.  Wo sits in LDS (shared by the four waves),
@@ -187,7 +192,8 @@ struct I2tArgs {
 };
 constexpr int I2_KEYS = 6;             // prompt tokens per query: iou + 4 mask tokens + the text prompt
 constexpr int I2_PITCH = 136;           // bf16 per LDS row of Wo (272 B: conflict-free b128 reads)
-constexpr int I2_LDS = 256 * I2_PITCH * 2 + 3 * 256 * 4 + 4 * 2 * I2_KEYS * 128 * 2;
+constexpr int I2_WAVES = 8;             // two per SIMD: the LDS round trips of one hide under the arithmetic of the other
+constexpr int I2_LDS = 256 * I2_PITCH * 2 + 3 * 256 * 4 + I2_WAVES * 2 * I2_KEYS * 128 * 4;
 
 __device__ __forceinline__ float kg_sum(float v) {      // sum over the four lanes that share l16
     float x, y;
@@ -195,33 +201,34 @@ __device__ __forceinline__ float kg_sum(float v) {      // sum over the four lan
     wg_permlane_swap<1>(v, x, y); return x + y;
 }
 
-__global__ __launch_bounds__(256) void wg_dec_i2t_rows_kernel(I2tArgs a) {
+__global__ __launch_bounds__(64 * I2_WAVES) void wg_dec_i2t_rows_kernel(I2tArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char i2_smem[];
     bf16* wos = (bf16*)i2_smem;                                   // [256][I2_PITCH]
     float* vec = (float*)(i2_smem + 256 * I2_PITCH * 2);           // bias | gamma | beta, fp32 [3][256]
-    bf16* kvs = (bf16*)(vec + 3 * 256);                            // per wave: k [6][128] | v [6][128]
+    float* kvs = vec + 3 * 256;                                    // per wave: k [6][128] | v [6][128], fp32
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l16 = lane & 15, kg = lane >> 4;
-    for (int i = threadIdx.x; i < 256 * 16; i += 256) *(bf16x8*)(wos + (i >> 4) * I2_PITCH + 8 * (i & 15)) = *(const bf16x8*)(a.wo + (long)i * 8);
-    {
+    for (int i = threadIdx.x; i < 256 * 16; i += 64 * I2_WAVES) *(bf16x8*)(wos + (i >> 4) * I2_PITCH + 8 * (i & 15)) = *(const bf16x8*)(a.wo + (long)i * 8);
+    if (threadIdx.x < 256) {
         const int i = threadIdx.x;
         vec[i] = (float)a.bo[i];
         vec[256 + i] = (float)a.g[i];
         vec[512 + i] = (float)a.b[i];
     }
     __syncthreads();
-    bf16* ks_ = kvs + wave * 2 * I2_KEYS * 128;
-    bf16* vs_ = ks_ + I2_KEYS * 128;
+    float* ks_ = kvs + wave * 2 * I2_KEYS * 128;
+    float* vs_ = ks_ + I2_KEYS * 128;
     const long groups = a.rows / 16;
-    for (long grp = (long)blockIdx.x * 4 + wave; grp < groups; grp += (long)gridDim.x * 4) {
+    for (long grp = (long)blockIdx.x * I2_WAVES + wave; grp < groups; grp += (long)gridDim.x * I2_WAVES) {
         const long r0 = grp * 16;
         const long p = r0 / a.hw;                                  // hw % 16 == 0: a group never straddles two prompts
         const long row = r0 + l16;
         const long srow = a.row_mod > 0 ? row % a.row_mod : row;   // row of q / res
         // prompt tokens of this prompt -> the wave's slab
         for (int i = lane; i < 2 * I2_KEYS * 16; i += 64) {
-            const bf16* src = (i < I2_KEYS * 16 ? a.kq : a.vq) + p * I2_KEYS * 128 + (i % (I2_KEYS * 16)) * 8;
-            *(bf16x8*)(ks_ + i * 8) = *(const bf16x8*)src;
+            const bf16x8 t = *(const bf16x8*)((i < I2_KEYS * 16 ? a.kq : a.vq) + p * I2_KEYS * 128 + (i % (I2_KEYS * 16)) * 8);
+            *(f32x4*)(ks_ + i * 8) = (f32x4){(float)t[0], (float)t[1], (float)t[2], (float)t[3]};
+            *(f32x4*)(ks_ + i * 8 + 4) = (f32x4){(float)t[4], (float)t[5], (float)t[6], (float)t[7]};
         }
         bf16x8 qv[4][2];
 #pragma unroll
@@ -245,16 +252,21 @@ __global__ __launch_bounds__(256) void wg_dec_i2t_rows_kernel(I2tArgs a) {
                 qf[d] = (float)qv[hh][0][d] * 0.25f;               // 1 / sqrt(16)
                 qf[8 + d] = (float)qv[hh][1][d] * 0.25f;
             }
-            float sc[I2_KEYS], m = -1e30f;
+            // the two lanes that share (token, head) -- kg even / odd, lane ^ 16 -- take three keys each and swap the scores:
+            // v_permlane16_swap leaves the even row's value in its first operand and the odd row's in the second, on BOTH lanes
+            float sc[I2_KEYS];
 #pragma unroll
-            for (int j = 0; j < I2_KEYS; ++j) {
-                const bf16x8 k0 = *(const bf16x8*)(ks_ + j * 128 + hoff), k1 = *(const bf16x8*)(ks_ + j * 128 + hoff + 8);
+            for (int t = 0; t < 3; ++t) {
+                const float* kp = ks_ + (3 * (kg & 1) + t) * 128 + hoff;
                 float acc = 0.f;
 #pragma unroll
-                for (int d = 0; d < 8; ++d) acc += qf[d] * (float)k0[d] + qf[8 + d] * (float)k1[d];
-                sc[j] = acc;
-                m = fmaxf(m, acc);
+                for (int d4 = 0; d4 < 4; ++d4) {
+                    const f32x4 kk = *(const f32x4*)(kp + 4 * d4);
+                    acc += qf[4 * d4] * kk[0] + qf[4 * d4 + 1] * kk[1] + qf[4 * d4 + 2] * kk[2] + qf[4 * d4 + 3] * kk[3];
+                }
+                wg_permlane_swap<0>(acc, sc[t], sc[3 + t]);
             }
+            float m = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(sc[4], sc[5]));
             float l = 0.f;
 #pragma unroll
             for (int j = 0; j < I2_KEYS; ++j) {
@@ -265,9 +277,13 @@ __global__ __launch_bounds__(256) void wg_dec_i2t_rows_kernel(I2tArgs a) {
             float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < I2_KEYS; ++j) {
-                const bf16x8 vv = *(const bf16x8*)(vs_ + j * 128 + hoff + 8 * (kg & 1));
+                const float* vp = vs_ + j * 128 + hoff + 8 * (kg & 1);
+                const f32x4 v0 = *(const f32x4*)vp, v1 = *(const f32x4*)(vp + 4);
 #pragma unroll
-                for (int d = 0; d < 8; ++d) o[d] += sc[j] * (float)vv[d];
+                for (int d = 0; d < 4; ++d) {
+                    o[d] += sc[j] * v0[d];
+                    o[4 + d] += sc[j] * v1[d];
+                }
             }
 #pragma unroll
             for (int d = 0; d < 8; ++d) {
@@ -832,7 +848,7 @@ extern "C" int wg_dec_i2t_rows_bf16(const void* q, long ldq, const void* kq, con
         (void)hipFuncSetAttribute((const void*)wg_dec_i2t_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, I2_LDS);
         attr_done = true;
     }
-    const long wgs = (a.rows / 16 + 3) / 4;
-    hipLaunchKernelGGL(wg_dec_i2t_rows_kernel, dim3((unsigned)(wgs < 256 ? wgs : 256)), dim3(256), I2_LDS, (hipStream_t)stream, a);
+    const long wgs = (a.rows / 16 + I2_WAVES - 1) / I2_WAVES;
+    hipLaunchKernelGGL(wg_dec_i2t_rows_kernel, dim3((unsigned)(wgs < 256 ? wgs : 256)), dim3(64 * I2_WAVES), I2_LDS, (hipStream_t)stream, a);
     return wg_check_launch("wg_dec_i2t_rows");
 }
