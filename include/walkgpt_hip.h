@@ -54,6 +54,13 @@ int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, cons
                           long ldr, int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32,
                           int tile_hint, void* stream);
 
+/* Skinny rows (M <= 16: the [SEG] hidden states) with the LayerNorm in front, one launch:
+ *   C = act(LayerNorm(A; gamma, beta, eps) . W^T + bias)     -- the head of text_hidden_fcs[0] (utils/utils_walkgpt.py:321-323).
+ * N % 16 == 0, K % 128 == 0; every workgroup (16 output columns) repeats the exact two-pass row statistics in fp32. */
+int wg_gemm_skinny_ln_supported(int M, int N, int K, long lda, long ldw, long ldc);
+int wg_gemm_skinny_ln_bias_act_bf16(const void* A, long lda, const void* gamma, const void* beta, float eps, const void* W, long ldw,
+                                    const void* bias, void* C, long ldc, int M, int N, int K, int act, int out_f32, void* stream);
+
 /* The same product with the LayerNorm in front of it folded in (image_encoder.py:177-178 norm1 -> attn.qkv, :191 norm2 ->
  * mlp.lin1; HF CLIPEncoderLayer layer_norm1 -> q/k/v_proj, layer_norm2 -> mlp.fc1):
  *   C = act(rstd_m * (A Wg^T - mean_m * colsum) + bias_f32),  Wg = bf16(W * gamma), colsum[n] = sum_k Wg[n,k] (fp32),
@@ -160,22 +167,29 @@ int wg_upscale_mask_bf16(const void* x, long ldx, const void* w1, const void* b1
  *   prompts share one image); partials [P, 8, n_splits, 108] fp32 = {running max[6], sum[6], o[6][16]}, n_splits = ceil(hw / 1024).
  * wg_dec_mlp_partial_f32: slice s of 8 of mlp(x): relu(x lin1[256 s .. +255]^T + b1) lin2[:, 256 s .. +255]^T -> partials [P,8,6,256].
  * wg_dec_heads_f32: output_hypernetworks_mlps[i](x[:, 1 + i]) -> hyper_out [P,4,32]; iou_prediction_head(x[:, 0]) -> iou_out [P,4];
- *   weights: 30 bf16 pointers = (hypernetwork 0..3, IoU head) x layers[0..2] x (weight, bias). */
+ *   weights: 30 bf16 pointers = (hypernetwork 0..3, IoU head) x layers[0..2] x (weight, bias).
+ * Both take an optional `combine` table of 5 pointers {attention partials, out_proj weight [256,128], out_proj bias, LayerNorm gamma, beta}:
+ *   when given, x holds the tokens BEFORE the COMBINE stage and the launch runs that stage itself (one launch less on the chain):
+ *   the MLP kernel writes the tokens after norm2 to x_out (a buffer other than x); the heads kernel applies the final attention's
+ *   out_proj + norm_final_attn to the token row each workgroup needs. */
 int wg_dec_tokens_f32(int stages, int skip_pe, float* queries, float* query_pe, const float* init_tokens, const void* init_prompt,
                       const void* const* weights, int n_weights, float* q_t2i, const float* attn_partials, int n_splits, const float* mlp_partials, void* k_i2t, void* v_i2t, int P,
                       float eps, void* stream);
 int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const void* Vimg, long ld_img, long img_rows_per_prompt, int hw,
                             float* partials, int n_splits, int P, void* stream);
-int wg_dec_mlp_partial_f32(const float* x, const void* lin1_w, const void* lin1_b, const void* lin2_w, float* partials, int P, void* stream);
-int wg_dec_heads_f32(const float* x, const void* const* weights, int n_weights, float* hyper_out, float* iou_out, int P, void* stream);
+int wg_dec_mlp_partial_f32(const float* x, const void* const* combine, int n_splits, float eps, float* x_out, const void* lin1_w,
+                           const void* lin1_b, const void* lin2_w, float* partials, int P, void* stream);
+int wg_dec_heads_f32(const float* x, const void* const* combine, int n_splits, float eps, const void* const* weights, int n_weights,
+                     float* hyper_out, float* iou_out, int P, void* stream);
 
 /* Image side of a TwoWayAttentionBlock after its token stages (transformer.py:173-180), one launch:
  *   keys = norm4(keys + out_proj(softmax(q k^T / 4) v)),  every image token attending to the six prompt tokens.
  * q [rows or hw][ldq] bf16: the q columns (128) of the fused image-side projection; kq / vq [P,6,128] bf16 (SUM_MLP stage above);
  * wo [256,128], bo [256]: cross_attn_image_to_token.out_proj; res: the image tokens themselves (bf16 rows, stride ldr); ln_g / ln_b: norm4;
+ * res_bias [256] bf16 or null: a constant row added to res (the dense no-mask embedding when the caller folded it into the first block);
  * row_mod = hw when q and res hold ONE image shared by all P prompts, 0 when they hold P*hw rows; out [P*hw, 256] bf16.  hw % 16 == 0. */
 int wg_dec_i2t_rows_bf16(const void* q, long ldq, const void* kq, const void* vq, const void* wo, const void* bo, const void* res, long ldr,
-                         int row_mod, const void* ln_g, const void* ln_b, float eps, void* out, int P, int hw, void* stream);
+                         const void* res_bias, int row_mod, const void* ln_g, const void* ln_b, float eps, void* out, int P, int hw, void* stream);
 
 /* Sam.postprocess_masks (sam.py:137-172): bilinear to img_size^2, crop [:in_h,:in_w], bilinear to (out_h,out_w), one pass. */
 int wg_postprocess_masks_f32(const float* low_res, float* out, int N, int low_h, int low_w, int img_size, int in_h,

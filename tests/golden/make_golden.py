@@ -35,9 +35,16 @@ def _import_reference():
     sys.modules["torchvision.ops.boxes"].box_area = None
     sys.modules["torchvision.transforms.functional"].resize = None
     sys.modules["torchvision.transforms.functional"].to_pil_image = None
-    sys.path.insert(0, REF)
-    from model.segment_anything import modeling as sam_modeling
-    from utils import utils_walkgpt
+    # the reference's `model` / `utils` are namespace packages (no __init__.py): this repo's drop-in aliases of the same names are regular
+    # packages and would win wherever they sit on sys.path, so the repo root leaves the path while the reference is imported
+    saved = list(sys.path)
+    sys.path[:] = [REF] + [q for q in saved if os.path.abspath(q or ".") != ROOT]
+    try:
+        from model.segment_anything import modeling as sam_modeling
+        from utils import utils_walkgpt
+    finally:
+        sys.path[:] = saved
+    assert sam_modeling.__file__.startswith(REF) and utils_walkgpt.__file__.startswith(REF)
     return sam_modeling, utils_walkgpt
 
 
@@ -134,10 +141,11 @@ def make_decoder(name):
     with torch.no_grad():
         sparse, dense = pe16(points=None, boxes=None, masks=None, text_embeds=text.bfloat16())
         sparse = sparse.to(torch.bfloat16)   # model/walkgpt.py:521: `sparse_embeddings.to(pred_embeddings[i].dtype)`
-        masks16, _ = dec16(image_embeddings=emb.bfloat16(), image_pe=pe16.get_dense_pe(), sparse_prompt_embeddings=sparse,
+        masks16, iou16 = dec16(image_embeddings=emb.bfloat16(), image_pe=pe16.get_dense_pe(), sparse_prompt_embeddings=sparse,
                            dense_prompt_embeddings=dense, multimask_output=False)
         post16 = sam_modeling.Sam.postprocess_masks(holder, masks16, input_size=c["input_size"], original_size=c["original_size"])
     out["masks_bf16"] = masks16.float().numpy()
+    out["iou_bf16"] = iou16.float().numpy()
     out["post_bf16"] = post16.float().numpy()
     a, b = post.numpy() > 0, post16.float().numpy() > 0
     print("  %s: reference bf16 vs fp32: mask rel L2 %.4f, pixel IoU %.5f, positive fraction %.3f" % (

@@ -124,6 +124,24 @@ def test_gemm_skinny_rows(dev, M, N, K):
     assert (o16.float().cpu() - ref).abs().max().item() <= 3e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 512, 4096), (8, 512, 4096), (16, 512, 5120), (5, 256, 256), (20, 512, 4096)])
+def test_layernorm_linear_skinny(dev, M, N, K):
+    """LayerNorm fused in front of the skinny GEMM (head of text_hidden_fcs[0]); M = 20 takes the two-kernel route."""
+    g = torch.Generator().manual_seed(13)
+    x = (torch.randn(M, K, generator=g) * 2.0 + 0.7).to(torch.bfloat16)
+    x[:, 3] += 40.0                                         # an outlier channel, as LLM hidden states have
+    gam = (1.0 + 0.2 * torch.randn(K, generator=g)).to(torch.bfloat16)
+    bet = (0.1 * torch.randn(K, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16)
+    ln = torch.nn.functional.layer_norm(x.float(), (K,), gam.float(), bet.float(), 1e-5)
+    ref = _ref_act(ln.to(torch.bfloat16).float() @ w.float().t() + b.float(), ops.ACT_GELU)   # (the normalised rows enter the MFMA as bf16)
+    out = ops.layernorm_linear(x.to(dev), gam.to(dev), bet.to(dev), 1e-5, w.to(dev), b.to(dev), act=ops.ACT_GELU, out_f32=True)
+    assert out.shape == (M, N)
+    assert (out.cpu() - ref).abs().max().item() <= 2e-2     # a bf16 ulp of a normalised value (|x^| up to ~20) moving one product
+    assert ((out.cpu() - ref).norm() / ref.norm()).item() < 2e-3
+
+
 @pytest.mark.parametrize("M,D,eps", [(4100, 768, 1e-6), (1025, 1024, 1e-5), (37, 256, 1e-6), (9, 4096, 1e-5),
                                      (3, 5120, 1e-5), (50, 64, 1e-6), (100003, 64, 1e-6), (77, 32, 1e-5), (1001, 128, 1e-5)])
 def test_layernorm_rows(dev, M, D, eps):

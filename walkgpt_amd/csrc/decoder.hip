@@ -185,6 +185,7 @@ struct I2tArgs {
     const bf16* kq; const bf16* vq;     // [P, 6, 128]: projected prompt tokens
     const bf16* wo; const bf16* bo;     // out_proj [256, 128], [256]
     const bf16* res; long ldr;          // the image tokens themselves [rows or hw][ldr]
+    const bf16* res_bias;               // [256] or null: constant row added to res
     int row_mod;                        // hw when q / res are shared by all prompts (one image), 0 otherwise
     const bf16* g; const bf16* b; float eps;
     bf16* out;                          // [P * hw, 256]
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(64 * I2_WAVES) void wg_dec_i2t_rows_kernel(I2tArgs 
     for (int i = threadIdx.x; i < 256 * 16; i += 64 * I2_WAVES) *(bf16x8*)(wos + (i >> 4) * I2_PITCH + 8 * (i & 15)) = *(const bf16x8*)(a.wo + (long)i * 8);
     if (threadIdx.x < 256) {
         const int i = threadIdx.x;
-        vec[i] = (float)a.bo[i];
+        vec[i] = (float)a.bo[i] + (a.res_bias ? (float)a.res_bias[i] : 0.f);
         vec[256 + i] = (float)a.g[i];
         vec[512 + i] = (float)a.b[i];
     }
@@ -410,63 +411,101 @@ struct TokArgs {
     float eps;
 };
 
-// y[r][n] = act(x[r][:] . W[n][:] + b[n]) (+ res[r][n]) for r < rows (<= 6), n < N; W rows are ldw elements apart.  x, y, res: LDS fp32.
-// sh / sl: LDS staging of the bf16 hi / lo split of x, [8][K + 8].  Every thread of the workgroup calls it; visible to all on return.
+// ---- Linear layers on the six token rows ---------------------------------------------------------------------------------------------------
+// One step of the chain = stage the inputs as bf16 hi + lo pairs in LDS (tok_stage), barrier, then ONE pass (tok_mm) over the column blocks
+// of every Linear that reads those inputs -- q, k and v of an attention are one pass, not three: the chain is a sequence of L2 / HBM round
+// trips (stage -> weights -> write), so what counts is the number of passes, not their width.
+struct TokJob {
+    const bf16* sh; const bf16* sl;      // staged input rows [8][K + 8] (hi, lo)
+    LinW W; long ldw; int N;             // y[r][n] = act(x[r][:] . W[n][:] + b[n]) (+ res[r][n]),  W rows ldw elements apart
+    float* y; int ldy; int act;
+    const float* res; int ldres;         // LDS fp32
+};
+
 template <int K, int THREADS = TK_THREADS>
-__device__ void tok_linear(const float* x, int ldx, int rows, LinW W, long ldw, int N, float* y, int ldy, int act, const float* res, int ldres,
-                           bf16* sh, bf16* sl) {
+__device__ __forceinline__ void tok_stage(const float* x, int ldx, const float* add, int rows, bf16* sh, bf16* sl) {
     constexpr int PITCH = K + 8;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < rows * K; i += THREADS) {
+    for (int i = threadIdx.x; i < rows * K; i += THREADS) {
         const int r = i / K, c = i % K;
-        const float v = x[r * ldx + c];
+        const float v = x[r * ldx + c] + (add ? add[r * ldx + c] : 0.f);
         const bf16 hi = (bf16)v;
         sh[r * PITCH + c] = hi;
         sl[r * PITCH + c] = (bf16)(v - (float)hi);
     }
-    __syncthreads();
-    const int lane = tid & 63, wave = tid >> 6;
+}
+
+// The column blocks (16 outputs) of all NJ jobs form one list; a wave takes blocks wave, wave + NWAVES, ... two at a time, so 16 independent
+// 1-KiB weight fragments are in flight per wave.  Rows >= `rows` of the 16-row A operand are zero: a valid row is read and a select applied
+// (no branch inside the loop -- at a control-flow join hipcc waits for every weight load in flight).  Ends with a barrier.
+template <int K, int NJ, int THREADS = TK_THREADS>
+__device__ void tok_mm(const TokJob (&jobs)[NJ], int rows) {
+    constexpr int PITCH = K + 8;
+    constexpr int NWAVES = THREADS / 64;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);    // scalar: block -> job selection below stays in SGPRs
     const int l16 = lane & 15, kg = lane >> 4;
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
-    // two column blocks of 16 per pass: 16 independent 1-KiB weight fragments in flight per wave (the loop is a chain of L2 / HBM round
-    // trips, not of MFMAs)
-    constexpr int NWAVES = THREADS / 64;
     const bool live = l16 < rows;
     const int arow = live ? l16 : 0;
-    for (int nb0 = wave; nb0 * 16 < N; nb0 += 2 * NWAVES) {
-        const int n_a = nb0 * 16 + l16, n_b = (nb0 + NWAVES) * 16 + l16;
-        const bf16* wpa = W.w + (long)(n_a < N ? n_a : N - 1) * ldw + 8 * kg;
-        const bf16* wpb = W.w + (long)(n_b < N ? n_b : N - 1) * ldw + 8 * kg;
+    int total = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) total += (jobs[j].N + 15) / 16;
+    for (int b0 = wave; b0 < total; b0 += 2 * NWAVES) {
+        // block -> (job, column block) by a chain of selects over the statically indexed job table (a run-time index into it would put
+        // the table in scratch memory); a block past the end repeats the pass's first one and is not written
+        TokJob jsel[2];
+        int nb[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int b = b0 + u * NWAVES;
+            if (b >= total) b = b0;
+            jsel[u] = jobs[0];
+            bool go = true;
+#pragma unroll
+            for (int q = 1; q < NJ; ++q) {
+                const int nblk = (jobs[q - 1].N + 15) / 16;
+                go = go && b >= nblk;
+                if (go) { b -= nblk; jsel[u] = jobs[q]; }
+            }
+            nb[u] = b;
+        }
+        const TokJob& ja = jsel[0];
+        const TokJob& jq = jsel[1];
+        const int n_a = nb[0] * 16 + l16, n_b = nb[1] * 16 + l16;
+        const bf16* wpa = ja.W.w + (long)(n_a < ja.N ? n_a : ja.N - 1) * ja.ldw + 8 * kg;
+        const bf16* wpb = jq.W.w + (long)(n_b < jq.N ? n_b : jq.N - 1) * jq.ldw + 8 * kg;
+        const bf16* aha = ja.sh + arow * PITCH + 8 * kg, *ala = ja.sl + arow * PITCH + 8 * kg;
+        const bf16* ahb = jq.sh + arow * PITCH + 8 * kg, *alb = jq.sl + arow * PITCH + 8 * kg;
         f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
         for (int ks = 0; ks < K / 32; ++ks) {
             const bf16x8 fa = *(const bf16x8*)(wpa + 32 * ks);
             const bf16x8 fb = *(const bf16x8*)(wpb + 32 * ks);
-            // rows >= `rows` of the 16-row A operand are zero: read a valid row and select (no branch inside the loop -- at a
-            // control-flow join hipcc waits for every weight load in flight)
-            bf16x8 ah = *(const bf16x8*)(sh + arow * PITCH + 32 * ks + 8 * kg);
-            bf16x8 al = *(const bf16x8*)(sl + arow * PITCH + 32 * ks + 8 * kg);
-            ah = live ? ah : zero;
-            al = live ? al : zero;
-            acc_a = mfma16(ah, fa, acc_a);
-            acc_a = mfma16(al, fa, acc_a);
-            acc_b = mfma16(ah, fb, acc_b);
-            acc_b = mfma16(al, fb, acc_b);
+            bf16x8 h0 = *(const bf16x8*)(aha + 32 * ks), l0 = *(const bf16x8*)(ala + 32 * ks);
+            bf16x8 h1 = *(const bf16x8*)(ahb + 32 * ks), l1 = *(const bf16x8*)(alb + 32 * ks);
+            h0 = live ? h0 : zero; l0 = live ? l0 : zero;
+            h1 = live ? h1 : zero; l1 = live ? l1 : zero;
+            acc_a = mfma16(h0, fa, acc_a);
+            acc_a = mfma16(l0, fa, acc_a);
+            acc_b = mfma16(h1, fb, acc_b);
+            acc_b = mfma16(l1, fb, acc_b);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+            if (u == 1 && b0 + NWAVES >= total) break;
+            const TokJob& jj = u == 0 ? ja : jq;
             const int n = u == 0 ? n_a : n_b;
             const f32x4 acc = u == 0 ? acc_a : acc_b;
-            if (n < N) {
-                const float bias = W.b ? (float)W.b[n] : 0.f;
+            if (n < jj.N) {
+                const float bias = jj.W.b ? (float)jj.W.b[n] : 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 4 * kg + i;
                     if (r < rows) {
                         float v = acc[i] + bias;
-                        if (act == WG_ACT_RELU) v = fmaxf(v, 0.f);
-                        if (res) v += res[r * ldres + n];
-                        y[r * ldy + n] = v;
+                        if (jj.act == WG_ACT_RELU) v = fmaxf(v, 0.f);
+                        if (jj.res) v += jj.res[r * jj.ldres + n];
+                        jj.y[r * jj.ldy + n] = v;
                     }
                 }
             }
@@ -475,10 +514,21 @@ __device__ void tok_linear(const float* x, int ldx, int rows, LinW W, long ldw, 
     __syncthreads();
 }
 
+// one Linear: y = act(x W^T + b) (+ res); x, y, res in LDS (fp32), every thread of the workgroup calls it, visible to all on return
+template <int K, int THREADS = TK_THREADS>
+__device__ void tok_linear(const float* x, int ldx, int rows, LinW W, long ldw, int N, float* y, int ldy, int act, const float* res, int ldres,
+                           bf16* sh, bf16* sl) {
+    tok_stage<K, THREADS>(x, ldx, nullptr, rows, sh, sl);
+    __syncthreads();
+    const TokJob job[1] = {{sh, sl, W, ldw, N, y, ldy, act, res, ldres}};
+    tok_mm<K, 1, THREADS>(job, rows);
+}
+
 // LayerNorm over the last dimension (256) of `rows` LDS rows, in place; one wave per row.
+template <int THREADS = TK_THREADS>
 __device__ void tok_layernorm(float* x, int rows, NormW nw, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = wave; r < rows; r += TK_THREADS / 64) {
+    for (int r = wave; r < rows; r += THREADS / 64) {
         float v[4], s = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -496,12 +546,6 @@ __device__ void tok_layernorm(float* x, int rows, NormW nw, float eps) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) x[r * TK_C + lane + 64 * j] = v[j] * rstd * (float)nw.g[lane + 64 * j] + (float)nw.b[lane + 64 * j];
     }
-    __syncthreads();
-}
-
-// out[r][:] = a[r][:] + b[r][:]  (6 x 256)
-__device__ void tok_add(float* out, const float* a, const float* b) {
-    for (int i = threadIdx.x; i < TK_N * TK_C; i += TK_THREADS) out[i] = a[i] + b[i];
     __syncthreads();
 }
 
@@ -537,9 +581,48 @@ __device__ void tok_self_attention(const float* q, const float* k, const float* 
     __syncthreads();
 }
 
+// COMBINE for token rows row0 .. row0 + rows - 1 of prompt p: merge the key splits of every (head, row),
+//     o = sum_s o_s e^(m_s - M) / sum_s l_s e^(m_s - M),
+// then x = LayerNorm(x + out_proj(o)).  x: LDS [rows][256] (residual in, result out); ao: LDS scratch [rows][128].
+struct CombineW { const float* part; int n_splits; LinW wo; NormW nw; float eps; };
+template <int THREADS = TK_THREADS>
+__device__ void tok_combine(const CombineW& c, long p, int row0, int rows, float* x, float* ao, bf16* sh, bf16* sl) {
+    for (int i = threadIdx.x; i < 8 * rows * 16; i += THREADS) {
+        const int d = i & 15, r = (i >> 4) % rows, h = i / (16 * rows), t = row0 + r;
+        const float* pp = c.part + (p * 8 + h) * c.n_splits * TK_PART;
+        float M = -1e30f, L = 0.f, o = 0.f;
+        for (int s0 = 0; s0 < c.n_splits; s0 += 4) {        // four splits' loads in flight at a time
+            float mm[4], ll[4], oo[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool in = s0 + u < c.n_splits;
+                const float* q_ = pp + (in ? s0 + u : s0) * TK_PART;
+                mm[u] = in ? q_[t] : -1e30f;
+                ll[u] = in ? q_[TK_N + t] : 0.f;
+                oo[u] = in ? q_[2 * TK_N + t * 16 + d] : 0.f;
+            }
+            const float Mn = fmaxf(fmaxf(fmaxf(mm[0], mm[1]), fmaxf(mm[2], mm[3])), M);
+            const float sc = __expf(M - Mn);
+            L *= sc;
+            o *= sc;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float w = __expf(mm[u] - Mn);
+                L += ll[u] * w;
+                o += oo[u] * w;
+            }
+            M = Mn;
+        }
+        ao[r * 128 + h * 16 + d] = o / L;
+    }
+    __syncthreads();
+    tok_linear<128, THREADS>(ao, 128, rows, c.wo, 128, TK_C, x, TK_C, 0, x, TK_C, sh, sl);
+    tok_layernorm<THREADS>(x, rows, c.nw, c.eps);
+}
+
 __global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
     __shared__ float qs[TK_N * TK_C], pes[TK_N * TK_C], t0[TK_N * TK_C], t1[TK_N * TK_C], t2[TK_N * TK_C], t3[TK_N * TK_C];
-    __shared__ __attribute__((aligned(16))) bf16 sh[8 * (TK_C + 8)], sl[8 * (TK_C + 8)];
+    __shared__ __attribute__((aligned(16))) bf16 sh[2][8 * (TK_C + 8)], sl[2][8 * (TK_C + 8)];
     const int p = blockIdx.x;
     const int tid = threadIdx.x;
     for (int i = tid; i < TK_N * TK_C; i += TK_THREADS) {
@@ -562,11 +645,13 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
     }
     __syncthreads();
     if (a.stages & ST_SUM_MLP) {
-        // ---- norm3, then k / v of the image -> token attention (:172-178) ----------------------------------------------------------------
+        // ---- norm3, then k / v of the image -> token attention (:172-178), one pass ----------------------------------------------------------
         tok_layernorm(qs, TK_N, a.norm3, a.eps);
-        tok_add(t3, qs, pes);
-        tok_linear<TK_C>(t3, TK_C, TK_N, a.i2t_k, TK_C, 128, t0, 128, 0, nullptr, 0, sh, sl);
-        tok_linear<TK_C>(qs, TK_C, TK_N, a.i2t_v, TK_C, 128, t1, 128, 0, nullptr, 0, sh, sl);
+        tok_stage<TK_C>(qs, TK_C, pes, TK_N, sh[0], sl[0]);
+        tok_stage<TK_C>(qs, TK_C, nullptr, TK_N, sh[1], sl[1]);
+        __syncthreads();
+        const TokJob kv[2] = {{sh[0], sl[0], a.i2t_k, TK_C, 128, t0, 128, 0, nullptr, 0}, {sh[1], sl[1], a.i2t_v, TK_C, 128, t1, 128, 0, nullptr, 0}};
+        tok_mm<TK_C, 2>(kv, TK_N);
         for (int i = tid; i < TK_N * 128; i += TK_THREADS) {
             a.k_i2t[(long)p * TK_N * 128 + i] = (bf16)t0[i];
             a.v_i2t[(long)p * TK_N * 128 + i] = (bf16)t1[i];
@@ -574,60 +659,30 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
         __syncthreads();
     }
     if (a.stages & ST_SELF) {
-        // ---- self attention (:153-160): layer 0 replaces the queries and skips the positional term --------------------------------------
-        if (a.skip_pe) {
-            tok_linear<TK_C>(qs, TK_C, TK_N, a.self_attn.q, TK_C, TK_C, t0, TK_C, 0, nullptr, 0, sh, sl);
-            tok_linear<TK_C>(qs, TK_C, TK_N, a.self_attn.k, TK_C, TK_C, t1, TK_C, 0, nullptr, 0, sh, sl);
-        } else {
-            tok_add(t3, qs, pes);
-            tok_linear<TK_C>(t3, TK_C, TK_N, a.self_attn.q, TK_C, TK_C, t0, TK_C, 0, nullptr, 0, sh, sl);
-            tok_linear<TK_C>(t3, TK_C, TK_N, a.self_attn.k, TK_C, TK_C, t1, TK_C, 0, nullptr, 0, sh, sl);
-        }
-        tok_linear<TK_C>(qs, TK_C, TK_N, a.self_attn.v, TK_C, TK_C, t2, TK_C, 0, nullptr, 0, sh, sl);
+        // ---- self attention (:153-160): layer 0 replaces the queries and skips the positional term; q, k, v in one pass -----------------------
+        tok_stage<TK_C>(qs, TK_C, a.skip_pe ? nullptr : pes, TK_N, sh[0], sl[0]);
+        tok_stage<TK_C>(qs, TK_C, nullptr, TK_N, sh[1], sl[1]);
+        __syncthreads();
+        const TokJob qkv[3] = {{sh[0], sl[0], a.self_attn.q, TK_C, TK_C, t0, TK_C, 0, nullptr, 0},
+                               {sh[0], sl[0], a.self_attn.k, TK_C, TK_C, t1, TK_C, 0, nullptr, 0},
+                               {sh[1], sl[1], a.self_attn.v, TK_C, TK_C, t2, TK_C, 0, nullptr, 0}};
+        tok_mm<TK_C, 3>(qkv, TK_N);
         tok_self_attention(t0, t1, t2, t3);
-        tok_linear<TK_C>(t3, TK_C, TK_N, a.self_attn.o, TK_C, TK_C, qs, TK_C, 0, a.skip_pe ? nullptr : qs, TK_C, sh, sl);
+        tok_linear<TK_C>(t3, TK_C, TK_N, a.self_attn.o, TK_C, TK_C, qs, TK_C, 0, a.skip_pe ? nullptr : qs, TK_C, sh[0], sl[0]);
         tok_layernorm(qs, TK_N, a.norm1, a.eps);
     }
     if (a.stages & ST_Q_T2I) {
         // ---- q of the token -> image attention (:162-165; tail: :96-101), internal width 128 ------------------------------------------------
-        tok_add(t3, qs, pes);
-        tok_linear<TK_C>(t3, TK_C, TK_N, a.t2i_q, TK_C, 128, t0, 128, 0, nullptr, 0, sh, sl);
+        tok_stage<TK_C>(qs, TK_C, pes, TK_N, sh[0], sl[0]);
+        __syncthreads();
+        const TokJob qj[1] = {{sh[0], sl[0], a.t2i_q, TK_C, 128, t0, 128, 0, nullptr, 0}};
+        tok_mm<TK_C, 1>(qj, TK_N);
         for (int i = tid; i < TK_N * 128; i += TK_THREADS) a.q_t2i[(long)p * TK_N * 128 + i] = t0[i];
         __syncthreads();
     }
     if (a.stages & ST_COMBINE) {
-        // ---- merge the key splits of every (head, query): o = sum_s o_s e^(m_s - M) / sum_s l_s e^(m_s - M) -----------------------------------
-        for (int i = tid; i < 8 * TK_N * 16; i += TK_THREADS) {
-            const int d = i & 15, t = (i >> 4) % TK_N, h = i / (16 * TK_N);
-            const float* pp = a.attn_part + ((long)p * 8 + h) * a.n_splits * TK_PART;
-            float M = -1e30f, L = 0.f, o = 0.f;
-            for (int s0 = 0; s0 < a.n_splits; s0 += 4) {        // four splits' loads in flight at a time
-                float mm[4], ll[4], oo[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const bool in = s0 + u < a.n_splits;
-                    const float* q_ = pp + (in ? s0 + u : s0) * TK_PART;
-                    mm[u] = in ? q_[t] : -1e30f;
-                    ll[u] = in ? q_[TK_N + t] : 0.f;
-                    oo[u] = in ? q_[2 * TK_N + t * 16 + d] : 0.f;
-                }
-                const float Mn = fmaxf(fmaxf(fmaxf(mm[0], mm[1]), fmaxf(mm[2], mm[3])), M);
-                const float sc = __expf(M - Mn);
-                L *= sc;
-                o *= sc;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const float w = __expf(mm[u] - Mn);
-                    L += ll[u] * w;
-                    o += oo[u] * w;
-                }
-                M = Mn;
-            }
-            t1[t * 128 + h * 16 + d] = o / L;
-        }
-        __syncthreads();
-        tok_linear<128>(t1, 128, TK_N, a.t2i_o, 128, TK_C, qs, TK_C, 0, qs, TK_C, sh, sl);
-        tok_layernorm(qs, TK_N, a.norm2, a.eps);
+        const CombineW c{a.attn_part, a.n_splits, a.t2i_o, a.norm2, a.eps};
+        tok_combine(c, p, 0, TK_N, qs, t1, sh[0], sl[0]);
     }
     for (int i = tid; i < TK_N * TK_C; i += TK_THREADS) a.queries[(long)p * TK_N * TK_C + i] = qs[i];
 }
@@ -726,14 +781,21 @@ __global__ __launch_bounds__(64 * AT_WAVES) void wg_dec_attn_partial_kernel(Attn
     }
 }
 
-// one slice (256 hidden units) of the MLP of a prompt's six tokens: part[p][slice] = relu(x lin1_s^T + b1_s) lin2[:, slice]^T
-struct MlpArgs { const float* x; LinW lin1; const bf16* lin2_w; float* part; };
+// one slice (256 hidden units) of the MLP of a prompt's six tokens: part[p][slice] = relu(x lin1_s^T + b1_s) lin2[:, slice]^T.
+// With `comb.part` set, x is first taken through COMBINE (every slice repeats it: 6 x 128 x 256 MACs against a launch saved) and slice 0
+// writes it to x_out -- a buffer other than x_in, which the other slices are still reading.
+struct MlpArgs { const float* x; CombineW comb; float* x_out; LinW lin1; const bf16* lin2_w; float* part; };
 __global__ __launch_bounds__(TK_THREADS) void wg_dec_mlp_partial_kernel(MlpArgs a) {
     __shared__ float xs[TK_N * TK_C], hs[TK_N * TK_C], ys[TK_N * TK_C];
     __shared__ __attribute__((aligned(16))) bf16 sh[8 * (TK_C + 8)], sl[8 * (TK_C + 8)];
     const int slice = blockIdx.x % TK_SLICES, p = blockIdx.x / TK_SLICES;
     for (int i = threadIdx.x; i < TK_N * TK_C; i += TK_THREADS) xs[i] = a.x[(long)p * TK_N * TK_C + i];
     __syncthreads();
+    if (a.comb.part) {
+        tok_combine(a.comb, p, 0, TK_N, xs, hs, sh, sl);
+        if (slice == 0)
+            for (int i = threadIdx.x; i < TK_N * TK_C; i += TK_THREADS) a.x_out[(long)p * TK_N * TK_C + i] = xs[i];
+    }
     const LinW l1{a.lin1.w + (long)slice * 256 * TK_C, a.lin1.b + slice * 256};
     tok_linear<TK_C>(xs, TK_C, TK_N, l1, TK_C, 256, hs, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
     const LinW l2{a.lin2_w + slice * 256, nullptr};                  // columns slice*256 .. +255 of lin2.weight [256, 2048]
@@ -742,15 +804,18 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_mlp_partial_kernel(MlpArgs 
     for (int i = threadIdx.x; i < TK_N * TK_C; i += TK_THREADS) out[i] = ys[i];
 }
 
-// hypernetwork MLPs on the mask tokens (rows 1..4), IoU head on row 0 (mask_decoder.py:146-160): one (prompt, head) pair per workgroup
-struct HeadArgs { const float* x; LinW mlp[5][3]; float* hyper_out; float* iou_out; };
+// hypernetwork MLPs on the mask tokens (rows 1..4), IoU head on row 0 (mask_decoder.py:146-160): one (prompt, head) pair per workgroup.
+// With `comb.part` set, the workgroup first takes ITS token row through COMBINE (final attention out_proj + norm_final_attn).
+struct HeadArgs { const float* x; CombineW comb; LinW mlp[5][3]; float* hyper_out; float* iou_out; };
 __global__ __launch_bounds__(256) void wg_dec_heads_kernel(HeadArgs a) {
     __shared__ float x0[TK_C], x1[TK_C], x2[TK_C];
     __shared__ __attribute__((aligned(16))) bf16 sh[8 * (TK_C + 8)], sl[8 * (TK_C + 8)];
     const int i = blockIdx.x % 5, p = blockIdx.x / 5;
-    const float* x = a.x + ((long)p * TK_N + (i < 4 ? 1 + i : 0)) * TK_C;
+    const int row = i < 4 ? 1 + i : 0;
+    const float* x = a.x + ((long)p * TK_N + row) * TK_C;
     for (int c = threadIdx.x; c < TK_C; c += 256) x0[c] = x[c];
     __syncthreads();
+    if (a.comb.part) tok_combine<256>(a.comb, p, row, 1, x0, x1, sh, sl);
     tok_linear<TK_C, 256>(x0, TK_C, 1, a.mlp[i][0], TK_C, TK_C, x1, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
     tok_linear<TK_C, 256>(x1, TK_C, 1, a.mlp[i][1], TK_C, TK_C, x2, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
     tok_linear<TK_C, 256>(x2, TK_C, 1, a.mlp[i][2], TK_C, i < 4 ? 32 : 4, x0, TK_C, 0, nullptr, 0, sh, sl);
@@ -804,23 +869,43 @@ extern "C" int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const v
     return wg_check_launch("wg_dec_attn_partial");
 }
 
-// x [P,6,256] fp32 (the tokens after norm2); lin1 [2048,256] + bias, lin2 weight [256,2048] (bias added by the SUM_MLP stage);
-// partials [P, 8, 6, 256] fp32.
-extern "C" int wg_dec_mlp_partial_f32(const float* x, const void* lin1_w, const void* lin1_b, const void* lin2_w, float* partials, int P,
-                                      void* stream) {
+// combine: 6 pointers {attention partials (fp32 [P,8,n_splits,108]), out_proj weight [256,128], bias, LayerNorm gamma, beta} or null
+static bool wg_parse_combine(const void* const* combine, int n_splits, float eps, CombineW& c) {
+    c = CombineW{nullptr, 0, LinW{nullptr, nullptr}, NormW{nullptr, nullptr}, eps};
+    if (!combine) return true;
+    for (int i = 0; i < 5; ++i)
+        if (!combine[i]) return false;
+    if (n_splits <= 0 || ((uintptr_t)combine[1] & 15)) return false;
+    c.part = (const float*)combine[0]; c.n_splits = n_splits;
+    c.wo = LinW{(const bf16*)combine[1], (const bf16*)combine[2]};
+    c.nw = NormW{(const bf16*)combine[3], (const bf16*)combine[4]};
+    return true;
+}
+
+// x [P,6,256] fp32; lin1 [2048,256] + bias, lin2 weight [256,2048] (bias added by the SUM_MLP stage); partials [P, 8, 6, 256] fp32.
+// combine == null: x holds the tokens after norm2.  combine != null (5 pointers: attention partials, token->image out_proj weight, bias,
+// norm2 gamma, beta): x holds the tokens BEFORE the COMBINE stage, which this launch runs itself; the tokens after norm2 go to x_out
+// (a buffer other than x).
+extern "C" int wg_dec_mlp_partial_f32(const float* x, const void* const* combine, int n_splits, float eps, float* x_out, const void* lin1_w,
+                                      const void* lin1_b, const void* lin2_w, float* partials, int P, void* stream) {
     WG_REQUIRE(x && lin1_w && lin1_b && lin2_w && partials && P > 0, "dec_mlp_partial: bad arguments");
     WG_REQUIRE((((uintptr_t)lin1_w | (uintptr_t)lin2_w) & 15) == 0, "dec_mlp_partial: misaligned weights");
-    MlpArgs a{x, LinW{(const bf16*)lin1_w, (const bf16*)lin1_b}, (const bf16*)lin2_w, partials};
+    MlpArgs a{x, CombineW{}, x_out, LinW{(const bf16*)lin1_w, (const bf16*)lin1_b}, (const bf16*)lin2_w, partials};
+    WG_REQUIRE(wg_parse_combine(combine, n_splits, eps, a.comb), "dec_mlp_partial: bad combine table");
+    WG_REQUIRE(!combine || (x_out && x_out != x), "dec_mlp_partial: combine needs x_out, distinct from x");
     hipLaunchKernelGGL(wg_dec_mlp_partial_kernel, dim3((unsigned)(P * TK_SLICES)), dim3(TK_THREADS), 0, (hipStream_t)stream, a);
     return wg_check_launch("wg_dec_mlp_partial");
 }
 
-// x [P,6,256] fp32 (the tokens after norm_final_attn); weights: 30 bf16 pointers = 5 MLPs (hypernetwork 0..3, IoU head) x 3 layers x
-// (weight, bias) -> hyper_out [P,4,32], iou_out [P,4] fp32.
-extern "C" int wg_dec_heads_f32(const float* x, const void* const* weights, int n_weights, float* hyper_out, float* iou_out, int P, void* stream) {
+// x [P,6,256] fp32; weights: 30 bf16 pointers = 5 MLPs (hypernetwork 0..3, IoU head) x 3 layers x (weight, bias) -> hyper_out [P,4,32],
+// iou_out [P,4] fp32.  combine == null: x holds the tokens after norm_final_attn; otherwise (table as above, with the final attention's
+// out_proj and norm_final_attn) x holds them before the final COMBINE, which every workgroup runs on its own token row.
+extern "C" int wg_dec_heads_f32(const float* x, const void* const* combine, int n_splits, float eps, const void* const* weights, int n_weights,
+                                float* hyper_out, float* iou_out, int P, void* stream) {
     WG_REQUIRE(x && weights && n_weights == 30 && hyper_out && iou_out && P > 0, "dec_heads: bad arguments");
     HeadArgs a{};
     a.x = x; a.hyper_out = hyper_out; a.iou_out = iou_out;
+    WG_REQUIRE(wg_parse_combine(combine, n_splits, eps, a.comb), "dec_heads: bad combine table");
     for (int i = 0; i < 5; ++i)
         for (int j = 0; j < 3; ++j) {
             const void* wp = weights[(i * 3 + j) * 2];
@@ -835,13 +920,13 @@ extern "C" int wg_dec_heads_f32(const float* x, const void* const* weights, int 
 // (wg_dec_tokens_f32, SUM_MLP), out_proj [256,128] + bias, res = the image tokens (bf16 rows, stride ldr), norm4 -> out [P*hw, 256] bf16.
 // row_mod = hw when q and res hold ONE image shared by all P prompts, 0 when they have P*hw rows.
 extern "C" int wg_dec_i2t_rows_bf16(const void* q, long ldq, const void* kq, const void* vq, const void* wo, const void* bo, const void* res,
-                                    long ldr, int row_mod, const void* ln_g, const void* ln_b, float eps, void* out, int P, int hw, void* stream) {
+                                    long ldr, const void* res_bias, int row_mod, const void* ln_g, const void* ln_b, float eps, void* out, int P, int hw, void* stream) {
     WG_REQUIRE(q && kq && vq && wo && bo && res && ln_g && ln_b && out, "dec_i2t_rows: null operand");
     WG_REQUIRE(P > 0 && hw > 0 && hw % 16 == 0 && (row_mod == 0 || row_mod == hw), "dec_i2t_rows: hw must be a positive multiple of 16");
     WG_REQUIRE(ldq % 8 == 0 && ldr % 4 == 0, "dec_i2t_rows: misaligned leading dimension");
     WG_REQUIRE((((uintptr_t)q | (uintptr_t)kq | (uintptr_t)vq | (uintptr_t)wo) & 15) == 0 && (((uintptr_t)res | (uintptr_t)out) & 7) == 0,
                "dec_i2t_rows: misaligned operand");
-    I2tArgs a{(const bf16*)q, ldq, (const bf16*)kq, (const bf16*)vq, (const bf16*)wo, (const bf16*)bo, (const bf16*)res, ldr, row_mod,
+    I2tArgs a{(const bf16*)q, ldq, (const bf16*)kq, (const bf16*)vq, (const bf16*)wo, (const bf16*)bo, (const bf16*)res, ldr, (const bf16*)res_bias, row_mod,
               (const bf16*)ln_g, (const bf16*)ln_b, eps, (bf16*)out, (long)P * hw, hw};
     static bool attr_done = false;
     if (!attr_done) {

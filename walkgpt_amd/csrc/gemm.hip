@@ -36,6 +36,9 @@ struct GemmArgs {
     unsigned c_bytes, r_bytes;   // extents of C and R for the staged epilogue's buffer descriptors (0: not addressable in 32 bits)
     const float* scale_a;        // fp8 operands (wg_gemm_fp8_bias_act): per-row scale of A [M] and per-output-channel scale of W [N];
     const float* scale_w;        //   A, W then point at e4m3 bytes and lda / ldw / K count PAIRS of bytes (see the entry point)
+    const bf16* sk_gamma;        // skinny kernel only: LayerNorm(A) applied to the rows on their way into the MFMA (gamma, beta [K], eps)
+    const bf16* sk_beta;
+    float sk_eps;
 };
 
 // Linear tile index -> (tile row, tile column).  With col_block = c > 0 the grid is walked in blocks of c tile columns, row-major
@@ -902,28 +905,74 @@ __global__ __launch_bounds__(256) void wg_gemm_rowwave_kernel(GemmArgs g) {
 // weight matrix, and a compute unit ingests ~30 GB/s with plain loads, so a 128-wide tile (32 workgroups for N = 4096) leaves the matrix
 // behind 32 straws: 42 us for the 32 MB of text_hidden_fcs[0].  Here one workgroup owns 16 output columns, its four waves split K,
 // and the rows ride as a 16-row MFMA A operand (rows >= M zero); the partial sums meet in LDS.
-__global__ __launch_bounds__(256) void wg_gemm_skinny_kernel(GemmArgs g) {
-    __shared__ f32x4 red[3][64];
+// NW waves split K: 4 for short rows, 16 at K >= 2048 -- what a wave can keep in flight (8 fragments of 1 KB) over the ~2 us a miss takes
+// is ~4 GB/s, so the 4 MB of text_hidden_fcs[0] (32 workgroups at N = 512) need every wave the compute units can hold.
+// LN: the rows go through LayerNorm (two exact passes over the row for mean and variance, fp32) on their way into the MFMA -- every
+// workgroup repeats the statistics of the <= 16 rows (they are L2-resident and tiny next to its weight columns), which saves the separate
+// LayerNorm launch in front of text_hidden_fcs[0] (utils_walkgpt.py:321-323).
+template <int NW, bool LN>
+__global__ __launch_bounds__(64 * NW) void wg_gemm_skinny_kernel(GemmArgs g) {
+    __shared__ f32x4 red[NW - 1][64];
+    __shared__ float stat[NW][16];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l16 = lane & 15, kg = lane >> 4;
     const int n = blockIdx.x * 16 + l16;                 // N % 16 == 0
-    const int kw = g.K / 4;                              // K % 128 == 0: every wave takes whole 32-deep MFMA steps
+    const int kw = g.K / NW;                             // K % (32 NW) == 0: every wave takes whole 32-deep MFMA steps
     const bool live = l16 < g.M;
     const bf16* wp = g.W + (long)n * g.ldw + wave * kw + 8 * kg;
     const bf16* ap = g.A + (long)(live ? l16 : 0) * g.lda + wave * kw + 8 * kg;
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+    float mean = 0.f, rstd = 1.f;
+    if constexpr (LN) {
+        // sum over the wave's K slice of row l16 (lanes kg = 0..3 hold interleaved 8-element pieces), then over the waves through LDS
+        auto row_total = [&](float v) {
+            float x, y;
+            wg_permlane_swap<0>(v, x, y); v = x + y;
+            wg_permlane_swap<1>(v, x, y); v = x + y;
+            __syncthreads();                             // (stat is reused by the second statistic)
+            if (kg == 0) stat[wave][l16] = v;
+            __syncthreads();
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += stat[w][l16];
+            return t;
+        };
+        float s = 0.f;
+        for (int k = 0; k < kw; k += 32) {
+            const bf16x8 a = *(const bf16x8*)(ap + k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)a[j];
+        }
+        mean = row_total(s) / (float)g.K;
+        float sq = 0.f;
+        for (int k = 0; k < kw; k += 32) {
+            const bf16x8 a = *(const bf16x8*)(ap + k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = (float)a[j] - mean;
+                sq += d * d;
+            }
+        }
+        rstd = 1.0f / sqrtf(row_total(sq) / (float)g.K + g.sk_eps);
+    }
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
     for (int k = 0; k < kw; k += 32) {
         const bf16x8 b = *(const bf16x8*)(wp + k);
         bf16x8 a = *(const bf16x8*)(ap + k);
+        if constexpr (LN) {
+            const bf16x8 gm = *(const bf16x8*)(g.sk_gamma + wave * kw + 8 * kg + k), bt = *(const bf16x8*)(g.sk_beta + wave * kw + 8 * kg + k);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = (bf16)(((float)a[j] - mean) * rstd * (float)gm[j] + (float)bt[j]);
+        }
         a = live ? a : zero;                             // select, not branch: a join inside the loop would serialise the loads
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
     }
     if (wave) red[wave - 1][lane] = acc;
     __syncthreads();
     if (wave) return;
-    acc += red[0][lane] + red[1][lane] + red[2][lane];
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w) acc += red[w][lane];
     const float bias = g.bias ? (float)g.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                        // accumulator: rows 4*kg + i of column l16
@@ -1352,13 +1401,28 @@ extern "C" int wg_gemm_pick_tile(int M, int N) { return wg_gemm_pick_tile_ex(M, 
 
 static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const void* bias, const void* residual, long ldr,
                             int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32, int tile_hint,
-                            const float* ln_stats, const float* ln_s, const float* ln_b, void* stream);
+                            const float* ln_stats, const float* ln_s, const float* ln_b, void* stream, const bf16* sk_gamma = nullptr,
+                            const bf16* sk_beta = nullptr, float sk_eps = 0.f);
 
 extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, const void* bias,
                                      const void* residual, long ldr, int res_row_mod, void* C, long ldc, int M, int N,
                                      int K, int act, int out_f32, int tile_hint, void* stream) {
     return wg_gemm_dispatch(A, lda, W, ldw, bias, residual, ldr, res_row_mod, C, ldc, M, N, K, act, out_f32, tile_hint, nullptr, nullptr,
                             nullptr, stream);
+}
+
+// Skinny rows with the LayerNorm in front: C = act(LayerNorm(A; gamma, beta, eps) . W^T + b) for M <= 16, N % 16 == 0, K % 128 == 0 (the
+// head of text_hidden_fcs[0], utils_walkgpt.py:321-323); wg_gemm_skinny_ln_supported() tells the caller whether the shape qualifies.
+extern "C" int wg_gemm_skinny_ln_supported(int M, int N, int K, long lda, long ldw, long ldc) {
+    return (M >= 1 && M <= 16 && N % 16 == 0 && K % 128 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0) ? 1 : 0;
+}
+extern "C" int wg_gemm_skinny_ln_bias_act_bf16(const void* A, long lda, const void* gamma, const void* beta, float eps, const void* W, long ldw,
+                                               const void* bias, void* C, long ldc, int M, int N, int K, int act, int out_f32, void* stream) {
+    WG_REQUIRE(gamma && beta && (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "gemm_skinny_ln: null or misaligned LayerNorm operand");
+    WG_REQUIRE(wg_gemm_skinny_ln_supported(M, N, K, lda, ldw, ldc) && (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) == 0,
+               "gemm_skinny_ln: shape M=%d N=%d K=%d is not a skinny one", M, N, K);
+    return wg_gemm_dispatch(A, lda, W, ldw, bias, nullptr, 0, 0, C, ldc, M, N, K, act, out_f32, 5, nullptr, nullptr, nullptr, stream,
+                            (const bf16*)gamma, (const bf16*)beta, eps);
 }
 
 // C = act(LayerNorm(A) . W^T + b) with the LayerNorm folded in: A = the raw rows, Wg = W * gamma (bf16), colsum[n] = sum_k Wg[n,k],
@@ -1379,7 +1443,8 @@ extern "C" int wg_gemm_ln_bias_act_bf16(const void* A, long lda, const void* Wg,
 
 static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const void* bias, const void* residual, long ldr,
                             int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32, int tile_hint,
-                            const float* ln_stats, const float* ln_s, const float* ln_b, void* stream) {
+                            const float* ln_stats, const float* ln_s, const float* ln_b, void* stream, const bf16* sk_gamma,
+                            const bf16* sk_beta, float sk_eps) {
     WG_REQUIRE(A && W && C, "gemm: null operand");
     WG_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
     WG_REQUIRE(act >= 0 && act <= 3, "gemm: bad activation %d", act);
@@ -1393,6 +1458,7 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
     g.col_block = 0;
     g.ln_stats = ln_stats; g.ln_s = ln_s; g.ln_b = ln_b;
     g.scale_a = g.scale_w = nullptr;
+    g.sk_gamma = sk_gamma; g.sk_beta = sk_beta; g.sk_eps = sk_eps;
     {   // byte extents for the staged epilogue's buffer descriptors (it addresses C and R with 32-bit byte offsets)
         const long cb = ((long)(M - 1) * ldc + N) * 2;
         const long rrows = res_row_mod > 0 ? (res_row_mod < M ? res_row_mod : M) : M;
@@ -1421,7 +1487,11 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
     if (tile == 12 && !(can_stage && M >= 128 && M % 128 >= 1 && M % 128 <= 16)) tile = 1;
     switch (tile) {
         case 5:
-            hipLaunchKernelGGL(wg_gemm_skinny_kernel, dim3(N / 16), dim3(256), 0, st, g);
+            if (g.sk_gamma) {
+                if (K >= 2048 && K % 512 == 0) hipLaunchKernelGGL((wg_gemm_skinny_kernel<16, true>), dim3(N / 16), dim3(1024), 0, st, g);
+                else hipLaunchKernelGGL((wg_gemm_skinny_kernel<4, true>), dim3(N / 16), dim3(256), 0, st, g);
+            } else if (K >= 2048 && K % 512 == 0) hipLaunchKernelGGL((wg_gemm_skinny_kernel<16, false>), dim3(N / 16), dim3(1024), 0, st, g);
+            else hipLaunchKernelGGL((wg_gemm_skinny_kernel<4, false>), dim3(N / 16), dim3(256), 0, st, g);
             return wg_check_launch("wg_gemm_bias_act_bf16(skinny)");
         case 12: return launch_tail(g, st);                            // 128x128 tiles, last row tile absorbs M % 128 <= 16 rows
         case 11: return launch_persist<128, 128, 2, 2>(g, st);         // persistent 128x128 tiles, 2 workgroups / CU
@@ -1459,6 +1529,7 @@ extern "C" int wg_gemm_fp8_bias_act(const void* Aq, long lda, const float* scale
     g.col_block = 0;
     g.ln_stats = nullptr; g.ln_s = nullptr; g.ln_b = nullptr;
     g.scale_a = scale_a; g.scale_w = scale_w;
+    g.sk_gamma = g.sk_beta = nullptr; g.sk_eps = 0.f;
     const long cb = ((long)(M - 1) * ldc + N) * 2;
     const long rrows = res_row_mod > 0 ? (res_row_mod < M ? res_row_mod : M) : M;
     const long rb = residual ? ((rrows - 1) * ldr + N) * 2 : 0;

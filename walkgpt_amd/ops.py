@@ -168,6 +168,29 @@ def ln_linear(x, fold, eps, act=ACT_NONE, tail_tiles=False):
     return out
 
 
+def layernorm_linear(x, gamma, beta, eps, weight, bias=None, act=ACT_NONE, out_f32=False):
+    """act(LayerNorm(x) @ weight.T + bias) for a handful of rows (M <= 16: the [SEG] hidden states into text_hidden_fcs) in one launch
+    (wg_gemm_skinny_ln_bias_act_bf16); other shapes run LayerNorm and the GEMM as two kernels."""
+    _need_gpu(x, gamma, beta, weight, bias)
+    assert x.dtype == _BF16 and weight.dtype == _BF16 and gamma.dtype == _BF16 and beta.dtype == _BF16
+    M, K, lda = _rows(x)
+    N = weight.shape[0]
+    L = _lib.lib()
+    if _FORCE_TILE or not L.wg_gemm_skinny_ln_supported(M, N, K, lda, weight.stride(0), N):
+        return linear(layernorm(x, gamma, beta, eps), weight, bias, act=act, out_f32=out_f32)
+    assert weight.shape[1] == K and weight.stride(1) == 1 and gamma.numel() == K and beta.numel() == K
+    out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32 if out_f32 else _BF16)
+    ev = _timed(5, M, N, K)
+    if ev is not None:
+        ev[0].record()
+    rc = L.wg_gemm_skinny_ln_bias_act_bf16(x.data_ptr(), lda, gamma.data_ptr(), beta.data_ptr(), float(eps), weight.data_ptr(),
+                                           weight.stride(0), _ptr(bias), out.data_ptr(), N, M, N, K, act, 1 if out_f32 else 0, _stream())
+    if ev is not None:
+        ev[1].record()
+    _lib.check(rc, "wg_gemm_skinny_ln_bias_act_bf16")
+    return out
+
+
 def _rows_per_batch(t):
     """[B, L, D] (contiguous rows, possibly a column slice of a wider buffer) -> (B, L, ld, rows per batch)."""
     assert t.dim() == 3 and t.stride(2) == 1
@@ -417,24 +440,40 @@ def dec_attn_partial(q_t2i, k_img, v_img):
     return part
 
 
-def dec_mlp_partial(x, lin1_w, lin1_b, lin2_w, out=None):
+def _combine_table(combine, P):
+    """(attention partials [P, 8, n_splits, 108] fp32, out_proj weight [256, 128], bias, LayerNorm gamma, beta) -> (ctypes table, n_splits)"""
+    import ctypes
+    if combine is None:
+        return None, 0
+    part, wo, bo, g, b = combine
+    _need_gpu(part, wo, bo, g, b)
+    assert part.dtype == torch.float32 and part.is_contiguous() and part.dim() == 4 and part.shape[0] == P and part.shape[1] == 8
+    assert part.shape[3] == _TOK_PART and wo.shape == (256, 128) and bo.numel() == 256 and g.numel() == 256 and b.numel() == 256
+    assert all(t.dtype == _BF16 and t.is_contiguous() for t in (wo, bo, g, b))
+    return (ctypes.c_void_p * 5)(part.data_ptr(), wo.data_ptr(), bo.data_ptr(), g.data_ptr(), b.data_ptr()), part.shape[2]
+
+
+def dec_mlp_partial(x, lin1_w, lin1_b, lin2_w, combine=None, eps=1e-5):
     """The eight 256-unit slices of mlp(x) for x [P, 6, 256] fp32 (wg_dec_mlp_partial_f32) -> fp32 [P, 8, 6, 256]; lin2's bias is added
-    by dec_tokens(TOK_SUM_MLP)."""
+    by dec_tokens(TOK_SUM_MLP).  With `combine` (see _combine_table) x holds the tokens before the COMBINE stage, which the launch runs
+    itself: returns (partials, tokens after the LayerNorm -- a new buffer)."""
     _need_gpu(x, lin1_w, lin1_b, lin2_w)
     P = x.shape[0]
     _f32_tokens(x, P, 256)
     assert lin1_w.shape == (2048, 256) and lin2_w.shape == (256, 2048) and lin1_b.shape == (2048,)
     assert all(t.dtype == _BF16 and t.is_contiguous() for t in (lin1_w, lin1_b, lin2_w))
-    if out is None:
-        out = torch.empty(P, 8, 6, 256, device=x.device, dtype=torch.float32)
-    rc = _lib.lib().wg_dec_mlp_partial_f32(x.data_ptr(), lin1_w.data_ptr(), lin1_b.data_ptr(), lin2_w.data_ptr(), out.data_ptr(), P, _stream())
+    out = torch.empty(P, 8, 6, 256, device=x.device, dtype=torch.float32)
+    table, n_splits = _combine_table(combine, P)
+    x_out = torch.empty_like(x) if combine is not None else None
+    rc = _lib.lib().wg_dec_mlp_partial_f32(x.data_ptr(), table, n_splits, float(eps), _ptr(x_out), lin1_w.data_ptr(), lin1_b.data_ptr(),
+                                           lin2_w.data_ptr(), out.data_ptr(), P, _stream())
     _lib.check(rc, "wg_dec_mlp_partial_f32")
-    return out
+    return out if combine is None else (out, x_out)
 
 
-def dec_heads(x, weights):
+def dec_heads(x, weights, combine=None, eps=1e-5):
     """The four hypernetwork MLPs and the IoU head on x [P, 6, 256] fp32 (wg_dec_heads_f32); weights: 30 bf16 tensors
-    -> (hyper fp32 [P, 4, 32], iou fp32 [P, 4])."""
+    -> (hyper fp32 [P, 4, 32], iou fp32 [P, 4]).  With `combine` the launch first applies the final attention's COMBINE stage."""
     import ctypes
     _need_gpu(x, *weights)
     P = x.shape[0]
@@ -446,16 +485,19 @@ def dec_heads(x, weights):
     hyper = torch.empty(P, 4, 32, device=x.device, dtype=torch.float32)
     iou = torch.empty(P, 4, device=x.device, dtype=torch.float32)
     table = (ctypes.c_void_p * 30)(*[w.data_ptr() for w in weights])
-    rc = _lib.lib().wg_dec_heads_f32(x.data_ptr(), table, 30, hyper.data_ptr(), iou.data_ptr(), P, _stream())
+    ctab, n_splits = _combine_table(combine, P)
+    rc = _lib.lib().wg_dec_heads_f32(x.data_ptr(), ctab, n_splits, float(eps), table, 30, hyper.data_ptr(), iou.data_ptr(), P, _stream())
     _lib.check(rc, "wg_dec_heads_f32")
     return hyper, iou
 
 
-def dec_i2t_rows(q_img, k_i2t, v_i2t, out_w, out_b, keys, ln_g, ln_b, eps, P):
+def dec_i2t_rows(q_img, k_i2t, v_i2t, out_w, out_b, keys, ln_g, ln_b, eps, P, res_bias=None):
     """transformer.py:173-180 in one launch (wg_dec_i2t_rows_bf16): norm4(keys + out_proj(attention of every image token over the six
     prompt tokens)).  q_img [1 | P, hw, 128] bf16 (column slice of the image-side projection), k_i2t / v_i2t [P, 6, 128] bf16,
-    keys [1 | P, hw, 256] bf16 -> bf16 [P, hw, 256]."""
-    _need_gpu(q_img, k_i2t, v_i2t, out_w, out_b, keys, ln_g, ln_b)
+    keys [1 | P, hw, 256] bf16 -> bf16 [P, hw, 256].  res_bias [256] bf16: the residual is keys + res_bias (a constant row the caller
+    never added to the image tokens)."""
+    _need_gpu(q_img, k_i2t, v_i2t, out_w, out_b, keys, ln_g, ln_b, res_bias)
+    assert res_bias is None or (res_bias.dtype == _BF16 and res_bias.numel() == 256 and res_bias.is_contiguous())
     hw = keys.shape[1]
     assert q_img.dtype == _BF16 and q_img.shape[-1] == 128 and q_img.stride(-1) == 1 and q_img.shape[:2] == keys.shape[:2]
     assert keys.dtype == _BF16 and keys.shape[-1] == 256 and keys.stride(-1) == 1 and keys.shape[0] in (1, P)
@@ -466,7 +508,7 @@ def dec_i2t_rows(q_img, k_i2t, v_i2t, out_w, out_b, keys, ln_g, ln_b, eps, P):
     shared = keys.shape[0] == 1 and P > 1
     out = torch.empty(P, hw, 256, device=keys.device, dtype=_BF16)
     rc = _lib.lib().wg_dec_i2t_rows_bf16(q_img.data_ptr(), q_img.stride(1), k_i2t.data_ptr(), v_i2t.data_ptr(), out_w.data_ptr(),
-                                         out_b.data_ptr(), keys.data_ptr(), keys.stride(1), hw if shared else 0, ln_g.data_ptr(),
+                                         out_b.data_ptr(), keys.data_ptr(), keys.stride(1), _ptr(res_bias), hw if shared else 0, ln_g.data_ptr(),
                                          ln_b.data_ptr(), float(eps), out.data_ptr(), P, hw, _stream())
     _lib.check(rc, "wg_dec_i2t_rows_bf16")
     return out

@@ -329,16 +329,20 @@ class DecoderAttention(nn.Module):
         return ops.linear(o, self.out_proj.weight, self.out_proj.bias, residual=residual, res_row_mod=res_row_mod)
 
 
-def _pe_folded_projection(pe_rows, parts):
+def _pe_folded_projection(pe_rows, parts, src_bias=None):
     """Fused image-side projection operands.  (x + pe) W^T + b == x W^T + (pe W^T + b), and pe is input independent, so
     every projection that reads the image tokens `x` of one layer becomes a column block of ONE GEMM `x @ Wcat^T + R[row %
-    hw]`.  parts: [(Linear, adds_pe)]; returns (Wcat [sum N, C], R [hw, sum N]) in bf16."""
+    hw]`.  parts: [(Linear, adds_pe)]; src_bias [1, C]: a constant row the caller would otherwise add to every image token first
+    (the dense no-mask embedding) -- it joins the table the same way.  Returns (Wcat [sum N, C], R [hw, sum N]) in bf16."""
     ws, rs = [], []
     hw = pe_rows.shape[0]
+    with_pe = pe_rows if src_bias is None else (pe_rows.float() + src_bias.float()).to(pe_rows.dtype)
     for lin, adds_pe in parts:
         ws.append(lin.weight)
         if adds_pe:
-            rs.append(ops.linear(pe_rows, lin.weight, lin.bias))
+            rs.append(ops.linear(with_pe, lin.weight, lin.bias))
+        elif src_bias is not None:
+            rs.append(ops.linear(src_bias.reshape(1, -1).to(pe_rows.dtype).contiguous(), lin.weight, lin.bias).expand(hw, -1))
         else:
             rs.append(lin.bias.unsqueeze(0).expand(hw, -1))
     return torch.cat(ws, 0).contiguous(), torch.cat(rs, 1).contiguous()
@@ -362,38 +366,47 @@ class TwoWayAttentionBlock(nn.Module):
         self.cross_attn_image_to_token = DecoderAttention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
         self.skip_first_layer_pe = skip_first_layer_pe
 
-    def _image_side(self, key_pe):
-        """[K_t2i | V_t2i | Q_i2t] of the image tokens as one GEMM (cached per positional-encoding tensor / weights)."""
+    def _image_side(self, key_pe, src_bias=None):
+        """[K_t2i | V_t2i | Q_i2t] of the image tokens as one GEMM (cached per positional-encoding tensor / weights / constant row)."""
         t2i, i2t = self.cross_attn_token_to_image, self.cross_attn_image_to_token
         key = (key_pe.data_ptr(), key_pe._version) + tuple((p.data_ptr(), p._version) for p in
                                                            (t2i.k_proj.weight, t2i.v_proj.weight, i2t.q_proj.weight,
                                                             t2i.k_proj.bias, t2i.v_proj.bias, i2t.q_proj.bias))
+        if src_bias is not None:
+            key += (src_bias.data_ptr(), src_bias._version)
         if getattr(self, "_img_key", None) != key:
             self._img_val = _pe_folded_projection(key_pe.reshape(-1, key_pe.shape[-1]),
-                                                  [(t2i.k_proj, True), (t2i.v_proj, False), (i2t.q_proj, True)])
+                                                  [(t2i.k_proj, True), (t2i.v_proj, False), (i2t.q_proj, True)], src_bias)
             self._img_key = key
         return self._img_val
 
-    def image_side(self, keys, key_pe):
+    def image_side(self, keys, key_pe, src_bias=None):
         """[K_t2i | V_t2i | Q_i2t] of this block's image tokens: the three projections that read `keys` (the reference recomputes
-        keys + key_pe for two of them) as one fused GEMM with the positional term folded into an additive table."""
-        wcat, rtab = self._image_side(key_pe)
+        keys + key_pe for two of them) as one fused GEMM with the positional term folded into an additive table.  src_bias [1, C]:
+        the block's image tokens are keys + src_bias (mask_decoder.py:136: the dense no-mask embedding), never materialised."""
+        wcat, rtab = self._image_side(key_pe, src_bias)
         return ops.linear(keys, wcat, residual=rtab, res_row_mod=keys.shape[1])          # [1|P, hw, 3d]
 
-    def image_to_token(self, proj, keys, kq, vq, P):
+    def fused_i2t_ok(self, keys, n_tokens):
+        i2t = self.cross_attn_image_to_token
+        return i2t.internal_dim == 128 and i2t.num_heads == 8 and keys.shape[-1] == 256 and n_tokens == 6 and keys.shape[1] % 16 == 0
+
+    def image_to_token(self, proj, keys, kq, vq, P, src_bias=None):
         """transformer.py:173-180: image->token attention on the projected operands, out_proj + residual, norm4 -- one launch for SAM's
         geometry (ops.dec_i2t_rows), three otherwise."""
         i2t = self.cross_attn_image_to_token
         hw = keys.shape[1]
         d = i2t.internal_dim
-        if d == 128 and i2t.num_heads == 8 and keys.shape[-1] == 256 and kq.shape[1] == 6 and hw % 16 == 0:
+        if self.fused_i2t_ok(keys, kq.shape[1]):
             return ops.dec_i2t_rows(proj[..., 2 * d:], kq, vq, i2t.out_proj.weight, i2t.out_proj.bias, keys, self.norm4.weight,
-                                    self.norm4.bias, self.norm4.eps, P)
+                                    self.norm4.bias, self.norm4.eps, P, res_bias=src_bias)
+        if src_bias is not None:
+            keys = ops.add_rows(keys, src_bias)
         keys = i2t.run_projected(proj[..., 2 * d:], kq, vq, P, residual=keys, res_row_mod=hw if keys.shape[0] == 1 and P > 1 else 0)
         return ops.layernorm(keys, self.norm4.weight, self.norm4.bias, self.norm4.eps)
 
-    def mlp_partials(self, queries):
-        return ops.dec_mlp_partial(queries, self.mlp.lin1.weight, self.mlp.lin1.bias, self.mlp.lin2.weight)
+    def mlp_partials(self, queries, combine=None):
+        return ops.dec_mlp_partial(queries, self.mlp.lin1.weight, self.mlp.lin1.bias, self.mlp.lin2.weight, combine=combine, eps=self.norm2.eps)
 
     def check_fused(self):
         if self.norm1.eps != self.norm2.eps or self.norm1.eps != self.norm3.eps or self.mlp._act_code != ops.ACT_RELU:
@@ -455,13 +468,15 @@ class TwoWayTransformer(nn.Module):
         self.final_attn_token_to_image = DecoderAttention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
         self.norm_final_attn = nn.LayerNorm(embedding_dim)
 
-    def run_tokens(self, src_tokens, pe_tokens, out_tokens, prompts):
+    def run_tokens(self, src_tokens, pe_tokens, out_tokens, prompts, src_bias=None):
         """transformer.py:62-106: the depth TwoWayAttentionBlocks and the final token->image attention + norm_final_attn.
         src_tokens [1|P, hw, C] bf16, pe_tokens [1, hw, C] bf16; out_tokens [5, C] fp32 (iou + mask tokens), prompts [P, 1, C] bf16: the
-        point embedding of prompt p is cat(out_tokens, prompts[p]) (mask_decoder.py:125-132), built by the first launch
-        -> (queries fp32 [P, 6, C]; keys [P, hw, C] bf16).
+        point embedding of prompt p is cat(out_tokens, prompts[p]) (mask_decoder.py:125-132), built by the first launch; src_bias [1, C]:
+        the image tokens are src_tokens + src_bias (the dense no-mask embedding, mask_decoder.py:136), folded into the first block
+        -> (queries fp32 [P, 6, C] BEFORE the final attention's out_proj + norm_final_attn; the `combine` operands of that step, which
+        ops.dec_heads applies in its own launch; keys [P, hw, C] bf16).
         Launch chain per block: tokens[close previous block | self attention | q] -> (previous block's image->token attention, norm4)
-        -> image-side GEMM -> attention partials -> tokens[combine, out_proj, norm2] -> MLP partials."""
+        -> image-side GEMM -> attention partials -> MLP partials (which first merge the partials: out_proj, norm2)."""
         if self.embedding_dim != 256 or self.num_heads != 8 or out_tokens.shape[0] != 5 or prompts.shape[1] != 1 or self.mlp_dim != 2048:
             raise NotImplementedError("the fused token kernels are built for SAM's decoder geometry (256 channels, 8 heads, 5 + 1 tokens, "
                                       "MLP 2048); got %d / %d / %d + %d / %d" % (self.embedding_dim, self.num_heads, out_tokens.shape[0],
@@ -497,14 +512,15 @@ class TwoWayTransformer(nn.Module):
                            init_prompt=prompts.to(BF16).contiguous() if first else None)
             first = False
             if prev is not None:
-                keys = prev.image_to_token(prev_proj, keys, kq, vq, P)
-            proj = layer.image_side(keys, pe_tokens) if layer is not None else self.final_image_side(keys, pe_tokens)
+                keys = prev.image_to_token(prev_proj, keys, kq, vq, P, src_bias)
+                src_bias = None                                   # (part of `keys` from here on)
+            proj = layer.image_side(keys, pe_tokens, src_bias) if layer is not None else self.final_image_side(keys, pe_tokens)
             part = ops.dec_attn_partial(q, proj[..., :d], proj[..., d:2 * d])
-            ops.dec_tokens(ops.TOK_COMBINE, False, queries, query_pe, table, attn_partials=part, eps=eps)
+            combine = (part, t2i.out_proj.weight, t2i.out_proj.bias, norm.weight, norm.bias)
             if layer is not None:
-                mlp_part = layer.mlp_partials(queries)
+                mlp_part, queries = layer.mlp_partials(queries, combine)
             prev, prev_proj = layer, proj
-        return queries, keys
+        return queries, combine, keys
 
     def final_image_side(self, keys, pe_tokens):
         """[K | V] of the final token->image attention (positional term folded into the additive table)."""
@@ -583,8 +599,9 @@ class MaskDecoder(nn.Module, _Prepared):
                 w += _lin_pair(layer)
         return w
 
-    def predict_masks_tokens(self, src_tokens, pe_tokens, sparse, h, w, mask_slice):
-        """src_tokens [1|P, hw, C] (image embedding + dense prompt, channels-last rows), pe_tokens [1, hw, C],
+    def predict_masks_tokens(self, src_tokens, pe_tokens, sparse, h, w, mask_slice, src_bias=None):
+        """src_tokens [1|P, hw, C] (image embedding + dense prompt, channels-last rows; or the image embedding alone with the dense
+        no-mask embedding as src_bias [1, C]), pe_tokens [1, hw, C],
         sparse [P, n, C] -> (masks fp32 [P, k, 4h, 4w], iou fp32 [P, k]).
         Launches: TwoWayTransformer.run_tokens, then one kernel for the hypernetwork / IoU heads and one for upscaling + the
         hypernetwork product."""
@@ -594,8 +611,10 @@ class MaskDecoder(nn.Module, _Prepared):
         tr = self.transformer
         if self.num_mask_tokens != 4 or sparse.shape[1] != 1 or self.transformer_dim != 256:
             raise NotImplementedError("the fused decoder kernels are built for 4 mask tokens + one text prompt per query (mask_decoder.py:125-132)")
-        queries, keys = tr.run_tokens(src_tokens, pe_tokens, p["out_tokens_f32"], sparse)
-        hyper, iou = ops.dec_heads(queries, self.head_weights())
+        if src_bias is not None and (len(tr.layers) == 0 or not tr.layers[0].fused_i2t_ok(src_tokens, 6)):
+            src_tokens, src_bias = ops.add_rows(src_tokens, src_bias), None
+        queries, final, keys = tr.run_tokens(src_tokens, pe_tokens, p["out_tokens_f32"], sparse, src_bias)
+        hyper, iou = ops.dec_heads(queries, self.head_weights(), combine=final, eps=tr.norm_final_attn.eps)
         ln1 = self.output_upscaling[1]
         k0, nk = mask_slice
         masks = ops.upscale_mask(keys, p["up1_w"], self.output_upscaling[0].bias, ln1.weight, ln1.bias, ln1.eps, p["up2_w"],
@@ -611,7 +630,10 @@ class MaskDecoder(nn.Module, _Prepared):
         emb = ops.nchw_to_tokens(image_embeddings.contiguous())                 # [b, hw, C]
         d = dense_prompt_embeddings
         if d.stride(0) == 0 and d.stride(2) == 0 and d.stride(3) == 0 and b == 1:
-            src = ops.add_rows(emb, d[0, :, 0, 0].to(BF16).reshape(1, c).contiguous())   # shared by all prompts
+            pe = ops.nchw_to_tokens(image_pe.to(BF16).contiguous())[:1]
+            sl = (1, self.num_mask_tokens - 1) if multimask_output else (0, 1)
+            return self.predict_masks_tokens(emb, pe, sparse_prompt_embeddings, h, w, sl,      # one image shared by all prompts
+                                             src_bias=d[0, :, 0, 0].to(BF16).reshape(1, c).contiguous())
         else:
             src = ops.add_rows(emb.expand(P, -1, -1).contiguous() if b == 1 else emb,
                                ops.nchw_to_tokens(d.to(BF16).contiguous()).reshape(-1, c))

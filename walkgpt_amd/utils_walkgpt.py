@@ -156,8 +156,8 @@ class CalibratedTextProjector(nn.Module):
         _check_bf16_gpu(x, "hidden states")
         if self.use_residual:
             raise NotImplementedError("use_residual=True is never configured by WalkGPT (walkgpt.py:115-123)")
-        y = _ln(x.contiguous(), self.net[0])
-        y = ops.linear(y, self.net[1].weight, self.net[1].bias, act=ops.ACT_GELU)
+        ln = self.net[0]
+        y = ops.layernorm_linear(x.contiguous(), ln.weight, ln.bias, ln.eps, self.net[1].weight, self.net[1].bias, act=ops.ACT_GELU)
         y = ops.linear(y, self.net[3].weight, self.net[3].bias)
         return ops.ctp_tail(y, self.net[4].weight, self.net[4].bias, self.text_type.reshape(-1), self.log_temp, self.net[4].eps)
 

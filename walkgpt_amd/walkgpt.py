@@ -101,13 +101,14 @@ class WalkGPTGrounding(nn.Module):
             text = self._cat_rows(pred_embeddings)
             sparse, _ = vm.prompt_encoder(points=None, boxes=None, masks=None, text_embeds=text.unsqueeze(1))
             if len(counts) == emb_tokens.shape[0] and all(c == 1 for c in counts):
-                src = ops.add_rows(emb_tokens, no_mask)                         # one prompt per image: no gather
+                src = emb_tokens                                                # one prompt per image: no gather
             elif len([c for c in counts if c > 0]) == 1:
                 i = next(k for k, c in enumerate(counts) if c > 0)
-                src = ops.add_rows(emb_tokens[i:i + 1], no_mask)                # one image: shared by its prompts
+                src = emb_tokens[i:i + 1]                                       # one image: shared by its prompts
             else:
-                src = ops.add_rows(emb_tokens.index_select(0, self._prompt_image_index(tuple(counts), dev)), no_mask)
-            low_res, _iou = vm.mask_decoder.predict_masks_tokens(src, pe, sparse, h, w, sl)
+                src = emb_tokens.index_select(0, self._prompt_image_index(tuple(counts), dev))
+            # (+ the dense no-mask embedding, mask_decoder.py:136: folded into the decoder's first block instead of a pass over src)
+            low_res, _iou = vm.mask_decoder.predict_masks_tokens(src, pe, sparse, h, w, sl, src_bias=no_mask)
             off = 0
             same = len(set(zip(map(tuple, resize_list), map(tuple, original_size_list)))) == 1
             if same and sl[1] == 1:
