@@ -172,6 +172,11 @@ int wg_upscale_mask_bf16(const void* x, long ldx, const void* w1, const void* b1
  *   when given, x holds the tokens BEFORE the COMBINE stage and the launch runs that stage itself (one launch less on the chain):
  *   the MLP kernel writes the tokens after norm2 to x_out (a buffer other than x); the heads kernel applies the final attention's
  *   out_proj + norm_final_attn to the token row each workgroup needs. */
+/* Every weight MATRIX the four wg_dec_* token kernels take (not biases / LayerNorm vectors) is in fragment order, made once per checkpoint:
+ *   wg_tile_weight_bf16: W [N][K] bf16 (row stride ld) -> T[ceil(N/16)][K/32][64][8],  T[nb][ks][lane][j] = W[16 nb + lane%16][32 ks + 8 (lane/16) + j]
+ *   (rows >= N zero): the 1 KiB a wave loads per MFMA step is contiguous (3x the per-CU streaming rate of the row-major pattern).
+ *   mlp.lin2.weight [256, 2048] is tiled per 256-column slice (8 calls with W + 256 s, ld 2048, N = K = 256 -> T + 65536 s). */
+int wg_tile_weight_bf16(const void* W, long ld, int N, int K, void* tiled, void* stream);
 int wg_dec_tokens_f32(int stages, int skip_pe, float* queries, float* query_pe, const float* init_tokens, const void* init_prompt,
                       const void* const* weights, int n_weights, float* q_t2i, const float* attn_partials, int n_splits, const float* mlp_partials, void* k_i2t, void* v_i2t, int P,
                       float eps, void* stream);

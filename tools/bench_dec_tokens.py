@@ -32,7 +32,7 @@ for P in (1, 8, 112):
             "attn": t(lambda: ops.dec_attn_partial(qt, proj[..., :128], proj[..., 128:256])),
             "combine": t(lambda: ops.dec_tokens(8, False, q, pe, tab, attn_partials=part)),
             "mlp": t(lambda: l1.mlp_partials(q)),
-            "combine+mlp": t(lambda: l1.mlp_partials(q, (part, l1.cross_attn_token_to_image.out_proj.weight, l1.cross_attn_token_to_image.out_proj.bias, l1.norm2.weight, l1.norm2.bias))),
+            "combine+mlp": t(lambda: l1.mlp_partials(q, (part, M._tiled(l1.cross_attn_token_to_image.out_proj.weight), l1.cross_attn_token_to_image.out_proj.bias, l1.norm2.weight, l1.norm2.bias))),
             "heads": t(lambda: ops.dec_heads(q, md.head_weights())),
         }
         print("P=%3d hw=%4d: " % (P, hw) + "  ".join("%s %.1f us" % kv for kv in r.items()), flush=True)

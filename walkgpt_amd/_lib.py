@@ -47,6 +47,7 @@ SIGNATURES = {
     "wg_gemm_skinny_ln_supported": [c_int, c_int, c_int, c_long, c_long, c_long],
     "wg_gemm_skinny_ln_bias_act_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int,
                                         c_int, c_int, c_int, c_int, c_void_p],
+    "wg_tile_weight_bf16": [c_void_p, c_long, c_int, c_int, c_void_p, c_void_p],
     "wg_dec_heads_f32": [c_void_p, c_void_p, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p],
     "wg_dec_i2t_rows_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_float,
                              c_void_p, c_int, c_int, c_void_p],

@@ -377,7 +377,14 @@ extern "C" int wg_upscale_mask_bf16(const void* x, long ldx, const void* w1, con
 //   wg_dec_heads_f32         the four hypernetwork MLPs and the IoU head: grid (prompt, 5), one 3-layer MLP each
 //
 // Linear layers run on the matrix pipe with the tokens as a 16-row A operand (rows 6..15 zero) split into a bf16 hi + lo pair (~16
-// significant bits); weights are bf16 (the checkpoint's precision), streamed from L2 as B fragments.
+// significant bits); weights are bf16 (the checkpoint's precision), streamed as B fragments.
+//
+// WEIGHT LAYOUT.  Every weight matrix these kernels read is pre-tiled in FRAGMENT ORDER (wg_tile_weight_bf16, once per checkpoint):
+//     T[nb][ks][lane][j] = W[16 nb + (lane & 15)][32 ks + 8 (lane >> 4) + j],     rows >= N zero,
+// i.e. the 1 KiB a wave loads for MFMA step ks of column block nb is contiguous.  With the row-major [N][K] matrix the same instruction
+// touches 16 rows x 64 B -- 16 half-used cache lines -- and ONE compute unit pulled 33 GB/s through that pattern even when the matrix was
+// L2-resident, against 96 GB/s for contiguous 1-KiB pieces (tools/micro/cu_ingest.hip; 29 vs 36 GB/s when cold): these kernels are exactly
+// that streaming, a workgroup per prompt walking 0.2 - 0.7 MB of weights.
 // =====================================================================================================================================
 namespace {
 
@@ -417,7 +424,7 @@ struct TokArgs {
 // trips (stage -> weights -> write), so what counts is the number of passes, not their width.
 struct TokJob {
     const bf16* sh; const bf16* sl;      // staged input rows [8][K + 8] (hi, lo)
-    LinW W; long ldw; int N;             // y[r][n] = act(x[r][:] . W[n][:] + b[n]) (+ res[r][n]),  W rows ldw elements apart
+    LinW W; int N;                       // y[r][n] = act(x[r][:] . W[n][:] + b[n]) (+ res[r][n]),  W in fragment order (below)
     float* y; int ldy; int act;
     const float* res; int ldres;         // LDS fp32
 };
@@ -472,15 +479,15 @@ __device__ void tok_mm(const TokJob (&jobs)[NJ], int rows) {
         const TokJob& ja = jsel[0];
         const TokJob& jq = jsel[1];
         const int n_a = nb[0] * 16 + l16, n_b = nb[1] * 16 + l16;
-        const bf16* wpa = ja.W.w + (long)(n_a < ja.N ? n_a : ja.N - 1) * ja.ldw + 8 * kg;
-        const bf16* wpb = jq.W.w + (long)(n_b < jq.N ? n_b : jq.N - 1) * jq.ldw + 8 * kg;
+        const bf16* wpa = ja.W.w + (long)nb[0] * (K / 32) * 512 + lane * 8;      // fragment (nb, ks) = 1 KiB at ((nb * K/32 + ks) * 64 + lane) * 8
+        const bf16* wpb = jq.W.w + (long)nb[1] * (K / 32) * 512 + lane * 8;
         const bf16* aha = ja.sh + arow * PITCH + 8 * kg, *ala = ja.sl + arow * PITCH + 8 * kg;
         const bf16* ahb = jq.sh + arow * PITCH + 8 * kg, *alb = jq.sl + arow * PITCH + 8 * kg;
         f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
         for (int ks = 0; ks < K / 32; ++ks) {
-            const bf16x8 fa = *(const bf16x8*)(wpa + 32 * ks);
-            const bf16x8 fb = *(const bf16x8*)(wpb + 32 * ks);
+            const bf16x8 fa = *(const bf16x8*)(wpa + 512 * ks);
+            const bf16x8 fb = *(const bf16x8*)(wpb + 512 * ks);
             bf16x8 h0 = *(const bf16x8*)(aha + 32 * ks), l0 = *(const bf16x8*)(ala + 32 * ks);
             bf16x8 h1 = *(const bf16x8*)(ahb + 32 * ks), l1 = *(const bf16x8*)(alb + 32 * ks);
             h0 = live ? h0 : zero; l0 = live ? l0 : zero;
@@ -516,11 +523,11 @@ __device__ void tok_mm(const TokJob (&jobs)[NJ], int rows) {
 
 // one Linear: y = act(x W^T + b) (+ res); x, y, res in LDS (fp32), every thread of the workgroup calls it, visible to all on return
 template <int K, int THREADS = TK_THREADS>
-__device__ void tok_linear(const float* x, int ldx, int rows, LinW W, long ldw, int N, float* y, int ldy, int act, const float* res, int ldres,
+__device__ void tok_linear(const float* x, int ldx, int rows, LinW W, int N, float* y, int ldy, int act, const float* res, int ldres,
                            bf16* sh, bf16* sl) {
     tok_stage<K, THREADS>(x, ldx, nullptr, rows, sh, sl);
     __syncthreads();
-    const TokJob job[1] = {{sh, sl, W, ldw, N, y, ldy, act, res, ldres}};
+    const TokJob job[1] = {{sh, sl, W, N, y, ldy, act, res, ldres}};
     tok_mm<K, 1, THREADS>(job, rows);
 }
 
@@ -616,7 +623,7 @@ __device__ void tok_combine(const CombineW& c, long p, int row0, int rows, float
         ao[r * 128 + h * 16 + d] = o / L;
     }
     __syncthreads();
-    tok_linear<128, THREADS>(ao, 128, rows, c.wo, 128, TK_C, x, TK_C, 0, x, TK_C, sh, sl);
+    tok_linear<128, THREADS>(ao, 128, rows, c.wo, TK_C, x, TK_C, 0, x, TK_C, sh, sl);
     tok_layernorm<THREADS>(x, rows, c.nw, c.eps);
 }
 
@@ -650,7 +657,7 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
         tok_stage<TK_C>(qs, TK_C, pes, TK_N, sh[0], sl[0]);
         tok_stage<TK_C>(qs, TK_C, nullptr, TK_N, sh[1], sl[1]);
         __syncthreads();
-        const TokJob kv[2] = {{sh[0], sl[0], a.i2t_k, TK_C, 128, t0, 128, 0, nullptr, 0}, {sh[1], sl[1], a.i2t_v, TK_C, 128, t1, 128, 0, nullptr, 0}};
+        const TokJob kv[2] = {{sh[0], sl[0], a.i2t_k, 128, t0, 128, 0, nullptr, 0}, {sh[1], sl[1], a.i2t_v, 128, t1, 128, 0, nullptr, 0}};
         tok_mm<TK_C, 2>(kv, TK_N);
         for (int i = tid; i < TK_N * 128; i += TK_THREADS) {
             a.k_i2t[(long)p * TK_N * 128 + i] = (bf16)t0[i];
@@ -663,19 +670,19 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
         tok_stage<TK_C>(qs, TK_C, a.skip_pe ? nullptr : pes, TK_N, sh[0], sl[0]);
         tok_stage<TK_C>(qs, TK_C, nullptr, TK_N, sh[1], sl[1]);
         __syncthreads();
-        const TokJob qkv[3] = {{sh[0], sl[0], a.self_attn.q, TK_C, TK_C, t0, TK_C, 0, nullptr, 0},
-                               {sh[0], sl[0], a.self_attn.k, TK_C, TK_C, t1, TK_C, 0, nullptr, 0},
-                               {sh[1], sl[1], a.self_attn.v, TK_C, TK_C, t2, TK_C, 0, nullptr, 0}};
+        const TokJob qkv[3] = {{sh[0], sl[0], a.self_attn.q, TK_C, t0, TK_C, 0, nullptr, 0},
+                               {sh[0], sl[0], a.self_attn.k, TK_C, t1, TK_C, 0, nullptr, 0},
+                               {sh[1], sl[1], a.self_attn.v, TK_C, t2, TK_C, 0, nullptr, 0}};
         tok_mm<TK_C, 3>(qkv, TK_N);
         tok_self_attention(t0, t1, t2, t3);
-        tok_linear<TK_C>(t3, TK_C, TK_N, a.self_attn.o, TK_C, TK_C, qs, TK_C, 0, a.skip_pe ? nullptr : qs, TK_C, sh[0], sl[0]);
+        tok_linear<TK_C>(t3, TK_C, TK_N, a.self_attn.o, TK_C, qs, TK_C, 0, a.skip_pe ? nullptr : qs, TK_C, sh[0], sl[0]);
         tok_layernorm(qs, TK_N, a.norm1, a.eps);
     }
     if (a.stages & ST_Q_T2I) {
         // ---- q of the token -> image attention (:162-165; tail: :96-101), internal width 128 ------------------------------------------------
         tok_stage<TK_C>(qs, TK_C, pes, TK_N, sh[0], sl[0]);
         __syncthreads();
-        const TokJob qj[1] = {{sh[0], sl[0], a.t2i_q, TK_C, 128, t0, 128, 0, nullptr, 0}};
+        const TokJob qj[1] = {{sh[0], sl[0], a.t2i_q, 128, t0, 128, 0, nullptr, 0}};
         tok_mm<TK_C, 1>(qj, TK_N);
         for (int i = tid; i < TK_N * 128; i += TK_THREADS) a.q_t2i[(long)p * TK_N * 128 + i] = t0[i];
         __syncthreads();
@@ -796,10 +803,10 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_mlp_partial_kernel(MlpArgs 
         if (slice == 0)
             for (int i = threadIdx.x; i < TK_N * TK_C; i += TK_THREADS) a.x_out[(long)p * TK_N * TK_C + i] = xs[i];
     }
-    const LinW l1{a.lin1.w + (long)slice * 256 * TK_C, a.lin1.b + slice * 256};
-    tok_linear<TK_C>(xs, TK_C, TK_N, l1, TK_C, 256, hs, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
-    const LinW l2{a.lin2_w + slice * 256, nullptr};                  // columns slice*256 .. +255 of lin2.weight [256, 2048]
-    tok_linear<TK_C>(hs, TK_C, TK_N, l2, TK_HID, TK_C, ys, TK_C, 0, nullptr, 0, sh, sl);
+    const LinW l1{a.lin1.w + (long)slice * 256 * TK_C, a.lin1.b + slice * 256};   // rows slice*256 .. +255 of lin1.weight = 16 column blocks
+    tok_linear<TK_C>(xs, TK_C, TK_N, l1, 256, hs, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
+    const LinW l2{a.lin2_w + (long)slice * 256 * TK_C, nullptr};     // columns slice*256 .. +255 of lin2.weight [256, 2048], tiled per slice
+    tok_linear<TK_C>(hs, TK_C, TK_N, l2, TK_C, ys, TK_C, 0, nullptr, 0, sh, sl);
     float* out = a.part + ((long)p * TK_SLICES + slice) * TK_N * TK_C;
     for (int i = threadIdx.x; i < TK_N * TK_C; i += TK_THREADS) out[i] = ys[i];
 }
@@ -816,9 +823,9 @@ __global__ __launch_bounds__(256) void wg_dec_heads_kernel(HeadArgs a) {
     for (int c = threadIdx.x; c < TK_C; c += 256) x0[c] = x[c];
     __syncthreads();
     if (a.comb.part) tok_combine<256>(a.comb, p, row, 1, x0, x1, sh, sl);
-    tok_linear<TK_C, 256>(x0, TK_C, 1, a.mlp[i][0], TK_C, TK_C, x1, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
-    tok_linear<TK_C, 256>(x1, TK_C, 1, a.mlp[i][1], TK_C, TK_C, x2, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
-    tok_linear<TK_C, 256>(x2, TK_C, 1, a.mlp[i][2], TK_C, i < 4 ? 32 : 4, x0, TK_C, 0, nullptr, 0, sh, sl);
+    tok_linear<TK_C, 256>(x0, TK_C, 1, a.mlp[i][0], TK_C, x1, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
+    tok_linear<TK_C, 256>(x1, TK_C, 1, a.mlp[i][1], TK_C, x2, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
+    tok_linear<TK_C, 256>(x2, TK_C, 1, a.mlp[i][2], i < 4 ? 32 : 4, x0, TK_C, 0, nullptr, 0, sh, sl);
     if (i < 4) {
         if (threadIdx.x < 32) a.hyper_out[((long)p * 4 + i) * 32 + threadIdx.x] = x0[threadIdx.x];
     } else if (threadIdx.x < 4) {
@@ -826,7 +833,31 @@ __global__ __launch_bounds__(256) void wg_dec_heads_kernel(HeadArgs a) {
     }
 }
 
+// W [N][K] (row stride ld) -> fragment order T[ceil(N / 16)][K / 32][64][8] (see WEIGHT LAYOUT above); one thread per 16-byte piece
+__global__ void wg_tile_weight_kernel(const bf16* w, long ld, int N, int K, bf16* t) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;      // piece index = (nb * K/32 + ks) * 64 + lane
+    const int KS = K / 32;
+    const long total = (long)((N + 15) / 16) * KS * 64;
+    if (i >= total) return;
+    const int lane = (int)(i & 63), ks = (int)((i >> 6) % KS), nb = (int)((i >> 6) / KS);
+    const int n = nb * 16 + (lane & 15), k = ks * 32 + 8 * (lane >> 4);
+    bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (n < N) v = *(const bf16x8*)(w + (long)n * ld + k);
+    *(bf16x8*)(t + i * 8) = v;
+}
+
 }  // namespace
+
+// One-time re-layout of a weight matrix for the token-side kernels: W [N][K] bf16 (row stride ld >= K, K % 32 == 0, 16-byte aligned rows)
+// -> tiled [ceil(N / 16)][K / 32][64][8] bf16 (rows beyond N zero).  A K-slice of a wider matrix is tiled by passing W + k0 with its ld.
+extern "C" int wg_tile_weight_bf16(const void* W, long ld, int N, int K, void* tiled, void* stream) {
+    WG_REQUIRE(W && tiled && N > 0 && K > 0 && K % 32 == 0 && ld >= K && ld % 8 == 0, "tile_weight: bad arguments");
+    WG_REQUIRE((((uintptr_t)W | (uintptr_t)tiled) & 15) == 0, "tile_weight: misaligned operand");
+    const long total = (long)((N + 15) / 16) * (K / 32) * 64;
+    hipLaunchKernelGGL(wg_tile_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16*)W, ld, N, K,
+                       (bf16*)tiled);
+    return wg_check_launch("wg_tile_weight");
+}
 
 // Flat pointer table of wg_dec_tokens_f32 (bf16 device pointers, weight then bias / gamma then beta; entries of stages that are not
 // requested may be null), 24 entries:

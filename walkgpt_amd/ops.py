@@ -380,6 +380,26 @@ def linear_fp8(xq, x_scale, wq, w_scale, bias=None, act=ACT_NONE, residual=None,
     return out
 
 
+def tile_weight(w, k_slices=1):
+    """Weight matrix [N, K] bf16 -> fragment order [k_slices, ceil(N / 16), K / (32 k_slices), 64, 8] for the token-side decoder kernels
+    (wg_tile_weight_bf16; squeezed to 4-D when k_slices == 1).  k_slices > 1 tiles each K-slice on its own (mlp.lin2 of the two-way block)."""
+    _need_gpu(w)
+    assert w.dtype == _BF16 and w.dim() == 2 and w.stride(1) == 1
+    N, K = w.shape
+    assert K % (32 * k_slices) == 0
+    ks = K // k_slices
+    out = torch.empty(k_slices, (N + 15) // 16, ks // 32, 64, 8, device=w.device, dtype=_BF16)
+    for s in range(k_slices):
+        rc = _lib.lib().wg_tile_weight_bf16(w.data_ptr() + 2 * s * ks, w.stride(0), N, ks, out[s].data_ptr(), _stream())
+        _lib.check(rc, "wg_tile_weight_bf16")
+    return out[0] if k_slices == 1 else out
+
+
+def _tiled_ok(t, N, K, k_slices=1):
+    shape = ((N + 15) // 16, K // (32 * k_slices), 64, 8)
+    return t.dtype == _BF16 and t.is_contiguous() and tuple(t.shape) == ((k_slices,) + shape if k_slices > 1 else shape)
+
+
 TOK_SUM_MLP, TOK_SELF, TOK_Q_T2I, TOK_COMBINE, TOK_INIT = 1, 2, 4, 8, 16
 _TOK_PART = 6 * 18          # floats of one attention partial (csrc/decoder.hip)
 
@@ -392,7 +412,7 @@ def dec_tokens(stages, skip_pe, queries, query_pe, weights, q_t2i=None, attn_par
                eps=1e-5, init_tokens=None, init_prompt=None):
     """Per-prompt stages of the token side of SAM's two-way transformer (csrc/decoder.hip: wg_dec_tokens_f32; stage bits TOK_*).
     queries / query_pe [P, 6, 256] fp32 (queries updated in place); weights: the 24-slot table the C-ABI documents (bf16 tensors or
-    None for the slots of stages that do not run).  TOK_INIT: queries and query_pe are OUTPUTS, both set to
+    None for the slots of stages that do not run; the weight matrices in fragment order, ops.tile_weight).  TOK_INIT: queries and query_pe are OUTPUTS, both set to
     cat(init_tokens [5, 256] fp32, init_prompt [P, 256] bf16) before the other stages run."""
     import ctypes
     _need_gpu(queries, query_pe, q_t2i, attn_partials, mlp_partials, k_i2t, v_i2t, init_tokens, init_prompt, *weights)
@@ -448,8 +468,8 @@ def _combine_table(combine, P):
     part, wo, bo, g, b = combine
     _need_gpu(part, wo, bo, g, b)
     assert part.dtype == torch.float32 and part.is_contiguous() and part.dim() == 4 and part.shape[0] == P and part.shape[1] == 8
-    assert part.shape[3] == _TOK_PART and wo.shape == (256, 128) and bo.numel() == 256 and g.numel() == 256 and b.numel() == 256
-    assert all(t.dtype == _BF16 and t.is_contiguous() for t in (wo, bo, g, b))
+    assert part.shape[3] == _TOK_PART and _tiled_ok(wo, 256, 128) and bo.numel() == 256 and g.numel() == 256 and b.numel() == 256
+    assert all(t.dtype == _BF16 and t.is_contiguous() for t in (bo, g, b))
     return (ctypes.c_void_p * 5)(part.data_ptr(), wo.data_ptr(), bo.data_ptr(), g.data_ptr(), b.data_ptr()), part.shape[2]
 
 
@@ -460,8 +480,8 @@ def dec_mlp_partial(x, lin1_w, lin1_b, lin2_w, combine=None, eps=1e-5):
     _need_gpu(x, lin1_w, lin1_b, lin2_w)
     P = x.shape[0]
     _f32_tokens(x, P, 256)
-    assert lin1_w.shape == (2048, 256) and lin2_w.shape == (256, 2048) and lin1_b.shape == (2048,)
-    assert all(t.dtype == _BF16 and t.is_contiguous() for t in (lin1_w, lin1_b, lin2_w))
+    assert _tiled_ok(lin1_w, 2048, 256) and _tiled_ok(lin2_w, 256, 2048, 8) and lin1_b.shape == (2048,)     # ops.tile_weight(w), (w, 8)
+    assert lin1_b.dtype == _BF16 and lin1_b.is_contiguous()
     out = torch.empty(P, 8, 6, 256, device=x.device, dtype=torch.float32)
     table, n_splits = _combine_table(combine, P)
     x_out = torch.empty_like(x) if combine is not None else None
@@ -480,8 +500,7 @@ def dec_heads(x, weights, combine=None, eps=1e-5):
     _f32_tokens(x, P, 256)
     assert len(weights) == 30 and all(w.dtype == _BF16 and w.is_contiguous() for w in weights)
     for i in range(5):
-        shapes = [tuple(weights[(3 * i + j) * 2].shape) for j in range(3)]
-        assert shapes == [(256, 256), (256, 256), (32 if i < 4 else 4, 256)], shapes
+        assert all(_tiled_ok(weights[(3 * i + j) * 2], n, 256) for j, n in enumerate((256, 256, 32 if i < 4 else 4))), i
     hyper = torch.empty(P, 4, 32, device=x.device, dtype=torch.float32)
     iou = torch.empty(P, 4, device=x.device, dtype=torch.float32)
     table = (ctypes.c_void_p * 30)(*[w.data_ptr() for w in weights])

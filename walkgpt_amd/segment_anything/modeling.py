@@ -348,8 +348,28 @@ def _pe_folded_projection(pe_rows, parts, src_bias=None):
     return torch.cat(ws, 0).contiguous(), torch.cat(rs, 1).contiguous()
 
 
+import weakref
+
+_TILED = {}   # id(weight Parameter) -> (weak reference, identity key, fragment-order copy); tensors compare element-wise, so no WeakKeyDictionary
+
+
+def _tiled(weight, k_slices=1):
+    """ops.tile_weight(weight), cached until the parameter's storage, version, dtype or device changes (the token-side decoder kernels
+    stream their weight matrices in MFMA fragment order; the copy is made once per checkpoint)."""
+    key = (weight.data_ptr(), weight._version, weight.dtype, str(weight.device), k_slices)
+    wid = id(weight)
+    ent = _TILED.get(wid)
+    if ent is None or ent[0]() is not weight or ent[1] != key:
+        with torch.no_grad():
+            tiled = ops.tile_weight(weight.detach().contiguous(), k_slices)
+        ent = (weakref.ref(weight, lambda _r, wid=wid: _TILED.pop(wid, None)), key, tiled)
+        _TILED[wid] = ent
+    return ent[2]
+
+
 def _lin_pair(lin):
-    return [lin.weight, lin.bias]
+    """[weight in fragment order, bias] of a Linear on the token side of the mask decoder"""
+    return [_tiled(lin.weight), lin.bias]
 
 
 class TwoWayAttentionBlock(nn.Module):
@@ -406,7 +426,8 @@ class TwoWayAttentionBlock(nn.Module):
         return ops.layernorm(keys, self.norm4.weight, self.norm4.bias, self.norm4.eps)
 
     def mlp_partials(self, queries, combine=None):
-        return ops.dec_mlp_partial(queries, self.mlp.lin1.weight, self.mlp.lin1.bias, self.mlp.lin2.weight, combine=combine, eps=self.norm2.eps)
+        return ops.dec_mlp_partial(queries, _tiled(self.mlp.lin1.weight), self.mlp.lin1.bias, _tiled(self.mlp.lin2.weight, 8), combine=combine,
+                                   eps=self.norm2.eps)
 
     def check_fused(self):
         if self.norm1.eps != self.norm2.eps or self.norm1.eps != self.norm3.eps or self.mlp._act_code != ops.ACT_RELU:
@@ -516,7 +537,7 @@ class TwoWayTransformer(nn.Module):
                 src_bias = None                                   # (part of `keys` from here on)
             proj = layer.image_side(keys, pe_tokens, src_bias) if layer is not None else self.final_image_side(keys, pe_tokens)
             part = ops.dec_attn_partial(q, proj[..., :d], proj[..., d:2 * d])
-            combine = (part, t2i.out_proj.weight, t2i.out_proj.bias, norm.weight, norm.bias)
+            combine = (part, _tiled(t2i.out_proj.weight), t2i.out_proj.bias, norm.weight, norm.bias)
             if layer is not None:
                 mlp_part, queries = layer.mlp_partials(queries, combine)
             prev, prev_proj = layer, proj
