@@ -54,12 +54,13 @@ int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, cons
                           long ldr, int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32,
                           int tile_hint, void* stream);
 
-/* Skinny rows (M <= 16: the [SEG] hidden states) with the LayerNorm in front, one launch:
- *   C = act(LayerNorm(A; gamma, beta, eps) . W^T + bias)     -- the head of text_hidden_fcs[0] (utils/utils_walkgpt.py:321-323).
- * N % 16 == 0, K % 128 == 0; every workgroup (16 output columns) repeats the exact two-pass row statistics in fp32. */
+/* Skinny rows (M <= 16: the [SEG] hidden states through text_hidden_fcs[0], utils/utils_walkgpt.py:321-323), one launch:
+ *   C = act(LN?(A; gamma, beta, eps) . W^T + bias);  gamma == beta == null: no LayerNorm in front.
+ * N % 16 == 0, K % 128 == 0; every workgroup (16 output columns) repeats the exact two-pass row statistics in fp32.
+ * w_tiled != 0: W is in fragment order (wg_tile_weight_bf16; ldw ignored) -- contiguous 1-KiB wave loads. */
 int wg_gemm_skinny_ln_supported(int M, int N, int K, long lda, long ldw, long ldc);
 int wg_gemm_skinny_ln_bias_act_bf16(const void* A, long lda, const void* gamma, const void* beta, float eps, const void* W, long ldw,
-                                    const void* bias, void* C, long ldc, int M, int N, int K, int act, int out_f32, void* stream);
+                                    int w_tiled, const void* bias, void* C, long ldc, int M, int N, int K, int act, int out_f32, void* stream);
 
 /* The same product with the LayerNorm in front of it folded in (image_encoder.py:177-178 norm1 -> attn.qkv, :191 norm2 ->
  * mlp.lin1; HF CLIPEncoderLayer layer_norm1 -> q/k/v_proj, layer_norm2 -> mlp.fc1):
@@ -163,8 +164,9 @@ int wg_upscale_mask_bf16(const void* x, long ldx, const void* w1, const void* b1
  *   self_attn q,k,v,out [0..7] | norm1 [8,9] | token->image q,out [10..13] | norm2 or norm_final_attn [14,15] | mlp.lin2.bias [16] |
  *   unused [17] | norm3 [18,19] | image->token k,v [20..23].
  * wg_dec_attn_partial_f32: softmax(q k^T / 4) v per (prompt, head, split of 1024 keys), a wave per 256 keys.  Kimg / Vimg: the projected image
- *   tokens (k_proj(keys + key_pe), v_proj(keys)) as bf16 rows [P or 1][hw][128] with row stride ld_img (img_rows_per_prompt = 0 when all
- *   prompts share one image); partials [P, 8, n_splits, 108] fp32 = {running max[6], sum[6], o[6][16]}, n_splits = ceil(hw / 1024).
+ *   tokens (k_proj(keys + key_pe), v_proj(keys)) as bf16 rows [P or 1][hw] with row stride ld_img, head h's 16 columns at + h * head_stride
+ *   (16: two plain 128-column blocks; 32: columns ordered [K_h | V_h] per head, Vimg = Kimg + 16: one 64-byte piece per key and head)
+ *   (img_rows_per_prompt = 0 when all prompts share one image); partials [P, 8, n_splits, 108] fp32 = {running max[6], sum[6], o[6][16]}, n_splits = ceil(hw / 1024).
  * wg_dec_mlp_partial_f32: slice s of 8 of mlp(x): relu(x lin1[256 s .. +255]^T + b1) lin2[:, 256 s .. +255]^T -> partials [P,8,6,256].
  * wg_dec_heads_f32: output_hypernetworks_mlps[i](x[:, 1 + i]) -> hyper_out [P,4,32]; iou_prediction_head(x[:, 0]) -> iou_out [P,4];
  *   weights: 30 bf16 pointers = (hypernetwork 0..3, IoU head) x layers[0..2] x (weight, bias).
@@ -180,7 +182,7 @@ int wg_tile_weight_bf16(const void* W, long ld, int N, int K, void* tiled, void*
 int wg_dec_tokens_f32(int stages, int skip_pe, float* queries, float* query_pe, const float* init_tokens, const void* init_prompt,
                       const void* const* weights, int n_weights, float* q_t2i, const float* attn_partials, int n_splits, const float* mlp_partials, void* k_i2t, void* v_i2t, int P,
                       float eps, void* stream);
-int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const void* Vimg, long ld_img, long img_rows_per_prompt, int hw,
+int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const void* Vimg, long ld_img, int head_stride, long img_rows_per_prompt, int hw,
                             float* partials, int n_splits, int P, void* stream);
 int wg_dec_mlp_partial_f32(const float* x, const void* const* combine, int n_splits, float eps, float* x_out, const void* lin1_w,
                            const void* lin1_b, const void* lin2_w, float* partials, int P, void* stream);

@@ -140,6 +140,29 @@ def test_layernorm_linear_skinny(dev, M, N, K):
     assert out.shape == (M, N)
     assert (out.cpu() - ref).abs().max().item() <= 2e-2     # a bf16 ulp of a normalised value (|x^| up to ~20) moving one product
     assert ((out.cpu() - ref).norm() / ref.norm()).item() < 2e-3
+    # the same through the weight matrix in fragment order: identical arithmetic, identical bits
+    wt = ops.tile_weight(w.to(dev))
+    out_t = ops.layernorm_linear(x.to(dev), gam.to(dev), bet.to(dev), 1e-5, w.to(dev), b.to(dev), act=ops.ACT_GELU, out_f32=True, weight_tiled=wt)
+    assert torch.equal(out_t, out)
+    # and without the LayerNorm
+    plain = ops.layernorm_linear(x.to(dev), None, None, 0.0, w.to(dev), b.to(dev), out_f32=True, weight_tiled=wt)
+    assert torch.equal(plain, ops.linear(x.to(dev), w.to(dev), b.to(dev), out_f32=True))
+
+
+def test_tile_weight_layout(dev):
+    """wg_tile_weight_bf16: T[nb][ks][lane][j] = W[16 nb + lane % 16][32 ks + 8 (lane // 16) + j], rows beyond N zero; K-slices tile on their own."""
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(36, 128, generator=g).to(torch.bfloat16)
+    t = ops.tile_weight(w.to(dev)).cpu()
+    assert t.shape == (3, 4, 64, 8)
+    wp = torch.zeros(48, 128, dtype=torch.bfloat16)
+    wp[:36] = w
+    ref = wp.reshape(3, 16, 4, 4, 8).permute(0, 2, 3, 1, 4).reshape(3, 4, 64, 8)
+    assert torch.equal(t, ref)
+    t2 = ops.tile_weight(w.to(dev), 2).cpu()
+    assert t2.shape == (2, 3, 2, 64, 8)
+    for s in range(2):
+        assert torch.equal(t2[s], wp[:, 64 * s:64 * s + 64].reshape(3, 16, 2, 4, 8).permute(0, 2, 3, 1, 4).reshape(3, 2, 64, 8))
 
 
 @pytest.mark.parametrize("M,D,eps", [(4100, 768, 1e-6), (1025, 1024, 1e-5), (37, 256, 1e-6), (9, 4096, 1e-5),

@@ -25,11 +25,11 @@ for P in (1, 8, 112):
         kq = torch.empty(P, 6, 128, device=dev, dtype=torch.bfloat16); vq = torch.empty_like(kq)
         qt = torch.empty(P, 6, 128, device=dev)
         tab = M.token_stage_table(self_blk=l1, t2i=l1.cross_attn_token_to_image, norm=l1.norm2, sum_blk=l0)
-        part = ops.dec_attn_partial(qt, proj[..., :128], proj[..., 128:256])
+        part = ops.dec_attn_partial(qt, proj[..., :256])
         mp = l1.mlp_partials(q)
         r = {
             "sum|self|q": t(lambda: ops.dec_tokens(7, False, q, pe, tab, q_t2i=qt, mlp_partials=mp, k_i2t=kq, v_i2t=vq)),
-            "attn": t(lambda: ops.dec_attn_partial(qt, proj[..., :128], proj[..., 128:256])),
+            "attn": t(lambda: ops.dec_attn_partial(qt, proj[..., :256])),
             "combine": t(lambda: ops.dec_tokens(8, False, q, pe, tab, attn_partials=part)),
             "mlp": t(lambda: l1.mlp_partials(q)),
             "combine+mlp": t(lambda: l1.mlp_partials(q, (part, M._tiled(l1.cross_attn_token_to_image.out_proj.weight), l1.cross_attn_token_to_image.out_proj.bias, l1.norm2.weight, l1.norm2.bias))),

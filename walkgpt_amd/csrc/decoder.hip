@@ -28,7 +28,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + w
 
 struct UpArgs {
     const bf16* x; long ldx;           // image tokens [P*hw, 256]
-    const bf16* w1; const bf16* b1;    // ConvT 1 as a GEMM: [(dy,dx,64), 256], bias [64]
+    const bf16* w1; const bf16* b1;    // ConvT 1 as a GEMM: [(dy,dx,64), 256] in fragment order (wg_tile_weight_bf16), bias [64]
     const bf16* g1; const bf16* be1;   // LayerNorm2d(64)
     const bf16* w2; const bf16* b2;    // ConvT 2 as a GEMM: [(dy,dx,32), 64], bias [32]
     const float* hyper;                // [P, nmask_total, 32]
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void wg_upscale_mask_kernel(UpArgs a) {
 #pragma unroll
     for (int nb = 0; nb < 4; ++nb)
 #pragma unroll
-        for (int ks = 0; ks < 8; ++ks) wf[nb][ks] = *(const bf16x8*)(a.w1 + (long)(wave * 64 + nb * 16 + l16) * 256 + 32 * ks + 8 * kg);
+        for (int ks = 0; ks < 8; ++ks) wf[nb][ks] = *(const bf16x8*)(a.w1 + ((long)((wave * 4 + nb) * 8 + ks) * 64 + lane) * 8);   // fragment order
     float b1v[4], g1v[4], be1v[4], b2v[2];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
 constexpr int AT_WAVES = 4;
 constexpr int AT_KEYS = 256 * AT_WAVES;    // keys per workgroup
 struct AttnPartArgs {
-    const float* q; const bf16* K; const bf16* V; long ld, img_bs; int hw, n_splits; float* part;
+    const float* q; const bf16* K; const bf16* V; long ld, img_bs; int head_stride, hw, n_splits; float* part;
 };
 __global__ __launch_bounds__(64 * AT_WAVES) void wg_dec_attn_partial_kernel(AttnPartArgs a) {
     __shared__ __attribute__((aligned(16))) float qsh[TK_N * 16];
@@ -709,8 +709,8 @@ __global__ __launch_bounds__(64 * AT_WAVES) void wg_dec_attn_partial_kernel(Attn
     for (int i = threadIdx.x; i < TK_N * 16; i += 64 * AT_WAVES)
         qsh[i] = a.q[((long)p * TK_N + i / 16) * 128 + h * 16 + (i & 15)] * 0.25f;   // 1 / sqrt(16)
     __syncthreads();
-    const bf16* Kp = a.K + (long)p * a.img_bs * a.ld + h * 16;
-    const bf16* Vp = a.V + (long)p * a.img_bs * a.ld + h * 16;
+    const bf16* Kp = a.K + (long)p * a.img_bs * a.ld + h * a.head_stride;
+    const bf16* Vp = a.V + (long)p * a.img_bs * a.ld + h * a.head_stride;
     float m[TK_N], l[TK_N], acc[TK_N][16];
 #pragma unroll
     for (int t = 0; t < TK_N; ++t) {
@@ -814,18 +814,18 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_mlp_partial_kernel(MlpArgs 
 // hypernetwork MLPs on the mask tokens (rows 1..4), IoU head on row 0 (mask_decoder.py:146-160): one (prompt, head) pair per workgroup.
 // With `comb.part` set, the workgroup first takes ITS token row through COMBINE (final attention out_proj + norm_final_attn).
 struct HeadArgs { const float* x; CombineW comb; LinW mlp[5][3]; float* hyper_out; float* iou_out; };
-__global__ __launch_bounds__(256) void wg_dec_heads_kernel(HeadArgs a) {
+__global__ __launch_bounds__(TK_THREADS) void wg_dec_heads_kernel(HeadArgs a) {
     __shared__ float x0[TK_C], x1[TK_C], x2[TK_C];
     __shared__ __attribute__((aligned(16))) bf16 sh[8 * (TK_C + 8)], sl[8 * (TK_C + 8)];
     const int i = blockIdx.x % 5, p = blockIdx.x / 5;
     const int row = i < 4 ? 1 + i : 0;
     const float* x = a.x + ((long)p * TK_N + row) * TK_C;
-    for (int c = threadIdx.x; c < TK_C; c += 256) x0[c] = x[c];
+    for (int c = threadIdx.x; c < TK_C; c += TK_THREADS) x0[c] = x[c];
     __syncthreads();
-    if (a.comb.part) tok_combine<256>(a.comb, p, row, 1, x0, x1, sh, sl);
-    tok_linear<TK_C, 256>(x0, TK_C, 1, a.mlp[i][0], TK_C, x1, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
-    tok_linear<TK_C, 256>(x1, TK_C, 1, a.mlp[i][1], TK_C, x2, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
-    tok_linear<TK_C, 256>(x2, TK_C, 1, a.mlp[i][2], i < 4 ? 32 : 4, x0, TK_C, 0, nullptr, 0, sh, sl);
+    if (a.comb.part) tok_combine(a.comb, p, row, 1, x0, x1, sh, sl);
+    tok_linear<TK_C>(x0, TK_C, 1, a.mlp[i][0], TK_C, x1, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
+    tok_linear<TK_C>(x1, TK_C, 1, a.mlp[i][1], TK_C, x2, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
+    tok_linear<TK_C>(x2, TK_C, 1, a.mlp[i][2], i < 4 ? 32 : 4, x0, TK_C, 0, nullptr, 0, sh, sl);
     if (i < 4) {
         if (threadIdx.x < 32) a.hyper_out[((long)p * 4 + i) * 32 + threadIdx.x] = x0[threadIdx.x];
     } else if (threadIdx.x < 4) {
@@ -888,14 +888,16 @@ extern "C" int wg_dec_tokens_f32(int stages, int skip_pe, float* queries, float*
     return wg_check_launch("wg_dec_tokens");
 }
 
-// q [P,6,128] fp32; Kimg / Vimg [P or 1][hw][128] bf16 with row stride ld_img (img_rows_per_prompt = 0: one image shared by all prompts);
+// q [P,6,128] fp32; Kimg / Vimg: head h's 16 columns at Kimg + h * head_stride of each of the [P or 1][hw] rows (stride ld_img) -- head_stride 16:
+// plain [.., 128] blocks; 32: the projection's columns ordered [K_h | V_h] per head, one 64-byte piece per (key, head) -- (img_rows_per_prompt = 0: one image shared by all prompts);
 // partials [P, 8, n_splits, 108] fp32 with n_splits = ceil(hw / 1024).
-extern "C" int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const void* Vimg, long ld_img, long img_rows_per_prompt, int hw,
+extern "C" int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const void* Vimg, long ld_img, int head_stride, long img_rows_per_prompt, int hw,
                                        float* partials, int n_splits, int P, void* stream) {
     WG_REQUIRE(q && Kimg && Vimg && partials && P > 0 && hw > 0 && ld_img % 8 == 0, "dec_attn_partial: bad arguments");
     WG_REQUIRE(n_splits == (hw + AT_KEYS - 1) / AT_KEYS, "dec_attn_partial: n_splits must be ceil(hw / 1024)");
     WG_REQUIRE((((uintptr_t)Kimg | (uintptr_t)Vimg) & 15) == 0, "dec_attn_partial: misaligned image projections");
-    AttnPartArgs a{q, (const bf16*)Kimg, (const bf16*)Vimg, ld_img, img_rows_per_prompt, hw, n_splits, partials};
+    WG_REQUIRE(head_stride == 16 || head_stride == 32, "dec_attn_partial: head_stride must be 16 (K and V blocks) or 32 (K | V interleaved per head)");
+    AttnPartArgs a{q, (const bf16*)Kimg, (const bf16*)Vimg, ld_img, img_rows_per_prompt, head_stride, hw, n_splits, partials};
     hipLaunchKernelGGL(wg_dec_attn_partial_kernel, dim3((unsigned)(P * 8 * n_splits)), dim3(64 * AT_WAVES), 0, (hipStream_t)stream, a);
     return wg_check_launch("wg_dec_attn_partial");
 }
@@ -943,7 +945,7 @@ extern "C" int wg_dec_heads_f32(const float* x, const void* const* combine, int 
             WG_REQUIRE(wp && ((uintptr_t)wp & 15) == 0 && weights[(i * 3 + j) * 2 + 1], "dec_heads: weight %d null or misaligned", i * 3 + j);
             a.mlp[i][j] = LinW{(const bf16*)wp, (const bf16*)weights[(i * 3 + j) * 2 + 1]};
         }
-    hipLaunchKernelGGL(wg_dec_heads_kernel, dim3((unsigned)(P * 5)), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(wg_dec_heads_kernel, dim3((unsigned)(P * 5)), dim3(TK_THREADS), 0, (hipStream_t)stream, a);
     return wg_check_launch("wg_dec_heads");
 }
 

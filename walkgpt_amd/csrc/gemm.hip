@@ -39,6 +39,7 @@ struct GemmArgs {
     const bf16* sk_gamma;        // skinny kernel only: LayerNorm(A) applied to the rows on their way into the MFMA (gamma, beta [K], eps)
     const bf16* sk_beta;
     float sk_eps;
+    int sk_tiled;                // skinny kernel only: W is in MFMA fragment order (wg_tile_weight_bf16) instead of row-major [N][K]
 };
 
 // Linear tile index -> (tile row, tile column).  With col_block = c > 0 the grid is walked in blocks of c tile columns, row-major
@@ -910,7 +911,7 @@ __global__ __launch_bounds__(256) void wg_gemm_rowwave_kernel(GemmArgs g) {
 // LN: the rows go through LayerNorm (two exact passes over the row for mean and variance, fp32) on their way into the MFMA -- every
 // workgroup repeats the statistics of the <= 16 rows (they are L2-resident and tiny next to its weight columns), which saves the separate
 // LayerNorm launch in front of text_hidden_fcs[0] (utils_walkgpt.py:321-323).
-template <int NW, bool LN>
+template <int NW, bool LN, bool TILED>
 __global__ __launch_bounds__(64 * NW) void wg_gemm_skinny_kernel(GemmArgs g) {
     __shared__ f32x4 red[NW - 1][64];
     __shared__ float stat[NW][16];
@@ -919,7 +920,9 @@ __global__ __launch_bounds__(64 * NW) void wg_gemm_skinny_kernel(GemmArgs g) {
     const int n = blockIdx.x * 16 + l16;                 // N % 16 == 0
     const int kw = g.K / NW;                             // K % (32 NW) == 0: every wave takes whole 32-deep MFMA steps
     const bool live = l16 < g.M;
-    const bf16* wp = g.W + (long)n * g.ldw + wave * kw + 8 * kg;
+    // TILED: fragment (column block, k step) is one contiguous KiB (3x the per-CU streaming rate of 16 rows x 64 B, tools/micro/cu_ingest.hip)
+    const bf16* wp = TILED ? g.W + (((long)blockIdx.x * (g.K / 32) + wave * (kw / 32)) * 64 + lane) * 8 : g.W + (long)n * g.ldw + wave * kw + 8 * kg;
+    constexpr int WSTEP = TILED ? 16 : 1;                // elements of W per element of k
     const bf16* ap = g.A + (long)(live ? l16 : 0) * g.lda + wave * kw + 8 * kg;
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     float mean = 0.f, rstd = 1.f;
@@ -958,7 +961,7 @@ __global__ __launch_bounds__(64 * NW) void wg_gemm_skinny_kernel(GemmArgs g) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
     for (int k = 0; k < kw; k += 32) {
-        const bf16x8 b = *(const bf16x8*)(wp + k);
+        const bf16x8 b = *(const bf16x8*)(wp + k * WSTEP);
         bf16x8 a = *(const bf16x8*)(ap + k);
         if constexpr (LN) {
             const bf16x8 gm = *(const bf16x8*)(g.sk_gamma + wave * kw + 8 * kg + k), bt = *(const bf16x8*)(g.sk_beta + wave * kw + 8 * kg + k);
@@ -1402,7 +1405,7 @@ extern "C" int wg_gemm_pick_tile(int M, int N) { return wg_gemm_pick_tile_ex(M, 
 static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const void* bias, const void* residual, long ldr,
                             int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32, int tile_hint,
                             const float* ln_stats, const float* ln_s, const float* ln_b, void* stream, const bf16* sk_gamma = nullptr,
-                            const bf16* sk_beta = nullptr, float sk_eps = 0.f);
+                            const bf16* sk_beta = nullptr, float sk_eps = 0.f, int sk_tiled = 0);
 
 extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, const void* bias,
                                      const void* residual, long ldr, int res_row_mod, void* C, long ldc, int M, int N,
@@ -1411,18 +1414,21 @@ extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, lon
                             nullptr, stream);
 }
 
-// Skinny rows with the LayerNorm in front: C = act(LayerNorm(A; gamma, beta, eps) . W^T + b) for M <= 16, N % 16 == 0, K % 128 == 0 (the
-// head of text_hidden_fcs[0], utils_walkgpt.py:321-323); wg_gemm_skinny_ln_supported() tells the caller whether the shape qualifies.
+// Skinny rows, optionally with the LayerNorm in front and / or the weight matrix in fragment order:
+//     C = act(LN?(A; gamma, beta, eps) . W^T + b)  for M <= 16, N % 16 == 0, K % 128 == 0        (text_hidden_fcs[0], utils_walkgpt.py:321-323)
+// gamma == beta == null: no LayerNorm.  w_tiled: W was re-laid by wg_tile_weight_bf16 (ldw ignored).  wg_gemm_skinny_ln_supported() tells the
+// caller whether the shape qualifies.
 extern "C" int wg_gemm_skinny_ln_supported(int M, int N, int K, long lda, long ldw, long ldc) {
     return (M >= 1 && M <= 16 && N % 16 == 0 && K % 128 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0) ? 1 : 0;
 }
 extern "C" int wg_gemm_skinny_ln_bias_act_bf16(const void* A, long lda, const void* gamma, const void* beta, float eps, const void* W, long ldw,
-                                               const void* bias, void* C, long ldc, int M, int N, int K, int act, int out_f32, void* stream) {
-    WG_REQUIRE(gamma && beta && (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "gemm_skinny_ln: null or misaligned LayerNorm operand");
-    WG_REQUIRE(wg_gemm_skinny_ln_supported(M, N, K, lda, ldw, ldc) && (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) == 0,
-               "gemm_skinny_ln: shape M=%d N=%d K=%d is not a skinny one", M, N, K);
-    return wg_gemm_dispatch(A, lda, W, ldw, bias, nullptr, 0, 0, C, ldc, M, N, K, act, out_f32, 5, nullptr, nullptr, nullptr, stream,
-                            (const bf16*)gamma, (const bf16*)beta, eps);
+                                               int w_tiled, const void* bias, void* C, long ldc, int M, int N, int K, int act, int out_f32,
+                                               void* stream) {
+    WG_REQUIRE((gamma != nullptr) == (beta != nullptr) && (((uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, "gemm_skinny: LayerNorm operands");
+    WG_REQUIRE(wg_gemm_skinny_ln_supported(M, N, K, lda, w_tiled ? 8 : ldw, ldc) && (((uintptr_t)A | (uintptr_t)W | (uintptr_t)C) & 15) == 0,
+               "gemm_skinny: shape M=%d N=%d K=%d is not a skinny one", M, N, K);
+    return wg_gemm_dispatch(A, lda, W, w_tiled ? K : ldw, bias, nullptr, 0, 0, C, ldc, M, N, K, act, out_f32, 5, nullptr, nullptr, nullptr, stream,
+                            (const bf16*)gamma, (const bf16*)beta, eps, w_tiled);
 }
 
 // C = act(LayerNorm(A) . W^T + b) with the LayerNorm folded in: A = the raw rows, Wg = W * gamma (bf16), colsum[n] = sum_k Wg[n,k],
@@ -1444,7 +1450,7 @@ extern "C" int wg_gemm_ln_bias_act_bf16(const void* A, long lda, const void* Wg,
 static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const void* bias, const void* residual, long ldr,
                             int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32, int tile_hint,
                             const float* ln_stats, const float* ln_s, const float* ln_b, void* stream, const bf16* sk_gamma,
-                            const bf16* sk_beta, float sk_eps) {
+                            const bf16* sk_beta, float sk_eps, int sk_tiled) {
     WG_REQUIRE(A && W && C, "gemm: null operand");
     WG_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
     WG_REQUIRE(act >= 0 && act <= 3, "gemm: bad activation %d", act);
@@ -1458,7 +1464,7 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
     g.col_block = 0;
     g.ln_stats = ln_stats; g.ln_s = ln_s; g.ln_b = ln_b;
     g.scale_a = g.scale_w = nullptr;
-    g.sk_gamma = sk_gamma; g.sk_beta = sk_beta; g.sk_eps = sk_eps;
+    g.sk_gamma = sk_gamma; g.sk_beta = sk_beta; g.sk_eps = sk_eps; g.sk_tiled = sk_tiled;
     {   // byte extents for the staged epilogue's buffer descriptors (it addresses C and R with 32-bit byte offsets)
         const long cb = ((long)(M - 1) * ldc + N) * 2;
         const long rrows = res_row_mod > 0 ? (res_row_mod < M ? res_row_mod : M) : M;
@@ -1487,11 +1493,21 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
     if (tile == 12 && !(can_stage && M >= 128 && M % 128 >= 1 && M % 128 <= 16)) tile = 1;
     switch (tile) {
         case 5:
-            if (g.sk_gamma) {
-                if (K >= 2048 && K % 512 == 0) hipLaunchKernelGGL((wg_gemm_skinny_kernel<16, true>), dim3(N / 16), dim3(1024), 0, st, g);
-                else hipLaunchKernelGGL((wg_gemm_skinny_kernel<4, true>), dim3(N / 16), dim3(256), 0, st, g);
-            } else if (K >= 2048 && K % 512 == 0) hipLaunchKernelGGL((wg_gemm_skinny_kernel<16, false>), dim3(N / 16), dim3(1024), 0, st, g);
-            else hipLaunchKernelGGL((wg_gemm_skinny_kernel<4, false>), dim3(N / 16), dim3(256), 0, st, g);
+            {
+                const bool wide = K >= 2048 && K % 512 == 0;
+                const int variant = (wide ? 4 : 0) | (g.sk_gamma ? 2 : 0) | (g.sk_tiled ? 1 : 0);
+                const dim3 grid(N / 16), blk(wide ? 1024 : 256);
+                switch (variant) {
+                    case 0: hipLaunchKernelGGL((wg_gemm_skinny_kernel<4, false, false>), grid, blk, 0, st, g); break;
+                    case 1: hipLaunchKernelGGL((wg_gemm_skinny_kernel<4, false, true>), grid, blk, 0, st, g); break;
+                    case 2: hipLaunchKernelGGL((wg_gemm_skinny_kernel<4, true, false>), grid, blk, 0, st, g); break;
+                    case 3: hipLaunchKernelGGL((wg_gemm_skinny_kernel<4, true, true>), grid, blk, 0, st, g); break;
+                    case 4: hipLaunchKernelGGL((wg_gemm_skinny_kernel<16, false, false>), grid, blk, 0, st, g); break;
+                    case 5: hipLaunchKernelGGL((wg_gemm_skinny_kernel<16, false, true>), grid, blk, 0, st, g); break;
+                    case 6: hipLaunchKernelGGL((wg_gemm_skinny_kernel<16, true, false>), grid, blk, 0, st, g); break;
+                    default: hipLaunchKernelGGL((wg_gemm_skinny_kernel<16, true, true>), grid, blk, 0, st, g); break;
+                }
+            }
             return wg_check_launch("wg_gemm_bias_act_bf16(skinny)");
         case 12: return launch_tail(g, st);                            // 128x128 tiles, last row tile absorbs M % 128 <= 16 rows
         case 11: return launch_persist<128, 128, 2, 2>(g, st);         // persistent 128x128 tiles, 2 workgroups / CU
@@ -1529,7 +1545,7 @@ extern "C" int wg_gemm_fp8_bias_act(const void* Aq, long lda, const float* scale
     g.col_block = 0;
     g.ln_stats = nullptr; g.ln_s = nullptr; g.ln_b = nullptr;
     g.scale_a = scale_a; g.scale_w = scale_w;
-    g.sk_gamma = g.sk_beta = nullptr; g.sk_eps = 0.f;
+    g.sk_gamma = g.sk_beta = nullptr; g.sk_eps = 0.f; g.sk_tiled = 0;
     const long cb = ((long)(M - 1) * ldc + N) * 2;
     const long rrows = res_row_mod > 0 ? (res_row_mod < M ? res_row_mod : M) : M;
     const long rb = residual ? ((rrows - 1) * ldr + N) * 2 : 0;

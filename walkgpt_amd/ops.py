@@ -168,23 +168,28 @@ def ln_linear(x, fold, eps, act=ACT_NONE, tail_tiles=False):
     return out
 
 
-def layernorm_linear(x, gamma, beta, eps, weight, bias=None, act=ACT_NONE, out_f32=False):
-    """act(LayerNorm(x) @ weight.T + bias) for a handful of rows (M <= 16: the [SEG] hidden states into text_hidden_fcs) in one launch
-    (wg_gemm_skinny_ln_bias_act_bf16); other shapes run LayerNorm and the GEMM as two kernels."""
-    _need_gpu(x, gamma, beta, weight, bias)
-    assert x.dtype == _BF16 and weight.dtype == _BF16 and gamma.dtype == _BF16 and beta.dtype == _BF16
+def layernorm_linear(x, gamma, beta, eps, weight, bias=None, act=ACT_NONE, out_f32=False, weight_tiled=None):
+    """act(LayerNorm(x) @ weight.T + bias) (gamma None: no LayerNorm) for a handful of rows (M <= 16: the [SEG] hidden states into
+    text_hidden_fcs) in one launch (wg_gemm_skinny_ln_bias_act_bf16); other shapes run LayerNorm and the GEMM as two kernels.
+    weight_tiled: tile_weight(weight), read instead of `weight` by the one-launch form."""
+    _need_gpu(x, gamma, beta, weight, bias, weight_tiled)
+    assert x.dtype == _BF16 and weight.dtype == _BF16
     M, K, lda = _rows(x)
     N = weight.shape[0]
     L = _lib.lib()
     if _FORCE_TILE or not L.wg_gemm_skinny_ln_supported(M, N, K, lda, weight.stride(0), N):
-        return linear(layernorm(x, gamma, beta, eps), weight, bias, act=act, out_f32=out_f32)
-    assert weight.shape[1] == K and weight.stride(1) == 1 and gamma.numel() == K and beta.numel() == K
+        return linear(x if gamma is None else layernorm(x, gamma, beta, eps), weight, bias, act=act, out_f32=out_f32)
+    assert weight.shape[1] == K and weight.stride(1) == 1
+    assert gamma is None or (gamma.dtype == _BF16 and beta.dtype == _BF16 and gamma.numel() == K and beta.numel() == K)
+    assert weight_tiled is None or _tiled_ok(weight_tiled, N, K)
     out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32 if out_f32 else _BF16)
     ev = _timed(5, M, N, K)
     if ev is not None:
         ev[0].record()
-    rc = L.wg_gemm_skinny_ln_bias_act_bf16(x.data_ptr(), lda, gamma.data_ptr(), beta.data_ptr(), float(eps), weight.data_ptr(),
-                                           weight.stride(0), _ptr(bias), out.data_ptr(), N, M, N, K, act, 1 if out_f32 else 0, _stream())
+    w = weight if weight_tiled is None else weight_tiled
+    rc = L.wg_gemm_skinny_ln_bias_act_bf16(x.data_ptr(), lda, _ptr(gamma), _ptr(beta), float(eps), w.data_ptr(), weight.stride(0),
+                                           0 if weight_tiled is None else 1, _ptr(bias), out.data_ptr(), N, M, N, K, act,
+                                           1 if out_f32 else 0, _stream())
     if ev is not None:
         ev[1].record()
     _lib.check(rc, "wg_gemm_skinny_ln_bias_act_bf16")
@@ -442,19 +447,19 @@ def dec_tokens(stages, skip_pe, queries, query_pe, weights, q_t2i=None, attn_par
     return queries
 
 
-def dec_attn_partial(q_t2i, k_img, v_img):
-    """Token->image attention partials (wg_dec_attn_partial_f32).  q_t2i [P, 6, 128] fp32; k_img / v_img [1 | P, hw, 128] bf16 column
-    slices of the projected image tokens -> fp32 [P, 8, ceil(hw / 1024), 108] for dec_tokens(TOK_COMBINE)."""
-    _need_gpu(q_t2i, k_img, v_img)
+def dec_attn_partial(q_t2i, kv_img):
+    """Token->image attention partials (wg_dec_attn_partial_f32).  q_t2i [P, 6, 128] fp32; kv_img [1 | P, hw, 256] bf16: the projected image
+    tokens with the columns ordered [K_h | V_h] for head h = 0..7 (16 + 16 each; a column slice of the fused image-side projection)
+    -> fp32 [P, 8, ceil(hw / 1024), 108] for the COMBINE step."""
+    _need_gpu(q_t2i, kv_img)
     P = q_t2i.shape[0]
     _f32_tokens(q_t2i, P, 128)
-    hw = k_img.shape[1]
-    assert k_img.dtype == _BF16 and v_img.dtype == _BF16 and k_img.shape[-1] == 128 and k_img.stride(-1) == 1 and v_img.stride(-1) == 1
-    assert v_img.shape == k_img.shape and k_img.stride(1) == v_img.stride(1) and k_img.shape[0] in (1, P)
-    img_bs = 0 if k_img.shape[0] == 1 and P > 1 else (k_img.stride(0) // k_img.stride(1) if k_img.shape[0] > 1 else hw)
+    hw = kv_img.shape[1]
+    assert kv_img.dtype == _BF16 and kv_img.shape[-1] == 256 and kv_img.stride(-1) == 1 and kv_img.shape[0] in (1, P)
+    img_bs = 0 if kv_img.shape[0] == 1 and P > 1 else (kv_img.stride(0) // kv_img.stride(1) if kv_img.shape[0] > 1 else hw)
     n_splits = (hw + 1023) // 1024
     part = torch.empty(P, 8, n_splits, _TOK_PART, device=q_t2i.device, dtype=torch.float32)
-    rc = _lib.lib().wg_dec_attn_partial_f32(q_t2i.data_ptr(), k_img.data_ptr(), v_img.data_ptr(), k_img.stride(1), img_bs, hw,
+    rc = _lib.lib().wg_dec_attn_partial_f32(q_t2i.data_ptr(), kv_img.data_ptr(), kv_img.data_ptr() + 32, kv_img.stride(1), 32, img_bs, hw,
                                             part.data_ptr(), n_splits, P, _stream())
     _lib.check(rc, "wg_dec_attn_partial_f32")
     return part
@@ -534,12 +539,12 @@ def dec_i2t_rows(q_img, k_i2t, v_i2t, out_w, out_b, keys, ln_g, ln_b, eps, P, re
 
 
 def upscale_mask(keys, up1_w, up1_b, ln_g, ln_b, eps, up2_w, up2_b, hyper, h, w, first_mask, num_masks):
-    """mask_decoder.py:140-160 in one launch.  keys [P, h*w, 256] bf16 image tokens; up1_w [(dy,dx,64), 256], up2_w [(dy,dx,32), 64]
-    (re-laid ConvTranspose2d weights); hyper [P, nmask, 32] fp32 -> fp32 [P, num_masks, 4h, 4w]."""
+    """mask_decoder.py:140-160 in one launch.  keys [P, h*w, 256] bf16 image tokens; up1_w [(dy,dx,64), 256] (in fragment order,
+    ops.tile_weight), up2_w [(dy,dx,32), 64] (re-laid ConvTranspose2d weights); hyper [P, nmask, 32] fp32 -> fp32 [P, num_masks, 4h, 4w]."""
     _need_gpu(keys, up1_w, up1_b, ln_g, ln_b, up2_w, up2_b, hyper)
     P = keys.shape[0]
     assert keys.dtype == _BF16 and keys.is_contiguous() and keys.shape[1:] == (h * w, 256)
-    assert up1_w.shape == (256, 256) and up2_w.shape == (128, 64) and up1_w.is_contiguous() and up2_w.is_contiguous()
+    assert _tiled_ok(up1_w, 256, 256) and up2_w.shape == (128, 64) and up2_w.is_contiguous()     # up1_w: ops.tile_weight of the re-laid ConvT
     assert hyper.dtype == torch.float32 and hyper.is_contiguous() and hyper.shape[0] == P and hyper.shape[2] == 32
     masks = torch.empty(P, num_masks, 4 * h, 4 * w, device=keys.device, dtype=torch.float32)
     rc = _lib.lib().wg_upscale_mask_bf16(keys.data_ptr(), 256, up1_w.data_ptr(), up1_b.data_ptr(), ln_g.data_ptr(), ln_b.data_ptr(),

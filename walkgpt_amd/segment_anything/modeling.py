@@ -348,6 +348,15 @@ def _pe_folded_projection(pe_rows, parts, src_bias=None):
     return torch.cat(ws, 0).contiguous(), torch.cat(rs, 1).contiguous()
 
 
+def _interleave_kv_heads(wcat, rtab, d, heads):
+    """Reorder the first 2d output columns of a fused projection ([K (d) | V (d) | ...]) to [K_h | V_h] per head, so the token->image
+    attention kernel finds everything it needs of (key, head) in one 64-byte piece."""
+    c = d // heads
+    old = torch.arange(2 * d, device=wcat.device).reshape(2, heads, c).permute(1, 0, 2).reshape(-1)     # new column -> old column
+    idx = torch.cat([old, torch.arange(2 * d, wcat.shape[0], device=wcat.device)])
+    return wcat[idx].contiguous(), rtab[:, idx].contiguous()
+
+
 import weakref
 
 _TILED = {}   # id(weight Parameter) -> (weak reference, identity key, fragment-order copy); tensors compare element-wise, so no WeakKeyDictionary
@@ -387,7 +396,8 @@ class TwoWayAttentionBlock(nn.Module):
         self.skip_first_layer_pe = skip_first_layer_pe
 
     def _image_side(self, key_pe, src_bias=None):
-        """[K_t2i | V_t2i | Q_i2t] of the image tokens as one GEMM (cached per positional-encoding tensor / weights / constant row)."""
+        """[(K_h | V_h of token->image, per head) | Q_i2t] of the image tokens as one GEMM (cached per positional-encoding tensor / weights /
+        constant row)."""
         t2i, i2t = self.cross_attn_token_to_image, self.cross_attn_image_to_token
         key = (key_pe.data_ptr(), key_pe._version) + tuple((p.data_ptr(), p._version) for p in
                                                            (t2i.k_proj.weight, t2i.v_proj.weight, i2t.q_proj.weight,
@@ -395,8 +405,9 @@ class TwoWayAttentionBlock(nn.Module):
         if src_bias is not None:
             key += (src_bias.data_ptr(), src_bias._version)
         if getattr(self, "_img_key", None) != key:
-            self._img_val = _pe_folded_projection(key_pe.reshape(-1, key_pe.shape[-1]),
-                                                  [(t2i.k_proj, True), (t2i.v_proj, False), (i2t.q_proj, True)], src_bias)
+            self._img_val = _interleave_kv_heads(*_pe_folded_projection(key_pe.reshape(-1, key_pe.shape[-1]),
+                                                                        [(t2i.k_proj, True), (t2i.v_proj, False), (i2t.q_proj, True)], src_bias),
+                                                 t2i.internal_dim, t2i.num_heads)
             self._img_key = key
         return self._img_val
 
@@ -445,7 +456,7 @@ class TwoWayAttentionBlock(nn.Module):
         vq = torch.empty_like(kq)
         ops.dec_tokens(ops.TOK_SELF | ops.TOK_Q_T2I, self.skip_first_layer_pe, queries, query_pe, table, q_t2i=q, eps=self.norm1.eps)
         proj = self.image_side(keys, key_pe)
-        part = ops.dec_attn_partial(q, proj[..., :d], proj[..., d:2 * d])
+        part = ops.dec_attn_partial(q, proj[..., :2 * d])
         ops.dec_tokens(ops.TOK_COMBINE, False, queries, query_pe, table, attn_partials=part, eps=self.norm1.eps)
         ops.dec_tokens(ops.TOK_SUM_MLP, False, queries, query_pe, table, mlp_partials=self.mlp_partials(queries), k_i2t=kq, v_i2t=vq,
                        eps=self.norm1.eps)
@@ -536,7 +547,7 @@ class TwoWayTransformer(nn.Module):
                 keys = prev.image_to_token(prev_proj, keys, kq, vq, P, src_bias)
                 src_bias = None                                   # (part of `keys` from here on)
             proj = layer.image_side(keys, pe_tokens, src_bias) if layer is not None else self.final_image_side(keys, pe_tokens)
-            part = ops.dec_attn_partial(q, proj[..., :d], proj[..., d:2 * d])
+            part = ops.dec_attn_partial(q, proj[..., :2 * d])
             combine = (part, _tiled(t2i.out_proj.weight), t2i.out_proj.bias, norm.weight, norm.bias)
             if layer is not None:
                 mlp_part, queries = layer.mlp_partials(queries, combine)
@@ -549,7 +560,8 @@ class TwoWayTransformer(nn.Module):
         key = (pe_tokens.data_ptr(), pe_tokens._version) + tuple((p.data_ptr(), p._version) for p in
                                                                  (fa.k_proj.weight, fa.v_proj.weight, fa.k_proj.bias, fa.v_proj.bias))
         if getattr(self, "_fin_key", None) != key:
-            self._fin_val = _pe_folded_projection(pe_tokens.reshape(-1, pe_tokens.shape[-1]), [(fa.k_proj, True), (fa.v_proj, False)])
+            self._fin_val = _interleave_kv_heads(*_pe_folded_projection(pe_tokens.reshape(-1, pe_tokens.shape[-1]),
+                                                                        [(fa.k_proj, True), (fa.v_proj, False)]), fa.internal_dim, fa.num_heads)
             self._fin_key = key
         wcat, rtab = self._fin_val
         return ops.linear(keys, wcat, residual=rtab, res_row_mod=keys.shape[1])
@@ -605,7 +617,7 @@ class MaskDecoder(nn.Module, _Prepared):
         # ConvTranspose2d(k=2, s=2) == per-pixel GEMM whose output columns are (dy, dx, c_out): weight [Cin, Cout, 2, 2]
         # -> [(dy, dx, Cout), Cin]; the bias repeats over the four sub-pixels.
         return {
-            "up1_w": c1.weight.permute(2, 3, 1, 0).reshape(-1, c1.weight.shape[0]).contiguous(),
+            "up1_w": ops.tile_weight(c1.weight.permute(2, 3, 1, 0).reshape(-1, c1.weight.shape[0]).contiguous()),   # fragment order
             "up2_w": c3.weight.permute(2, 3, 1, 0).reshape(-1, c3.weight.shape[0]).contiguous(),
             "out_tokens_f32": torch.cat([self.iou_token.weight, self.mask_tokens.weight], 0).float().contiguous(),
         }

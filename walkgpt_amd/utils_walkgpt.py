@@ -152,13 +152,26 @@ class CalibratedTextProjector(nn.Module):
         if self.net[3].bias is not None:
             nn.init.zeros_(self.net[3].bias)
 
+    def _tiled(self, weight):
+        """ops.tile_weight(weight), cached per (storage, version)"""
+        cache = self.__dict__.setdefault("_tiled_cache", {})
+        key = (weight.data_ptr(), weight._version, weight.dtype, str(weight.device))
+        ent = cache.get(id(weight))
+        if ent is None or ent[0] != key:
+            with torch.no_grad():
+                ent = cache[id(weight)] = (key, ops.tile_weight(weight.detach().contiguous()))
+        return ent[1]
+
     def forward(self, x):
         _check_bf16_gpu(x, "hidden states")
         if self.use_residual:
             raise NotImplementedError("use_residual=True is never configured by WalkGPT (walkgpt.py:115-123)")
         ln = self.net[0]
-        y = ops.layernorm_linear(x.contiguous(), ln.weight, ln.bias, ln.eps, self.net[1].weight, self.net[1].bias, act=ops.ACT_GELU)
-        y = ops.linear(y, self.net[3].weight, self.net[3].bias)
+        x = x.contiguous()
+        few = x.numel() // x.shape[-1] <= 16          # a handful of [SEG] rows: one-launch skinny GEMMs on weights kept in fragment order
+        t1, t3 = (self._tiled(self.net[1].weight), self._tiled(self.net[3].weight)) if few else (None, None)
+        y = ops.layernorm_linear(x, ln.weight, ln.bias, ln.eps, self.net[1].weight, self.net[1].bias, act=ops.ACT_GELU, weight_tiled=t1)
+        y = ops.layernorm_linear(y, None, None, 0.0, self.net[3].weight, self.net[3].bias, weight_tiled=t3)
         return ops.ctp_tail(y, self.net[4].weight, self.net[4].bias, self.text_type.reshape(-1), self.log_temp, self.net[4].eps)
 
 
