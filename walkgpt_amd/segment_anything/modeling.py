@@ -612,13 +612,17 @@ class MaskDecoder(nn.Module, _Prepared):
             [MLP(transformer_dim, transformer_dim, transformer_dim // 8, 3) for _ in range(self.num_mask_tokens)])
         self.iou_prediction_head = MLP(transformer_dim, iou_head_hidden_dim, self.num_mask_tokens, iou_head_depth)
 
+    @staticmethod
+    def _convt_as_gemm(weight):
+        """ConvTranspose2d(k=2, s=2) == per-pixel GEMM whose output columns are (dy, dx, c_out): weight [Cin, Cout, 2, 2]
+        -> [(dy, dx, Cout), Cin]; the bias repeats over the four sub-pixels."""
+        return weight.permute(2, 3, 1, 0).reshape(-1, weight.shape[0]).contiguous()
+
     def _build_prepared(self):
         c1, c3 = self.output_upscaling[0], self.output_upscaling[3]
-        # ConvTranspose2d(k=2, s=2) == per-pixel GEMM whose output columns are (dy, dx, c_out): weight [Cin, Cout, 2, 2]
-        # -> [(dy, dx, Cout), Cin]; the bias repeats over the four sub-pixels.
         return {
-            "up1_w": ops.tile_weight(c1.weight.permute(2, 3, 1, 0).reshape(-1, c1.weight.shape[0]).contiguous()),   # fragment order
-            "up2_w": c3.weight.permute(2, 3, 1, 0).reshape(-1, c3.weight.shape[0]).contiguous(),
+            "up1_w": ops.tile_weight(self._convt_as_gemm(c1.weight)),      # MFMA fragment order (wg_upscale_mask_bf16 keeps it in registers)
+            "up2_w": self._convt_as_gemm(c3.weight),
             "out_tokens_f32": torch.cat([self.iou_token.weight, self.mask_tokens.weight], 0).float().contiguous(),
         }
 
