@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--sq")
+    ap.add_argument("--sq-cmd", default=None, help="the command of the --sq pass when it differs from --cmd")
     ap.add_argument("--steps", type=int, required=True, help="full steps the profiled command ran (timed + warm-up)")
     ap.add_argument("--cmd", required=True)
     ap.add_argument("--config", default=None, help='JSON the bench compares with its own run before it reports roofline.traffic')
@@ -111,7 +112,14 @@ def main():
         f.write(", ".join("`%s` x%d (%.2f ms)" % (k[:50], n, ns / 1e6) for k, (n, ns) in sorted(once.items(), key=lambda kv: -kv[1][1])[:10]) + "\n")
     if a.sq:
         acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
-        for r in csv.DictReader(open(one(a.sq, "counter_collection.csv"))):
+        rows = list(csv.DictReader(open(one(a.sq, "counter_collection.csv"))))
+        # one steady-state step: the dispatches between the last two SAM patch gathers (model construction and the first step's one-time
+        # preparation -- weight casts, folds, re-layouts -- are not part of the path and would otherwise rank among its kernels)
+        marks = sorted({int(r["Dispatch_Id"]) for r in rows if "wg_patchify_kernel<true>" in r["Kernel_Name"]})
+        lo, hi = (marks[-2], marks[-1]) if len(marks) >= 2 else (0, 1 << 62)
+        for r in rows:
+            if not lo <= int(r["Dispatch_Id"]) < hi:
+                continue
             e = acc[short(r["Kernel_Name"])][r["Counter_Name"]]
             e[0] += 1
             e[1] += float(r["Counter_Value"])
@@ -121,7 +129,7 @@ def main():
                     "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY` (kernels serialised by "
                     "the counter collection).\n\nmatrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs); VALU busy = "
                     "4 x SQ_ACTIVE_INST_VALU over the same SIMD-cycles; parked = SQ_WAIT_ANY / SQ_WAVE_CYCLES (waves at s_waitcnt / s_barrier); "
-                    "issue-stalled = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES.  Kernels ranked by their share of GPU-active cycles.\n\n" % (a.tag, a.cmd))
+                    "issue-stalled = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES.  Only ONE steady-state step is counted: the dispatches between the last two SAM patch gathers (model construction and first-step preparation excluded); kernels ranked by their share of GPU-active cycles.\n\n" % (a.tag, a.sq_cmd or a.cmd))
             f.write("| kernel | launches | share of active cycles | matrix pipe busy | VALU busy | waves parked | issue-stalled |\n|---|---|---|---|---|---|---|\n")
             tot = sum(v.get("GRBM_GUI_ACTIVE", [0, 0.0])[1] for _, v in ranked) or 1.0
             for k, v in ranked[:12]:
