@@ -23,6 +23,7 @@
 //            registers and relh costs one LDS read per tile.
 // LDS swizzles (source-side, undone on the read): K rows for ds_read_b128, V rows for the transposed read.
 #include "wg_common.h"
+#include <type_traits>
 
 #define LOG2E 1.4426950408889634f
 #define NEG_BIG (-1.0e30f)
@@ -510,7 +511,12 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], ot[d], 0, 0, 0);
     };
 
-    for (int t = 0; t < nt; ++t) {
+    // Windows whose last tile holds keys in its first key block only (S = 14 at four padded rows per tile: rows 12, 13 | 14, 15): the dead
+    // block's S^T MFMAs, exponentials, V^T reads and P.V MFMAs are skipped there -- an eighth of a four-tile window's loop.
+    constexpr bool HALF_LAST = GRID && RPT > 1 && (S % RPT) != 0 && (S % RPT) * RP <= 32;
+    auto tile = [&](int t, auto half_c) __attribute__((always_inline)) {
+        constexpr bool HALF = decltype(half_c)::value;
+        constexpr int NE = HALF ? 16 : 32;           // score elements per lane that can hold a key
         const int buf = t & 1;
         WG_STAMP(0);
         if (t + 1 < nt) {
@@ -519,9 +525,11 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         }
         bias_begin(t);
 #pragma unroll
-        for (int g = 0; g < NQK; ++g) qk_read(kv + buf * TILE2, g);
+        for (int g = 0; g < NQK; ++g)
+            if (!HALF || (g & 1) == 0) qk_read(kv + buf * TILE2, g);
 #pragma unroll
-        for (int g = 0; g < NQK; ++g) qk_one(sa, g);
+        for (int g = 0; g < NQK; ++g)
+            if (!HALF || (g & 1) == 0) qk_one(sa, g);
         // V^T fragments: inline-asm reads (invisible to hipcc's wait insertion), issued as early as the registers allow so that
         // their LDS latency hides under the softmax: right behind the S^T MFMAs, or -- key-bias variants, whose bias row
         // occupies 32 registers until it is applied -- after the running max.  Every LDS read hipcc does know about is retired
@@ -533,30 +541,88 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         }
         if constexpr (EARLY_VT) {
 #pragma unroll
-            for (int g = 0; g < NPV; ++g) vt_pair(g, buf);
+            for (int g = 0; g < NPV; ++g)
+                if (!HALF || g / DB < 2) vt_pair(g, buf);
         }
         float mt = NEG_BIG;
-        if (ragged && t + 1 == nt) bias_max(sa, t, 0, 32, mt, true);
-        else bias_max(sa, t, 0, 32, mt, false);
+        if (ragged && t + 1 == nt) bias_max(sa, t, 0, NE, mt, true);
+        else bias_max(sa, t, 0, NE, mt, false);
         const float off = bias_end(mt);
         if constexpr (!EARLY_VT) {
 #pragma unroll
-            for (int g = 0; g < NPV; ++g) vt_pair(g, buf);
+            for (int g = 0; g < NPV; ++g)
+                if (!HALF || g / DB < 2) vt_pair(g, buf);
         }
         WG_STAMP(1);
-        probs(sa, off, 0, 32);
+        probs(sa, off, 0, NE);
         WG_STAMP(2);
         // O^T += V^T . P^T  (operands of the asm reads above: wait for them here, fenced from the MFMAs)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < NPV; ++g) pv_one(g);
+        for (int g = 0; g < NPV; ++g)
+            if (!HALF || g / DB < 2) pv_one(g);
         WG_STAMP(3);
 #if !(defined(WG_ATTN_ABL) && WG_ATTN_ABL == 5)   // (ablation build 5: no per-tile wait / barrier -- wrong results, timing only)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 #endif
         WG_STAMP(4);
+    };
+    if constexpr (HALF_LAST) {
+        for (int t = 0; t + 1 < nt; ++t) tile(t, std::false_type());
+        tile(nt - 1, std::true_type());
+    } else {
+        // (the same loop written out: instantiating it through the generic lambda above shifts hipcc's register allocation and one
+        // head_dim-128 variant starts to spill)
+        for (int t = 0; t < nt; ++t) {
+            const int buf = t & 1;
+            WG_STAMP(0);
+            if (t + 1 < nt) {
+                stage(t + 1, buf ^ 1, false);
+                stage(t + 1, buf ^ 1, true);
+            }
+            bias_begin(t);
+    #pragma unroll
+            for (int g = 0; g < NQK; ++g) qk_read(kv + buf * TILE2, g);
+    #pragma unroll
+            for (int g = 0; g < NQK; ++g) qk_one(sa, g);
+            // V^T fragments: inline-asm reads (invisible to hipcc's wait insertion), issued as early as the registers allow so that
+            // their LDS latency hides under the softmax: right behind the S^T MFMAs, or -- key-bias variants, whose bias row
+            // occupies 32 registers until it is applied -- after the running max.  Every LDS read hipcc does know about is retired
+            // first: its wait would cover these too.
+            constexpr bool EARLY_VT = !KB;
+            if constexpr (GRID) {
+    #pragma unroll
+                for (int i = 0; i < RPT; ++i) asm volatile("" : "+v"(rh[i]));
+            }
+            if constexpr (EARLY_VT) {
+    #pragma unroll
+                for (int g = 0; g < NPV; ++g) vt_pair(g, buf);
+            }
+            float mt = NEG_BIG;
+            if (ragged && t + 1 == nt) bias_max(sa, t, 0, 32, mt, true);
+            else bias_max(sa, t, 0, 32, mt, false);
+            const float off = bias_end(mt);
+            if constexpr (!EARLY_VT) {
+    #pragma unroll
+                for (int g = 0; g < NPV; ++g) vt_pair(g, buf);
+            }
+            WG_STAMP(1);
+            probs(sa, off, 0, 32);
+            WG_STAMP(2);
+            // O^T += V^T . P^T  (operands of the asm reads above: wait for them here, fenced from the MFMAs)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+            for (int g = 0; g < NPV; ++g) pv_one(g);
+            WG_STAMP(3);
+    #if !(defined(WG_ATTN_ABL) && WG_ATTN_ABL == 5)   // (ablation build 5: no per-tile wait / barrier -- wrong results, timing only)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+    #endif
+            WG_STAMP(4);
+        }
     }
 
 #ifdef WG_ATTN_STAMP
@@ -692,7 +758,7 @@ extern "C" int wg_sam_attn_relpos_bf16(const void* qkv, const void* qkv_bias, co
     WG_SAM_CASE(64, 32, 8)
     WG_SAM_CASE(32, 14, 7)
     WG_SAM_CASE(32, 28, 5)
-    WG_SAM_CASE(80, 14, 7)
+    WG_SAM_CASE(80, 14, 7)   // (two 4-wave workgroups per window: 166.8 vs 160.6 us at B = 8, 16 heads)
     WG_SAM_CASE(80, 64, 8)
 #undef WG_SAM_CASE
     wg_set_error("sam_attn: (head_dim %d, window %d) has no compiled kernel", head_dim, window);
