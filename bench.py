@@ -67,6 +67,9 @@ def parse(argv=None):
     ap.add_argument("--with-msqp", action="store_true", default=None, help="also run the Multi-Scale Query Projector on the SAM tokens")
     ap.add_argument("--tail-tiles", action="store_true", help="allow the tail-absorbing 128x128 GEMM tiles (wins with --single-stream)")
     ap.add_argument("--side-priority", type=int, default=0, help="HIP priority of the CLIP stream (-1 = high)")
+    ap.add_argument("--clip-skip-unused-layer", action="store_true",
+                    help="NOT the headline: stop the CLIP tower after the last hidden state the path reads (hidden_states[-2]); the reference runs "
+                         "layer 24 and discards it (clip_encoder.py:77-93).  Same outputs, 1/24 of the tower less; the FLOP count follows")
     ap.add_argument("--single-stream", action="store_true", help="run the CLIP tower and the SAM branch back to back")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-decode-graph", action="store_true", help="launch the decode chain eagerly instead of replaying its captured HIP graph")
@@ -96,7 +99,8 @@ def workload_label(args, world):
     return ("%s: bs=%d/GPU x %d GPU, 448x448 source images (CLIP input 448^2, SAM input 1024^2), CLIP ViT-L/14 + SAM %s encoder%s + CTP + "
             "prompt encoder + mask decoder + postprocess to %dx%d, T=%d [SEG]/image, %s GEMMs, random-init weights"
             % (config_name(args, world), args.batch, world, args.sam, " + MSQP" if args.with_msqp else "", args.original, args.original,
-               args.seg_tokens, args.dtype))
+               args.seg_tokens, args.dtype)
+            + (" [NOT the headline workload: CLIP layer 24, whose output the path discards, is not run]" if args.clip_skip_unused_layer else ""))
 
 
 def free_port():
@@ -143,6 +147,8 @@ def build_model(args, dev):
     pe.positional_encoding_gaussian_matrix.data = pe.positional_encoding_gaussian_matrix.data.float()
     if args.dtype == "fp8":
         model.set_gemm_dtype("fp8")
+    if args.clip_skip_unused_layer:
+        model.vision_tower.run_all_layers = False
     return model
 
 
@@ -471,7 +477,8 @@ def main():
     n_l, fl, sec, byt = per_kernel[dom]
     achieved_tf = fl / sec / 1e12
     peak = PEAK_TF["fp8" if dom == 20 else "bf16"]
-    gf_step = B * (GF_CLIP_L_448 + GF_SAM[args.sam] + (GF_MSQP if args.with_msqp else 0.0) + T * (GF_DECODE_PER_TOKEN + GF_CTP_PER_TOKEN))
+    gf_clip = GF_CLIP_L_448 if not args.clip_skip_unused_layer else GF_CLIP_L_448 - (GF_CLIP_L_448 - 0.6) / 24.0   # (0.6 GF: patch embedding)
+    gf_step = B * (gf_clip + GF_SAM[args.sam] + (GF_MSQP if args.with_msqp else 0.0) + T * (GF_DECODE_PER_TOKEN + GF_CTP_PER_TOKEN))
     roofline = {"bound": "mfma", "kernel": KERNEL_NAMES.get(dom, str(dom)),
                 "achieved": round(achieved_tf, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / peak, 4), "traffic": None,
