@@ -2,7 +2,9 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from walkgpt_amd import ops
+from walkgpt_amd import ops, _lib
+if os.environ.get("WG_LIB"):      # A/B against another build of the library in the same call (same box)
+    _lib.LIB_PATH = os.path.abspath(os.environ["WG_LIB"])
 dev = torch.device("cuda:0")
 def t(fn, n=20):
     for _ in range(5): fn()
