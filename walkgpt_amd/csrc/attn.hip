@@ -326,15 +326,17 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     if constexpr (GRID) {
         // width table -> registers (through the LDS scatter); height table -> stays in LDS (same slot)
         const float inv_sc2 = 1.0f / (a.scale * LOG2E);
+        // (mytab is private to the wave and a wave's LDS operations execute in order: the scatter, the reads below and the second scatter into
+        // the same slot need no workgroup barrier)
         rel_pass(0);
-        __syncthreads();
+        asm volatile("" ::: "memory");
 #pragma unroll
         for (int e = 0; e < 16 * NC; ++e) {
             const int j = e % NRW;
             const int kw = (j & 3) + 8 * (j >> 2) + 4 * hi;   // this lane's j-th column slot inside a padded row
             relw_c[e >> 4][e & 15] = (kw < S ? mytab[ql_lane * SP + kw] : NEG_BIG) * inv_sc2;
         }
-        __syncthreads();
+        asm volatile("" ::: "memory");
         rel_pass(1);
     } else {
         if (KB) {
