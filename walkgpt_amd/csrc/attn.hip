@@ -654,6 +654,406 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     }
 }
 
+// =====================================================================================================================================
+// Windowed attention (S <= 32: SAM's 14 x 14 windows), PERSISTENT form of wg_attn_kernel<HD, S, NW, false>.
+//
+// A window has 4 key tiles, and in-kernel stamps (tools/attn_window_stamps.py on the one-unit-per-workgroup kernel) put 40 % of a
+// workgroup's life BEFORE its first tile: waiting for the query rows / the first K, V tile from memory and building the rel-pos tables,
+// plus 7 % storing the output -- with one (ViT-H: 7 waves x 215 registers) or two workgroups per CU nothing else runs meanwhile.
+// Here a workgroup walks units (window, head, query chunk) bid, bid + grid, ...: the NEXT unit's query rows are requested when the
+// current unit's loop starts and its first K / V tile is staged (LDS-DMA) into the free buffer during the current unit's last tile, so
+// the next unit begins with everything on chip; the rel-pos table rows (the same for every unit) are fetched once per workgroup.
+// Arithmetic and data layout are those of wg_attn_kernel (see there); only the unit loop, the per-unit staging state and the
+// dead-key-block skip of the last tile are spelled out again.
+// =====================================================================================================================================
+template <int HD, int S, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void wg_attn_window_kernel(AttnArgs a, int total_units) {
+    static_assert(S > 0 && S <= 32, "window sides up to 32 (padded rows of 16 / 32 slots)");
+    constexpr int HDP = (HD == 80) ? 96 : (HD == 16 ? 32 : HD);
+    constexpr int ROWB = (HD == 80) ? 208 : HDP * 2;
+    constexpr int ROWBV = (HD == 80) ? 192 : ROWB;
+    constexpr int TILE = 64 * ROWB, TILEV = 64 * ROWBV, TILE2 = TILE + TILEV;
+    constexpr int KSTEPS = HD / 16;
+    constexpr int DB = HDP / 32;
+    constexpr int SS = S * S;
+    constexpr int RP = S <= 16 ? 16 : 32;
+    constexpr int RPT = 64 / RP;
+    constexpr int NTG = (S + RPT - 1) / RPT;
+    static_assert(NTG % 2 == 0, "the next unit's first tile goes to buffer 0: an even number of tiles per unit");
+    constexpr int SP = NTG * RPT + 1;
+    constexpr int NRW = RP / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* kv = smem;                                                  // [2 buffers][K tile | V tile]
+    float* tab = (float*)(smem + 2 * TILE2);                          // per-wave rel-pos table in key space
+    constexpr int RELROWS = 2 * S - 1;
+    bf16* rels = (bf16*)(tab + NW * 32 * SP);                         // rel_w | rel_h table rows [2][RELROWS][HD], once per workgroup
+    char* qslab = (char*)(rels + 2 * RELROWS * HD);                   // per wave: the NEXT unit's query fragments, KSTEPS x 1 KiB (LDS-DMA)
+    // head_dim 80 is out of registers (215 before the unit loop's state): the width term of the bias (C operand of a tile's first S^T MFMAs,
+    // 16 registers) lives in a lane-private LDS row there and is read per tile
+    constexpr bool RELW_LDS = (HD == 80);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql_lane = lane & 31, hi = lane >> 5;
+    float* relw_lds = (float*)(qslab + NW * KSTEPS * 1024) + (wave * 64 + lane) * 20;   // 80-byte pitch: conflict-free b128 reads
+
+    // ---- a unit: (batch, window, head, query chunk) ---------------------------------------------------------------------------------
+    struct Unit { int b, wy, wx, hcol, qh, qw, klim0, qvalid; long qrow; };
+    const int groups = a.B * a.nW * a.nW * a.heads;
+    auto decode = [&](int bid, Unit& u) __attribute__((always_inline)) {
+        int grp, qc;
+        if (a.qchunks > 1 && (groups & 7) == 0) {       // XCD-aware: all query chunks of a (window, head) on one XCD's L2
+            const int per = 8 * a.qchunks;
+            const int blk = bid / per, rem = bid % per;
+            grp = blk * 8 + (rem & 7);
+            qc = rem >> 3;
+        } else {
+            grp = bid / a.qchunks;
+            qc = bid % a.qchunks;
+        }
+        const int head = grp % a.heads, bw = grp / a.heads, nw2 = a.nW * a.nW;
+        u.b = bw / nw2;
+        const int wi = bw % nw2;
+        u.wy = wi / a.nW;
+        u.wx = wi % a.nW;
+        u.hcol = head * HD;
+        const int ql_raw = (qc * NW + wave) * 32 + ql_lane;
+        const int ql = ql_raw < SS ? ql_raw : SS - 1;
+        u.qh = ql / S;
+        u.qw = ql % S;
+        const int gy = u.wy * S + u.qh, gx = u.wx * S + u.qw;
+        const bool inside = gy < a.Hg && gx < a.Hg;
+        u.qvalid = (ql_raw < SS && inside) ? 1 : 0;
+        u.qrow = (long)u.b * a.Hg * a.Hg + (inside ? gy * a.Hg + gx : 0);
+        u.klim0 = S < a.Hg - u.wy * S ? S : a.Hg - u.wy * S;     // window rows that exist in the image
+    };
+    auto load_q = [&](const Unit& u, bf16x8 (&q)[KSTEPS]) __attribute__((always_inline)) {
+        const bf16* qp = a.Q + u.qrow * a.ldq + u.hcol + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) q[s] = *(const bf16x8*)(qp + 16 * s);
+    };
+    char* myq = qslab + wave * KSTEPS * 1024;
+    auto dma_q = [&](const Unit& u) __attribute__((always_inline)) {      // the same fragments, global -> LDS without passing through registers
+        const bf16* qp = a.Q + u.qrow * a.ldq + u.hcol + 8 * hi;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(qp + 16 * s), WG_LDS_PTR(myq + s * 1024), 16, 0, 0);
+    };
+
+    // rel-pos table rows: the same for every unit -> LDS, once per workgroup (held in registers they cost 32 - 40 VGPRs across the unit loop)
+    constexpr int NJB = (RELROWS + 31) / 32;
+    for (int i = tid; i < 2 * RELROWS * HD / 8; i += NW * 64) {
+        const int which = i / (RELROWS * HD / 8), r = i % (RELROWS * HD / 8);
+        *(bf16x8*)(rels + (long)i * 8) = *(const bf16x8*)((which == 0 ? a.rel_w : a.rel_h) + (long)r * 8);
+    }
+
+    // ---- K / V staging: running per-lane source pointers, re-seeded per unit (see wg_attn_kernel) -------------------------------------
+    constexpr int NINSTK = TILE / 1024, NINSTV = TILEV / 1024;
+    constexpr int NPW = (NINSTK + NW - 1) / NW;
+    static_assert(NPW <= 3, "running-pointer staging");
+    const bf16* runp[2][NPW];
+    unsigned coff[2][NPW];
+    int kslot[2][NPW];
+    bool padx[2][NPW];
+    auto init_run = [&](const Unit& u) __attribute__((always_inline)) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int cpr = (o ? ROWBV : ROWB) / 16, ninst = o ? NINSTV : NINSTK;
+#pragma unroll
+            for (int i = 0; i < NPW; ++i) {
+                const int ii = wave + i * NW < ninst ? wave + i * NW : ninst - 1;
+                const int ci = ii * 64 + lane;
+                const int row = ci / cpr, cs = ci % cpr;
+                int c = cs ^ (o ? swzV<HD>(row) : swzK<HD>(row));
+                if (HDP != HD && c * 8 >= HD) c = HD / 8 - 1;
+                coff[o][i] = c * 8;
+                int kw = row % RP;
+                kw = kw < S ? kw : S - 1;
+                kslot[o][i] = row / RP;
+                padx[o][i] = u.wx * S + kw >= a.Hg;
+                const long r = (long)u.b * a.Hg * a.Hg + (long)(u.wy * S + kslot[o][i]) * a.Hg + u.wx * S + kw;
+                if (o == 0) runp[0][i] = padx[0][i] ? a.padK + u.hcol + coff[0][i] : a.K + r * a.ldk + u.hcol + coff[0][i];
+                else runp[1][i] = padx[1][i] ? a.padV + u.hcol + coff[1][i] : a.V + r * a.ldv + u.hcol + coff[1][i];
+            }
+        }
+    };
+    const unsigned strideK = (unsigned)((long)RPT * a.Hg * a.ldk);
+    const unsigned strideV = (unsigned)((long)RPT * a.Hg * a.ldv);
+    auto stage = [&](int t, int buf, bool isV, const Unit& u) __attribute__((always_inline)) {
+        char* dst = kv + buf * TILE2 + (isV ? TILE : 0);
+        const int lim = u.klim0 - t * RPT;
+        const int o = isV ? 1 : 0;
+        const int ninst = isV ? NINSTV : NINSTK;
+        const bf16* alt = (isV ? a.padV : a.padK) + u.hcol;
+#pragma unroll
+        for (int i = 0; i < NPW; ++i) {
+            const int ii = wave + i * NW;
+            if (ii < ninst) {
+                const bf16* src = kslot[o][i] < lim ? runp[o][i] : alt + coff[o][i];
+                __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(src), WG_LDS_PTR(dst + ii * 1024), 16, 0, 0);
+            }
+            runp[o][i] += padx[o][i] ? 0u : (isV ? strideV : strideK);
+        }
+    };
+
+    // ---- per-lane constants of the loop -------------------------------------------------------------------------------------------------
+    float* mytab = tab + wave * 32 * SP;
+    const float* relh_tab = mytab + ql_lane * SP;
+    const float sc2 = a.scale * LOG2E;
+    const float inv_sc2 = 1.0f / sc2;
+    constexpr float RESCALE_THR = 6.0f;
+    constexpr int NQK = 2 * KSTEPS;
+    constexpr int NPV = 4 * DB;
+    constexpr bool HALF_LAST = (S % RPT) != 0 && (S % RPT) * RP <= 32;   // the last tile holds keys in its first key block only
+    unsigned vt_ad[DB];
+    {
+        const int g = lane >> 4, i16 = lane & 15;
+        const int rq = i16 >> 2, cp = i16 & 3;
+        const unsigned vbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem) + (unsigned)TILE;
+#pragma unroll
+        for (int d = 0; d < DB; ++d) {
+            const int col = 32 * d + 16 * (g & 1) + 4 * cp;
+            const int chunk = col >> 3;
+            vt_ad[d] = vbase + (4 * hi + rq) * ROWBV + ((chunk ^ swzV<HD>(4 * hi + rq)) << 4) + (col & 7) * 2;
+        }
+    }
+
+    Unit cur;
+    decode(blockIdx.x, cur);
+    bf16x8 qf[KSTEPS];
+    load_q(cur, qf);
+    init_run(cur);
+    stage(0, 0, false, cur);
+    stage(0, 0, true, cur);
+    __syncthreads();                      // the rel-pos rows in LDS are visible to every wave
+
+    for (int bid = blockIdx.x;;) {
+        const int nbid = bid + (int)gridDim.x;
+        const bool more = nbid < total_units;
+
+        // ---- rel-pos tables of this unit's queries: T^T = Rel . Q^T by MFMA, scattered to key space (wave-private LDS) --------------------
+        f32x16 relw_c;
+        (void)relw_c;
+        auto rel_pass = [&](int which) __attribute__((always_inline)) {
+            const int qpos = which == 0 ? cur.qw : cur.qh;
+            for (int k = S + hi; k < SP; k += 2) mytab[ql_lane * SP + k] = NEG_BIG;
+#pragma unroll
+            for (int jb = 0; jb < NJB; ++jb) {
+                int j = jb * 32 + ql_lane;
+                j = j < 2 * S - 1 ? j : 2 * S - 2;
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) {
+                    const bf16x8 rf = *(const bf16x8*)(rels + ((long)which * RELROWS + j) * HD + 16 * s + 8 * hi);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(rf, qf[s], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int jj = jb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int kpos = qpos + S - 1 - jj;
+                    if (jj < 2 * S - 1 && kpos >= 0 && kpos < S) mytab[ql_lane * SP + kpos] = acc[r] * LOG2E;
+                }
+            }
+        };
+        rel_pass(0);
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int j = e % NRW;
+            const int kw = (j & 3) + 8 * (j >> 2) + 4 * hi;
+            const float wv = (kw < S ? mytab[ql_lane * SP + kw] : NEG_BIG) * inv_sc2;
+            if constexpr (RELW_LDS) relw_lds[e] = wv;
+            else relw_c[e] = wv;
+        }
+        asm volatile("" ::: "memory");
+        rel_pass(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+
+        f32x16 ot[DB];
+#pragma unroll
+        for (int d = 0; d < DB; ++d)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
+        float m_run = NEG_BIG;
+        float l_run = 0.f;
+        f32x16 sa[2];
+        u32x2 vt[4][DB][2];
+        bf16x8 pf[4];
+        bf16x8 kfr[NQK];
+        float rh[RPT];
+
+        auto tile = [&](int t, auto half_c) __attribute__((always_inline)) {
+            constexpr bool HALF = decltype(half_c)::value;
+            constexpr int NE = HALF ? 16 : 32;
+            const int buf = t & 1;
+            if (t + 1 < NTG) {
+                stage(t + 1, buf ^ 1, false, cur);
+                stage(t + 1, buf ^ 1, true, cur);
+                if (t == 0 && more) {             // the next unit's queries: requested behind tile 1's pieces, left in flight over this tile's wait
+                    Unit nxt;
+                    decode(nbid, nxt);
+                    dma_q(nxt);
+                }
+            } else if (more) {               // last tile: the next unit's first tile into the free buffer (buffer 0: NTG is even)
+                Unit nxt;
+                decode(nbid, nxt);
+                init_run(nxt);
+                stage(0, buf ^ 1, false, nxt);
+                stage(0, buf ^ 1, true, nxt);
+            }
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) rh[i] = relh_tab[t * RPT + i];
+            const char* kbuf = kv + buf * TILE2;
+#pragma unroll
+            for (int g = 0; g < NQK; ++g) {
+                if (HALF && (g & 1)) continue;
+                const int kb = g & 1, s = g >> 1;
+                const int row = kb * 32 + ql_lane;
+                const int c = (2 * s + hi) ^ swzK<HD>(row);
+                kfr[g] = *(const bf16x8*)(kbuf + row * ROWB + c * 16);
+            }
+#pragma unroll
+            for (int g = 0; g < NQK; ++g) {
+                if (HALF && (g & 1)) continue;
+                const int kb = g & 1, s = g >> 1;
+                if (s == 0) {                 // (+ width term of the bias: C operand)
+                    if constexpr (RELW_LDS) {
+                        f32x16 wc;
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const f32x4 w4 = *(const f32x4*)(relw_lds + 4 * q4);
+                            wc[4 * q4] = w4[0]; wc[4 * q4 + 1] = w4[1]; wc[4 * q4 + 2] = w4[2]; wc[4 * q4 + 3] = w4[3];
+                        }
+                        sa[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g], qf[s], wc, 0, 0, 0);
+                    } else {
+                        sa[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g], qf[s], relw_c, 0, 0, 0);
+                    }
+                }
+                else sa[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g], qf[s], sa[kb], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) asm volatile("" : "+v"(rh[i]));
+            // V^T fragments (inline-asm transposed reads, see wg_attn_kernel), behind the S^T MFMAs
+#pragma unroll
+            for (int g = 0; g < NPV; ++g) {
+                const int ks = g / DB, d = g % DB;
+                if (HALF && ks >= 2) continue;
+                const unsigned ad = vt_ad[d] + (unsigned)(buf * TILE2);
+                switch (ks) {
+                    case 0: vt[0][d][0] = wg_ds_read_tr<0 * 16 * ROWBV>(ad); vt[0][d][1] = wg_ds_read_tr<0 * 16 * ROWBV + 8 * ROWBV>(ad); break;
+                    case 1: vt[1][d][0] = wg_ds_read_tr<1 * 16 * ROWBV>(ad); vt[1][d][1] = wg_ds_read_tr<1 * 16 * ROWBV + 8 * ROWBV>(ad); break;
+                    case 2: vt[2][d][0] = wg_ds_read_tr<2 * 16 * ROWBV>(ad); vt[2][d][1] = wg_ds_read_tr<2 * 16 * ROWBV + 8 * ROWBV>(ad); break;
+                    default: vt[3][d][0] = wg_ds_read_tr<3 * 16 * ROWBV>(ad); vt[3][d][1] = wg_ds_read_tr<3 * 16 * ROWBV + 8 * ROWBV>(ad); break;
+                }
+            }
+            // height term + running max
+            float mt = NEG_BIG;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int kb = e >> 4, r = e & 15;
+                const int sl0 = 32 * kb + (r & 3) + 8 * (r >> 2);
+                const float v = sa[kb][r] * sc2 + rh[sl0 / RP];
+                sa[kb][r] = v;
+                mt = fmaxf(mt, v);
+            }
+            mt = wg_xor32_max(mt);
+            if (__any(mt > m_run + RESCALE_THR)) {
+                const float m_new = fmaxf(m_run, mt);
+                const float alpha = wg_exp2(m_run - m_new);
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int d = 0; d < DB; ++d)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
+            }
+            const float off = m_run;
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int kb = e >> 4, r = e & 15;
+                const float p = wg_exp2(sa[kb][r] - off);
+                l_run += p;
+                pf[kb * 2 + (r >> 3)][r & 7] = (bf16)p;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int g = 0; g < NPV; ++g) {
+                const int ks = g / DB, d = g % DB;
+                if (HALF && ks >= 2) continue;
+                u32x4 vv = {vt[ks][d][0][0], vt[ks][d][0][1], vt[ks][d][1][0], vt[ks][d][1][1]};
+                ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf[ks], ot[d], 0, 0, 0);
+            }
+            // memory operations retire in issue order: in tile 0 the KSTEPS query pieces are the youngest and may stay outstanding
+            if (t == 0 && more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KSTEPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        };
+        if constexpr (HALF_LAST) {
+            for (int t = 0; t + 1 < NTG; ++t) tile(t, std::false_type());
+            tile(NTG - 1, std::true_type());
+        } else {
+            for (int t = 0; t < NTG; ++t) tile(t, std::false_type());
+        }
+
+        // ---- O = O^T / l, 8-byte stores ------------------------------------------------------------------------------------------------
+        const float l_tot = wg_xor32_sum(l_run);
+        if (cur.qvalid != 0) {
+            const float inv = 1.0f / l_tot;
+            bf16* op = a.O + cur.qrow * a.ldo + cur.hcol;
+#pragma unroll
+            for (int d = 0; d < DB; ++d) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    if (HDP != HD && 32 * d + 8 * g4 + 4 * hi >= HD) continue;
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (bf16)(ot[d][g4 * 4 + e] * inv);
+                    *(bf16x4*)(op + 32 * d + 8 * g4 + 4 * hi) = o;
+                }
+            }
+        }
+        if (!more) break;
+        decode(nbid, cur);
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) qf[s] = *(const bf16x8*)(myq + s * 1024 + lane * 16);   // (landed before tile 1's barrier)
+        bid = nbid;
+    }
+}
+
+template <int HD, int S, int NW>
+static int launch_attn_window(const AttnArgs& a, int groups, hipStream_t st) {
+    constexpr int TILE = 64 * ((HD == 80) ? 208 + 192 : 4 * (HD == 16 ? 32 : HD));
+    constexpr int RP = S <= 16 ? 16 : 32;
+    constexpr int RPT = 64 / RP;
+    constexpr int SP = ((S + RPT - 1) / RPT) * RPT + 1;
+    const size_t lds = 2 * TILE + (size_t)NW * 32 * SP * 4 + 2 * (2 * S - 1) * HD * 2 + (size_t)NW * (HD / 16) * 1024 + (HD == 80 ? (size_t)NW * 64 * 80 : 0);
+    static int per_cu = 0;
+    if (!per_cu) {
+        (void)hipFuncSetAttribute((const void*)wg_attn_window_kernel<HD, S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)wg_attn_window_kernel<HD, S, NW>, NW * 64, lds) != hipSuccess || nb < 1) nb = 1;
+        per_cu = nb;
+    }
+    // as many workgroups as the chip holds at once, trimmed so that every workgroup walks the same number of units (+-1) and the
+    // XCD-aware unit order keeps its period
+    const int total = groups * a.qchunks;
+    const int period = 8 * a.qchunks;
+    const int cap = 256 * per_cu;
+    int grid = total;
+    if (total > cap) {
+        const int rounds = (total + cap - 1) / cap;
+        grid = (total + rounds - 1) / rounds;
+        grid = (grid + period - 1) / period * period;
+        if (grid > cap) grid = cap / period * period;
+    }
+    hipLaunchKernelGGL((wg_attn_window_kernel<HD, S, NW>), dim3(grid), dim3(NW * 64), lds, st, a, total);
+    return wg_check_launch("wg_attn(window)");
+}
+
 template <int HD, int S, int NW, bool KB>
 static int launch_attn_impl(const AttnArgs& a, int groups, hipStream_t st) {
     constexpr int TILE = 64 * ((HD == 80) ? 208 + 192 : 4 * (HD == 16 ? 32 : HD));   // bytes of a K tile + a V tile (head_dim 80: 208- and 192-byte rows)
@@ -753,7 +1153,8 @@ extern "C" int wg_sam_attn_relpos_bf16(const void* qkv, const void* qkv_bias, co
 #define WG_SAM_CASE(HD_, S_, NW_)                                  \
     if (head_dim == HD_ && window == S_) {                         \
         a.qchunks = (qblocks + NW_ - 1) / NW_;                     \
-        return launch_attn<HD_, S_, NW_>(a, groups, st);           \
+        if constexpr (S_ <= 32) return launch_attn_window<HD_, S_, NW_>(a, groups, st);   \
+        else return launch_attn<HD_, S_, NW_>(a, groups, st);      \
     }
     WG_SAM_CASE(64, 14, 4)   // two 4-wave workgroups per window (one idle query slot in eight) measured 5 % faster than one of 7 waves
     WG_SAM_CASE(64, 64, 8)
