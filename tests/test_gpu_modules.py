@@ -327,3 +327,36 @@ def test_decoder_image_to_token_rows_vs_torch(dev, P, hw, shared):
     err = (out.float().cpu() - ref).abs().max().item()
     assert err <= 0.04, err                      # bf16 output rounding of values up to ~6
     assert rel_err(out.float().cpu().numpy(), ref.numpy()) < 3e-3
+
+
+def test_decoder_multimask_branch_vs_oracle(dev):
+    """mask_decoder.py:106-111 with multimask_output=True: masks 1..3 and their IoU predictions (WalkGPT itself asks for mask 0 only;
+    the module keeps SAM's switch).  HIP against the oracle's fp32 decoder on the g32 case's weights and inputs."""
+    from oracle import sam as osam
+    c = cases.DECODERS["g32"]
+    g = c["grid"]
+    sam = M._build_sam(128, 1, 2, [0], image_size=g * 16)
+    w = cases.decoder_case_weights(c)
+    load_into(sam.prompt_encoder, w, "prompt_encoder.", dev, strict=False)
+    load_into(sam.mask_decoder, w, "mask_decoder.", dev)
+    sam.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix.data = \
+        w["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].to(dev)
+    sam.to(dev)
+    emb, text = cases.decoder_inputs(c)
+    with torch.no_grad():
+        dpe = sam.prompt_encoder.get_dense_pe()
+        sparse, dense = sam.prompt_encoder(points=None, boxes=None, masks=None, text_embeds=text.to(dev, torch.bfloat16))
+        m3, i3 = sam.mask_decoder(image_embeddings=emb.to(dev, torch.bfloat16), image_pe=dpe, sparse_prompt_embeddings=sparse,
+                                  dense_prompt_embeddings=dense, multimask_output=True)
+        m1, i1 = sam.mask_decoder(image_embeddings=emb.to(dev, torch.bfloat16), image_pe=dpe, sparse_prompt_embeddings=sparse,
+                                  dense_prompt_embeddings=dense, multimask_output=False)
+        wf = {k: v.float() for k, v in w.items()}
+        T = text.shape[0]
+        o_dense = wf["prompt_encoder.no_mask_embed.weight"].reshape(1, -1, 1, 1).expand(T, -1, g, g)
+        o_pe = dpe.float().cpu()
+        om3, oi3 = osam.mask_decoder(wf, emb.float(), o_pe, text.float(), o_dense, multimask_output=True)
+    assert m3.shape == om3.shape == (T, 3, 4 * g, 4 * g) and i3.shape == (T, 3)
+    assert rel_err(m3.cpu().numpy(), om3.numpy()) < 0.02
+    assert rel_err(i3.cpu().numpy(), oi3.numpy()) < 0.02
+    # the three masks are not the single-mask output shifted by one: mask 0 is a different token
+    assert rel_err(m3[:, :1].cpu().numpy(), m1.cpu().numpy()) > 0.05
