@@ -54,9 +54,9 @@ int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, cons
                           long ldr, int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32,
                           int tile_hint, void* stream);
 
-/* Skinny rows (M <= 16: the [SEG] hidden states through text_hidden_fcs[0], utils/utils_walkgpt.py:321-323), one launch:
+/* Skinny rows (M <= 128: the [SEG] hidden states through text_hidden_fcs[0], utils/utils_walkgpt.py:321-323), one launch:
  *   C = act(LN?(A; gamma, beta, eps) . W^T + bias);  gamma == beta == null: no LayerNorm in front.
- * N % 16 == 0, K % 128 == 0; every workgroup (16 output columns) repeats the exact two-pass row statistics in fp32.
+ * N % 16 == 0, K % 128 == 0; a workgroup per (16 output columns, 16 rows) repeats the exact two-pass row statistics of its rows in fp32.
  * w_tiled != 0: W is in fragment order (wg_tile_weight_bf16; ldw ignored) -- contiguous 1-KiB wave loads. */
 int wg_gemm_skinny_ln_supported(int M, int N, int K, long lda, long ldw, long ldc);
 int wg_gemm_skinny_ln_bias_act_bf16(const void* A, long lda, const void* gamma, const void* beta, float eps, const void* W, long ldw,
@@ -166,7 +166,8 @@ int wg_upscale_mask_bf16(const void* x, long ldx, const void* w1, const void* b1
  * wg_dec_attn_partial_f32: softmax(q k^T / 4) v per (prompt, head, split of 1024 keys), a wave per 256 keys.  Kimg / Vimg: the projected image
  *   tokens (k_proj(keys + key_pe), v_proj(keys)) as bf16 rows [P or 1][hw] with row stride ld_img, head h's 16 columns at + h * head_stride
  *   (16: two plain 128-column blocks; 32: columns ordered [K_h | V_h] per head, Vimg = Kimg + 16: one 64-byte piece per key and head)
- *   (img_rows_per_prompt = 0 when all prompts share one image); partials [P, 8, n_splits, 108] fp32 = {running max[6], sum[6], o[6][16]}, n_splits = ceil(hw / 1024).
+ *   (img_rows_per_prompt = 0 when all prompts share one image; prompt_image [P] int32 != null: prompt p reads image prompt_image[p] --
+ *   the first block, whose image tokens are those of the image for every one of its prompts); partials [P, 8, n_splits, 108] fp32 = {running max[6], sum[6], o[6][16]}, n_splits = ceil(hw / 1024).
  * wg_dec_mlp_partial_f32: slice s of 8 of mlp(x): relu(x lin1[256 s .. +255]^T + b1) lin2[:, 256 s .. +255]^T -> partials [P,8,6,256].
  * wg_dec_heads_f32: output_hypernetworks_mlps[i](x[:, 1 + i]) -> hyper_out [P,4,32]; iou_prediction_head(x[:, 0]) -> iou_out [P,4];
  *   weights: 30 bf16 pointers = (hypernetwork 0..3, IoU head) x layers[0..2] x (weight, bias).
@@ -182,7 +183,8 @@ int wg_tile_weight_bf16(const void* W, long ld, int N, int K, void* tiled, void*
 int wg_dec_tokens_f32(int stages, int skip_pe, float* queries, float* query_pe, const float* init_tokens, const void* init_prompt,
                       const void* const* weights, int n_weights, float* q_t2i, const float* attn_partials, int n_splits, const float* mlp_partials, void* k_i2t, void* v_i2t, int P,
                       float eps, void* stream);
-int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const void* Vimg, long ld_img, int head_stride, long img_rows_per_prompt, int hw,
+int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const void* Vimg, long ld_img, int head_stride, long img_rows_per_prompt,
+                            const int* prompt_image, int hw,
                             float* partials, int n_splits, int P, void* stream);
 int wg_dec_mlp_partial_f32(const float* x, const void* const* combine, int n_splits, float eps, float* x_out, const void* lin1_w,
                            const void* lin1_b, const void* lin2_w, float* partials, int P, void* stream);
@@ -194,9 +196,10 @@ int wg_dec_heads_f32(const float* x, const void* const* combine, int n_splits, f
  * q [rows or hw][ldq] bf16: the q columns (128) of the fused image-side projection; kq / vq [P,6,128] bf16 (SUM_MLP stage above);
  * wo [256,128], bo [256]: cross_attn_image_to_token.out_proj; res: the image tokens themselves (bf16 rows, stride ldr); ln_g / ln_b: norm4;
  * res_bias [256] bf16 or null: a constant row added to res (the dense no-mask embedding when the caller folded it into the first block);
- * row_mod = hw when q and res hold ONE image shared by all P prompts, 0 when they hold P*hw rows; out [P*hw, 256] bf16.  hw % 16 == 0. */
+ * row_mod = hw when q and res hold ONE image shared by all P prompts, 0 when they hold P*hw rows; prompt_image [P] int32 != null: q and
+ * res hold one block of hw rows per IMAGE and prompt p reads block prompt_image[p]; out [P*hw, 256] bf16.  hw % 16 == 0. */
 int wg_dec_i2t_rows_bf16(const void* q, long ldq, const void* kq, const void* vq, const void* wo, const void* bo, const void* res, long ldr,
-                         const void* res_bias, int row_mod, const void* ln_g, const void* ln_b, float eps, void* out, int P, int hw, void* stream);
+                         const void* res_bias, int row_mod, const int* prompt_image, const void* ln_g, const void* ln_b, float eps, void* out, int P, int hw, void* stream);
 
 /* Sam.postprocess_masks (sam.py:137-172): bilinear to img_size^2, crop [:in_h,:in_w], bilinear to (out_h,out_w), one pass. */
 int wg_postprocess_masks_f32(const float* low_res, float* out, int N, int low_h, int low_w, int img_size, int in_h,

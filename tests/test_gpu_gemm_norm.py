@@ -124,9 +124,11 @@ def test_gemm_skinny_rows(dev, M, N, K):
     assert (o16.float().cpu() - ref).abs().max().item() <= 3e-2
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 512, 4096), (8, 512, 4096), (16, 512, 5120), (5, 256, 256), (20, 512, 4096)])
+@pytest.mark.parametrize("M,N,K", [(1, 512, 4096), (8, 512, 4096), (16, 512, 5120), (5, 256, 256), (20, 512, 4096), (112, 512, 4096),
+                                   (128, 256, 512), (130, 512, 4096)])
 def test_layernorm_linear_skinny(dev, M, N, K):
-    """LayerNorm fused in front of the skinny GEMM (head of text_hidden_fcs[0]); M = 20 takes the two-kernel route."""
+    """LayerNorm fused in front of the skinny GEMM (head of text_hidden_fcs[0]), up to eight 16-row blocks; M = 130 takes the two-kernel
+    route."""
     g = torch.Generator().manual_seed(13)
     x = (torch.randn(M, K, generator=g) * 2.0 + 0.7).to(torch.bfloat16)
     x[:, 3] += 40.0                                         # an outlier channel, as LLM hidden states have
@@ -146,7 +148,11 @@ def test_layernorm_linear_skinny(dev, M, N, K):
     assert torch.equal(out_t, out)
     # and without the LayerNorm
     plain = ops.layernorm_linear(x.to(dev), None, None, 0.0, w.to(dev), b.to(dev), out_f32=True, weight_tiled=wt)
-    assert torch.equal(plain, ops.linear(x.to(dev), w.to(dev), b.to(dev), out_f32=True))
+    other = ops.linear(x.to(dev), w.to(dev), b.to(dev), out_f32=True)
+    if M <= 16:
+        assert torch.equal(plain, other)                    # the same kernel, row-major weights
+    else:                                                   # ops.linear takes a tiled kernel there: another summation order
+        assert (plain - other).abs().max().item() <= 2e-2 and ((plain - other).norm() / other.norm()).item() < 1e-3
 
 
 def test_tile_weight_layout(dev):

@@ -305,6 +305,27 @@ def test_grounding_pipeline_end_to_end_vs_oracle(dev):
     assert not any(torch.equal(a, b) for a, b in zip(em2, em))
 
 
+def test_decoder_first_block_reads_images_through_the_prompt_map(dev):
+    """Token->image attention partials and the image->token rows kernel with one block of image tokens per IMAGE and a prompt -> image map
+    (what the first decoder block uses when images have several prompts) == the same kernels on per-prompt copies, bit for bit."""
+    g = torch.Generator().manual_seed(33)
+    B, hw, P = 3, 1024, 7
+    pimg = torch.tensor([0, 0, 1, 2, 2, 2, 1], dtype=torch.int32)
+    proj = torch.randn(B, hw, 384, generator=g).to(torch.bfloat16).to(dev)
+    keys = torch.randn(B, hw, 256, generator=g).to(torch.bfloat16).to(dev)
+    q = torch.randn(P, 6, 128, generator=g).to(dev)
+    kq, vq = (torch.randn(P, 6, 128, generator=g).to(torch.bfloat16).to(dev) for _ in range(2))
+    wo = (torch.randn(256, 128, generator=g) / 128 ** 0.5).to(torch.bfloat16).to(dev)
+    bo, gam, bet, rb = (torch.randn(256, generator=g).to(torch.bfloat16).to(dev) for _ in range(4))
+    idx = pimg.long().to(dev)
+    a = ops.dec_attn_partial(q, proj[..., :256], pimg.to(dev))
+    b = ops.dec_attn_partial(q, proj.index_select(0, idx)[..., :256].contiguous())
+    assert torch.equal(a, b)
+    a = ops.dec_i2t_rows(proj[..., 256:], kq, vq, wo, bo, keys, gam, bet, 1e-5, P, res_bias=rb, prompt_image=pimg.to(dev))
+    b = ops.dec_i2t_rows(proj.index_select(0, idx)[..., 256:], kq, vq, wo, bo, keys.index_select(0, idx), gam, bet, 1e-5, P, res_bias=rb)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("P,hw,shared", [(1, 4096, False), (3, 64, False), (5, 1024, True)])
 def test_decoder_image_to_token_rows_vs_torch(dev, P, hw, shared):
     """wg_dec_i2t_rows_bf16 (transformer.py:173-180 in one launch) against fp32 torch on the same bf16 operands."""

@@ -187,6 +187,7 @@ struct I2tArgs {
     const bf16* res; long ldr;          // the image tokens themselves [rows or hw][ldr]
     const bf16* res_bias;               // [256] or null: constant row added to res
     int row_mod;                        // hw when q / res are shared by all prompts (one image), 0 otherwise
+    const int* pimg;                    // or: prompt p's q / res rows are those of image pimg[p] (hw rows per image)
     const bf16* g; const bf16* b; float eps;
     bf16* out;                          // [P * hw, 256]
     long rows; int hw;
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(64 * I2_WAVES) void wg_dec_i2t_rows_kernel(I2tArgs 
         const long r0 = grp * 16;
         const long p = r0 / a.hw;                                  // hw % 16 == 0: a group never straddles two prompts
         const long row = r0 + l16;
-        const long srow = a.row_mod > 0 ? row % a.row_mod : row;   // row of q / res
+        const long srow = a.pimg ? (long)a.pimg[p] * a.hw + (row - p * a.hw) : (a.row_mod > 0 ? row % a.row_mod : row);   // row of q / res
         // prompt tokens of this prompt -> the wave's slab
         for (int i = lane; i < 2 * I2_KEYS * 16; i += 64) {
             const bf16x8 t = *(const bf16x8*)((i < I2_KEYS * 16 ? a.kq : a.vq) + p * I2_KEYS * 128 + (i % (I2_KEYS * 16)) * 8);
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
 constexpr int AT_WAVES = 4;
 constexpr int AT_KEYS = 256 * AT_WAVES;    // keys per workgroup
 struct AttnPartArgs {
-    const float* q; const bf16* K; const bf16* V; long ld, img_bs; int head_stride, hw, n_splits; float* part;
+    const float* q; const bf16* K; const bf16* V; long ld, img_bs; const int* pimg; int head_stride, hw, n_splits; float* part;
 };
 __global__ __launch_bounds__(64 * AT_WAVES) void wg_dec_attn_partial_kernel(AttnPartArgs a) {
     __shared__ __attribute__((aligned(16))) float qsh[TK_N * 16];
@@ -709,8 +710,9 @@ __global__ __launch_bounds__(64 * AT_WAVES) void wg_dec_attn_partial_kernel(Attn
     for (int i = threadIdx.x; i < TK_N * 16; i += 64 * AT_WAVES)
         qsh[i] = a.q[((long)p * TK_N + i / 16) * 128 + h * 16 + (i & 15)] * 0.25f;   // 1 / sqrt(16)
     __syncthreads();
-    const bf16* Kp = a.K + (long)p * a.img_bs * a.ld + h * a.head_stride;
-    const bf16* Vp = a.V + (long)p * a.img_bs * a.ld + h * a.head_stride;
+    const long img = a.pimg ? a.pimg[p] : p;             // the image whose tokens prompt p attends to (first block: shared by an image's prompts)
+    const bf16* Kp = a.K + img * a.img_bs * a.ld + h * a.head_stride;
+    const bf16* Vp = a.V + img * a.img_bs * a.ld + h * a.head_stride;
     float m[TK_N], l[TK_N], acc[TK_N][16];
 #pragma unroll
     for (int t = 0; t < TK_N; ++t) {
@@ -889,15 +891,17 @@ extern "C" int wg_dec_tokens_f32(int stages, int skip_pe, float* queries, float*
 }
 
 // q [P,6,128] fp32; Kimg / Vimg: head h's 16 columns at Kimg + h * head_stride of each of the [P or 1][hw] rows (stride ld_img) -- head_stride 16:
-// plain [.., 128] blocks; 32: the projection's columns ordered [K_h | V_h] per head, one 64-byte piece per (key, head) -- (img_rows_per_prompt = 0: one image shared by all prompts);
+// plain [.., 128] blocks; 32: the projection's columns ordered [K_h | V_h] per head, one 64-byte piece per (key, head) -- (img_rows_per_prompt = 0: one image shared by all prompts; prompt_image != null: prompt p reads image prompt_image[p], images
+// img_rows_per_prompt rows apart);
 // partials [P, 8, n_splits, 108] fp32 with n_splits = ceil(hw / 1024).
-extern "C" int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const void* Vimg, long ld_img, int head_stride, long img_rows_per_prompt, int hw,
+extern "C" int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const void* Vimg, long ld_img, int head_stride, long img_rows_per_prompt,
+                                       const int* prompt_image, int hw,
                                        float* partials, int n_splits, int P, void* stream) {
     WG_REQUIRE(q && Kimg && Vimg && partials && P > 0 && hw > 0 && ld_img % 8 == 0, "dec_attn_partial: bad arguments");
     WG_REQUIRE(n_splits == (hw + AT_KEYS - 1) / AT_KEYS, "dec_attn_partial: n_splits must be ceil(hw / 1024)");
     WG_REQUIRE((((uintptr_t)Kimg | (uintptr_t)Vimg) & 15) == 0, "dec_attn_partial: misaligned image projections");
     WG_REQUIRE(head_stride == 16 || head_stride == 32, "dec_attn_partial: head_stride must be 16 (K and V blocks) or 32 (K | V interleaved per head)");
-    AttnPartArgs a{q, (const bf16*)Kimg, (const bf16*)Vimg, ld_img, img_rows_per_prompt, head_stride, hw, n_splits, partials};
+    AttnPartArgs a{q, (const bf16*)Kimg, (const bf16*)Vimg, ld_img, img_rows_per_prompt, prompt_image, head_stride, hw, n_splits, partials};
     hipLaunchKernelGGL(wg_dec_attn_partial_kernel, dim3((unsigned)(P * 8 * n_splits)), dim3(64 * AT_WAVES), 0, (hipStream_t)stream, a);
     return wg_check_launch("wg_dec_attn_partial");
 }
@@ -953,13 +957,13 @@ extern "C" int wg_dec_heads_f32(const float* x, const void* const* combine, int 
 // (wg_dec_tokens_f32, SUM_MLP), out_proj [256,128] + bias, res = the image tokens (bf16 rows, stride ldr), norm4 -> out [P*hw, 256] bf16.
 // row_mod = hw when q and res hold ONE image shared by all P prompts, 0 when they have P*hw rows.
 extern "C" int wg_dec_i2t_rows_bf16(const void* q, long ldq, const void* kq, const void* vq, const void* wo, const void* bo, const void* res,
-                                    long ldr, const void* res_bias, int row_mod, const void* ln_g, const void* ln_b, float eps, void* out, int P, int hw, void* stream) {
+                                    long ldr, const void* res_bias, int row_mod, const int* prompt_image, const void* ln_g, const void* ln_b, float eps, void* out, int P, int hw, void* stream) {
     WG_REQUIRE(q && kq && vq && wo && bo && res && ln_g && ln_b && out, "dec_i2t_rows: null operand");
     WG_REQUIRE(P > 0 && hw > 0 && hw % 16 == 0 && (row_mod == 0 || row_mod == hw), "dec_i2t_rows: hw must be a positive multiple of 16");
     WG_REQUIRE(ldq % 8 == 0 && ldr % 4 == 0, "dec_i2t_rows: misaligned leading dimension");
     WG_REQUIRE((((uintptr_t)q | (uintptr_t)kq | (uintptr_t)vq | (uintptr_t)wo) & 15) == 0 && (((uintptr_t)res | (uintptr_t)out) & 7) == 0,
                "dec_i2t_rows: misaligned operand");
-    I2tArgs a{(const bf16*)q, ldq, (const bf16*)kq, (const bf16*)vq, (const bf16*)wo, (const bf16*)bo, (const bf16*)res, ldr, (const bf16*)res_bias, row_mod,
+    I2tArgs a{(const bf16*)q, ldq, (const bf16*)kq, (const bf16*)vq, (const bf16*)wo, (const bf16*)bo, (const bf16*)res, ldr, (const bf16*)res_bias, row_mod, prompt_image,
               (const bf16*)ln_g, (const bf16*)ln_b, eps, (bf16*)out, (long)P * hw, hw};
     static bool attr_done = false;
     if (!attr_done) {

@@ -918,12 +918,14 @@ __global__ __launch_bounds__(64 * NW) void wg_gemm_skinny_kernel(GemmArgs g) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l16 = lane & 15, kg = lane >> 4;
     const int n = blockIdx.x * 16 + l16;                 // N % 16 == 0
+    const int m0 = blockIdx.y * 16;                      // rows m0 .. m0 + 15 (M <= 128: up to eight row blocks, each re-reading its weight
+                                                         // columns from L2 -- still N / 16 x M / 16 workgroups spread over the chip)
     const int kw = g.K / NW;                             // K % (32 NW) == 0: every wave takes whole 32-deep MFMA steps
-    const bool live = l16 < g.M;
+    const bool live = m0 + l16 < g.M;
     // TILED: fragment (column block, k step) is one contiguous KiB (3x the per-CU streaming rate of 16 rows x 64 B, tools/micro/cu_ingest.hip)
     const bf16* wp = TILED ? g.W + (((long)blockIdx.x * (g.K / 32) + wave * (kw / 32)) * 64 + lane) * 8 : g.W + (long)n * g.ldw + wave * kw + 8 * kg;
     constexpr int WSTEP = TILED ? 16 : 1;                // elements of W per element of k
-    const bf16* ap = g.A + (long)(live ? l16 : 0) * g.lda + wave * kw + 8 * kg;
+    const bf16* ap = g.A + (long)(live ? m0 + l16 : 0) * g.lda + wave * kw + 8 * kg;
     const bf16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
     float mean = 0.f, rstd = 1.f;
     if constexpr (LN) {
@@ -979,7 +981,7 @@ __global__ __launch_bounds__(64 * NW) void wg_gemm_skinny_kernel(GemmArgs g) {
     const float bias = g.bias ? (float)g.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                        // accumulator: rows 4*kg + i of column l16
-        const int m = 4 * kg + i;
+        const int m = m0 + 4 * kg + i;
         if (m >= g.M) continue;
         float v = wg_act(acc[i] + bias, g.act);
         if (g.R) v += (float)g.R[(long)(g.res_mod > 0 ? m % g.res_mod : m) * g.ldr + n];
@@ -1415,11 +1417,11 @@ extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, lon
 }
 
 // Skinny rows, optionally with the LayerNorm in front and / or the weight matrix in fragment order:
-//     C = act(LN?(A; gamma, beta, eps) . W^T + b)  for M <= 16, N % 16 == 0, K % 128 == 0        (text_hidden_fcs[0], utils_walkgpt.py:321-323)
+//     C = act(LN?(A; gamma, beta, eps) . W^T + b)  for M <= 128, N % 16 == 0, K % 128 == 0       (text_hidden_fcs[0], utils_walkgpt.py:321-323)
 // gamma == beta == null: no LayerNorm.  w_tiled: W was re-laid by wg_tile_weight_bf16 (ldw ignored).  wg_gemm_skinny_ln_supported() tells the
 // caller whether the shape qualifies.
 extern "C" int wg_gemm_skinny_ln_supported(int M, int N, int K, long lda, long ldw, long ldc) {
-    return (M >= 1 && M <= 16 && N % 16 == 0 && K % 128 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0) ? 1 : 0;
+    return (M >= 1 && M <= 128 && N % 16 == 0 && K % 128 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 4 == 0) ? 1 : 0;
 }
 extern "C" int wg_gemm_skinny_ln_bias_act_bf16(const void* A, long lda, const void* gamma, const void* beta, float eps, const void* W, long ldw,
                                                int w_tiled, const void* bias, void* C, long ldc, int M, int N, int K, int act, int out_f32,
@@ -1488,7 +1490,7 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
     const bool small_ops = (long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31);
     if (tile == 11 && !(can_stage && small_ops)) tile = 1;
     if (tile == 16 && !(can_stage && small_ops && (!bias || ((uintptr_t)bias % 16 == 0 && N % 8 == 0)))) tile = 14;
-    if (tile == 5 && !(M <= 16 && N % 16 == 0 && K % 128 == 0)) tile = 1;
+    if (tile == 5 && !(M <= 128 && N % 16 == 0 && K % 128 == 0)) tile = 1;
     if (tile != 1 && tile != 2 && tile != 5 && tile != 11 && tile != 12 && tile != 14 && tile != 16) tile = 1;
     if (tile == 12 && !(can_stage && M >= 128 && M % 128 >= 1 && M % 128 <= 16)) tile = 1;
     switch (tile) {
@@ -1496,7 +1498,7 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
             {
                 const bool wide = K >= 2048 && K % 512 == 0;
                 const int variant = (wide ? 4 : 0) | (g.sk_gamma ? 2 : 0) | (g.sk_tiled ? 1 : 0);
-                const dim3 grid(N / 16), blk(wide ? 1024 : 256);
+                const dim3 grid(N / 16, (M + 15) / 16), blk(wide ? 1024 : 256);
                 switch (variant) {
                     case 0: hipLaunchKernelGGL((wg_gemm_skinny_kernel<4, false, false>), grid, blk, 0, st, g); break;
                     case 1: hipLaunchKernelGGL((wg_gemm_skinny_kernel<4, false, true>), grid, blk, 0, st, g); break;

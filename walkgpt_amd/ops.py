@@ -169,7 +169,7 @@ def ln_linear(x, fold, eps, act=ACT_NONE, tail_tiles=False):
 
 
 def layernorm_linear(x, gamma, beta, eps, weight, bias=None, act=ACT_NONE, out_f32=False, weight_tiled=None):
-    """act(LayerNorm(x) @ weight.T + bias) (gamma None: no LayerNorm) for a handful of rows (M <= 16: the [SEG] hidden states into
+    """act(LayerNorm(x) @ weight.T + bias) (gamma None: no LayerNorm) for a handful of rows (M <= 128: the [SEG] hidden states into
     text_hidden_fcs) in one launch (wg_gemm_skinny_ln_bias_act_bf16); other shapes run LayerNorm and the GEMM as two kernels.
     weight_tiled: tile_weight(weight), read instead of `weight` by the one-launch form."""
     _need_gpu(x, gamma, beta, weight, bias, weight_tiled)
@@ -447,20 +447,30 @@ def dec_tokens(stages, skip_pe, queries, query_pe, weights, q_t2i=None, attn_par
     return queries
 
 
-def dec_attn_partial(q_t2i, kv_img):
+def _prompt_image_ok(prompt_image, P, n_images):
+    assert prompt_image.dtype == torch.int32 and prompt_image.is_contiguous() and prompt_image.numel() == P and n_images >= 1
+
+
+def dec_attn_partial(q_t2i, kv_img, prompt_image=None):
     """Token->image attention partials (wg_dec_attn_partial_f32).  q_t2i [P, 6, 128] fp32; kv_img [1 | P, hw, 256] bf16: the projected image
-    tokens with the columns ordered [K_h | V_h] for head h = 0..7 (16 + 16 each; a column slice of the fused image-side projection)
+    tokens with the columns ordered [K_h | V_h] for head h = 0..7 (16 + 16 each; a column slice of the fused image-side projection);
+    with prompt_image (int32 [P]): kv_img [B, hw, 256] holds one block per IMAGE and prompt p attends to block prompt_image[p]
     -> fp32 [P, 8, ceil(hw / 1024), 108] for the COMBINE step."""
-    _need_gpu(q_t2i, kv_img)
+    _need_gpu(q_t2i, kv_img, prompt_image)
     P = q_t2i.shape[0]
     _f32_tokens(q_t2i, P, 128)
     hw = kv_img.shape[1]
-    assert kv_img.dtype == _BF16 and kv_img.shape[-1] == 256 and kv_img.stride(-1) == 1 and kv_img.shape[0] in (1, P)
-    img_bs = 0 if kv_img.shape[0] == 1 and P > 1 else (kv_img.stride(0) // kv_img.stride(1) if kv_img.shape[0] > 1 else hw)
+    assert kv_img.dtype == _BF16 and kv_img.shape[-1] == 256 and kv_img.stride(-1) == 1
+    if prompt_image is not None:
+        _prompt_image_ok(prompt_image, P, kv_img.shape[0])
+        img_bs = kv_img.stride(0) // kv_img.stride(1) if kv_img.shape[0] > 1 else hw
+    else:
+        assert kv_img.shape[0] in (1, P)
+        img_bs = 0 if kv_img.shape[0] == 1 and P > 1 else (kv_img.stride(0) // kv_img.stride(1) if kv_img.shape[0] > 1 else hw)
     n_splits = (hw + 1023) // 1024
     part = torch.empty(P, 8, n_splits, _TOK_PART, device=q_t2i.device, dtype=torch.float32)
-    rc = _lib.lib().wg_dec_attn_partial_f32(q_t2i.data_ptr(), kv_img.data_ptr(), kv_img.data_ptr() + 32, kv_img.stride(1), 32, img_bs, hw,
-                                            part.data_ptr(), n_splits, P, _stream())
+    rc = _lib.lib().wg_dec_attn_partial_f32(q_t2i.data_ptr(), kv_img.data_ptr(), kv_img.data_ptr() + 32, kv_img.stride(1), 32, img_bs,
+                                            _ptr(prompt_image), hw, part.data_ptr(), n_splits, P, _stream())
     _lib.check(rc, "wg_dec_attn_partial_f32")
     return part
 
@@ -515,24 +525,27 @@ def dec_heads(x, weights, combine=None, eps=1e-5):
     return hyper, iou
 
 
-def dec_i2t_rows(q_img, k_i2t, v_i2t, out_w, out_b, keys, ln_g, ln_b, eps, P, res_bias=None):
+def dec_i2t_rows(q_img, k_i2t, v_i2t, out_w, out_b, keys, ln_g, ln_b, eps, P, res_bias=None, prompt_image=None):
     """transformer.py:173-180 in one launch (wg_dec_i2t_rows_bf16): norm4(keys + out_proj(attention of every image token over the six
     prompt tokens)).  q_img [1 | P, hw, 128] bf16 (column slice of the image-side projection), k_i2t / v_i2t [P, 6, 128] bf16,
     keys [1 | P, hw, 256] bf16 -> bf16 [P, hw, 256].  res_bias [256] bf16: the residual is keys + res_bias (a constant row the caller
-    never added to the image tokens)."""
-    _need_gpu(q_img, k_i2t, v_i2t, out_w, out_b, keys, ln_g, ln_b, res_bias)
+    never added to the image tokens).  prompt_image (int32 [P]): q_img / keys hold one block per IMAGE, prompt p reads block prompt_image[p]."""
+    _need_gpu(q_img, k_i2t, v_i2t, out_w, out_b, keys, ln_g, ln_b, res_bias, prompt_image)
     assert res_bias is None or (res_bias.dtype == _BF16 and res_bias.numel() == 256 and res_bias.is_contiguous())
     hw = keys.shape[1]
     assert q_img.dtype == _BF16 and q_img.shape[-1] == 128 and q_img.stride(-1) == 1 and q_img.shape[:2] == keys.shape[:2]
-    assert keys.dtype == _BF16 and keys.shape[-1] == 256 and keys.stride(-1) == 1 and keys.shape[0] in (1, P)
+    assert keys.dtype == _BF16 and keys.shape[-1] == 256 and keys.stride(-1) == 1 and (prompt_image is not None or keys.shape[0] in (1, P))
+    if prompt_image is not None:
+        _prompt_image_ok(prompt_image, P, keys.shape[0])
     assert k_i2t.shape == (P, 6, 128) and v_i2t.shape == (P, 6, 128) and k_i2t.is_contiguous() and v_i2t.is_contiguous()
     assert out_w.shape == (256, 128) and out_w.is_contiguous() and out_b.numel() == 256 and ln_g.numel() == 256 and ln_b.numel() == 256
     for t in (q_img, keys):          # rows of all prompts must be evenly spaced
         assert t.shape[0] == 1 or t.stride(0) == hw * t.stride(1)
-    shared = keys.shape[0] == 1 and P > 1
+    shared = prompt_image is None and keys.shape[0] == 1 and P > 1
     out = torch.empty(P, hw, 256, device=keys.device, dtype=_BF16)
     rc = _lib.lib().wg_dec_i2t_rows_bf16(q_img.data_ptr(), q_img.stride(1), k_i2t.data_ptr(), v_i2t.data_ptr(), out_w.data_ptr(),
-                                         out_b.data_ptr(), keys.data_ptr(), keys.stride(1), _ptr(res_bias), hw if shared else 0, ln_g.data_ptr(),
+                                         out_b.data_ptr(), keys.data_ptr(), keys.stride(1), _ptr(res_bias), hw if shared else 0, _ptr(prompt_image),
+                                         ln_g.data_ptr(),
                                          ln_b.data_ptr(), float(eps), out.data_ptr(), P, hw, _stream())
     _lib.check(rc, "wg_dec_i2t_rows_bf16")
     return out

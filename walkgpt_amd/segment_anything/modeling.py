@@ -422,7 +422,7 @@ class TwoWayAttentionBlock(nn.Module):
         i2t = self.cross_attn_image_to_token
         return i2t.internal_dim == 128 and i2t.num_heads == 8 and keys.shape[-1] == 256 and n_tokens == 6 and keys.shape[1] % 16 == 0
 
-    def image_to_token(self, proj, keys, kq, vq, P, src_bias=None):
+    def image_to_token(self, proj, keys, kq, vq, P, src_bias=None, prompt_image=None):
         """transformer.py:173-180: image->token attention on the projected operands, out_proj + residual, norm4 -- one launch for SAM's
         geometry (ops.dec_i2t_rows), three otherwise."""
         i2t = self.cross_attn_image_to_token
@@ -430,7 +430,9 @@ class TwoWayAttentionBlock(nn.Module):
         d = i2t.internal_dim
         if self.fused_i2t_ok(keys, kq.shape[1]):
             return ops.dec_i2t_rows(proj[..., 2 * d:], kq, vq, i2t.out_proj.weight, i2t.out_proj.bias, keys, self.norm4.weight,
-                                    self.norm4.bias, self.norm4.eps, P, res_bias=src_bias)
+                                    self.norm4.bias, self.norm4.eps, P, res_bias=src_bias, prompt_image=prompt_image)
+        if prompt_image is not None:           # (general geometries: one copy of the image tokens per prompt, as the reference makes)
+            keys, proj = keys.index_select(0, prompt_image.long()), proj.index_select(0, prompt_image.long())
         if src_bias is not None:
             keys = ops.add_rows(keys, src_bias)
         keys = i2t.run_projected(proj[..., 2 * d:], kq, vq, P, residual=keys, res_row_mod=hw if keys.shape[0] == 1 and P > 1 else 0)
@@ -500,11 +502,14 @@ class TwoWayTransformer(nn.Module):
         self.final_attn_token_to_image = DecoderAttention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
         self.norm_final_attn = nn.LayerNorm(embedding_dim)
 
-    def run_tokens(self, src_tokens, pe_tokens, out_tokens, prompts, src_bias=None):
+    def run_tokens(self, src_tokens, pe_tokens, out_tokens, prompts, src_bias=None, prompt_image=None):
         """transformer.py:62-106: the depth TwoWayAttentionBlocks and the final token->image attention + norm_final_attn.
         src_tokens [1|P, hw, C] bf16, pe_tokens [1, hw, C] bf16; out_tokens [5, C] fp32 (iou + mask tokens), prompts [P, 1, C] bf16: the
         point embedding of prompt p is cat(out_tokens, prompts[p]) (mask_decoder.py:125-132), built by the first launch; src_bias [1, C]:
-        the image tokens are src_tokens + src_bias (the dense no-mask embedding, mask_decoder.py:136), folded into the first block
+        the image tokens are src_tokens + src_bias (the dense no-mask embedding, mask_decoder.py:136), folded into the first block;
+        prompt_image (int32 [P]): src_tokens holds one block per IMAGE and prompt p belongs to image prompt_image[p] -- the reference
+        repeats the image embedding per prompt (mask_decoder.py:135); the first block's image-side projection is the same for all prompts of
+        an image, so it runs once per image and the first block's kernels read it through the map
         -> (queries fp32 [P, 6, C] BEFORE the final attention's out_proj + norm_final_attn; the `combine` operands of that step, which
         ops.dec_heads applies in its own launch; keys [P, hw, C] bf16).
         Launch chain per block: tokens[close previous block | self attention | q] -> (previous block's image->token attention, norm4)
@@ -544,10 +549,10 @@ class TwoWayTransformer(nn.Module):
                            init_prompt=prompts.to(BF16).contiguous() if first else None)
             first = False
             if prev is not None:
-                keys = prev.image_to_token(prev_proj, keys, kq, vq, P, src_bias)
-                src_bias = None                                   # (part of `keys` from here on)
+                keys = prev.image_to_token(prev_proj, keys, kq, vq, P, src_bias, prompt_image)
+                src_bias = prompt_image = None                    # (keys are per prompt and carry the bias from here on)
             proj = layer.image_side(keys, pe_tokens, src_bias) if layer is not None else self.final_image_side(keys, pe_tokens)
-            part = ops.dec_attn_partial(q, proj[..., :2 * d])
+            part = ops.dec_attn_partial(q, proj[..., :2 * d], prompt_image)
             combine = (part, _tiled(t2i.out_proj.weight), t2i.out_proj.bias, norm.weight, norm.bias)
             if layer is not None:
                 mlp_part, queries = layer.mlp_partials(queries, combine)
@@ -636,9 +641,9 @@ class MaskDecoder(nn.Module, _Prepared):
                 w += _lin_pair(layer)
         return w
 
-    def predict_masks_tokens(self, src_tokens, pe_tokens, sparse, h, w, mask_slice, src_bias=None):
+    def predict_masks_tokens(self, src_tokens, pe_tokens, sparse, h, w, mask_slice, src_bias=None, prompt_image=None):
         """src_tokens [1|P, hw, C] (image embedding + dense prompt, channels-last rows; or the image embedding alone with the dense
-        no-mask embedding as src_bias [1, C]), pe_tokens [1, hw, C],
+        no-mask embedding as src_bias [1, C]; with prompt_image (int32 [P]) one block per image instead of per prompt), pe_tokens [1, hw, C],
         sparse [P, n, C] -> (masks fp32 [P, k, 4h, 4w], iou fp32 [P, k]).
         Launches: TwoWayTransformer.run_tokens, then one kernel for the hypernetwork / IoU heads and one for upscaling + the
         hypernetwork product."""
@@ -648,9 +653,12 @@ class MaskDecoder(nn.Module, _Prepared):
         tr = self.transformer
         if self.num_mask_tokens != 4 or sparse.shape[1] != 1 or self.transformer_dim != 256:
             raise NotImplementedError("the fused decoder kernels are built for 4 mask tokens + one text prompt per query (mask_decoder.py:125-132)")
-        if src_bias is not None and (len(tr.layers) == 0 or not tr.layers[0].fused_i2t_ok(src_tokens, 6)):
-            src_tokens, src_bias = ops.add_rows(src_tokens, src_bias), None
-        queries, final, keys = tr.run_tokens(src_tokens, pe_tokens, p["out_tokens_f32"], sparse, src_bias)
+        if len(tr.layers) == 0 or not tr.layers[0].fused_i2t_ok(src_tokens, 6):
+            if prompt_image is not None:
+                src_tokens, prompt_image = src_tokens.index_select(0, prompt_image.long()), None
+            if src_bias is not None:
+                src_tokens, src_bias = ops.add_rows(src_tokens, src_bias), None
+        queries, final, keys = tr.run_tokens(src_tokens, pe_tokens, p["out_tokens_f32"], sparse, src_bias, prompt_image)
         hyper, iou = ops.dec_heads(queries, self.head_weights(), combine=final, eps=tr.norm_final_attn.eps)
         ln1 = self.output_upscaling[1]
         k0, nk = mask_slice

@@ -168,7 +168,7 @@ class CalibratedTextProjector(nn.Module):
             raise NotImplementedError("use_residual=True is never configured by WalkGPT (walkgpt.py:115-123)")
         ln = self.net[0]
         x = x.contiguous()
-        few = x.numel() // x.shape[-1] <= 16          # a handful of [SEG] rows: one-launch skinny GEMMs on weights kept in fragment order
+        few = x.numel() // x.shape[-1] <= 128         # up to 128 [SEG] rows: one-launch skinny GEMMs on weights kept in fragment order
         t1, t3 = (self._tiled(self.net[1].weight), self._tiled(self.net[3].weight)) if few else (None, None)
         y = ops.layernorm_linear(x, ln.weight, ln.bias, ln.eps, self.net[1].weight, self.net[1].bias, act=ops.ACT_GELU, weight_tiled=t1)
         y = ops.layernorm_linear(y, None, None, 0.0, self.net[3].weight, self.net[3].bias, weight_tiled=t3)

@@ -100,15 +100,17 @@ class WalkGPTGrounding(nn.Module):
         if P > 0:
             text = self._cat_rows(pred_embeddings)
             sparse, _ = vm.prompt_encoder(points=None, boxes=None, masks=None, text_embeds=text.unsqueeze(1))
+            pimg = None
             if len(counts) == emb_tokens.shape[0] and all(c == 1 for c in counts):
                 src = emb_tokens                                                # one prompt per image: no gather
             elif len([c for c in counts if c > 0]) == 1:
                 i = next(k for k, c in enumerate(counts) if c > 0)
                 src = emb_tokens[i:i + 1]                                       # one image: shared by its prompts
             else:
-                src = emb_tokens.index_select(0, self._prompt_image_index(tuple(counts), dev))
+                src = emb_tokens       # one block per image; the decoder's first block reads it through the prompt -> image map
+                pimg = self._prompt_image_index(tuple(counts), dev)
             # (+ the dense no-mask embedding, mask_decoder.py:136: folded into the decoder's first block instead of a pass over src)
-            low_res, _iou = vm.mask_decoder.predict_masks_tokens(src, pe, sparse, h, w, sl, src_bias=no_mask)
+            low_res, _iou = vm.mask_decoder.predict_masks_tokens(src, pe, sparse, h, w, sl, src_bias=no_mask, prompt_image=pimg)
             off = 0
             same = len(set(zip(map(tuple, resize_list), map(tuple, original_size_list)))) == 1
             if same and sl[1] == 1:
@@ -153,7 +155,7 @@ class WalkGPTGrounding(nn.Module):
         cache = self.__dict__.setdefault("_pidx_cache", {})
         key = (counts, str(dev))
         if key not in cache:
-            cache[key] = torch.tensor([i for i, c in enumerate(counts) for _ in range(c)], device=dev)
+            cache[key] = torch.tensor([i for i, c in enumerate(counts) for _ in range(c)], device=dev, dtype=torch.int32)
         return cache[key]
 
     def decode_from_hidden_graphed(self, emb_tokens, seg_hidden: Sequence[torch.Tensor], resize_list, original_size_list):
