@@ -702,9 +702,25 @@ constexpr int AT_KEYS = 256 * AT_WAVES;    // keys per workgroup
 struct AttnPartArgs {
     const float* q; const bf16* K; const bf16* V; long ld, img_bs; const int* pimg; int head_stride, hw, n_splits; float* part;
 };
+// max / sum over the 16 lanes of a DPP row; every lane of the row ends with the result
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, WG_DPP(v, 0xB1));
+    v = fmaxf(v, WG_DPP(v, 0x4E));
+    v = fmaxf(v, WG_DPP(v, 0x124));
+    v = fmaxf(v, WG_DPP(v, 0x128));
+    return v;
+}
+__device__ __forceinline__ float row16_add(float v) {
+    v += WG_DPP(v, 0xB1);
+    v += WG_DPP(v, 0x4E);
+    v += WG_DPP(v, 0x124);
+    v += WG_DPP(v, 0x128);
+    return v;
+}
+
 __global__ __launch_bounds__(64 * AT_WAVES) void wg_dec_attn_partial_kernel(AttnPartArgs a) {
     __shared__ __attribute__((aligned(16))) float qsh[TK_N * 16];
-    __shared__ float wpart[AT_WAVES][TK_PART];
+    __shared__ float wpart[AT_WAVES * 4][TK_PART];       // one softmax state per 16-lane row of every wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int split = blockIdx.x % a.n_splits, h = (blockIdx.x / a.n_splits) & 7, p = blockIdx.x / (a.n_splits * 8);
     for (int i = threadIdx.x; i < TK_N * 16; i += 64 * AT_WAVES)
@@ -713,14 +729,6 @@ __global__ __launch_bounds__(64 * AT_WAVES) void wg_dec_attn_partial_kernel(Attn
     const long img = a.pimg ? a.pimg[p] : p;             // the image whose tokens prompt p attends to (first block: shared by an image's prompts)
     const bf16* Kp = a.K + img * a.img_bs * a.ld + h * a.head_stride;
     const bf16* Vp = a.V + img * a.img_bs * a.ld + h * a.head_stride;
-    float m[TK_N], l[TK_N], acc[TK_N][16];
-#pragma unroll
-    for (int t = 0; t < TK_N; ++t) {
-        m[t] = -1e30f;
-        l[t] = 0.f;
-#pragma unroll
-        for (int d = 0; d < 16; ++d) acc[t][d] = 0.f;
-    }
     const int j0 = split * AT_KEYS + wave * 256;
     // all of this lane's four keys are requested before the first one is used
     bf16x8 kk[4][2], vv[4][2];
@@ -731,56 +739,87 @@ __global__ __launch_bounds__(64 * AT_WAVES) void wg_dec_attn_partial_kernel(Attn
         kk[u][0] = *(const bf16x8*)(Kp + jj * a.ld); kk[u][1] = *(const bf16x8*)(Kp + jj * a.ld + 8);
         vv[u][0] = *(const bf16x8*)(Vp + jj * a.ld); vv[u][1] = *(const bf16x8*)(Vp + jj * a.ld + 8);
     }
+    // scores of the four keys against the six tokens, then ONE softmax state per lane: no running maximum, no rescaling
+    float sc[4][TK_N];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const bool valid = j0 + u * 64 + lane < a.hw;
-        float kf[16], vf[16];
+        float kf[16];
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
-            kf[d] = (float)kk[u][0][d]; kf[8 + d] = (float)kk[u][1][d];
-            vf[d] = (float)vv[u][0][d]; vf[8 + d] = (float)vv[u][1][d];
+            kf[d] = (float)kk[u][0][d];
+            kf[8 + d] = (float)kk[u][1][d];
         }
 #pragma unroll
         for (int t = 0; t < TK_N; ++t) {
-            float s = 0.f;
+            float s_ = 0.f;
 #pragma unroll
             for (int d4 = 0; d4 < 4; ++d4) {
                 const f32x4 qv = *(const f32x4*)(qsh + t * 16 + 4 * d4);
-                s += qv[0] * kf[4 * d4] + qv[1] * kf[4 * d4 + 1] + qv[2] * kf[4 * d4 + 2] + qv[3] * kf[4 * d4 + 3];
+                s_ += qv[0] * kf[4 * d4] + qv[1] * kf[4 * d4 + 1] + qv[2] * kf[4 * d4 + 2] + qv[3] * kf[4 * d4 + 3];
             }
-            s = valid ? s : -1e30f;
-            const float mn = fmaxf(m[t], s);
-            const float al = __expf(m[t] - mn), pr = valid ? __expf(s - mn) : 0.f;
-            m[t] = mn;
-            l[t] = l[t] * al + pr;
-#pragma unroll
-            for (int d = 0; d < 16; ++d) acc[t][d] = acc[t][d] * al + pr * vf[d];
+            sc[u][t] = valid ? s_ : -1e30f;
         }
     }
-    // lanes -> wave
+    float m[TK_N], l[TK_N], acc[TK_N][16];
 #pragma unroll
     for (int t = 0; t < TK_N; ++t) {
-        const float M = wg_wave_max(m[t]);
-        const float w = __expf(m[t] - M);
-        const float L = wg_wave_sum(l[t] * w);
-        if (lane == 0) { wpart[wave][t] = M; wpart[wave][TK_N + t] = L; }
+        m[t] = row16_max(fmaxf(fmaxf(sc[0][t], sc[1][t]), fmaxf(sc[2][t], sc[3][t])));     // the maximum of the lane's 16-lane row
+        l[t] = 0.f;
 #pragma unroll
-        for (int d = 0; d < 16; ++d) {
-            const float sv = wg_wave_sum(acc[t][d] * w);
-            if (lane == d) wpart[wave][2 * TK_N + t * 16 + d] = sv;
+        for (int d = 0; d < 16; ++d) acc[t][d] = 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool valid = j0 + u * 64 + lane < a.hw;
+        float vf[16];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            vf[d] = (float)vv[u][0][d];
+            vf[8 + d] = (float)vv[u][1][d];
+        }
+#pragma unroll
+        for (int t = 0; t < TK_N; ++t) {
+            const float pr = valid ? __expf(sc[u][t] - m[t]) : 0.f;
+            l[t] += pr;
+#pragma unroll
+            for (int d = 0; d < 16; ++d) acc[t][d] += pr * vf[d];
         }
     }
+    // lanes -> 16-lane rows by DPP (the cross-row steps of a full wave reduction are permlane swaps with wait states: two thirds of the
+    // instructions of the first version of this kernel); the rows' states meet in LDS
+    const int row = lane >> 4, l16 = lane & 15;
+    float* mine = wpart[wave * 4 + row];
+    // step by step over ALL values (a DPP read of a register written by the previous instruction costs wait states; independent neighbours do not)
+#define WG_ROW_STEP(ctrl)                                                   \
+    _Pragma("unroll") for (int t = 0; t < TK_N; ++t) {                      \
+        l[t] += WG_DPP(l[t], ctrl);                                         \
+        _Pragma("unroll") for (int d = 0; d < 16; ++d) acc[t][d] += WG_DPP(acc[t][d], ctrl); \
+    }
+    WG_ROW_STEP(0xB1)
+    WG_ROW_STEP(0x4E)
+    WG_ROW_STEP(0x124)
+    WG_ROW_STEP(0x128)
+#undef WG_ROW_STEP
+#pragma unroll
+    for (int t = 0; t < TK_N; ++t) {
+        float ov = acc[t][0];                 // lane l16 of the row writes output dim l16 (every lane of the row holds every total)
+#pragma unroll
+        for (int d = 1; d < 16; ++d) ov = l16 == d ? acc[t][d] : ov;
+        mine[2 * TK_N + t * 16 + l16] = ov;
+        if (l16 == 0) { mine[t] = m[t]; mine[TK_N + t] = l[t]; }
+    }
     __syncthreads();
-    // waves -> workgroup
+    // rows and waves -> workgroup
     float* out = a.part + (((long)p * 8 + h) * a.n_splits + split) * TK_PART;
     if (threadIdx.x < TK_N * 16) {
         const int t = threadIdx.x >> 4, d = threadIdx.x & 15;
         float M = -1e30f;
 #pragma unroll
-        for (int w_ = 0; w_ < AT_WAVES; ++w_) M = fmaxf(M, wpart[w_][t]);
+        for (int w_ = 0; w_ < AT_WAVES * 4; ++w_) M = fmaxf(M, wpart[w_][t]);
         float L = 0.f, o = 0.f;
 #pragma unroll
-        for (int w_ = 0; w_ < AT_WAVES; ++w_) {
+        for (int w_ = 0; w_ < AT_WAVES * 4; ++w_) {
             const float w = __expf(wpart[w_][t] - M);
             L += wpart[w_][TK_N + t] * w;
             o += wpart[w_][2 * TK_N + t * 16 + d] * w;
