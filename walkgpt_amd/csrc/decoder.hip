@@ -156,14 +156,23 @@ __global__ __launch_bounds__(256) void wg_upscale_mask_kernel(UpArgs a) {
         for (int mk = 0; mk < a.num_masks; ++mk) {
             const float* hy = a.hyper + ((long)p * a.nmask_total + a.first_mask + mk) * 32;
             const float hy0 = hy[l16], hy1 = hy[16 + l16];
-            float mine = 0.f;
+            // the 16 (sub-sub-pixel, token row) sums of a mask: all of them through each DPP step together (independent neighbours: no wait states)
+            float part[16];
 #pragma unroll
             for (int ss = 0; ss < 4; ++ss)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float logit = row16_sum(gz[2 * ss][i] * hy0 + gz[2 * ss + 1][i] * hy1);
-                    mine = (l16 == 4 * ss + i) ? logit : mine;
-                }
+                for (int i = 0; i < 4; ++i) part[4 * ss + i] = gz[2 * ss][i] * hy0 + gz[2 * ss + 1][i] * hy1;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) part[e] += WG_DPP(part[e], 0xB1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) part[e] += WG_DPP(part[e], 0x4E);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) part[e] += WG_DPP(part[e], 0x124);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) part[e] += WG_DPP(part[e], 0x128);
+            float mine = part[0];
+#pragma unroll
+            for (int e = 1; e < 16; ++e) mine = (l16 == e) ? part[e] : mine;
             a.out[((long)p * a.num_masks + mk) * H4 * W4 + opix] = mine;
         }
     }

@@ -271,33 +271,38 @@ __device__ __forceinline__ void wg_src_index(int dst, float scale, int in_size, 
     l1 = s - (float)i0;
 }
 
-__device__ __forceinline__ float wg_up1(const float* m, int lh, int lw, int img, float sc_y, float sc_x, int yy, int xx) {
-    int y0, y1, x0, x1;
-    float ly, lx;
-    wg_src_index(yy, sc_y, lh, y0, y1, ly);
-    wg_src_index(xx, sc_x, lw, x0, x1, lx);
-    const float a = m[y0 * lw + x0], b = m[y0 * lw + x1], c = m[y1 * lw + x0], d = m[y1 * lw + x1];
-    return __fadd_rn(__fmul_rn(1.f - ly, __fadd_rn(__fmul_rn(1.f - lx, a), __fmul_rn(lx, b))),
-                     __fmul_rn(ly, __fadd_rn(__fmul_rn(1.f - lx, c), __fmul_rn(lx, d))));
-}
-
+// grid (output column blocks, output rows, masks): no 64-bit index division per pixel (the first version spent more on `i % out_w` than on
+// the sixteen taps); the four first-resample index sets a pixel needs (two rows, two columns) are formed once and shared by its four taps.
 __global__ __launch_bounds__(256) void wg_postprocess_kernel(const float* low, float* out, int N, int lh, int lw, int img,
                                                              int in_h, int in_w, int out_h, int out_w) {
-    const long total = (long)N * out_h * out_w;
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y, n = blockIdx.z;
+    if (ox >= out_w) return;
     const float s1y = (float)lh / (float)img, s1x = (float)lw / (float)img;
     const float s2y = (float)in_h / (float)out_h, s2x = (float)in_w / (float)out_w;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ox = (int)(i % out_w), oy = (int)((i / out_w) % out_h), n = (int)(i / ((long)out_w * out_h));
-        const float* m = low + (long)n * lh * lw;
-        int y0, y1, x0, x1;
-        float ly, lx;
-        wg_src_index(oy, s2y, in_h, y0, y1, ly);
-        wg_src_index(ox, s2x, in_w, x0, x1, lx);
-        const float a = wg_up1(m, lh, lw, img, s1y, s1x, y0, x0), b = wg_up1(m, lh, lw, img, s1y, s1x, y0, x1);
-        const float c = wg_up1(m, lh, lw, img, s1y, s1x, y1, x0), d = wg_up1(m, lh, lw, img, s1y, s1x, y1, x1);
-        out[i] = __fadd_rn(__fmul_rn(1.f - ly, __fadd_rn(__fmul_rn(1.f - lx, a), __fmul_rn(lx, b))),
-                           __fmul_rn(ly, __fadd_rn(__fmul_rn(1.f - lx, c), __fmul_rn(lx, d))));
-    }
+    const float* m = low + (long)n * lh * lw;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    wg_src_index(oy, s2y, in_h, y0, y1, ly);
+    wg_src_index(ox, s2x, in_w, x0, x1, lx);
+    int ya[2][2], xa[2][2];          // [second-resample tap][first-resample tap]
+    float lya[2], lxa[2];
+    wg_src_index(y0, s1y, lh, ya[0][0], ya[0][1], lya[0]);
+    wg_src_index(y1, s1y, lh, ya[1][0], ya[1][1], lya[1]);
+    wg_src_index(x0, s1x, lw, xa[0][0], xa[0][1], lxa[0]);
+    wg_src_index(x1, s1x, lw, xa[1][0], xa[1][1], lxa[1]);
+    float up[2][2];                  // the img^2 intermediate at (y0|y1, x0|x1), operation by operation as torch's first resample
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float a = m[ya[j][0] * lw + xa[i][0]], b = m[ya[j][0] * lw + xa[i][1]];
+            const float c = m[ya[j][1] * lw + xa[i][0]], d = m[ya[j][1] * lw + xa[i][1]];
+            up[j][i] = __fadd_rn(__fmul_rn(1.f - lya[j], __fadd_rn(__fmul_rn(1.f - lxa[i], a), __fmul_rn(lxa[i], b))),
+                                 __fmul_rn(lya[j], __fadd_rn(__fmul_rn(1.f - lxa[i], c), __fmul_rn(lxa[i], d))));
+        }
+    out[((long)n * out_h + oy) * out_w + ox] =
+        __fadd_rn(__fmul_rn(1.f - ly, __fadd_rn(__fmul_rn(1.f - lx, up[0][0]), __fmul_rn(lx, up[0][1]))),
+                  __fmul_rn(ly, __fadd_rn(__fmul_rn(1.f - lx, up[1][0]), __fmul_rn(lx, up[1][1]))));
 }
 
 extern "C" int wg_postprocess_masks_f32(const float* low_res, float* out, int N, int low_h, int low_w, int img_size,
@@ -305,10 +310,9 @@ extern "C" int wg_postprocess_masks_f32(const float* low_res, float* out, int N,
     WG_REQUIRE(low_res && out && N > 0 && low_h > 0 && low_w > 0 && img_size > 0, "postprocess: bad arguments");
     WG_REQUIRE(in_h > 0 && in_w > 0 && in_h <= img_size && in_w <= img_size && out_h > 0 && out_w > 0,
                "postprocess: crop (%d,%d) must lie inside the %d^2 padded image", in_h, in_w, img_size);
-    const long total = (long)N * out_h * out_w;
-    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(wg_postprocess_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, low_res, out, N, low_h, low_w,
-                       img_size, in_h, in_w, out_h, out_w);
+    WG_REQUIRE(out_h <= 65535 && N <= 65535, "postprocess: more than 65535 output rows or masks per call");
+    hipLaunchKernelGGL(wg_postprocess_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)N), dim3(256), 0, (hipStream_t)stream,
+                       low_res, out, N, low_h, low_w, img_size, in_h, in_w, out_h, out_w);
     return wg_check_launch("wg_postprocess_masks_f32");
 }
 
