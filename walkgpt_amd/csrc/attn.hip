@@ -515,6 +515,22 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
 
     // Windows whose last tile holds keys in its first key block only (S = 14 at four padded rows per tile: rows 12, 13 | 14, 15): the dead
     // block's S^T MFMAs, exponentials, V^T reads and P.V MFMAs are skipped there -- an eighth of a four-tile window's loop.
+#ifndef WG_ATTN_STAMP   // (the diagnostic build keeps every wave to its closing barrier)
+    if (!GRID && (qc * NW + wave) * 32 >= Lq) {
+        // a wave without a single query (the last chunk of a ragged query count: CLIP's 1025 = 32 blocks + 1 leaves three such waves in
+        // every ninth workgroup): it stages its share of the K / V tiles and keeps the barriers, nothing else -- its SIMD time goes to
+        // the other workgroups of the CU
+        for (int t = 0; t < nt; ++t) {
+            if (t + 1 < nt) {
+                stage(t + 1, (t & 1) ^ 1, false);
+                stage(t + 1, (t & 1) ^ 1, true);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        return;
+    }
+#endif
     constexpr bool HALF_LAST = GRID && RPT > 1 && (S % RPT) != 0 && (S % RPT) * RP <= 32;
     auto tile = [&](int t, auto half_c) __attribute__((always_inline)) {
         constexpr bool HALF = decltype(half_c)::value;
