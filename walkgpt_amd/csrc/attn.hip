@@ -285,7 +285,10 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         }
     };
 
-    const int nt = GRID ? NTG : (Lk + 63) / 64;
+    // plain mode without a key bias, one key past a multiple of 64 (CLIP: 1024 patches + the class token): that key is folded in after the
+    // loop on the vector ALU instead of costing a whole tile of MFMAs, exponentials and staging for one column
+    const bool lone_key = !GRID && !KB && (Lk & 63) == 1 && Lk > 64;
+    const int nt = GRID ? NTG : (lone_key ? Lk / 64 : (Lk + 63) / 64);
     stage(0, 0, false);
     stage(0, 0, true);
 
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     f32x16 sa[2];                                // scores of the tile
     u32x2 vt[4][DB][2];
     bf16x8 pf[4];  // P^T fragments: k-step (kb, s2) uses registers 8*s2 .. 8*s2+7 of block kb
-    const bool ragged = !GRID && (Lk & 63) != 0;  // plain mode: keys beyond Lk exist on the last tile only
+    const bool ragged = !GRID && (Lk & 63) != 0 && !lone_key;  // plain mode: keys beyond Lk exist on the last tile only
 
     // S^T MFMA g of a tile: k-step s of key block kb (the two accumulation chains alternate); its K fragment is read from LDS
     // two MFMAs ahead
@@ -648,6 +651,35 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     if (blockIdx.x == 0 && wg_attn_stamp_ptr)
         for (int i = tid; i < NW * 12 * 8; i += NW * 64) wg_attn_stamp_ptr[i] = ((unsigned*)(smem + 156 * 1024))[i];
 #endif
+    if constexpr (!GRID && !KB) {
+        if (lone_key) {
+            const long krow = (long)b * a.k_bs + (Lk - 1);
+            const bf16* kp = a.K + krow * a.ldk + hcol + 8 * hi;      // the lane's half of the head dims, as its query fragments
+            float dot = 0.f;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                const bf16x8 kf = *(const bf16x8*)(kp + 16 * s);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) dot += (float)qf[s][e] * (float)kf[e];
+            }
+            const float sv = wg_xor32_sum(dot) * sc2;                  // the other half of the dims lives in lane ^ 32
+            const float m_new = fmaxf(m_run, sv);
+            const float alpha = wg_exp2(m_run - m_new);
+            const float pl = wg_exp2(sv - m_new);
+            m_run = m_new;
+            l_run = l_run * alpha + (hi == 0 ? pl : 0.f);              // (the two lane halves' sums are added below)
+            const bf16* vp = a.V + krow * a.ldv + hcol + 4 * hi;
+#pragma unroll
+            for (int d = 0; d < DB; ++d)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    if (HDP != HD && 32 * d + 8 * g4 + 4 * hi >= HD) continue;
+                    const bf16x4 v4 = *(const bf16x4*)(vp + 32 * d + 8 * g4);   // O^T rows 32 d + 8 g4 + 4 hi .. +3 of this lane
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ot[d][g4 * 4 + e] = ot[d][g4 * 4 + e] * alpha + pl * (float)v4[e];
+                }
+        }
+    }
     // ---- epilogue: O = O^T / l, 8-byte stores ---------------------------------------------------------------------------
     const float l_tot = wg_xor32_sum(l_run);
     if (qvalid) {
