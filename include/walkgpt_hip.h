@@ -207,6 +207,10 @@ int wg_postprocess_masks_f32(const float* low_res, float* out, int N, int low_h,
 
 /* mask score = sum(sigmoid(x)[x>0]) / (count[x>0] + 1e-6) per mask (model/walkgpt.py:540-542, :737).  Two-pass,
  * atomics-free reduction; the caller provides wg_mask_score_workspace_floats(N, hw) floats of scratch. */
+/* Both of the above in one pass over the output: out [N, out_h, out_w] fp32 and score [N] fp32; scratch = wg_postprocess_score_workspace_floats. */
+long wg_postprocess_score_workspace_floats(int N, int out_h, int out_w);
+int wg_postprocess_masks_score_f32(const float* low_res, float* out, float* score, float* workspace, long workspace_floats, int N, int low_h,
+                                   int low_w, int img_size, int in_h, int in_w, int out_h, int out_w, void* stream);
 long wg_mask_score_workspace_floats(int N, long hw);
 int wg_mask_score_f32(const float* masks, float* score, float* workspace, long workspace_floats, int N, long hw,
                       void* stream);

@@ -94,6 +94,9 @@ def test_postprocess_and_score(dev, lh, img, inp, orig):
     assert (out.cpu() - ref).abs().max().item() < 1e-4 * ref.abs().max().item() + 1e-5
     sc = ops.mask_score(out[:, 0].contiguous()).cpu()
     assert torch.allclose(sc, osam.mask_score(ref[:, 0]), atol=1e-5)
+    # the one-pass form (postprocess + score): the same pixels bit for bit, the same score up to the summation order
+    out2, sc2 = ops.postprocess_masks_scored(m.to(dev), img, inp, orig)
+    assert torch.equal(out2, out[:, 0]) and torch.allclose(sc2.cpu(), sc, atol=1e-6)
 
 
 def test_mask_iou_and_losses_vs_reference_golden(dev):

@@ -52,6 +52,8 @@ SIGNATURES = {
     "wg_dec_i2t_rows_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_float,
                              c_void_p, c_int, c_int, c_void_p],
     "wg_postprocess_masks_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "wg_postprocess_masks_score_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                       c_void_p],
     "wg_mask_score_f32": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_void_p],
     "wg_mask_iou_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_void_p],
     "wg_mask_losses_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_float, c_void_p],
@@ -75,6 +77,7 @@ SIGNATURES = {
 }
 _SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, []),
             "wg_mask_score_workspace_floats": (c_long, [c_int, c_long]),
+            "wg_postprocess_score_workspace_floats": (c_long, [c_int, c_int, c_int]),
             "wg_mask_stats_workspace_floats": (c_long, [c_int, c_long]),
             "wg_match_cost_workspace_floats": (c_long, [c_int, c_int, c_int]),
             "wg_gemm_pick_tile": (c_int, [c_int, c_int]),

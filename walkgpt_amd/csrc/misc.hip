@@ -273,10 +273,15 @@ __device__ __forceinline__ void wg_src_index(int dst, float scale, int in_size, 
 
 // grid (output column blocks, output rows, masks): no 64-bit index division per pixel (the first version spent more on `i % out_w` than on
 // the sixteen taps); the four first-resample index sets a pixel needs (two rows, two columns) are formed once and shared by its four taps.
-__global__ __launch_bounds__(256) void wg_postprocess_kernel(const float* low, float* out, int N, int lh, int lw, int img,
+// SCORE: the workgroup also leaves {sum of sigmoid(x) over x > 0, count of x > 0} of its 256 pixels in score_ws -- the first pass of the mask
+// score (model/walkgpt.py:540-542) without reading the masks back.
+template <bool SCORE>
+__global__ __launch_bounds__(256) void wg_postprocess_kernel(const float* low, float* out, float* score_ws, int N, int lh, int lw, int img,
                                                              int in_h, int in_w, int out_h, int out_w) {
+    __shared__ float ssum[4], scnt[4];
     const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y, n = blockIdx.z;
-    if (ox >= out_w) return;
+    float res = 0.f;       // (a pixel outside the row contributes nothing to the score)
+    if (ox < out_w) {
     const float s1y = (float)lh / (float)img, s1x = (float)lw / (float)img;
     const float s2y = (float)in_h / (float)out_h, s2x = (float)in_w / (float)out_w;
     const float* m = low + (long)n * lh * lw;
@@ -300,9 +305,23 @@ __global__ __launch_bounds__(256) void wg_postprocess_kernel(const float* low, f
             up[j][i] = __fadd_rn(__fmul_rn(1.f - lya[j], __fadd_rn(__fmul_rn(1.f - lxa[i], a), __fmul_rn(lxa[i], b))),
                                  __fmul_rn(lya[j], __fadd_rn(__fmul_rn(1.f - lxa[i], c), __fmul_rn(lxa[i], d))));
         }
-    out[((long)n * out_h + oy) * out_w + ox] =
-        __fadd_rn(__fmul_rn(1.f - ly, __fadd_rn(__fmul_rn(1.f - lx, up[0][0]), __fmul_rn(lx, up[0][1]))),
-                  __fmul_rn(ly, __fadd_rn(__fmul_rn(1.f - lx, up[1][0]), __fmul_rn(lx, up[1][1]))));
+    res = __fadd_rn(__fmul_rn(1.f - ly, __fadd_rn(__fmul_rn(1.f - lx, up[0][0]), __fmul_rn(lx, up[0][1]))),
+                    __fmul_rn(ly, __fadd_rn(__fmul_rn(1.f - lx, up[1][0]), __fmul_rn(lx, up[1][1]))));
+    out[((long)n * out_h + oy) * out_w + ox] = res;
+    }
+    if constexpr (SCORE) {
+        float s_ = 0.f, c_ = 0.f;
+        if (res > 0.f) { s_ = 1.0f / (1.0f + __expf(-res)); c_ = 1.f; }
+        s_ = wg_wave_sum(s_);
+        c_ = wg_wave_sum(c_);
+        if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s_; scnt[threadIdx.x >> 6] = c_; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const long blk = ((long)n * out_h + oy) * gridDim.x + blockIdx.x;
+            score_ws[blk * 2 + 0] = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+            score_ws[blk * 2 + 1] = scnt[0] + scnt[1] + scnt[2] + scnt[3];
+        }
+    }
 }
 
 extern "C" int wg_postprocess_masks_f32(const float* low_res, float* out, int N, int low_h, int low_w, int img_size,
@@ -311,10 +330,11 @@ extern "C" int wg_postprocess_masks_f32(const float* low_res, float* out, int N,
     WG_REQUIRE(in_h > 0 && in_w > 0 && in_h <= img_size && in_w <= img_size && out_h > 0 && out_w > 0,
                "postprocess: crop (%d,%d) must lie inside the %d^2 padded image", in_h, in_w, img_size);
     WG_REQUIRE(out_h <= 65535 && N <= 65535, "postprocess: more than 65535 output rows or masks per call");
-    hipLaunchKernelGGL(wg_postprocess_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)N), dim3(256), 0, (hipStream_t)stream,
-                       low_res, out, N, low_h, low_w, img_size, in_h, in_w, out_h, out_w);
+    hipLaunchKernelGGL(wg_postprocess_kernel<false>, dim3((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)N), dim3(256), 0,
+                       (hipStream_t)stream, low_res, out, nullptr, N, low_h, low_w, img_size, in_h, in_w, out_h, out_w);
     return wg_check_launch("wg_postprocess_masks_f32");
 }
+
 
 // ------------------------------------------------------------------------------------------------------------
 // Mask score (walkgpt.py:540-542, :737): sum(sigmoid(x) [x>0]) / (count[x>0] + 1e-6) per mask.
@@ -374,6 +394,25 @@ extern "C" int wg_mask_score_f32(const float* masks, float* score, float* worksp
     else hipLaunchKernelGGL(wg_mask_score_partial_kernel<false>, dim3((unsigned)nblk, N), dim3(256), 0, (hipStream_t)stream, masks, workspace, hw, (int)nblk);
     hipLaunchKernelGGL(wg_mask_score_final_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, workspace, score, (int)nblk);
     return wg_check_launch("wg_mask_score_f32");
+}
+
+// Sam.postprocess_masks (sam.py:137-172) and the mask score of the result (model/walkgpt.py:540-542, :737) in one pass over the output: the
+// postprocess workgroups leave their {sum, count} partials in `workspace` (wg_postprocess_score_workspace_floats floats), one wave per mask
+// folds them in a fixed order.  out [N, out_h, out_w] fp32, score [N] fp32.
+extern "C" long wg_postprocess_score_workspace_floats(int N, int out_h, int out_w) { return (long)N * out_h * ((out_w + 255) / 256) * 2; }
+
+extern "C" int wg_postprocess_masks_score_f32(const float* low_res, float* out, float* score, float* workspace, long workspace_floats, int N,
+                                              int low_h, int low_w, int img_size, int in_h, int in_w, int out_h, int out_w, void* stream) {
+    WG_REQUIRE(low_res && out && score && workspace && N > 0 && low_h > 0 && low_w > 0 && img_size > 0, "postprocess_score: bad arguments");
+    WG_REQUIRE(in_h > 0 && in_w > 0 && in_h <= img_size && in_w <= img_size && out_h > 0 && out_w > 0,
+               "postprocess_score: crop (%d,%d) must lie inside the %d^2 padded image", in_h, in_w, img_size);
+    WG_REQUIRE(out_h <= 65535 && N <= 65535, "postprocess_score: more than 65535 output rows or masks per call");
+    const int gx = (out_w + 255) / 256;
+    WG_REQUIRE(workspace_floats >= (long)N * out_h * gx * 2, "postprocess_score: workspace too small (need %ld floats)", (long)N * out_h * gx * 2);
+    hipLaunchKernelGGL(wg_postprocess_kernel<true>, dim3((unsigned)gx, (unsigned)out_h, (unsigned)N), dim3(256), 0, (hipStream_t)stream, low_res, out,
+                       workspace, N, low_h, low_w, img_size, in_h, in_w, out_h, out_w);
+    hipLaunchKernelGGL(wg_mask_score_final_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, workspace, score, out_h * gx);
+    return wg_check_launch("wg_postprocess_masks_score_f32");
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -580,6 +580,24 @@ def postprocess_masks(low_res, img_size, input_size, original_size):
     return out
 
 
+def postprocess_masks_scored(low_res, img_size, input_size, original_size):
+    """postprocess_masks for single-channel masks plus their mask scores in the same pass (wg_postprocess_masks_score_f32):
+    fp32 [N, 1, lh, lw] -> (fp32 [N, H0, W0], fp32 [N])."""
+    _need_gpu(low_res)
+    assert low_res.dtype == torch.float32 and low_res.is_contiguous() and low_res.dim() == 4 and low_res.shape[1] == 1
+    N, _, lh, lw = low_res.shape
+    H0, W0 = int(original_size[0]), int(original_size[1])
+    out = torch.empty(N, H0, W0, device=low_res.device, dtype=torch.float32)
+    score = torch.empty(N, device=low_res.device, dtype=torch.float32)
+    L = _lib.lib()
+    nws = L.wg_postprocess_score_workspace_floats(N, H0, W0)
+    ws = torch.empty(nws, device=low_res.device, dtype=torch.float32)
+    rc = L.wg_postprocess_masks_score_f32(low_res.data_ptr(), out.data_ptr(), score.data_ptr(), ws.data_ptr(), nws, N, lh, lw, img_size,
+                                          int(input_size[0]), int(input_size[1]), H0, W0, _stream())
+    _lib.check(rc, "wg_postprocess_masks_score_f32")
+    return out, score
+
+
 def mask_score(masks):
     """fp32 [N, H, W] -> fp32 [N]."""
     _need_gpu(masks)

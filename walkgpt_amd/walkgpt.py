@@ -114,8 +114,8 @@ class WalkGPTGrounding(nn.Module):
             off = 0
             same = len(set(zip(map(tuple, resize_list), map(tuple, original_size_list)))) == 1
             if same and sl[1] == 1:
-                full = vm.postprocess_masks(low_res, input_size=resize_list[0], original_size=original_size_list[0])[:, 0]
-                scores = ops.mask_score(full)
+                # Sam.postprocess_masks + the mask score in one pass over the output
+                full, scores = ops.postprocess_masks_scored(low_res, vm.image_encoder.img_size, resize_list[0], original_size_list[0])
                 for i, c in enumerate(counts):
                     pred_masks[i], mask_scores[i] = full[off:off + c], scores[off:off + c]
                     off += c
