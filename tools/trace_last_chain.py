@@ -5,7 +5,7 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "wg_postprocess" in r["Kernel_Name"]]
 t0 = prev = None
 tot = 0.0
-for r in rows[idx[-2] + 3:idx[-1] + 3]:
+for r in rows[idx[-2] + 2:idx[-1] + 2]:
     st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     t0 = t0 or st
     print("%8.1f  gap %5.1f  dur %6.1f  %-62s wg %s" % ((st - t0) / 1e3, (st - prev) / 1e3 if prev else 0, (en - st) / 1e3, r["Kernel_Name"][:62],
