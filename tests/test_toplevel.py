@@ -105,8 +105,9 @@ def _build(dev, script=None):
     return m, lm, weights
 
 
-def _oracle_masks(weights, lm, x, ids_rows, row_img, hidden_fn, resize, orig):
-    """Oracle composition: SAM encoder -> MSQP -> resample -> splice -> TinyLM (fp32, CPU) -> CTP at the [SEG]-1 positions -> decode."""
+def _oracle_masks(weights, lm, x, ids_rows, row_img, hidden_fn, resize, orig, visual=None):
+    """Oracle composition: SAM encoder -> MSQP -> resample -> splice -> TinyLM (fp32, CPU) -> CTP at the [SEG]-1 positions -> decode.
+    visual = (features [n, N, H] fp32, vit mask [n, 256] or None): what the language model sees instead of the MSQP tokens."""
     from oracle import projectors as oproj
     from oracle import sam as osam
     from oracle import splice as osplice
@@ -118,10 +119,15 @@ def _oracle_masks(weights, lm, x, ids_rows, row_img, hidden_fn, resize, orig):
     lm32.load_state_dict({k: v.float().cpu() for k, v in lm.state_dict().items()})
     with torch.no_grad():
         emb = osam.image_encoder(w_all, x, dict(patch=c["patch"], depth=c["depth"], heads=c["heads"], global_idx=c["global_idx"], window=c["window"]))
-        vis = oproj.msqp(weights["wm"], emb.flatten(2).transpose(1, 2))
+        vit = None
+        if visual is None:
+            vis = oproj.msqp(weights["wm"], emb.flatten(2).transpose(1, 2))
+        else:
+            vis, vit = visual
+            vit = vit[row_img] if vit is not None else None
         feats = oproj.resample_tokens(vis)[row_img]
-        _, embeds, _ = osplice.prepare_inputs_labels_for_multimodal(ids_rows, None, None, feats, lm32.embed.weight.float())
-        hidden = lm32(inputs_embeds=embeds, output_hidden_states=True).hidden_states[-1]
+        amask, embeds, _ = osplice.prepare_inputs_labels_for_multimodal(ids_rows, None, None, feats, lm32.embed.weight.float(), vit)
+        hidden = lm32(inputs_embeds=embeds, attention_mask=amask, output_hidden_states=True).hidden_states[-1]
         mask = hidden_fn(ids_rows)
         dpe = osam.dense_pe(w_all, (g, g))
         out = []
@@ -176,7 +182,7 @@ def test_model_forward_collate_dict_vs_oracle(dev):
     got = res["pred_masks"][0].float().cpu()
     e = float((got - ref[0]).norm() / ref[0].norm())
     assert e < 0.06 and _iou(got.numpy(), ref[0].numpy()) > 0.97, e
-    # released behaviour: empty lists (walkgpt.py:541-555)
+    # an option of the adapter, not of the reference (whose own decode loop, walkgpt.py:511-543, takes LLM-space tokens and raises): skip the decode
     assert m(**dict(inf, decode_masks=False))["pred_masks"] == []
 
 
@@ -206,3 +212,132 @@ def test_evaluate_signature_and_masks_vs_oracle(dev):
     got = pred_masks[0].float().cpu()
     e = float((got - ref[0]).norm() / ref[0].norm())
     assert e < 0.06 and _iou(got.numpy(), ref[0].numpy()) > 0.97, e
+
+
+def _attach_tiny_clip(m, dev):
+    """The CLIP tower of the 'tiny' golden case behind the adapter, built the way the reference's build_model does it
+    (evaluation_walkgpt.py:244-248), plus an mm_projector 128 -> H."""
+    c = cases.CLIPS["tiny"]
+    cfg = dict(hidden_size=c["dim"], intermediate_size=4 * c["dim"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+               image_size=c["img"], patch_size=14, layer_norm_eps=1e-5)
+    args = SimpleNamespace(vision_tower="openai/clip-vit-large-patch14-336", mm_vision_select_layer=c["select_layer"], clip_config=cfg,
+                           resize_vision_tower=True, resize_vision_tower_size=c["img"], pad_train_clip_images=True, pretrain_mm_mlp_adapter=None)
+    g = m.get_model()
+    g.initialize_vision_modules(args)
+    w = cases.clip_weights(c)
+    g.get_vision_tower().vision_tower.load_state_dict(w, strict=True)
+    gen = torch.Generator().manual_seed(21)
+    with torch.no_grad():
+        g.mm_projector.weight.copy_(torch.randn(H, c["dim"], generator=gen) / c["dim"] ** 0.5)
+        g.mm_projector.bias.copy_(torch.randn(H, generator=gen) * 0.1)
+    g.get_vision_tower().to(dev).bfloat16()
+    g.mm_projector.to(dev).bfloat16()
+    return c, w
+
+
+@pytest.mark.gpu
+def test_evaluate_sends_images_clip_through_the_clip_tower(dev):
+    """walkgpt.py:629-639 -> llava_arch.py:160-193 -> clip_encoder.py:71-98: with a vision tower present, evaluate()'s language model
+    sees the CLIP features of `images_clip` (patch mask from clip_resize_list, mm_projector because the widths differ), not MSQP tokens."""
+    from oracle import clip as oclip
+    from oracle import splice as osplice
+    L0 = 8
+    P = 256                                                          # image positions in the spliced sequence
+    script = {L0 + P - 2: 7, L0 + P - 1: SEG, L0 + P: 9, L0 + P + 1: SEG, L0 + P + 2: EOS}
+    m, lm, weights = _build(dev, script)
+    c, wclip = _attach_tiny_clip(m, dev)
+    assert m.get_vision_tower() is not None
+    xs = cases.sam_encoder_input(weights["c"])[:1]
+    imgs = cases.clip_inputs(c)[0][1:2]                              # the padded image of the case
+    sizes = [tuple(c["clip_resize_list"][1])]
+    ids = torch.randint(3, 50, (1, L0), generator=torch.Generator().manual_seed(12))
+    ids[0, 1] = -200
+    resize, orig = [(512, 384)], [(200, 150)]
+    all_ids, pred_masks, counts, scores = m.evaluate(imgs.to(dev, torch.bfloat16), xs.to(dev, torch.bfloat16), ids.to(dev), resize, sizes,
+                                                     orig, max_new_tokens=16)
+    assert all_ids[0][0, L0:].tolist() == [7, SEG, 9, SEG, EOS] and counts[0].tolist() == [2]
+    # oracle: CLIP tower (fp32) -> mm_projector -> 16x16 resample + patch mask -> splice -> TinyLM -> CTP -> decode
+    with torch.no_grad():
+        km = oclip.patch_key_mask(1, (c["img"], c["img"]), sizes)
+        feats, _ = oclip.clip_tower(wclip, imgs.to(torch.bfloat16).float(), km, select_layer=c["select_layer"], heads=c["heads"], layers=c["layers"])
+        mp = m.get_model().mm_projector
+        vis = feats @ mp.weight.float().cpu().t() + mp.bias.float().cpu()
+        vit = oclip.llm_token_mask(km, 16)
+    assert float(vit.min()) == 0.0                                    # the case does mask image tokens out of the LLM's attention
+    out_ids = all_ids[0].cpu()
+    ev_mask = osplice.seg_token_mask(out_ids, [SEG])[:, :-1]
+    ref = _oracle_masks(weights, lm, xs, out_ids[:, :-1], torch.tensor([0]), lambda r: ev_mask[:, : r.shape[1] + 255], resize, orig,
+                        visual=(vis, vit))
+    got = pred_masks[0].float().cpu()
+    e = float((got - ref[0]).norm() / ref[0].norm())
+    assert e < 0.06 and _iou(got.numpy(), ref[0].numpy()) > 0.97, e
+    # the other visual input, on request: MSQP tokens of the SAM embedding (what model_forward feeds the LM)
+    m.evaluate_visual_input = "sam"
+    _, pm2, _, _ = m.evaluate(imgs.to(dev, torch.bfloat16), xs.to(dev, torch.bfloat16), ids.to(dev), resize, sizes, orig, max_new_tokens=16)
+    assert float((pm2[0].float().cpu() - got).abs().max()) > 1e-3    # a different visual input gives different [SEG] states
+
+
+@pytest.mark.gpu
+def test_generate_returns_the_structures_the_reference_reads(dev):
+    """evaluation_walkgpt.py:569-596: generate(images=<projected tokens>, input_ids=, attention_mask=, max_new_tokens=, num_beams=1,
+    return_dict_in_generate=True, clip_resize_list=) -> `.sequences` = prompt ids (with the -200 placeholder) + new ids, one row per prompt."""
+    L0 = 7
+    script = {L0 + 254: 5, L0 + 255: 6, L0 + 256: EOS}
+    m, lm, weights = _build(dev, script)
+    ids = torch.randint(3, 50, (2, L0), generator=torch.Generator().manual_seed(13))
+    ids[:, 1] = -200
+    toks = torch.randn(2, 36, H, generator=torch.Generator().manual_seed(14)).to(dev, torch.bfloat16)
+    out = m.generate(images=toks, input_ids=ids.to(dev), attention_mask=torch.ones(2, L0, dtype=torch.bool, device=dev), max_new_tokens=8,
+                     num_beams=1, return_dict_in_generate=True, output_hidden_states=True, clip_resize_list=[(28, 28)] * 2)
+    assert out.sequences.shape == (2, L0 + 3) and out.sequences[:, :L0].cpu().equal(ids)
+    assert out.sequences[:, L0:].tolist() == [[5, 6, EOS]] * 2
+    assert out.hidden_states[-1].shape == (2, L0 + 255 + 2, H)       # prompt + image positions + the new tokens that were fed back
+    seq = m.generate(images=toks, input_ids=ids.to(dev), max_new_tokens=2)
+    assert torch.is_tensor(seq) and seq.shape == (2, L0 + 2)
+    with pytest.raises(NotImplementedError):
+        m.generate(images=toks, input_ids=ids.to(dev), num_beams=4)
+
+
+@pytest.mark.gpu
+def test_c1_shapes_through_from_pretrained(dev):
+    """BASELINE config C1 at its real widths: one 448x448 image, SAM ViT-B, CLIP ViT-L/14, H_llm = 4096 projectors, built by the
+    reference's build_model sequence -- with a 2-layer random-init LLaMA so that it fits a test."""
+    from transformers import LlamaConfig
+    from model.walkgpt import walkgptForCausalLM
+    Hc, Vc, SEGc = 4096, 320, 300
+    cfg = LlamaConfig(vocab_size=Vc, hidden_size=Hc, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=32,
+                      num_key_value_heads=32, max_position_embeddings=2048, mm_hidden_size=1024)
+    torch.manual_seed(0)
+    model = walkgptForCausalLM.from_pretrained(cfg, torch_dtype=torch.bfloat16, low_cpu_mem_usage=True, sam="vit_b", train_mask_decoder=False,
+                                               out_dim=256, ce_loss_weight=1.0, dice_loss_weight=0.5, bce_loss_weight=2.0, seg_token_idx=SEGc,
+                                               vision_pretrained=None, vision_tower="openai/clip-vit-large-patch14-336", use_mm_start_end=False,
+                                               seg_token_num=1, logger=None, tokenizer=None, local_rank=0)
+    model.config.eos_token_id, model.config.bos_token_id, model.config.pad_token_id = 2, 1, 0
+    model.get_model().initialize_vision_modules(model.get_model().config)
+    model.get_model().get_vision_tower().to(dtype=torch.bfloat16, device=dev)
+    model.get_model().initialize_walkgpt_modules(model.get_model().config)
+    model.resize_token_embeddings(Vc + 2)
+    model.to(device=dev, dtype=torch.bfloat16)
+    model.eval()
+    vm = model.get_model().visual_model
+    with torch.no_grad():                                            # zero-initialised by default (image_encoder.py:71-74,232-233)
+        vm.image_encoder.pos_embed.normal_(0, 0.02)
+    assert model.get_model().mm_projector[0].weight.shape == (2 * Hc, 1024) and model.get_model().out_mm_projector.to_llama.weight.shape == (Hc, 1024)
+    g = torch.Generator().manual_seed(3)
+    images = torch.randn(1, 3, 1024, 1024, generator=g).to(dev, torch.bfloat16)
+    images_clip = torch.randn(1, 3, 448, 448, generator=g).to(dev, torch.bfloat16)
+    L = 24
+    ids = torch.randint(3, Vc, (2, L), generator=g)
+    ids[:, 1] = -200
+    ids[0, 9] = SEGc; ids[0, 15] = SEGc; ids[1, 20] = SEGc
+    orig = (448, 448)
+    res = model(images=images, images_clip=images_clip, input_ids=ids.to(dev), labels=ids.to(dev),
+                attention_masks=torch.ones(2, L, dtype=torch.bool, device=dev), offset=torch.tensor([0, 2], device=dev),
+                masks_list=[torch.zeros(3, *orig, device=dev)], label_list=[torch.zeros(orig, device=dev)], resize_list=[(1024, 1024)],
+                clip_resize_list=[(448, 448)], inference=True)
+    assert res["batch_seg_token_counts"] == [3] and res["pred_masks"][0].shape == (3,) + orig and res["mask_scores"][0].shape == (3,)
+    assert torch.isfinite(res["pred_masks"][0]).all() and float(res["pred_masks"][0].float().std()) > 0
+    out_ids, pred_masks, counts, scores = model.evaluate(images_clip, images, ids[:1].to(dev), [(1024, 1024)], [(448, 448)], [orig],
+                                                         max_new_tokens=4)
+    assert out_ids[0].shape[0] == 1 and L < out_ids[0].shape[1] <= L + 4 and out_ids[0][0, :L].cpu().equal(ids[0])
+    assert pred_masks[0].shape[1:] == orig and pred_masks[0].shape[0] == int(counts[0][0]) and torch.isfinite(pred_masks[0]).all()

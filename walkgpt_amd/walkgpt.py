@@ -32,13 +32,16 @@ class WalkGPTGrounding(nn.Module):
     """
 
     def __init__(self, sam="vit_h", llm_hidden=4096, out_dim=256, clip_config=None, clip_image_size=448,
-                 select_layer=-2, with_clip=True, with_projectors=True):
+                 select_layer=-2, with_clip=True, with_projectors=True, config=None, vision_pretrained=None):
         super().__init__()
-        if isinstance(sam, str):
-            self.visual_model = sam_modeling.sam_model_registry[sam]()
-        else:
-            self.visual_model = sam_modeling._build_sam(sam["embed_dim"], sam["depth"], sam["heads"], list(sam["global_idx"]),
-                                                        image_size=sam.get("img", 1024))
+        self._sam_spec, self._clip_config, self.vision_pretrained = sam, clip_config, vision_pretrained
+        # the configuration object the reference's scripts reach through `model.get_model().config` (evaluation_walkgpt.py:244-248);
+        # walkgptForCausalLM shares the language model's config here
+        self.config = config if config is not None else SimpleNamespace(
+            hidden_size=llm_hidden, out_dim=out_dim, train_mask_decoder=False, vision_tower_for_mask=False,
+            mm_vision_select_layer=select_layer, resize_vision_tower=True, resize_vision_tower_size=clip_image_size,
+            pad_train_clip_images=True)
+        self.visual_model = self._build_visual_model()
         if with_projectors:
             self.out_mm_projector = MultiScaleQFormerProjector(256, llm_hidden, target_square_side=6)  # walkgpt.py:99-102
             self.text_hidden_fcs = nn.ModuleList([CalibratedTextProjector(llm_hidden, out_dim)])        # :115-123
@@ -47,6 +50,76 @@ class WalkGPTGrounding(nn.Module):
                                    resize_vision_tower=True, resize_vision_tower_size=clip_image_size)
             self.vision_tower = CLIPVisionTower("openai/clip-vit-large-patch14-336", args, config=clip_config)
         self.eval()
+
+    def _build_visual_model(self):
+        sam = self._sam_spec
+        if isinstance(sam, str):
+            return sam_modeling.sam_model_registry[sam](self.vision_pretrained)
+        return sam_modeling._build_sam(sam["embed_dim"], sam["depth"], sam["heads"], list(sam["global_idx"]),
+                                       image_size=sam.get("img", 1024))
+
+    # -- construction-time surface the reference's build_model drives (evaluation_walkgpt.py:244-248) -----------------------------
+    def get_vision_tower(self):
+        """llava_arch.py:43-47."""
+        vt = getattr(self, "vision_tower", None)
+        return vt[0] if type(vt) is list else vt
+
+    def initialize_vision_modules(self, model_args, fsdp=None):
+        """LlavaMetaModel.initialize_vision_modules (llava_arch.py:49-86): build the CLIP tower named by `model_args.vision_tower`
+        (architecture from `model_args.clip_config` or ViT-L/14 -- nothing is downloaded here; weights arrive by load_state_dict),
+        record its width in the config and create `mm_projector` if the constructor has not."""
+        name = getattr(model_args, "vision_tower", None) or getattr(model_args, "mm_vision_tower", None)
+        if name is None:
+            raise ValueError("initialize_vision_modules: model_args.vision_tower is not set")
+        if not (name.startswith("openai") or name.startswith("laion") or "clip" in name):   # multimodal_encoder/builder.py:10-17
+            raise ValueError(f"Unknown vision tower: {name}")
+        self.config.mm_vision_tower = name
+        args = SimpleNamespace(
+            mm_vision_select_layer=getattr(model_args, "mm_vision_select_layer", -2),
+            mm_vision_select_feature=getattr(model_args, "mm_vision_select_feature", "patch"),
+            pad_train_clip_images=getattr(model_args, "pad_train_clip_images", True),
+            resize_vision_tower=getattr(model_args, "resize_vision_tower", True),
+            resize_vision_tower_size=getattr(model_args, "resize_vision_tower_size", 448))
+        tower = CLIPVisionTower(name, args, config=getattr(model_args, "clip_config", None) or self._clip_config)
+        if fsdp is not None and len(fsdp) > 0:
+            self.__dict__["vision_tower"] = [tower]          # a plain list, as the reference keeps it out of the module tree
+            self._modules.pop("vision_tower", None)
+        else:
+            self.vision_tower = tower
+        self.config.use_mm_proj = True
+        self.config.mm_hidden_size = tower.hidden_size
+        self.config.mm_vision_select_layer = args.mm_vision_select_layer
+        self.config.mm_vision_select_feature = args.mm_vision_select_feature
+        if not hasattr(self, "mm_projector"):
+            self.mm_projector = nn.Linear(self.config.mm_hidden_size, self.config.hidden_size)
+        adapter = getattr(model_args, "pretrain_mm_mlp_adapter", None)
+        if adapter is not None:
+            weights = torch.load(adapter, map_location="cpu")
+            self.mm_projector.load_state_dict({k.split("mm_projector.")[1]: v for k, v in weights.items() if "mm_projector" in k})
+
+    def initialize_walkgpt_modules(self, config):
+        """walkgptMetaModel.initialize_walkgpt_modules, the SAM branch (walkgpt.py:94-146; `vision_tower_for_mask` is forced off at
+        :178): (re)create TinyCrossAttn, MSQP, the SAM model (from `vision_pretrained` when given) and CTP, with the reference's
+        requires_grad pattern."""
+        from .utils_walkgpt import TinyCrossAttn
+        if getattr(config, "vision_tower_for_mask", False):
+            raise NotImplementedError("vision_tower_for_mask=True (MaskDecoderMultiScale) is not on the WalkGPT path: "
+                                      "walkgptForCausalLM.__init__ forces it to False (walkgpt.py:178)")
+        H = config.hidden_size
+        self.tiny_xattn = TinyCrossAttn(256)
+        self.out_mm_projector = MultiScaleQFormerProjector(256, H, pad_to_square=True, target_square_side=6)
+        self.visual_model = self._build_visual_model()
+        for p in self.visual_model.parameters():
+            p.requires_grad = False
+        if getattr(config, "train_mask_decoder", False):
+            self.visual_model.mask_decoder.train()
+            for p in self.visual_model.mask_decoder.parameters():
+                p.requires_grad = True
+        self.text_hidden_fcs = nn.ModuleList([CalibratedTextProjector(H, getattr(config, "out_dim", 256))])
+        self.text_hidden_fcs.train()
+        for p in self.text_hidden_fcs.parameters():
+            p.requires_grad = True
+        self.__dict__.pop("_decode_graphs", None)      # captured decode graphs hold the old modules' addresses
 
     def set_gemm_dtype(self, dtype):
         """"bf16" (default) or "fp8": operand type of the qkv / proj / MLP GEMMs of the SAM encoder blocks (BASELINE config C5; needs
