@@ -318,10 +318,12 @@ def probe_launch(args, rank, local_rank, world):
 KERNEL_NAMES = {1: "wg_gemm_kernel<128,128,64,2,2,2>", 2: "wg_gemm_kernel<256,256,64,2,2,4>", 3: "wg_gemm_rowwave_kernel", 5: "wg_gemm_skinny_kernel",
                 11: "wg_gemm_persist_kernel<128,128,2,2>", 12: "wg_gemm_kernel<128,128 tail (+16 rows)>",
                 14: "wg_gemm_kernel<256,256,64,2,2,4,ping-pong>",
-                16: "wg_gemm_pp_persist_kernel<false> (256x256 tiles, ping-pong, persistent)",
-                17: "wg_gemm_pp_persist_kernel<true> (256x256 tiles, ping-pong, persistent, LayerNorm folded in)",
+                16: "wg_gemm_pp_persist_kernel<0, false> (256x256 tiles, ping-pong, persistent)",
+                17: "wg_gemm_pp_persist_kernel<2, false> (256x256 tiles, ping-pong, persistent, LayerNorm folded in, row statistics from the producing GEMM's partial sums)",
+                18: "wg_gemm_pp_persist_kernel<0, true> (256x256 tiles, ping-pong, persistent, leaves the row sums of its output)",
                 20: "wg_gemm_fp8_kernel (256x256 tiles, block-scaled fp8 MFMA)"}
-PMC_PREFIX = {16: "wg_gemm_pp_persist_kernel<false>", 17: "wg_gemm_pp_persist_kernel<true>", 20: "wg_gemm_fp8_kernel"}
+PMC_PREFIX = {16: "wg_gemm_pp_persist_kernel<0, false>", 17: "wg_gemm_pp_persist_kernel<2, false>", 18: "wg_gemm_pp_persist_kernel<0, true>",
+              20: "wg_gemm_fp8_kernel"}
 
 
 def main():

@@ -74,6 +74,24 @@ int wg_gemm_ln_supported(int M, int N, int K, long lda, long ldw, long ldc);
 int wg_gemm_ln_bias_act_bf16(const void* A, long lda, const void* Wg, long ldw, const float* bias_f32, const float* colsum,
                              const float* stats, void* C, long ldc, int M, int N, int K, int act, void* stream);
 
+/* Row statistics handed from the GEMM that WRITES a residual-stream tensor to the LayerNorm-folded GEMM that reads it, instead of
+ * a wg_row_stats_bf16 pass in between (the reference recomputes them inside nn.LayerNorm: image_encoder.py:177-178 norm1 behind the
+ * previous block's mlp.lin2 (common.py:26) or the patch embedding (:422-426, :111-113); :191 norm2 behind attn.proj (:257); HF
+ * CLIPEncoderLayer layer_norm1 behind the previous layer's mlp.fc2, layer_norm2 behind self_attn.out_proj):
+ *   wg_gemm_bias_act_stats_bf16   = wg_gemm_bias_act_bf16 (bf16 output, persistent 256x256 kernel) that also writes
+ *                                   row_partials[N / 256][mpad][2] fp32 = {sum, sum of squares} of the bf16 values it stored, per
+ *                                   output row and 256-column tile; mpad = M rounded up to a multiple of 256 (rows >= M: unspecified).
+ *   wg_gemm_lnp_bias_act_bf16     = wg_gemm_ln_bias_act_bf16 whose statistics are such partial sums (n_partials * 256 == K <= 1280):
+ *                                   mean = S / K, rstd = (Q / K - mean^2 + eps)^-1/2 formed in the kernel.
+ * wg_gemm_row_partials_supported() != 0: the producer's shape qualifies (N % 256 == 0, N <= 1280, plus wg_gemm_ln_supported's rules). */
+int wg_gemm_row_partials_supported(int M, int N, int K, long lda, long ldw, long ldc);
+int wg_gemm_bias_act_stats_bf16(const void* A, long lda, const void* W, long ldw, const void* bias, const void* residual, long ldr,
+                                int res_row_mod, void* C, long ldc, int M, int N, int K, int act, float* row_partials, long mpad,
+                                void* stream);
+int wg_gemm_lnp_bias_act_bf16(const void* A, long lda, const void* Wg, long ldw, const float* bias_f32, const float* colsum,
+                              const float* row_partials, int n_partials, long mpad, float eps, void* C, long ldc, int M, int N, int K,
+                              int act, void* stream);
+
 /* y = act(LayerNorm(x) * gamma + beta) per row, biased variance, eps inside the sqrt.
  * nn.LayerNorm: image_encoder.py:177,191 (eps 1e-6), transformer.py:157-181, utils_walkgpt.py:166-167,207,311,315,
  * HF CLIP layer norms; LayerNorm2d (common.py:31-43) on channels-last rows: neck (image_encoder.py:98,106),

@@ -208,3 +208,60 @@ def test_ln_linear_folded(dev, M, N, K, act):
     xf = x.float()
     assert torch.allclose(st[:, 0], xf.mean(1), atol=1e-5, rtol=1e-5)
     assert torch.allclose(st[:, 1], (xf.var(1, unbiased=False) + 1e-6).rsqrt(), atol=1e-5, rtol=1e-4)
+
+
+@pytest.mark.parametrize("M,N,K,Kn", [(6000, 768, 512, 1024), (8200, 1024, 256, 512), (4099, 1280, 320, 1024), (16500, 256, 64, 256)])
+def test_row_partials_travel_from_gemm_to_ln_gemm(dev, M, N, K, Kn):
+    """wg_gemm_bias_act_stats_bf16 -> wg_gemm_lnp_bias_act_bf16: the GEMM that writes a residual-stream tensor leaves the rows'
+    {sum, sum of squares} per 256-column tile, and the LayerNorm-folded GEMM that reads the tensor forms mean / rstd from them
+    (image_encoder.py:177-178,191; no statistics pass in between).  Rows carry a mean of several sigma (one-pass variance)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16)
+    r = (torch.randn(M, N, generator=g) * (0.5 + torch.rand(M, 1, generator=g)) + 3.0 * torch.randn(M, 1, generator=g)).to(torch.bfloat16)
+    xd, wd, bd, rd = x.to(dev), w.to(dev), b.to(dev), r.to(dev)
+    y = ops.linear(xd, wd, bd, residual=rd, row_partials=True)
+    assert hasattr(y, "_wg_row_partials"), "the shape must take the statistics-producing kernel"
+    plain = ops.linear(xd, wd, bd, residual=rd)
+    assert torch.equal(y, plain)                                     # same arithmetic, same stores
+    part, mpad = y._wg_row_partials[0], y._wg_row_partials[1]
+    assert part.shape == (N // 256, mpad, 2) and mpad % 256 == 0 and mpad >= M
+    yt = y.float().view(M, N // 256, 256)
+    assert torch.allclose(part[:, :M, 0].t(), yt.sum(-1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(part[:, :M, 1].t(), (yt * yt).sum(-1), rtol=1e-5, atol=1e-3)
+    # consumer: the same LayerNorm-folded GEMM with statistics from the partial sums / from the statistics pass / in fp32 torch
+    gamma = (1.0 + 0.3 * torch.randn(N, generator=g)).to(torch.bfloat16)
+    beta = (0.2 * torch.randn(N, generator=g)).to(torch.bfloat16)
+    w2 = (torch.randn(Kn, N, generator=g) / N ** 0.5).to(torch.bfloat16)
+    b2 = torch.randn(Kn, generator=g).to(torch.bfloat16)
+    fold = ops.fold_layernorm(gamma.to(dev), beta.to(dev), w2.to(dev), b2.to(dev))
+    with ops.time_gemms() as rec:
+        got = ops.ln_linear(y, fold, 1e-6, act=ops.ACT_GELU)
+    assert [k for k, *_ in rec] == [17]                              # one launch: no row-statistics pass, no two-kernel route
+    ref = _ref_act(torch.nn.functional.linear(torch.nn.functional.layer_norm(y.float().cpu(), (N,), gamma.float(), beta.float(), 1e-6),
+                                              w2.float(), b2.float()), ops.ACT_GELU)
+    err = (got.float().cpu() - ref).abs().max().item()
+    assert err <= 0.03 * max(1.0, ref.abs().max().item()), err
+    via_pass = ops.ln_linear(plain, fold, 1e-6, act=ops.ACT_GELU)      # `plain` carries no partial sums: statistics pass + GEMM
+    d = (got.float() - via_pass.float()).abs().max().item()
+    assert d <= 0.02 * max(1.0, ref.abs().max().item()), d
+    # a view or an in-place edit drops the hand-over instead of using stale sums
+    y2 = y.clone()
+    y2._wg_row_partials = y._wg_row_partials[:2] + (y2._version,) + y._wg_row_partials[3:]
+    y2.mul_(2.0)
+    assert torch.equal(ops.ln_linear(y2, fold, 1e-6), ops.ln_linear(y2.clone(), fold, 1e-6))
+
+
+def test_row_partials_are_refused_for_shapes_the_kernel_cannot_take(dev):
+    L = ops._lib.lib()
+    assert L.wg_gemm_row_partials_supported(32768, 768, 768, 768, 768, 768) == 1
+    assert L.wg_gemm_row_partials_supported(32768, 2304, 768, 768, 768, 2304) == 0     # wider than five 256-column tiles
+    assert L.wg_gemm_row_partials_supported(32768, 320, 768, 768, 768, 320) == 0       # not whole column tiles
+    x = torch.randn(64, 64, device=dev).to(torch.bfloat16)
+    w = torch.randn(256, 64, device=dev).to(torch.bfloat16)
+    y = ops.linear(x, w, row_partials=True)                                            # too few rows for the persistent kernel: plain GEMM
+    assert not hasattr(y, "_wg_row_partials")
+    part = torch.empty(1, 256, 2, device=dev)
+    rc = L.wg_gemm_bias_act_stats_bf16(x.data_ptr(), 64, w.data_ptr(), 64, None, None, 0, 0, y.data_ptr(), 256, 64, 256, 64, 0, part.data_ptr(), 256, None)
+    assert rc != 0 and b"persistent" in L.wg_last_error()

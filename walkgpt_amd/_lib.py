@@ -18,6 +18,10 @@ SIGNATURES = {
     "wg_row_stats_bf16": [c_void_p, c_long, c_void_p, c_int, c_int, c_float, c_void_p],
     "wg_gemm_ln_bias_act_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int,
                                  c_int, c_int, c_void_p],
+    "wg_gemm_bias_act_stats_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_void_p, c_long,
+                                    c_int, c_int, c_int, c_int, c_void_p, c_long, c_void_p],
+    "wg_gemm_lnp_bias_act_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_long, c_float, c_void_p, c_long,
+                                  c_int, c_int, c_int, c_int, c_void_p],
     "wg_layernorm_rows": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_float, c_int,
                           c_void_p],
     "wg_mha_bf16": [c_void_p, c_long, c_long, c_void_p, c_long, c_void_p, c_long, c_long, c_void_p, c_long, c_long,
@@ -82,6 +86,7 @@ _SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, []),
             "wg_match_cost_workspace_floats": (c_long, [c_int, c_int, c_int]),
             "wg_gemm_pick_tile": (c_int, [c_int, c_int]),
             "wg_gemm_ln_supported": (c_int, [c_int, c_int, c_int, c_long, c_long, c_long]),
+            "wg_gemm_row_partials_supported": (c_int, [c_int, c_int, c_int, c_long, c_long, c_long]),
             "wg_gemm_pick_tile_ex": (c_int, [c_int, c_int, c_int])}
 
 

@@ -84,9 +84,9 @@ class _EncoderLayer(nn.Module, _Prepared):
         D = x.shape[-1]
         qkv = ops.ln_linear(x, p["qkv"], self.layer_norm1.eps, tail_tiles=tail_tiles)
         o = ops.mha(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], a.num_heads, a.scale, key_bias, small=False)
-        x = ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=x, tail_tiles=tail_tiles)
+        x = ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=x, tail_tiles=tail_tiles, row_partials=True)
         h = ops.ln_linear(x, p["fc1"], self.layer_norm2.eps, act=ops.ACT_QUICK_GELU, tail_tiles=tail_tiles)
-        return ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x, tail_tiles=tail_tiles)
+        return ops.linear(h, self.mlp.fc2.weight, self.mlp.fc2.bias, residual=x, tail_tiles=tail_tiles, row_partials=True)
 
 
 class _Encoder(nn.Module):

@@ -33,6 +33,11 @@ struct GemmArgs {
     const float* ln_stats;       // LayerNorm folded into this GEMM (persistent kernel only): [M][2] = {mean, rstd} of the rows of A,
     const float* ln_s;           //   [N] column sums of the (gamma-scaled, bf16) weight rows,
     const float* ln_b;           //   [N] folded bias  b + W beta:   C = rstd * (A W'^T - mean * s) + b'
+    const float* ln_part;        // ... or, instead of ln_stats, the rows' statistics as partial sums left by the GEMM that PRODUCED A
+    int ln_np; long ln_mpad;     //   (stats_part below): [ln_np][ln_mpad][2] = {sum x, sum x^2} per 256-column tile of A's row;
+    float ln_eps;                //   mean / rstd are formed in this kernel (K = the LayerNorm width)
+    float* stats_part;           // producer side (persistent kernel, bf16 output, N % 256 == 0): [tiles_n][stats_mpad][2] fp32 =
+    long stats_mpad;             //   {sum, sum of squares} of the STORED (bf16-rounded) values of each output row over the tile's 256 columns
     unsigned c_bytes, r_bytes;   // extents of C and R for the staged epilogue's buffer descriptors (0: not addressable in 32 bits)
     const float* scale_a;        // fp8 operands (wg_gemm_fp8_bias_act): per-row scale of A [M] and per-output-channel scale of W [N];
     const float* scale_w;        //   A, W then point at e4m3 bytes and lda / ldw / K count PAIRS of bytes (see the entry point)
@@ -1040,6 +1045,17 @@ static int launch_persist(GemmArgs& g, hipStream_t st) {
     return wg_check_launch("wg_gemm_bias_act_bf16(persistent)");
 }
 
+// STATS instances: spart[256 rows][4 column waves][2] -> {sum, sum of squares} of row `row_off + r` over the tile's 256 columns.
+// Every wave issues exactly one store instruction (odd lanes' stores fall outside the descriptor and are dropped): the tile loop's
+// counted waits rely on a fixed number of memory operations per wave.
+__device__ __forceinline__ void wg_stats_combine(const float* spart, int tid, float* out, long rows_total, int row_off) {
+    const f32x4 a = *(const f32x4*)(spart + (tid >> 1) * 8 + (tid & 1) * 4);    // {s0,q0,s1,q1} | {s2,q2,s3,q3} of row tid / 2
+    const f32x2 r2 = {a[0] + a[2], a[1] + a[3]};
+    const f32x2 o2 = {r2.x + WG_DPP(r2.x, 0xB1), r2.y + WG_DPP(r2.y, 0xB1)};    // + the partner lane's two waves
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (unsigned)(rows_total * 8), WG_RSRC_FLAGS);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), srs, (tid & 1) ? (int)0x80000000 : (row_off + (tid >> 1)) * 8, 0, 0);
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Persistent 256x256 tiles with the two-cluster ping-pong loop of wg_gemm_kernel (bf16 output, staged epilogue).
 // Tile-level stamps on the K = 768 shapes put 5 % of a tile's life into the first-slab latency and ~6 % into waiting for
@@ -1051,8 +1067,19 @@ static int launch_persist(GemmArgs& g, hipStream_t st) {
 //   * residual rows are loaded one 64-row slab at a time, the second slab's loads issued after the first slab's sums are
 //     formed but BEFORE its stores (registers reused; the later wait for them then never includes a store).
 // ---------------------------------------------------------------------------------------------------------------------
-template <bool LN>
+//   * LNMODE 0: bias / residual epilogue; 1: LayerNorm folded in, statistics {mean, rstd} per row read from g.ln_stats; 2: the same
+//     with the statistics formed here from the partial sums g.ln_part that the producing GEMM (STATS) left;
+//   * STATS: this GEMM's output is the input of a later LayerNorm: next to its bf16 rows it leaves, per row and 256-column tile,
+//     {sum, sum of squares} of the values it stored.  The separate row-statistics pass over the residual stream (72 launches per
+//     C2 step, 3.7 % of its kernel time; 10.8 % of C3's, where each of them queues behind a persistent grid) disappears: the
+//     statistics ride on data the epilogue already holds in registers.  Round 2 tried this with per-64-column centred sums written
+//     straight to memory from the store loop (one buffer store per output store): 11 spilled registers, +0.47 ms per step.  Here
+//     the sums are taken from the packed registers that feed a slab's stores (two v_dot2c per bf16 pair) while the residual
+//     registers are free, cross the waves through 8 KiB of LDS, and leave as ONE 8-byte store per row and tile behind the next
+//     tile's first barrier.
+template <int LNMODE, bool STATS>
 __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) {
+    constexpr bool LN = LNMODE != 0;
     constexpr bool FP8 = false;   // (the fp8 operands of wg_gemm_kernel<..., FP8 = true> share this loop's source; bf16 only here)
     constexpr int BM = 256, BN = 256, BK = 64, WN = 4;
     constexpr int WTM = 128, WTN = 64, FJ = 4;
@@ -1114,6 +1141,10 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
     };
     // LN: per tile parity  s[256] f32 | b'[256] f32 | stats[256][2] f32  (4 KiB), all by LDS-DMA like the bias row
     constexpr int EPIB = LN ? 4096 : 512;
+    // LNMODE 2: + raw[ln_np <= 5][256][2] f32 partial sums of the next tile's rows (single-buffered: turned into the parity's
+    // stats[] right behind the tile's first barrier, many barriers before the next DMA into it).  STATS: + part[256][4][2] f32.
+    char* const rawbuf = biasbuf + 2 * EPIB;
+    float* const spart = (float*)(biasbuf + 2 * EPIB);
     auto first_slab = [&](int m0, int n0, int par) {
         if (LN) {
             if (wave == 0) {
@@ -1122,11 +1153,24 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                 __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(g.ln_s + n), WG_LDS_PTR(biasbuf + par * EPIB), 16, 0, 0);
                 __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(g.ln_b + n), WG_LDS_PTR(biasbuf + par * EPIB + 1024), 16, 0, 0);
             } else if (wave == 1) {
+                if constexpr (LNMODE == 2) {
+                    // rows m0 .. m0+255 of every partial plane (the planes are padded to whole row tiles: no clamp needed)
+                    int ol = lane;                               // opaque: keeps the address out of the registers that live across the main loop
+                    asm volatile("" : "+v"(ol));
+                    const float* src = g.ln_part + 2 * ((long)m0 + ol * 2);
+#pragma unroll 1
+                    for (int p = 0; p < g.ln_np; ++p) {
+                        __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(src), WG_LDS_PTR(rawbuf + p * 2048), 16, 0, 0);
+                        __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(src + 256), WG_LDS_PTR(rawbuf + p * 2048 + 1024), 16, 0, 0);
+                        src += 2 * g.ln_mpad;
+                    }
+                } else {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     int m = m0 + u * 128 + lane * 2;
                     m = m < g.M ? m : 0;          // rows past M are never stored; the buffer holds an even number of rows
                     __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(g.ln_stats + 2 * (long)m), WG_LDS_PTR(biasbuf + par * EPIB + 2048 + u * 1024), 16, 0, 0);
+                }
                 }
             }
         } else if (g.bias && wave == 0 && lane < 32) {   // the tile's 256 bias values: one 512-byte LDS-DMA
@@ -1138,6 +1182,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
     };
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.c_bytes, WG_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.R, 0, g.r_bytes, WG_RSRC_FLAGS);
+    int sp_off = 0;    // STATS: row index (tile column * mpad + first row) of the tile whose row sums sit in spart
 
     int v = blockIdx.x;
     int m0, n0;
@@ -1174,8 +1219,30 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                 }
         };
         // the whole first slab (older than the previous tile's stores) has landed; those stores may still be draining
-        if (stores_in_flight) wg_wait_vmcnt<NSTORE>(); else wg_wait_vmcnt<0>();
+        if (stores_in_flight) wg_wait_vmcnt<NSTORE + (STATS ? 1 : 0)>(); else wg_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
+        if constexpr (LNMODE == 2) {
+            // this tile's row statistics from the partial sums that arrived with its first slab:  mean = S / K,
+            // var = Q / K - mean^2 (fp32 sums of bf16 values; |mean| stays within a few sigma on a residual stream), rstd = (var + eps)^-1/2
+            int ct = tid;
+            asm volatile("" : "+v"(ct));
+            if (ct < 256) {
+                float S = 0.f, Q = 0.f;
+#pragma unroll 1
+                for (int p = 0; p < g.ln_np; ++p) {
+                    const f32x2 v = *(const f32x2*)(rawbuf + p * 2048 + ct * 8);
+                    S += v.x; Q += v.y;
+                }
+                const float invk = 1.0f / (float)g.K;
+                const float mean = S * invk;
+                const float var = fmaxf(Q * invk - mean * mean, 0.f);
+                *(f32x2*)(biasbuf + par * EPIB + 2048 + ct * 8) = (f32x2){mean, __builtin_amdgcn_rsqf(var + g.ln_eps)};
+            }
+        }
+        if constexpr (STATS) {
+            // the previous tile's row sums: the four column waves' shares meet here (their LDS writes are behind the barrier above)
+            if (stores_in_flight) wg_stats_combine(spart, tid, g.stats_part, g.tiles_n * g.stats_mpad, sp_off);
+        }
         if (grp == 1) __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nk; ++kt) {
             const char* ldsA = smem + (kt & 1) * STAGE;
@@ -1310,6 +1377,27 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                     t[it] = __builtin_bit_cast(u32x4, o[it]);
                     asm volatile("" : "+v"(t[it]));
                 }
+                if constexpr (STATS) {
+                    // row sums of what is about to be stored (taken here, while the residual registers are free): lane el holds 8
+                    // consecutive columns of row it * 8 + el / 8 of this 64-row slab, the 8 lanes el % 8 share a row.  Partial of this
+                    // wave's 64 columns -> spart[row][wn] = {sum, sum of squares}.
+                    const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3F803F80u);
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        float sv = 0.f, qv = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const bf16x2 v2 = __builtin_bit_cast(bf16x2, t[it][k]);
+                            sv = __builtin_amdgcn_fdot2_f32_bf16(v2, ones, sv, false);
+                            qv = __builtin_amdgcn_fdot2_f32_bf16(v2, v2, qv, false);
+                        }
+                        sv += WG_DPP(sv, 0xB1); qv += WG_DPP(qv, 0xB1);      // quad_perm [1,0,3,2]
+                        sv += WG_DPP(sv, 0x4E); qv += WG_DPP(qv, 0x4E);      // quad_perm [2,3,0,1]
+                        sv += WG_DPP(sv, 0x141); qv += WG_DPP(qv, 0x141);    // row_half_mirror: the other quad of the 8 lanes
+                        if ((el & 7) == 0)
+                            *(f32x2*)(spart + ((wm * WTM + half * 64 + it * RPSl + (el >> 3)) * 4 + wn) * 2) = (f32x2){sv, qv};
+                    }
+                }
                 if (HAS_R && half + 1 < WTM / 64) wg_load_residual<CH, NIT>(rres, rrs, (int)g.ldr, g.res_mod, cm0 + wm * WTM + (half + 1) * 64, nbase, el);
                 const int n = nbase + (el % CH) * 8;
                 const int off0 = n < g.N ? ((cm0 + wm * WTM + half * 64 + el / CH) * (int)g.ldc + n) * 2 : (int)0x80000000;
@@ -1320,12 +1408,17 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
             }
         };
         if (g.R) finish(std::true_type{}); else finish(std::false_type{});
+        if constexpr (STATS) sp_off = (nbase / BN) * (int)g.stats_mpad + cm0;
         if (!has_next) break;
         v = vn;
         par ^= 1;
         // every wave issues all NSTORE store instructions of a tile (rows / columns outside the matrix are dropped by the buffer
         // range check, not branched around) and every load of the epilogue is consumed before the last stores issue: exact count
         stores_in_flight = true;
+    }
+    if constexpr (STATS) {   // the last tile's row sums
+        __syncthreads();
+        wg_stats_combine(spart, tid, g.stats_part, g.tiles_n * g.stats_mpad, sp_off);
     }
 }
 
@@ -1338,18 +1431,27 @@ static int launch_pp_persist(GemmArgs& g, hipStream_t st) {
         g.col_block = (wbytes > (3L << 20) && cb >= 2 && cb < g.tiles_n) ? cb : 0;
     }
     constexpr int stage = 512 * 128, slab = 64 * (64 * 2 + 16);
-    const int lds = 2 * stage + (8 - stage / slab) * slab + (g.ln_stats ? 2 * 4096 : 2 * 512);   // + the double-buffered bias row
-    static bool attr_done = false;
-    if (!attr_done) {
-        constexpr int base = 2 * stage + (8 - stage / slab) * slab;
-        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, base + 2 * 512);
-        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, base + 2 * 4096);
-        attr_done = true;
+    constexpr int base = 2 * stage + (8 - stage / slab) * slab;
+    // + the double-buffered bias row / LayerNorm operands, the raw partial sums of the next tile (mode 2), the row-sum exchange (STATS)
+    constexpr int lds_plain = base + 2 * 512, lds_stats = base + 2 * 512 + 256 * 4 * 8, lds_ln = base + 2 * 4096, lds_lnp = base + 2 * 4096 + 5 * 2048;
+    static_assert(lds_lnp <= 160 * 1024 && lds_stats <= 160 * 1024, "LDS budget of the persistent GEMM");
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static bool attr_done[64] = {};
+    if (dev >= 0 && dev < 64 && !attr_done[dev]) {   // the attribute is per device (a process may drive several)
+        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_plain);
+        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_stats);
+        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_ln);
+        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_lnp);
+        attr_done[dev] = true;
     }
     const int nwg = g.tiles_m * g.tiles_n;
-    const int grid = nwg < 256 ? nwg : 256;   // one resident workgroup per CU; a multiple of 8 keeps a workgroup's tiles on one XCD
-    if (g.ln_stats) hipLaunchKernelGGL(wg_gemm_pp_persist_kernel<true>, dim3(grid), dim3(512), lds, st, g);
-    else hipLaunchKernelGGL(wg_gemm_pp_persist_kernel<false>, dim3(grid), dim3(512), lds, st, g);
+    const int cus = wg_cu_count(dev);
+    const int grid = nwg < cus ? nwg : cus;   // one resident workgroup per CU; a multiple of 8 keeps a workgroup's tiles on one XCD
+    if (g.ln_part) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<2, false>), dim3(grid), dim3(512), lds_lnp, st, g);
+    else if (g.ln_stats) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<1, false>), dim3(grid), dim3(512), lds_ln, st, g);
+    else if (g.stats_part) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<0, true>), dim3(grid), dim3(512), lds_stats, st, g);
+    else hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<0, false>), dim3(grid), dim3(512), lds_plain, st, g);
     return wg_check_launch("wg_gemm_bias_act_bf16(ping-pong persistent)");
 }
 
@@ -1404,10 +1506,14 @@ extern "C" int wg_gemm_pick_tile_ex(int M, int N, int allow_tail) {
 
 extern "C" int wg_gemm_pick_tile(int M, int N) { return wg_gemm_pick_tile_ex(M, N, 0); }
 
+struct GemmStatsIO {   // row statistics travelling between two persistent GEMMs (see wg_gemm_pp_persist_kernel)
+    const float* ln_part = nullptr; int ln_np = 0; long ln_mpad = 0; float ln_eps = 0.f;   // consumer
+    float* stats_part = nullptr; long stats_mpad = 0;                                      // producer
+};
 static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const void* bias, const void* residual, long ldr,
                             int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32, int tile_hint,
                             const float* ln_stats, const float* ln_s, const float* ln_b, void* stream, const bf16* sk_gamma = nullptr,
-                            const bf16* sk_beta = nullptr, float sk_eps = 0.f, int sk_tiled = 0);
+                            const bf16* sk_beta = nullptr, float sk_eps = 0.f, int sk_tiled = 0, const GemmStatsIO* sio = nullptr);
 
 extern "C" int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, const void* bias,
                                      const void* residual, long ldr, int res_row_mod, void* C, long ldc, int M, int N,
@@ -1449,10 +1555,48 @@ extern "C" int wg_gemm_ln_bias_act_bf16(const void* A, long lda, const void* Wg,
     return wg_gemm_dispatch(A, lda, Wg, ldw, nullptr, nullptr, 0, 0, C, ldc, M, N, K, act, 0, 16, stats, colsum, bias_f32, stream);
 }
 
+// The producing side of the row statistics: wg_gemm_bias_act_bf16 that also leaves, for a later LayerNorm over its output rows,
+// row_partials[tile column][mpad][2] = {sum, sum of squares} (fp32) of the bf16 values it stored, per row and 256-column tile
+// (mpad = M rounded up to 256; N / 256 planes).  Replaces the wg_row_stats_bf16 pass in front of wg_gemm_ln_bias_act_bf16
+// (SAM: image_encoder.py:177-178,191 norm1 / norm2 behind lin2 / proj; CLIP: layer_norm1 / 2 behind fc2 / out_proj).
+// Shapes: the persistent 256x256 kernel with N % 256 == 0 (wg_gemm_row_partials_supported).
+extern "C" int wg_gemm_row_partials_supported(int M, int N, int K, long lda, long ldw, long ldc) {
+    return (wg_gemm_ln_supported(M, N, K, lda, ldw, ldc) && N % 256 == 0 && N <= 1280 &&
+            ((long)(N / 256) * (long)((M + 255) / 256 * 256) * 8 < (1L << 31))) ? 1 : 0;
+}
+extern "C" int wg_gemm_bias_act_stats_bf16(const void* A, long lda, const void* W, long ldw, const void* bias, const void* residual, long ldr,
+                                           int res_row_mod, void* C, long ldc, int M, int N, int K, int act, float* row_partials, long mpad,
+                                           void* stream) {
+    WG_REQUIRE(row_partials && ((uintptr_t)row_partials & 15) == 0, "gemm_stats: row_partials must be a 16-byte aligned buffer");
+    WG_REQUIRE(mpad % 256 == 0 && mpad >= M, "gemm_stats: mpad = %ld must be M = %d rounded up to a multiple of 256", mpad, M);
+    WG_REQUIRE(wg_gemm_row_partials_supported(M, N, K, lda, ldw, ldc) && ((uintptr_t)C & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
+                   (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0)),
+               "gemm_stats: shape M=%d N=%d K=%d does not run on the persistent 256x256 kernel with whole column tiles", M, N, K);
+    GemmStatsIO sio;
+    sio.stats_part = row_partials; sio.stats_mpad = mpad;
+    return wg_gemm_dispatch(A, lda, W, ldw, bias, residual, ldr, res_row_mod, C, ldc, M, N, K, act, 0, 16, nullptr, nullptr, nullptr, stream,
+                            nullptr, nullptr, 0.f, 0, &sio);
+}
+// The consuming side: wg_gemm_ln_bias_act_bf16 with the statistics given as the producer's partial sums (n_partials planes of mpad
+// rows; n_partials * 256 = K = the LayerNorm width, n_partials <= 5).  eps: the LayerNorm's.
+extern "C" int wg_gemm_lnp_bias_act_bf16(const void* A, long lda, const void* Wg, long ldw, const float* bias_f32, const float* colsum,
+                                         const float* row_partials, int n_partials, long mpad, float eps, void* C, long ldc, int M, int N, int K,
+                                         int act, void* stream) {
+    WG_REQUIRE(bias_f32 && colsum && row_partials, "gemm_lnp: null operand");
+    WG_REQUIRE((((uintptr_t)bias_f32 | (uintptr_t)colsum | (uintptr_t)row_partials) & 15) == 0, "gemm_lnp: misaligned operand");
+    WG_REQUIRE(n_partials >= 1 && n_partials <= 5 && n_partials * 256 == K, "gemm_lnp: %d partial planes do not cover K = %d", n_partials, K);
+    WG_REQUIRE(mpad % 256 == 0 && mpad >= M, "gemm_lnp: mpad = %ld must be M = %d rounded up to a multiple of 256", mpad, M);
+    WG_REQUIRE(wg_gemm_ln_supported(M, N, K, lda, ldw, ldc) && ((uintptr_t)C & 15) == 0, "gemm_lnp: shape M=%d N=%d K=%d does not run on the persistent 256x256 kernel", M, N, K);
+    GemmStatsIO sio;
+    sio.ln_part = row_partials; sio.ln_np = n_partials; sio.ln_mpad = mpad; sio.ln_eps = eps;
+    return wg_gemm_dispatch(A, lda, Wg, ldw, nullptr, nullptr, 0, 0, C, ldc, M, N, K, act, 0, 16, nullptr, colsum, bias_f32, stream,
+                            nullptr, nullptr, 0.f, 0, &sio);
+}
+
 static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, const void* bias, const void* residual, long ldr,
                             int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32, int tile_hint,
                             const float* ln_stats, const float* ln_s, const float* ln_b, void* stream, const bf16* sk_gamma,
-                            const bf16* sk_beta, float sk_eps, int sk_tiled) {
+                            const bf16* sk_beta, float sk_eps, int sk_tiled, const GemmStatsIO* sio) {
     WG_REQUIRE(A && W && C, "gemm: null operand");
     WG_REQUIRE(M > 0 && N > 0 && K > 0, "gemm: bad shape M=%d N=%d K=%d", M, N, K);
     WG_REQUIRE(act >= 0 && act <= 3, "gemm: bad activation %d", act);
@@ -1465,6 +1609,8 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
     g.tiles_m = g.tiles_n = 0;
     g.col_block = 0;
     g.ln_stats = ln_stats; g.ln_s = ln_s; g.ln_b = ln_b;
+    g.ln_part = sio ? sio->ln_part : nullptr; g.ln_np = sio ? sio->ln_np : 0; g.ln_mpad = sio ? sio->ln_mpad : 0; g.ln_eps = sio ? sio->ln_eps : 0.f;
+    g.stats_part = sio ? sio->stats_part : nullptr; g.stats_mpad = sio ? sio->stats_mpad : 0;
     g.scale_a = g.scale_w = nullptr;
     g.sk_gamma = sk_gamma; g.sk_beta = sk_beta; g.sk_eps = sk_eps; g.sk_tiled = sk_tiled;
     {   // byte extents for the staged epilogue's buffer descriptors (it addresses C and R with 32-bit byte offsets)
@@ -1489,7 +1635,10 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
                            (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0 && g.r_bytes != 0));
     const bool small_ops = (long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31);
     if (tile == 11 && !(can_stage && small_ops)) tile = 1;
-    if (tile == 16 && !(can_stage && small_ops && (!bias || ((uintptr_t)bias % 16 == 0 && N % 8 == 0)))) tile = 14;
+    if (tile == 16 && !(can_stage && small_ops && (!bias || ((uintptr_t)bias % 16 == 0 && N % 8 == 0)))) {
+        WG_REQUIRE(!(g.ln_part || g.stats_part || g.ln_stats), "gemm: this operand layout cannot take the persistent kernel's staged epilogue");
+        tile = 14;
+    }
     if (tile == 5 && !(M <= 128 && N % 16 == 0 && K % 128 == 0)) tile = 1;
     if (tile != 1 && tile != 2 && tile != 5 && tile != 11 && tile != 12 && tile != 14 && tile != 16) tile = 1;
     if (tile == 12 && !(can_stage && M >= 128 && M % 128 >= 1 && M % 128 <= 16)) tile = 1;
@@ -1546,6 +1695,7 @@ extern "C" int wg_gemm_fp8_bias_act(const void* Aq, long lda, const float* scale
     g.tiles_m = g.tiles_n = 0;
     g.col_block = 0;
     g.ln_stats = nullptr; g.ln_s = nullptr; g.ln_b = nullptr;
+    g.ln_part = nullptr; g.ln_np = 0; g.ln_mpad = 0; g.ln_eps = 0.f; g.stats_part = nullptr; g.stats_mpad = 0;
     g.scale_a = scale_a; g.scale_w = scale_w;
     g.sk_gamma = g.sk_beta = nullptr; g.sk_eps = 0.f; g.sk_tiled = 0;
     const long cb = ((long)(M - 1) * ldc + N) * 2;

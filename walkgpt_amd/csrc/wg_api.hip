@@ -23,3 +23,15 @@ int wg_check_launch(const char* what) {
 
 extern "C" const char* wg_last_error(void) { return g_err; }
 extern "C" int wg_version(void) { return 100; }  // 0.1.0 = major*10000 + minor*100 + patch
+
+// Compute units of a device, cached per device index (a benign race: every thread writes the same value).  Persistent kernels size
+// their grids from it; one process per GPU sees one entry, a process that drives several devices one entry each.
+int wg_cu_count(int device) {
+    static int cache[64] = {};
+    if (device < 0 || device >= 64) return 256;
+    if (cache[device] == 0) {
+        hipDeviceProp_t p;
+        cache[device] = (hipGetDeviceProperties(&p, device) == hipSuccess && p.multiProcessorCount > 0) ? p.multiProcessorCount : 256;
+    }
+    return cache[device];
+}

@@ -34,6 +34,7 @@ void wg_set_error(const char* fmt, ...);
         }                                     \
     } while (0)
 int wg_check_launch(const char* what);
+int wg_cu_count(int device);   // compute units of a device (cached): persistent grids are sized from it, not from a constant
 
 // ---- device helpers --------------------------------------------------------
 __device__ __forceinline__ float wg_bf2f(bf16 x) { return (float)x; }

@@ -75,8 +75,15 @@ def gemm_tile_for(M, N, K, lda, ldw, ldc, ldr, tail_tiles=False):
     return _lib.lib().wg_gemm_pick_tile_ex(M, N, 1 if tail_tiles else 0)
 
 
-def linear(x, weight, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out=None, out_f32=False, tile=0, tail_tiles=False):
-    """y = act(x @ weight.T + bias) (+ residual).  x [..., K] bf16, weight [N, K] bf16."""
+ROW_PARTIALS = _os.environ.get("WG_ROW_PARTIALS", "1") != "0"   # experiments: 0 = always take the row statistics in their own pass
+
+
+def linear(x, weight, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out=None, out_f32=False, tile=0, tail_tiles=False,
+           row_partials=False):
+    """y = act(x @ weight.T + bias) (+ residual).  x [..., K] bf16, weight [N, K] bf16.
+    row_partials: y feeds a LayerNorm that ln_linear folds into the next GEMM -- where the shape allows it the GEMM also leaves the
+    per-row partial sums of y (wg_gemm_bias_act_stats_bf16) and ln_linear(y, ...) picks them up instead of running a statistics
+    pass (they ride on the returned tensor object: a view or an in-place edit of y silently falls back to the pass)."""
     _need_gpu(x, weight, bias, residual, out)
     assert x.dtype == _BF16 and weight.dtype == _BF16
     M, K, lda = _rows(x)
@@ -93,6 +100,21 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out
         assert Nr == N
     if bias is not None:
         assert bias.dtype == _BF16 and bias.numel() == N
+    if (row_partials and ROW_PARTIALS and not out_f32 and tile == 0 and not _FORCE_TILE and not tail_tiles
+            and _lib.lib().wg_gemm_row_partials_supported(M, N, K, lda, weight.stride(0), ldc)
+            and (bias is None or bias.data_ptr() % 16 == 0) and (residual is None or (ldr % 8 == 0 and residual.data_ptr() % 16 == 0))):
+        mpad = (M + 255) // 256 * 256
+        part = torch.empty(N // 256, mpad, 2, device=x.device, dtype=torch.float32)
+        ev = _timed(18, M, N, K)  # 18: the statistics-producing instance of kernel 16
+        if ev is not None:
+            ev[0].record()
+        rc = _lib.lib().wg_gemm_bias_act_stats_bf16(x.data_ptr(), lda, weight.data_ptr(), weight.stride(0), _ptr(bias), _ptr(residual), ldr,
+                                                    res_row_mod, out.data_ptr(), ldc, M, N, K, act, part.data_ptr(), mpad, _stream())
+        if ev is not None:
+            ev[1].record()
+        _lib.check(rc, "wg_gemm_bias_act_stats_bf16")
+        out._wg_row_partials = (part, mpad, out._version, M, N)
+        return out
     if tile == 0:
         tile = gemm_tile_for(M, N, K, lda, weight.stride(0), ldc, ldr, tail_tiles)
     ev = _timed(tile, M, N, K)
@@ -155,8 +177,21 @@ def ln_linear(x, fold, eps, act=ACT_NONE, tail_tiles=False):
     L = _lib.lib()
     if not (LN_FUSE and not _FORCE_TILE and L.wg_gemm_ln_supported(M, N, K, lda, K, N)):
         return linear(layernorm(x, fold["gamma"], fold["beta"], eps), fold["weight"], fold["bias"], act=act, tail_tiles=tail_tiles)
-    st = row_stats(x, eps)
     out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=_BF16)
+    rp = getattr(x, "_wg_row_partials", None)
+    if rp is not None and rp[2] == x._version and rp[3] == M and rp[4] == K and ROW_PARTIALS:
+        # the GEMM that wrote x left its rows' partial sums (linear(..., row_partials=True)): no statistics pass
+        part, mpad = rp[0], rp[1]
+        ev = _timed(17, M, N, K)
+        if ev is not None:
+            ev[0].record()
+        rc = L.wg_gemm_lnp_bias_act_bf16(x.data_ptr(), lda, fold["wg"].data_ptr(), K, fold["bias_f32"].data_ptr(), fold["colsum"].data_ptr(),
+                                         part.data_ptr(), part.shape[0], mpad, float(eps), out.data_ptr(), N, M, N, K, act, _stream())
+        if ev is not None:
+            ev[1].record()
+        _lib.check(rc, "wg_gemm_lnp_bias_act_bf16")
+        return out
+    st = row_stats(x, eps)
     ev = _timed(17, M, N, K)  # 17: the LayerNorm-folded instance of kernel 16
     if ev is not None:
         ev[0].record()

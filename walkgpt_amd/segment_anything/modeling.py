@@ -151,9 +151,11 @@ class Block(nn.Module, _Prepared):
         qkv = ops.ln_linear(x, p["qkv"], self.norm1.eps)
         window = self.window_size if self.window_size > 0 else grid
         o = ops.sam_attention(qkv, a.qkv.bias, a.rel_pos_h, a.rel_pos_w, B, grid, window, a.num_heads)
-        x = ops.linear(o, a.proj.weight, a.proj.bias, residual=x)
+        # proj and lin2 write the residual stream that norm2 / the next block's norm1 read: they leave the rows' partial sums next
+        # to them and ln_linear picks those up (no statistics pass in between)
+        x = ops.linear(o, a.proj.weight, a.proj.bias, residual=x, row_partials=True)
         h = ops.ln_linear(x, p["lin1"], self.norm2.eps, act=self.mlp._act_code)
-        return ops.linear(h, self.mlp.lin2.weight, self.mlp.lin2.bias, residual=x)
+        return ops.linear(h, self.mlp.lin2.weight, self.mlp.lin2.bias, residual=x, row_partials=True)
 
     def _build(self):
         a, m = self.attn, self.mlp
@@ -211,7 +213,8 @@ class ImageEncoderViT(nn.Module, _Prepared):
             raise RuntimeError("image encoder expects %dx%d inputs" % (self.img_size, self.img_size))
         p = self._prep_get(self._build_prepared, (self.patch_embed.proj.weight, self.neck[0].weight, self.neck[2].weight, self.pos_embed))
         rows = ops.patchify(x.contiguous(), self.patch_size)
-        t = ops.linear(rows, p["patch_w"], self.patch_embed.proj.bias, residual=p["pos"], res_row_mod=g * g if p["pos"] is not None else 0)
+        t = ops.linear(rows, p["patch_w"], self.patch_embed.proj.bias, residual=p["pos"], res_row_mod=g * g if p["pos"] is not None else 0,
+                       row_partials=True)      # block 0's norm1 reads these rows: the GEMM leaves their statistics with them
         for blk in self.blocks:
             t = blk.rows(t, B, g)
         t = ops.linear(t, p["neck0_w"])
