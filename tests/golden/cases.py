@@ -226,6 +226,28 @@ CLIPS = {
 }
 
 
+# calibration of the tower's precision: the stand-in run in fp32 (full-precision weights) AND in bf16 (`.bfloat16()` module and input,
+# the precision the reference's callers use: evaluation_walkgpt.py:227-231,908-910), with hidden-state taps.  `taps`: indices into
+# hidden_states (0 = pre_layrnorm output); `stride`: token stride of what is stored (full-size outputs are stored as slices).
+CLIP_CALIBS = {
+    "tiny": dict(dim=128, heads=2, layers=12, img=112, select_layer=-2, batch=2, seed=41, clip_resize_list=[(112, 112), (70, 98)],
+                 taps=(0, 3, 6, 9, 11), stride=1, tap_stride=1),
+    # ONE full-size image: ViT-L/14 at 448 px, 1025 tokens, padded to (300, 448) -- image 3 of test_gpu_fullsize's batch
+    "vit_l_448": dict(dim=1024, heads=16, layers=24, img=448, select_layer=-2, batch=1, seed=43, clip_resize_list=[(300, 448)],
+                      taps=(0, 6, 12, 18, 23), stride=16, tap_stride=64, input=(8, "input.images_clip8", 8, 3)),
+}
+
+
+def clip_calib_inputs(c):
+    from oracle.clip import patch_key_mask
+    if "input" in c:
+        seed, key, n, pick = c["input"]
+        x = torch.from_numpy(synth.normal(seed, key, (n, 3, c["img"], c["img"])))[pick:pick + 1]
+    else:
+        x = torch.from_numpy(synth.normal(c["seed"], "input.images_clip", (c["batch"], 3, c["img"], c["img"])))
+    return x, patch_key_mask(x.shape[0], (c["img"], c["img"]), c["clip_resize_list"])
+
+
 def clip_weight_shapes(c):
     D, P = c["dim"], (c["img"] // 14) ** 2
     s = {"vision_model.embeddings.class_embedding": (D,),
@@ -337,6 +359,33 @@ SPLICES = {
     "r3": dict(rows=3, L=11, hidden=32, vocab=50, image_pos=[2, 0, 9], seed=101),   # placeholder mid-row, first and near the end
     "vit_mask": dict(rows=2, L=8, hidden=16, vocab=40, image_pos=[3, 5], seed=102, vit_mask=True, no_labels=True),
 }
+
+
+# --- [SEG] bookkeeping of walkgptForCausalLM.model_forward / evaluate (model/walkgpt.py:284-306, 406-447, 645-707) -----------------
+# rows of token ids with the image placeholder and [SEG] ids in them; `seg` an int or a list (the two forms of seg_token_idx, :284-292);
+# `offset`: image -> rows (training layout); `new`: the ids generate() appends per row (evaluate layout)
+SEGMASKS = {
+    "train_int": dict(mode="train", rows=4, L=14, seg=61, offset=[0, 2, 3, 4], seg_pos=[[3, 9], [13], [], [5, 6, 7]], seed=111),
+    "train_list": dict(mode="train", rows=3, L=12, seg=[61, 62], seg_token_num=2, offset=[0, 1, 3], seg_pos=[[4, 5], [2, 3, 9, 10], [6, 7]],
+                       seed=112),
+    "eval": dict(mode="eval", rows=3, L=10, seg=61, pad=[0, 3, 1], new=[[7, 61, 9, 61, 2], [61, 2], [8, 8, 2]], seed=113),
+}
+
+
+def segmask_inputs(c):
+    """input_ids [rows, L] int64 in [3, 60] with -200 at position 1 and the case's [SEG] ids placed (list form: ids alternate);
+    eval: rows right-padded with 0 (`pad` positions), as evaluate() strips them (:621-625)."""
+    rows, L = c["rows"], c["L"]
+    ids = (synth.uniform01(c["seed"], "input.ids", rows * L) * 57).astype(np.int64).reshape(rows, L) + 3
+    ids[:, 1] = -200
+    segs = c["seg"] if isinstance(c["seg"], list) else [c["seg"]]
+    for r, pos in enumerate(c.get("seg_pos", [[]] * rows)):
+        for j, q in enumerate(pos):
+            ids[r, q] = segs[j % len(segs)]
+    for r, n in enumerate(c.get("pad", [0] * rows)):
+        if n:
+            ids[r, L - n:] = 0
+    return torch.from_numpy(ids)
 
 
 def splice_inputs(c):

@@ -200,6 +200,49 @@ def make_clip(name):
                         emb=states[0].numpy())
 
 
+def make_clip_calib(name):
+    """The CLIP stand-in twice: fp32 with the full-precision synthetic weights, and bf16 the way the reference's callers run the
+    tower (`.bfloat16()` module, bf16 pixels; eager attention: fp32 softmax cast back, every layer output rounded to bf16).  The bf16
+    run is the calibration: how far the reference's OWN deployment precision sits from fp32, on the features and per layer."""
+    from transformers import CLIPVisionConfig, CLIPVisionModel
+    c = cases.CLIP_CALIBS[name]
+    cfg = CLIPVisionConfig(hidden_size=c["dim"], intermediate_size=4 * c["dim"], num_hidden_layers=c["layers"],
+                           num_attention_heads=c["heads"], image_size=c["img"], patch_size=14, hidden_act="quick_gelu")
+    cfg._attn_implementation = "eager"
+    model = CLIPVisionModel(cfg).eval()
+    vm = model.vision_model if hasattr(model, "vision_model") else model
+    w = cases.clip_weights(c)
+    vm.load_state_dict({k: (v if k.endswith("position_ids") else w["vision_model." + k].reshape(v.shape)) for k, v in vm.state_dict().items()},
+                       strict=True)
+    x, key_mask = cases.clip_calib_inputs(c)
+
+    def run(vm_, x_, dtype):
+        bias = ((1.0 - key_mask) * torch.finfo(dtype).min).to(dtype)[:, None, None, :]      # custom_clip.py:27-38
+        with torch.no_grad():
+            h = vm_.pre_layrnorm(vm_.embeddings(x_))
+            states = [h]
+            for layer in vm_.encoder.layers:
+                h = layer(h, attention_mask=bias)
+                h = h[0] if isinstance(h, tuple) else h
+                states.append(h)
+        return states
+
+    s32 = run(vm, x, torch.float32)
+    vm16 = vm.bfloat16()
+    s16 = run(vm16, x.bfloat16(), torch.bfloat16)
+    st, ts = c["stride"], c["tap_stride"]
+    out = {"sel": s32[c["select_layer"]][:, 1::st].numpy(), "pre": s32[-11][:, 1::st].numpy(),
+           "sel_bf16": s16[c["select_layer"]][:, 1::st].float().numpy(), "pre_bf16": s16[-11][:, 1::st].float().numpy()}
+    for t in c["taps"]:
+        out["h%d" % t] = s32[t][:, ::ts].numpy()
+        out["h%d_bf16" % t] = s16[t][:, ::ts].float().numpy()
+    np.savez_compressed(os.path.join(HERE, "clipcal_%s.npz" % name), **out)
+    e = lambda a, b: float((a.float() - b).norm() / b.norm())   # noqa: E731
+    print("   reference-bf16 vs fp32: sel %.4f pre %.4f; taps %s" % (
+        e(s16[c["select_layer"]], s32[c["select_layer"]]), e(s16[-11], s32[-11]),
+        " ".join("h%d %.4f" % (t, e(s16[t], s32[t])) for t in c["taps"])), flush=True)
+
+
 def make_metrics(name):
     """intersectionAndUnionGPU (utils/utils.py:192-204) and the mask losses (utils/utils_walkgpt.py:76-120)."""
     _, uw = _import_reference()
@@ -313,6 +356,142 @@ def make_splice(name):
     np.savez_compressed(os.path.join(HERE, "splice_%s.npz" % name), **save)
 
 
+def _load_ref_walkgpt():
+    """The reference's model/walkgpt.py, loaded outside its package.  Its imports of the LLaVA language model do not resolve here
+    (SURVEY.md 8c), so the two names it takes from there are placeholder classes in a synthetic package whose search path is the
+    reference's `model/` directory -- segment_anything and utils resolve to the reference's own files.  The placeholder
+    `LlavaLlamaForCausalLM.forward` / `.generate` hand back what the harness object carries (`_lm_output`, `_gen_outputs`): the
+    language model is outside the path; everything walkgpt.py itself does around it runs unmodified."""
+    import importlib
+    _import_reference()
+    if "_ref_model.walkgpt" in sys.modules:
+        return sys.modules["_ref_model.walkgpt"]
+
+    class LlavaLlamaModel:
+        pass
+
+    class LlavaLlamaForCausalLM:
+        def forward(self, **kw):
+            self._lm_calls.append(kw)
+            return self._lm_output
+
+        def generate(self, **kw):
+            self._gen_calls.append(kw)
+            return self._gen_outputs.pop(0)
+
+    pkg = types.ModuleType("_ref_model")
+    pkg.__path__ = [os.path.join(REF, "model")]
+    sys.modules["_ref_model"] = pkg
+    for name in ("llava_walkgpt", "llava_walkgpt.model", "llava_walkgpt.model.language_model"):
+        m = types.ModuleType("_ref_model." + name)
+        m.__path__ = []
+        sys.modules["_ref_model." + name] = m
+    stub = types.ModuleType("_ref_model.llava_walkgpt.model.language_model.llava_llama")
+    stub.LlavaLlamaForCausalLM, stub.LlavaLlamaModel = LlavaLlamaForCausalLM, LlavaLlamaModel
+    sys.modules[stub.__name__] = stub
+    saved = list(sys.path)
+    sys.path[:] = [REF] + [q for q in saved if os.path.abspath(q or ".") != ROOT]     # `from utils.utils_walkgpt import ...`
+    try:
+        mod = importlib.import_module("_ref_model.walkgpt")
+    finally:
+        sys.path[:] = saved
+    assert mod.__file__.startswith(REF)
+    return mod
+
+
+class _StopHere(Exception):
+    pass
+
+
+def _locals_of(exc, func_name):
+    tb = exc.__traceback__
+    while tb is not None:
+        if tb.tb_frame.f_code.co_name == func_name:
+            return tb.tb_frame.f_locals
+        tb = tb.tb_next
+    raise RuntimeError("frame %s not on the traceback" % func_name)
+
+
+def make_segmask(name):
+    """[SEG] bookkeeping of the reference's own walkgptForCausalLM.model_forward (walkgpt.py:284-306 mask, :406-447 gather and
+    per-image packing) and evaluate (:645-707), run from its source on a harness object: the language model and the vision modules
+    are stand-ins that return index-coded tensors (hidden[r, p, :] = 1000 r + p), so the rows `last_hidden_state[seg_token_mask]`
+    gathers say which positions the reference reads; the run is stopped at the first prompt-encoder call (model_forward) / at
+    get_visual_embs (evaluate) and the method's locals are read from the frame.  `.cuda()` is the identity here (no GPU)."""
+    ref = _load_ref_walkgpt()
+    c = cases.SEGMASKS[name]
+    ids = cases.segmask_inputs(c)
+    rows, L = ids.shape
+    Hh, g = 8, 4
+    cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+
+    def coded(n_rows, length):
+        r = torch.arange(n_rows)[:, None, None].float() * 1000.0
+        p = torch.arange(length)[None, :, None].float()
+        return (r + p).expand(n_rows, length, 256).contiguous()
+
+    def stop(*a, **k):
+        raise _StopHere()
+
+    obj = object.__new__(ref.walkgptForCausalLM)
+    obj.seg_token_idx = c["seg"]
+    obj.seg_token_num = c.get("seg_token_num", 1)
+    obj.image_feature_scale_num = 1
+    obj.config = types.SimpleNamespace()
+    obj._lm_calls, obj._gen_calls = [], []
+    ident = lambda t: t   # noqa: E731   text_hidden_fcs[0]: the coded states pass through
+    obj.model = types.SimpleNamespace(
+        text_hidden_fcs=[ident], out_mm_projector=lambda t: torch.zeros(t.shape[0], 36, Hh), mm_projector=None,
+        tiny_xattn=_load(ref.TinyCrossAttn(d=256), c["seed"], "tiny_xattn."),
+        visual_model=types.SimpleNamespace(prompt_encoder=stop, image_encoder=lambda x: torch.zeros(x.shape[0], 256, g, g)))
+    obj.get_visual_embs = (lambda x: torch.zeros(x.shape[0], 256, g, g)) if c["mode"] == "train" else stop
+    out = {}
+    try:
+        if c["mode"] == "train":
+            B = len(c["offset"]) - 1
+            obj._lm_output = types.SimpleNamespace(hidden_states=[coded(rows, L + 255)], image_features=[torch.zeros(rows, 36, Hh)],
+                                                   logits=None, loss=torch.zeros(()))
+            try:
+                with torch.no_grad():
+                    ref.walkgptForCausalLM.model_forward(
+                        obj, images=torch.zeros(B, 3, 8, 8), images_clip=torch.zeros(B, 3, 8, 8), input_ids=ids, labels=ids,
+                        attention_masks=torch.ones_like(ids).bool(), offset=torch.tensor(c["offset"]), masks_list=[], label_list=[],
+                        resize_list=[(8, 8)] * B, inference=False, clip_resize_list=[(8, 8)] * B)
+                raise RuntimeError("model_forward returned: the harness should have stopped it at the prompt encoder")
+            except _StopHere as e:
+                loc = _locals_of(e, "model_forward")
+        else:
+            new = c["new"]
+            outs = []
+            for r in range(rows):
+                row = ids[r]
+                row = row[: int(torch.where(row == 0)[0].min())] if bool((row == 0).any()) else row
+                seq = torch.cat([row, torch.tensor(new[r])])[None]
+                outs.append(types.SimpleNamespace(sequences=seq, hidden_states=[None, coded(1, seq.shape[1] - 1 + 255) + 1000.0 * r]))
+            obj._gen_outputs = outs
+            try:
+                with torch.no_grad():
+                    ref.walkgptForCausalLM.evaluate(obj, torch.zeros(1, 3, 8, 8), torch.zeros(1, 3, 8, 8), ids, [(8, 8)], [(8, 8)], [(8, 8)],
+                                                    max_new_tokens=8)
+                raise RuntimeError("evaluate returned: the harness should have stopped it at get_visual_embs")
+            except _StopHere as e:
+                loc = _locals_of(e, "evaluate")
+            out["gen_input_ids_len"] = np.array([int(k["input_ids"].shape[1]) for k in obj._gen_calls])
+            out["output_ids_len"] = np.array([int(o.shape[1]) for o in loc["all_output_ids"]])
+    finally:
+        torch.Tensor.cuda = cuda
+    out["seg_token_mask"] = loc["seg_token_mask"].numpy()                      # model_forward: all rows; evaluate: the last row's
+    pe = loc["pred_embeddings"]
+    out["batch_seg_token_counts"] = np.array([int(v) for v in (loc["batch_seg_token_counts"][0].tolist()
+                                                               if c["mode"] == "eval" else loc["batch_seg_token_counts"])])
+    out["gathered"] = np.concatenate([p[:, 0].numpy() for p in pe]) if len(pe) else np.zeros(0, np.float32)   # 1000 row + position
+    out["gathered_split"] = np.array([p.shape[0] for p in pe])
+    np.savez_compressed(os.path.join(HERE, "segmask_%s.npz" % name), **out)
+    print("   %s: mask %s, counts %s, gathered %s" % (name, out["seg_token_mask"].shape, out["batch_seg_token_counts"].tolist(),
+                                                      out["gathered"].astype(int).tolist()), flush=True)
+
+
 def _load_ref_llava_module(name):
     """A module of the reference's model/llava_walkgpt/model/ directory, loaded outside its package (see make_splice)."""
     import importlib
@@ -400,6 +579,8 @@ ALL = {
     "decoder": (make_decoder, cases.DECODERS),
     "projectors": (make_projectors, cases.PROJECTORS),
     "clip": (make_clip, cases.CLIPS),
+    "clipcal": (make_clip_calib, cases.CLIP_CALIBS),
+    "segmask": (make_segmask, cases.SEGMASKS),
 }
 
 if __name__ == "__main__":

@@ -79,3 +79,13 @@ def test_sam_vit_h_full_geometry_batch_of_4(dev):
     e = rel_err(out4[2].float().cpu().numpy(), one[0].float().cpu().numpy())
     assert e < 0.02, e
     assert rel_err(out4[0].float().cpu().numpy(), out4[2].float().cpu().numpy()) > 0.1
+
+
+def test_clip_vit_l_448_calibrated_against_reference_bf16(dev):
+    """One full-size image (ViT-L/14 @ 448, padded to 300 x 448) against the stand-in's fp32 run, next to the stand-in's own bf16
+    run: features, hidden-state taps 0 / 6 / 12 / 18 / 23 and text logits (tests/golden/clipcal_vit_l_448.npz)."""
+    from tests.test_gpu_modules import clip_calibration
+    cal = clip_calibration(dev, "vit_l_448")
+    for k, (e_hip, e_ref16) in cal.items():
+        assert e_hip <= 1.03 * e_ref16, (k, e_hip, e_ref16)
+    assert cal["sel"][0] < 0.013 and cal["h0"][0] < 0.005

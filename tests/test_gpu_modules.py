@@ -199,44 +199,60 @@ def test_clip_tower_vs_standin_golden(dev):
     assert rel_err(pre[0].float().cpu().numpy(), gold["pre"]) < 0.03
 
 
-def test_text_logits_through_lm_head_vs_oracle(dev):
-    """north_star: text logits within 1e-4 abs.  SURVEY.md 8c plans it build-vs-build: the HIP CLIP tower's features and the oracle's
-    fp32 features go through the SAME projector and the SAME random-init language model (fp32, CPU), and the logits are compared.
-    The tower hands its features over in bf16 (the reference's callers do too: evaluation_walkgpt.py:908-910), so the floor of ANY
-    bf16-output tower is the oracle's own features rounded once to bf16; both numbers are printed next to the 1e-4 bar, which bf16
-    feature storage cannot reach (a single rounding of the features already moves the logits by ~1e-3)."""
+def clip_calibration(dev, name):
+    """The HIP tower against the stand-in's fp32 run, next to the stand-in's OWN bf16 run (tests/golden/clipcal_*.npz:
+    `.bfloat16()` module and pixels, the precision the reference's callers use, evaluation_walkgpt.py:227-231,908-910): selected
+    features, the -11 features, hidden-state taps, and text logits through a projector (llava_arch.py:97-104) + a small fp32 LM.
+    Returns {quantity: (error of the HIP tower, error of the reference's bf16 run)}, errors = relative L2 against fp32."""
     from types import SimpleNamespace
-    from oracle import clip as oclip
-    from tests.test_toplevel import TinyLM, H, V
-    c = cases.CLIPS["tiny"]
-    cfg = dict(hidden_size=c["dim"], intermediate_size=4 * c["dim"], num_hidden_layers=c["layers"],
-               num_attention_heads=c["heads"], image_size=c["img"], patch_size=14, layer_norm_eps=1e-5)
-    args = SimpleNamespace(mm_vision_select_layer=c["select_layer"], pad_train_clip_images=True,
-                           resize_vision_tower=True, resize_vision_tower_size=c["img"])
+    from tests.test_toplevel import TinyLM, H
+    c = cases.CLIP_CALIBS[name]
+    gold = cases.load("clipcal_" + name)
+    cfg = dict(hidden_size=c["dim"], intermediate_size=4 * c["dim"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+               image_size=c["img"], patch_size=14, layer_norm_eps=1e-5)
+    args = SimpleNamespace(mm_vision_select_layer=c["select_layer"], pad_train_clip_images=True, resize_vision_tower=True,
+                           resize_vision_tower_size=c["img"])
     tower = CLIPVisionTower("synthetic", args, config=cfg)
-    w = cases.clip_weights(c)
-    load_into(tower.vision_tower, w, "", dev)
-    x, key_mask = cases.clip_inputs(c)
+    load_into(tower.vision_tower, cases.clip_weights(c), "", dev)
+    x, km = cases.clip_calib_inputs(c)
+    st, ts = c["stride"], c["tap_stride"]
     with torch.no_grad():
-        sel, _ = tower(x.to(dev, torch.bfloat16), attention_mask=key_mask.to(dev))
-        ref = oclip.clip_tower(w, x.to(torch.bfloat16).float(), key_mask, c["select_layer"], heads=c["heads"], layers=c["layers"])[0]
-        g = torch.Generator().manual_seed(77)
-        proj = torch.randn(H, c["dim"], generator=g) / c["dim"] ** 0.5            # mm_projector (llava_arch.py:97-104): Linear(clip_dim, H)
-        lm = TinyLM()
+        hs = tower.vision_tower.vision_model.hidden_states(x.to(dev, torch.bfloat16), km.to(dev), [c["select_layer"], -11] + list(c["taps"]))
+    sel = hs[c["select_layer"]][:, 1::st].float().cpu().numpy()
+    pre = hs[-11][:, 1::st].float().cpu().numpy()
+    out = {"sel": (rel_err(sel, gold["sel"]), rel_err(gold["sel_bf16"], gold["sel"])),
+           "pre": (rel_err(pre, gold["pre"]), rel_err(gold["pre_bf16"], gold["pre"]))}
+    for t in c["taps"]:
+        out["h%d" % t] = (rel_err(hs[t][:, ::ts].float().cpu().numpy(), gold["h%d" % t]), rel_err(gold["h%d_bf16" % t], gold["h%d" % t]))
+    g = torch.Generator().manual_seed(77)
+    proj = torch.randn(H, c["dim"], generator=g) / c["dim"] ** 0.5
+    lm = TinyLM()
 
-        def logits(feats):
-            return lm(inputs_embeds=feats.float() @ proj.t(), output_hidden_states=True).logits
+    def logits(f):
+        with torch.no_grad():
+            return lm(inputs_embeds=torch.from_numpy(np.asarray(f)).float() @ proj.t(), output_hidden_states=True).logits
 
-        l_ref = logits(ref)
-        l_hip = logits(sel.float().cpu())
-        d_hip = float((l_hip - l_ref).abs().max())
-        d_floor = float((logits(ref.to(torch.bfloat16).float()) - l_ref).abs().max())
-        r_hip = float((l_hip - l_ref).norm() / l_ref.norm())
-    print("text logits (std %.3f): |HIP tower - fp32 oracle| max %.2e (rel L2 %.4f); oracle features rounded once to bf16: max %.2e; "
-          "north_star bar 1e-4" % (float(l_ref.std()), d_hip, r_hip, d_floor))
-    assert d_floor > 1e-4                 # the bar is below what one bf16 rounding of the features does
-    assert d_hip < 12 * d_floor, (d_hip, d_floor)   # 12 layers of bf16 residual-stream storage vs one rounding at the end
-    assert r_hip < 0.04, r_hip            # the tower's features are within 3 % (test_clip_tower_vs_standin_golden); the head keeps that scale
+    l32, lh, l16 = logits(gold["sel"]), logits(sel), logits(gold["sel_bf16"])
+    l1 = logits(torch.from_numpy(gold["sel"]).bfloat16().float().numpy())
+    out["logits"] = (float((lh - l32).norm() / l32.norm()), float((l16 - l32).norm() / l32.norm()))
+    out["logits_max_abs"] = (float((lh - l32).abs().max()), float((l16 - l32).abs().max()))
+    print("%s: text logits (std %.2f): max |HIP - fp32| %.3e, reference-bf16 %.3e, fp32 features rounded once to bf16 %.3e (north_star "
+          "bar 1e-4); rel L2 %.4f / %.4f; features: %s" % (name, float(l32.std()), out["logits_max_abs"][0], out["logits_max_abs"][1],
+                                                           float((l1 - l32).abs().max()), out["logits"][0], out["logits"][1],
+                                                           " ".join("%s %.4f/%.4f" % (k, *v) for k, v in out.items() if k[0] in "sph")))
+    return out
+
+
+def test_clip_tower_and_text_logits_calibrated_against_reference_bf16(dev):
+    """north_star asks for text logits within 1e-4 abs of the reference's fp32 CPU path.  A tower whose WEIGHTS are bf16 -- the
+    deployed checkpoint -- sits 0.4 % from fp32 after the patch embedding alone (tap h0) and 1 % at the selected layer, whoever runs
+    it: the reference's own bf16 run shows the same figures.  So the measurable statement is the calibrated one, asserted here at
+    every tap and on the logits: the HIP tower is at least as close to fp32 as the reference's bf16 run (3 % margin for the different
+    rounding points: fp32 accumulators and fused epilogues here, a rounding after every op there)."""
+    cal = clip_calibration(dev, "tiny")
+    for k, (e_hip, e_ref16) in cal.items():
+        assert e_hip <= 1.03 * e_ref16, (k, e_hip, e_ref16)
+    assert cal["sel"][0] < 0.012 and cal["logits"][0] < 0.015
 
 
 def test_grounding_pipeline_end_to_end_vs_oracle(dev):

@@ -97,6 +97,25 @@ def test_clip_blocks_match_transformers_standin():
     _close(pre[0].numpy(), gold["pre"], 5e-5)
 
 
+def test_clip_calibration_fixture_taps():
+    """The calibration fixture (fp32 run + the stand-in's own bf16 run + hidden-state taps): the oracle reproduces every fp32 tap, and
+    the bf16 run sits where its header says -- about 1 % from fp32 at the selected layer, 0.4 % right after the patch embedding (the
+    floor a bf16 checkpoint sets for ANY implementation; the HIP tower is held to these numbers in test_gpu_modules)."""
+    c = cases.CLIP_CALIBS["tiny"]
+    gold = cases.load("clipcal_tiny")
+    w = cases.clip_weights(c)
+    x, key_mask = cases.clip_calib_inputs(c)
+    with torch.no_grad():
+        hs = oclip.clip_hidden_states(w, x, key_mask, heads=c["heads"], layers=c["layers"])
+    for t in c["taps"]:
+        _close(hs[t].numpy(), gold["h%d" % t], 5e-5)
+    _close(hs[c["select_layer"]][:, 1:].numpy(), gold["sel"], 5e-5)
+    rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))   # noqa: E731
+    assert 0.002 < rel(gold["h0_bf16"], gold["h0"]) < 0.006 and 0.006 < rel(gold["sel_bf16"], gold["sel"]) < 0.015
+    big = cases.load("clipcal_vit_l_448")
+    assert big["sel"].shape == (1, 64, 1024) and 0.006 < rel(big["sel_bf16"], big["sel"]) < 0.015
+
+
 def test_clip_wrapper_quirks():
     # resize_position_table keeps the reference's row bookkeeping: last row carried over, rest interpolated
     t = torch.arange(17 * 4, dtype=torch.float32).reshape(17, 4)

@@ -35,6 +35,62 @@ def test_reference_import_lines_resolve():
         walkgptForCausalLM.from_pretrained("some/checkpoint")         # the language model is injected, never built here
 
 
+def _bare_adapter(**attrs):
+    """walkgptForCausalLM without its modules: the [SEG] bookkeeping helpers are plain torch and run on the CPU."""
+    from walkgpt_amd.causal_lm import walkgptForCausalLM
+    m = walkgptForCausalLM.__new__(walkgptForCausalLM)
+    nn.Module.__init__(m)
+    for k, v in {"seg_token_num": 1, "image_feature_scale_num": 1, **attrs}.items():
+        setattr(m, k, v)
+    return m
+
+
+@pytest.mark.parametrize("name", ["train_int", "train_list"])
+def test_seg_token_bookkeeping_vs_reference_model_forward(name):
+    """model/walkgpt.py:284-306 (mask), :406-447 (gather + per-image packing) -- against what the reference's OWN model_forward did on
+    these rows (tests/golden/make_golden.py:make_segmask runs it from its source on a harness with index-coded hidden states)."""
+    from oracle import splice as osplice
+    c = cases.SEGMASKS[name]
+    gold = cases.load("segmask_" + name)
+    ids = cases.segmask_inputs(c)
+    m = _bare_adapter(seg_token_idx=c["seg"], seg_token_num=c.get("seg_token_num", 1))
+    mask = m._seg_token_mask(ids, pad_right=True)
+    assert np.array_equal(mask.numpy(), gold["seg_token_mask"])
+    segs = c["seg"] if isinstance(c["seg"], list) else [c["seg"]]
+    assert np.array_equal(osplice.seg_token_mask(ids, segs).numpy(), gold["seg_token_mask"])
+    rows, L = ids.shape
+    coded = (torch.arange(rows)[:, None, None] * 1000.0 + torch.arange(L + 255)[None, :, None]).expand(rows, L + 255, 4)
+    gathered = coded[mask]                                            # what last_hidden_state[seg_token_mask] picks (:409)
+    blocks, counts = m._queries_per_image(gathered, mask.int().sum(-1), c["offset"], inference=False)
+    assert counts == gold["batch_seg_token_counts"].tolist() and [b.shape[0] for b in blocks] == gold["gathered_split"].tolist()
+    assert np.array_equal(torch.cat(blocks)[:, 0].numpy(), gold["gathered"])
+
+
+def test_seg_token_bookkeeping_vs_reference_evaluate():
+    """model/walkgpt.py:621-625 (padding strip), :645-659 (mask without the right pad), :661-707 (per-row packing) against the reference's
+    own evaluate() on a harness whose generate() appends the case's ids."""
+    c = cases.SEGMASKS["eval"]
+    gold = cases.load("segmask_eval")
+    ids = cases.segmask_inputs(c)
+    m = _bare_adapter(seg_token_idx=c["seg"])
+    picked, counts, lens = [], [], []
+    for r in range(ids.shape[0]):
+        row = ids[r]
+        if bool((row == 0).any()):
+            row = row[: int(torch.where(row == 0)[0].min())]
+        lens.append(int(row.shape[0]))
+        out_ids = torch.cat([row, torch.tensor(c["new"][r])])[None]
+        mask = m._seg_token_mask(out_ids, pad_right=False)
+        coded = (1000.0 * r + torch.arange(out_ids.shape[1] - 1 + 255)[None, :, None]).expand(1, -1, 4)
+        e = m._pack_queries(coded[mask])
+        picked.append(e[:, 0])
+        counts.append(e.shape[0])
+    assert lens == gold["gen_input_ids_len"].tolist()                 # what the reference handed to generate() after the strip
+    assert np.array_equal(mask.numpy(), gold["seg_token_mask"])       # the last row's, as in the reference's frame
+    assert counts == gold["batch_seg_token_counts"].tolist()
+    assert np.array_equal(torch.cat(picked).numpy(), gold["gathered"])
+
+
 class TinyLM(nn.Module):
     """Stand-in for the injected causal LM (transformers protocol): two causal self-attention layers; `script` adds a large bias
     towards a fixed token at every position so that greedy decoding is reproducible across precisions."""

@@ -302,6 +302,18 @@ class walkgptForCausalLM(nn.Module):  # noqa: N801  (the reference's class name)
         Q, D = total // (n * f), batch_pred_embeddings.shape[-1]
         return batch_pred_embeddings.view(Q, f, n, D)[:, -1].reshape(Q * n, D)
 
+    def _queries_per_image(self, pred_embeddings, seg_token_counts, off, inference):
+        """walkgpt.py:413-447: the gathered [SEG] rows (row-major over the text rows) -> one block per image (`off`: image -> rows;
+        inference: every row belongs to the one image), each packed by _pack_queries.  Returns (blocks, batch_seg_token_counts)."""
+        seg_token_offset = torch.cat([seg_token_counts.new_zeros(1), seg_token_counts.cumsum(-1)], 0)
+        seg_off = [0, int(seg_token_offset[-1])] if inference else [int(seg_token_offset[o]) for o in off]
+        blocks, counts = [], []
+        for i in range(len(seg_off) - 1):
+            e = self._pack_queries(pred_embeddings[seg_off[i]:seg_off[i + 1]])
+            blocks.append(e)
+            counts.append(e.shape[0])
+        return blocks, counts
+
     def _embed_table(self):
         w = self.llm.get_input_embeddings().weight
         if w.dtype != BF16:
@@ -378,16 +390,7 @@ class walkgptForCausalLM(nn.Module):  # noqa: N801  (the reference's class name)
         pred_embeddings = self.model.text_hidden_fcs[0](seg_hidden.to(BF16)) if seg_hidden.shape[0] else seg_hidden.new_zeros(0, 256, dtype=BF16)
         pred_embeddings_nce = pred_embeddings
         seg_token_counts = seg_token_mask.int().sum(-1)
-        seg_token_offset = torch.cat([seg_token_counts.new_zeros(1), seg_token_counts.cumsum(-1)], 0)
-        if inference:
-            seg_off = [0, int(seg_token_offset[-1])]
-        else:
-            seg_off = [int(seg_token_offset[o]) for o in off]
-        pred_list, batch_seg_token_counts = [], []
-        for i in range(len(seg_off) - 1):
-            e = self._pack_queries(pred_embeddings[seg_off[i]:seg_off[i + 1]])
-            pred_list.append(e)
-            batch_seg_token_counts.append(e.shape[0])
+        pred_list, batch_seg_token_counts = self._queries_per_image(pred_embeddings, seg_token_counts, off, inference)
         # region-alignment InfoNCE (:449-473)
         seg_row_ids = torch.repeat_interleave(torch.arange(sam_tokens_256.size(0), device=images.device), seg_token_counts)
         loss_nce = torch.zeros((), device=images.device)

@@ -1046,14 +1046,16 @@ static int launch_persist(GemmArgs& g, hipStream_t st) {
 }
 
 // STATS instances: spart[256 rows][4 column waves][2] -> {sum, sum of squares} of row `row_off + r` over the tile's 256 columns.
-// Every wave issues exactly one store instruction (odd lanes' stores fall outside the descriptor and are dropped): the tile loop's
+// Every wave issues exactly one store instruction (those of waves 4-7 fall outside the descriptor and are dropped): the tile loop's
 // counted waits rely on a fixed number of memory operations per wave.
+// (A thread per row, no cross-lane step: the pairwise form -- two lanes per row joined by `x + dpp(x)` on both sums -- came out of this
+// hipcc with ONE v_mov_b32_dpp feeding both halves of a v_pk_add_f32 (op_sel_hi:[1,0]), i.e. sum-of-squares + the partner's SUM.)
 __device__ __forceinline__ void wg_stats_combine(const float* spart, int tid, float* out, long rows_total, int row_off) {
-    const f32x4 a = *(const f32x4*)(spart + (tid >> 1) * 8 + (tid & 1) * 4);    // {s0,q0,s1,q1} | {s2,q2,s3,q3} of row tid / 2
-    const f32x2 r2 = {a[0] + a[2], a[1] + a[3]};
-    const f32x2 o2 = {r2.x + WG_DPP(r2.x, 0xB1), r2.y + WG_DPP(r2.y, 0xB1)};    // + the partner lane's two waves
+    const int r = tid & 255;
+    const f32x4 a = *(const f32x4*)(spart + r * 8), b = *(const f32x4*)(spart + r * 8 + 4);    // {s0,q0,s1,q1}, {s2,q2,s3,q3} of row r
+    const f32x2 o2 = {(a[0] + a[2]) + (b[0] + b[2]), (a[1] + a[3]) + (b[1] + b[3])};
     const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)out, 0, (unsigned)(rows_total * 8), WG_RSRC_FLAGS);
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), srs, (tid & 1) ? (int)0x80000000 : (row_off + (tid >> 1)) * 8, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), srs, tid >= 256 ? (int)0x80000000 : (row_off + r) * 8, 0, 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1381,16 +1383,20 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                     // row sums of what is about to be stored (taken here, while the residual registers are free): lane el holds 8
                     // consecutive columns of row it * 8 + el / 8 of this 64-row slab, the 8 lanes el % 8 share a row.  Partial of this
                     // wave's 64 columns -> spart[row][wn] = {sum, sum of squares}.
-                    const bf16x2 ones = __builtin_bit_cast(bf16x2, 0x3F803F80u);
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
-                        float sv = 0.f, qv = 0.f;
+                        // (plain fp32 arithmetic on the unpacked pairs: v_dot2c_f32_bf16 would halve the count, but through the builtin
+                        // this hipcc reads dword 0 of the vector for every k, and as inline asm the DPP steps below would follow it
+                        // without the wait states the compiler only inserts behind instructions it can see)
+                        f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const bf16x2 v2 = __builtin_bit_cast(bf16x2, t[it][k]);
-                            sv = __builtin_amdgcn_fdot2_f32_bf16(v2, ones, sv, false);
-                            qv = __builtin_amdgcn_fdot2_f32_bf16(v2, v2, qv, false);
+                            const unsigned pr = t[it][k];
+                            const f32x2 v2 = {__builtin_bit_cast(float, pr << 16), __builtin_bit_cast(float, pr & 0xFFFF0000u)};
+                            s2 += v2;
+                            q2 += v2 * v2;
                         }
+                        float sv = s2.x + s2.y, qv = q2.x + q2.y;
                         sv += WG_DPP(sv, 0xB1); qv += WG_DPP(qv, 0xB1);      // quad_perm [1,0,3,2]
                         sv += WG_DPP(sv, 0x4E); qv += WG_DPP(qv, 0x4E);      // quad_perm [2,3,0,1]
                         sv += WG_DPP(sv, 0x141); qv += WG_DPP(qv, 0x141);    // row_half_mirror: the other quad of the 8 lanes
