@@ -50,6 +50,8 @@ int wg_gemm_pick_tile(int M, int N);
 /* same, optionally allowing tile 12 = 128x128 tiles whose last row tile absorbs M % 128 <= 16 leftover rows (CLIP's
  * M = B*1025): faster when GEMMs run back to back on one stream, slower when two streams share the chip. */
 int wg_gemm_pick_tile_ex(int M, int N, int allow_tail);
+/* the same with K in view: the kernel id wg_gemm_bias_act_bf16 really launches (the skinny kernel 5 needs K % 128 == 0, else tile 1) */
+int wg_gemm_pick_tile_mnk(int M, int N, int K, int allow_tail);
 int wg_gemm_bias_act_bf16(const void* A, long lda, const void* W, long ldw, const void* bias, const void* residual,
                           long ldr, int res_row_mod, void* C, long ldc, int M, int N, int K, int act, int out_f32,
                           int tile_hint, void* stream);

@@ -361,6 +361,41 @@ SPLICES = {
 }
 
 
+# --- end to end, confident masks: image -> SAM encoder -> (LLM states ->) CTP -> prompt encoder -> mask decoder -> postprocess ----------
+# The image is a few flat-coloured regions (+ a little noise), as a photograph of a few objects is; the decoder's transposed
+# convolutions are coherent across sub-pixels and weights / inputs are bf16-representable (as in DECODERS["conf_g64"]).  Image and
+# decoder seeds were searched with the oracle for margin: in the reference's fp32 run the logits of `conf_tiny` are farther than 2 % of
+# their rms from zero on all but 0.13 % of the pixels, so thresholded masks say something about arithmetic rather than about coin flips.
+E2ES = {
+    "conf_tiny": dict(enc="tiny", img_seed=166, dec_seed=50, regions=5, amp=3.0, noise=0.02, proj="h64", tokens=3, hidden_seed=8,
+                      resize=(512, 512), original=(224, 224)),
+}
+
+
+def e2e_inputs(c):
+    """(image [1,3,S,S] bf16-representable fp32, LLM hidden states at the [SEG]-1 positions [T, H] bf16-representable)."""
+    e = SAM_ENCODERS[c["enc"]]
+    S, R = e["img"], c["regions"]
+    u = synth.uniform01(c["img_seed"], "input.region_sites", 2 * R).reshape(R, 2) * S
+    yy, xx = np.mgrid[0:S, 0:S]
+    d = (yy[None] + 0.5 - u[:, 0, None, None]) ** 2 + (xx[None] + 0.5 - u[:, 1, None, None]) ** 2
+    region = torch.from_numpy(d.argmin(0))
+    vals = torch.from_numpy(synth.normal(c["img_seed"], "input.region_values", (R, 3))) * c["amp"]
+    x = vals[region].permute(2, 0, 1)[None].contiguous()
+    x = x + c["noise"] * torch.from_numpy(synth.normal(c["img_seed"], "input.images", (1, 3, S, S)))
+    hid = torch.from_numpy(synth.normal(c["hidden_seed"], "input.seg_hidden", (c["tokens"], PROJECTORS[c["proj"]]["llama_dim"])))
+    return _bf16_round(x), _bf16_round(hid)
+
+
+def e2e_weights(c):
+    """(encoder, decoder (conf style), CTP) weights, bf16-representable -- the deployed checkpoint is bf16."""
+    w_enc = {k: _bf16_round(v) for k, v in sam_encoder_weights(SAM_ENCODERS[c["enc"]]).items()}
+    w_dec = decoder_case_weights(dict(seed=c["dec_seed"], coherent_upscaler=True, bf16_weights=True))
+    pc = PROJECTORS[c["proj"]]    # (the CTP half of projector_weights: the MSQP half is 105 M values nobody needs here)
+    wt = {k: torch.from_numpy(synth.param(pc["seed"], "text_hidden_fcs.0." + k, sh)) for k, sh in ctp_weight_shapes(pc["llama_dim"]).items()}
+    return w_enc, w_dec, {k: _bf16_round(v) for k, v in wt.items()}
+
+
 # --- [SEG] bookkeeping of walkgptForCausalLM.model_forward / evaluate (model/walkgpt.py:284-306, 406-447, 645-707) -----------------
 # rows of token ids with the image placeholder and [SEG] ids in them; `seg` an int or a list (the two forms of seg_token_idx, :284-292);
 # `offset`: image -> rows (training layout); `new`: the ids generate() appends per row (evaluate layout)

@@ -12,6 +12,7 @@ expects (its own wrapper no longer imports); see oracle/clip.py for what that do
 import os
 import sys
 import types
+from functools import partial
 
 import numpy as np
 import torch
@@ -152,6 +153,61 @@ def make_decoder(name):
         name, float(np.linalg.norm(masks16.float().numpy() - masks.numpy()) / np.linalg.norm(masks.numpy())),
         (a & b).sum() / max(1, (a | b).sum()), a.mean()))
     np.savez_compressed(os.path.join(HERE, "decoder_%s.npz" % name), **out)
+
+
+def make_e2e(name):
+    """The whole grounding path of the reference's own modules on one image: ImageEncoderViT -> CalibratedTextProjector on the [SEG]
+    states -> PromptEncoder (text branch) -> MaskDecoder -> Sam.postprocess_masks, the wiring of evaluate() (walkgpt.py:713-737) --
+    in fp32 and with every module cast to bf16 (what the reference's callers run)."""
+    sam_modeling, uw = _import_reference()
+    c = cases.E2ES[name]
+    e = cases.SAM_ENCODERS[c["enc"]]
+    g = e["img"] // e["patch"]
+    w_enc, w_dec, w_ctp = cases.e2e_weights(c)
+    x, hid = cases.e2e_inputs(c)
+
+    def build():
+        enc = sam_modeling.ImageEncoderViT(
+            depth=e["depth"], embed_dim=e["embed_dim"], img_size=e["img"], mlp_ratio=4, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+            num_heads=e["heads"], patch_size=e["patch"], qkv_bias=True, use_rel_pos=True, global_attn_indexes=list(e["global_idx"]),
+            window_size=e["window"], out_chans=e["out"])
+        pe = sam_modeling.PromptEncoder(embed_dim=256, image_embedding_size=(g, g), input_image_size=(e["img"], e["img"]), mask_in_chans=16)
+        dec = sam_modeling.MaskDecoder(num_multimask_outputs=3, transformer=sam_modeling.TwoWayTransformer(
+            depth=2, embedding_dim=256, mlp_dim=2048, num_heads=8), transformer_dim=256, iou_head_depth=3, iou_head_hidden_dim=256)
+        ctp = uw.CalibratedTextProjector(in_dim=hid.shape[-1], out_dim=256, widen=2, use_residual=False)
+        enc.load_state_dict({k[len("image_encoder."):]: v for k, v in w_enc.items()}, strict=True)
+        for mod, prefix in ((pe, "prompt_encoder."), (dec, "mask_decoder.")):
+            mod.load_state_dict({k: (w_dec[prefix + k] if prefix + k in w_dec else torch.from_numpy(synth.param(c["dec_seed"], prefix + k, tuple(v.shape))))
+                                 for k, v in mod.state_dict().items()}, strict=True)
+        ctp.load_state_dict(w_ctp, strict=True)
+        return [m.eval() for m in (enc, pe, dec, ctp)]
+
+    holder = types.SimpleNamespace(image_encoder=types.SimpleNamespace(img_size=e["img"]))
+
+    def run(mods, dtype):
+        enc, pe, dec, ctp = mods
+        with torch.no_grad():
+            emb = enc(x.to(dtype))
+            pred = ctp(hid.to(dtype)[None])[0]                                        # [T, 256]  (walkgpt.py:664)
+            sparse, dense = pe(points=None, boxes=None, masks=None, text_embeds=pred.unsqueeze(1))
+            sparse = sparse.to(pred.dtype)                                             # :726
+            masks, iou = dec(image_embeddings=emb[0].unsqueeze(0), image_pe=pe.get_dense_pe(), sparse_prompt_embeddings=sparse,
+                             dense_prompt_embeddings=dense, multimask_output=False)
+            post = sam_modeling.Sam.postprocess_masks(holder, masks, input_size=c["resize"], original_size=c["original"])
+        return emb.float(), pred.float(), masks.float(), post.float()[:, 0]
+
+    emb, pred, masks, post = run(build(), torch.float32)
+    m16 = build()
+    for m in m16:
+        m.bfloat16()
+    emb16, pred16, masks16, post16 = run(m16, torch.bfloat16)
+    a, b = post.numpy() > 0, post16.numpy() > 0
+    rms = float(post.pow(2).mean().sqrt())
+    print("  %s: logits rms %.3f, |logit| < 2%% rms on %.5f of the pixels, positive %s; reference bf16 vs fp32: embedding %.4f, masks %.4f, pixel IoU %.5f"
+          % (name, rms, float((post.abs() < 0.02 * rms).float().mean()), np.round(a.mean(axis=(1, 2)), 3),
+             float((emb16 - emb).norm() / emb.norm()), float((masks16 - masks).norm() / masks.norm()), (a & b).sum() / max(1, (a | b).sum())))
+    np.savez_compressed(os.path.join(HERE, "e2e_%s.npz" % name), emb=cases.tap_embedding(emb).numpy(), pred=pred.numpy(), masks=masks.numpy(),
+                        post=post.numpy(), emb_bf16=cases.tap_embedding(emb16).numpy(), masks_bf16=masks16.numpy(), post_bf16=post16.numpy())
 
 
 def make_projectors(name):
@@ -581,6 +637,7 @@ ALL = {
     "clip": (make_clip, cases.CLIPS),
     "clipcal": (make_clip_calib, cases.CLIP_CALIBS),
     "segmask": (make_segmask, cases.SEGMASKS),
+    "e2e": (make_e2e, cases.E2ES),
 }
 
 if __name__ == "__main__":

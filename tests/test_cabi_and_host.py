@@ -157,3 +157,36 @@ def test_clip_tower_resizes_a_stock_position_table_on_load():
     tower.vision_tower.load_state_dict(sd, strict=True)
     got = tower.vision_tower.vision_model.embeddings.position_embedding.weight.detach().numpy()
     assert np.allclose(got, gold["table"], atol=1e-6)
+
+
+def test_tile_selector_sees_k():
+    """The kernel id host-side accounting reports is the one the library launches: M <= 16 rows take the skinny kernel (5) only when
+    K % 128 == 0; K = 192 passes the MFMA path's K % 64 rule and runs on the 128x128 tiles (1)."""
+    from walkgpt_amd import _lib, ops
+    L = _lib.lib()
+    assert L.wg_gemm_pick_tile_ex(8, 256, 0) == 5
+    assert L.wg_gemm_pick_tile_mnk(8, 256, 256, 0) == 5 and L.wg_gemm_pick_tile_mnk(8, 256, 192, 0) == 1
+    assert L.wg_gemm_pick_tile_mnk(32768, 768, 768, 0) == L.wg_gemm_pick_tile_ex(32768, 768, 0) == 16
+    assert ops.gemm_tile_for(8, 256, 192, 192, 192, 256, 0) == 1 and ops.gemm_tile_for(8, 256, 256, 256, 256, 256, 0) == 5
+
+
+@pytest.mark.parametrize("name", ["w56", "w448"])
+def test_loaded_position_table_is_resized_once_in_fp32(name):
+    """A checkpoint that still carries the stock position table is resized on its way into the tower with the reference's arithmetic
+    (clip_encoder.py:38-55: rows [:-1] taken as the grid, last row carried over, fp32 bilinear, ONE cast) -- the same table whatever
+    device the tensor sits on, equal to what the reference's own load_model produced (tests/golden/clipwrap_*.npz)."""
+    from types import SimpleNamespace
+    from tests.golden import cases
+    from walkgpt_amd.clip_encoder import CLIPVisionTower
+    c = cases.CLIPWRAPS[name]
+    gold = cases.load("clipwrap_" + name)
+    cfg = dict(hidden_size=c["dim"], intermediate_size=16, num_hidden_layers=1, num_attention_heads=1, image_size=c["old_side"] * 14,
+               patch_size=14, layer_norm_eps=1e-5)
+    args = SimpleNamespace(mm_vision_select_layer=-1, pad_train_clip_images=True, resize_vision_tower=True,
+                           resize_vision_tower_size=c["new_side"] * 14)
+    tower = CLIPVisionTower("synthetic", args, config=cfg)
+    sd = {k: v.clone() for k, v in tower.vision_tower.state_dict().items()}
+    sd["vision_model.embeddings.position_embedding.weight"] = cases.clipwrap_table(c)          # the stock-size table
+    tower.vision_tower.load_state_dict(sd, strict=True)
+    got = tower.vision_tower.vision_model.embeddings.position_embedding.weight
+    assert got.shape == (c["new_side"] ** 2 + 1, c["dim"]) and np.array_equal(got.detach().numpy(), gold["table"])

@@ -397,3 +397,105 @@ def test_decoder_multimask_branch_vs_oracle(dev):
     assert rel_err(i3.cpu().numpy(), oi3.numpy()) < 0.02
     # the three masks are not the single-mask output shifted by one: mask 0 is a different token
     assert rel_err(m3[:, :1].cpu().numpy(), m1.cpu().numpy()) > 0.05
+
+
+def _e2e_model(c, dev):
+    e = cases.SAM_ENCODERS[c["enc"]]
+    pc = cases.PROJECTORS[c["proj"]]
+    model = WalkGPTGrounding(sam=dict(embed_dim=e["embed_dim"], depth=e["depth"], heads=e["heads"], global_idx=e["global_idx"], img=e["img"]),
+                             llm_hidden=pc["llama_dim"], with_clip=False)
+    w_enc, w_dec, w_ctp = cases.e2e_weights(c)
+    load_into(model.visual_model.image_encoder, w_enc, "image_encoder.", dev)
+    load_into(model.visual_model.prompt_encoder, w_dec, "prompt_encoder.", dev, strict=False)
+    load_into(model.visual_model.mask_decoder, w_dec, "mask_decoder.", dev)
+    load_into(model.text_hidden_fcs[0], {"x." + k: v for k, v in w_ctp.items()}, "x.", dev)
+    model.to(dev).bfloat16()                 # (the MSQP of this model keeps its default init: it runs, its tokens are not looked at)
+    model.visual_model.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix.data = \
+        w_dec["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].to(dev)
+    return model
+
+
+def _iou_vs_band_gt(post, ref_post, dev):
+    """IoU of `post` and of the reference's masks against ONE ground truth: the reference's mask with a band of rows flipped."""
+    ref_post = torch.as_tensor(ref_post).to(dev)
+    gt = (ref_post > 0).float()
+    h = gt.shape[1]
+    gt[:, h // 3: h // 3 + h // 8, :] = 1.0 - gt[:, h // 3: h // 3 + h // 8, :]
+    i_h, u_h, _ = ops.mask_iou(post.float().contiguous(), gt.contiguous())
+    i_r, u_r, _ = ops.mask_iou(ref_post.contiguous(), gt.contiguous())
+    return (i_h[:, 1] / u_h[:, 1]).cpu().numpy(), (i_r[:, 1] / u_r[:, 1]).cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["conf_tiny"])
+def test_end_to_end_confident_masks_vs_reference(dev, name):
+    """north_star's mask bar -- within 1e-3 mIoU of the reference's PyTorch CPU path -- END TO END: image -> SAM encoder -> CTP on the
+    [SEG] states -> prompt encoder -> mask decoder -> postprocess through WalkGPTGrounding.forward, against the reference's own modules
+    run in fp32 on the same image (tests/golden/e2e_*.npz; its bf16 run alongside as the calibration).  Then the same case with the
+    encoder's GEMMs on fp8 operands (BASELINE config C5): its measured distance, with the bound it is held to."""
+    c = cases.E2ES[name]
+    gold = cases.load("e2e_" + name)
+    model = _e2e_model(c, dev)
+    x, hid = cases.e2e_inputs(c)
+    xd, hd = x.to(dev, torch.bfloat16), hid.to(dev, torch.bfloat16)
+    res = {}
+    for dt in ("bf16", "fp8"):
+        model.set_gemm_dtype(dt)
+        with torch.no_grad():
+            out = model(xd, None, [hd], [c["resize"]], [c["original"]])
+            emb = model.get_visual_embs(xd)
+        post = out["pred_masks"][0]
+        assert post.shape == gold["post"].shape
+        iou_h, iou_r = _iou_vs_band_gt(post, gold["post"], dev)
+        res[dt] = dict(emb=rel_err(cases.tap_embedding(emb.float().cpu()).numpy(), gold["emb"]), post=rel_err(post.cpu().numpy(), gold["post"]),
+                       pix=pixel_iou(post.cpu().numpy(), gold["post"]), d_iou=float(np.abs(iou_h - iou_r).max()),
+                       d_miou=float(abs(iou_h.mean() - iou_r.mean())))
+    model.set_gemm_dtype("bf16")
+    ref16 = dict(emb=rel_err(gold["emb_bf16"], gold["emb"]), post=rel_err(gold["post_bf16"], gold["post"]),
+                 pix=pixel_iou(gold["post_bf16"], gold["post"]))
+    print("e2e %s: embedding rel err HIP %.4f / fp8 %.4f (reference bf16 run %.4f); mask logits %.4f / %.4f (%.4f); pixel IoU vs reference %.5f / %.5f "
+          "(%.5f); |IoU vs GT - reference's| max %.5f / %.5f, mean %.5f / %.5f"
+          % (name, res["bf16"]["emb"], res["fp8"]["emb"], ref16["emb"], res["bf16"]["post"], res["fp8"]["post"], ref16["post"],
+             res["bf16"]["pix"], res["fp8"]["pix"], ref16["pix"], res["bf16"]["d_iou"], res["fp8"]["d_iou"], res["bf16"]["d_miou"], res["fp8"]["d_miou"]))
+    b = res["bf16"]
+    assert b["emb"] <= ref16["emb"] and b["post"] <= ref16["post"], (b, ref16)            # never further from fp32 than the reference's bf16 run
+    assert b["pix"] >= ref16["pix"] - 2e-4 and b["pix"] >= 1.0 - 1e-3, (b["pix"], ref16["pix"])
+    assert b["d_iou"] <= 1e-3 and b["d_miou"] <= 1e-3, b                                    # north_star: 1e-3 mIoU
+    f = res["fp8"]
+    assert f["pix"] >= 0.997 and f["d_iou"] <= 1e-3 and f["d_miou"] <= 5e-4, f              # config C5's operand type, end to end (measured:
+    #                                                         pixel IoU 0.99810, |IoU - reference's| <= 2.8e-4 per mask, 1.2e-4 on average)
+
+
+def test_decoder_takes_geometries_the_fused_kernels_do_not(dev):
+    """The reference's MaskDecoder accepts any number of sparse prompt tokens (mask_decoder.py:125-132) and TwoWayTransformer.forward is a
+    public entry (transformer.py:62-106); the fused token kernels are built for 5 + 1 tokens.  Other geometries run op by op
+    (MaskDecoder._predict_masks_general, TwoWayTransformer.run_general): two prompt tokens per query here, against the oracle."""
+    from oracle import sam as osam
+    c = cases.DECODERS["g32"]
+    g = c["grid"]
+    sam = M._build_sam(128, 1, 2, [0], image_size=g * 16)
+    w = cases.decoder_case_weights(c)
+    load_into(sam.prompt_encoder, w, "prompt_encoder.", dev, strict=False)
+    load_into(sam.mask_decoder, w, "mask_decoder.", dev)
+    sam.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix.data = w["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].to(dev)
+    sam.to(dev)
+    emb, text = cases.decoder_inputs(c)                                   # [1,256,g,g], [3,1,256]
+    two = torch.cat([text, text.flip(0) * 0.5], 1).to(torch.bfloat16).float()   # [3, 2, 256]: two prompt tokens per query
+    embq = emb.to(torch.bfloat16).float()
+    with torch.no_grad():
+        dpe = sam.prompt_encoder.get_dense_pe()
+        dense = sam.prompt_encoder.no_mask_embed.weight.reshape(1, -1, 1, 1).expand(3, -1, g, g)
+        assert not sam.mask_decoder.transformer.fused_ok(5, 2) and sam.mask_decoder.transformer.fused_ok(5, 1)
+        masks, iou = sam.mask_decoder(image_embeddings=embq.to(dev, torch.bfloat16), image_pe=dpe, sparse_prompt_embeddings=two.to(dev, torch.bfloat16),
+                                      dense_prompt_embeddings=dense, multimask_output=True)
+        wq = {k: v.float() for k, v in w.items()}
+        rdpe = osam.dense_pe(wq, (g, g))
+        rsp, rdense = osam.prompt_encoder_text(wq, two[:, :1], (g, g))
+        rm, ri = osam.mask_decoder(wq, embq, rdpe, two, rdense, multimask_output=True)
+        # the public transformer entry on its own
+        toks = torch.randn(2, 7, 256, generator=torch.Generator().manual_seed(1)).to(dev, torch.bfloat16)
+        q, k = sam.mask_decoder.transformer(embq.to(dev, torch.bfloat16).expand(2, -1, -1, -1), dpe.expand(2, -1, -1, -1), toks)
+        rq, rk = osam.two_way_transformer(wq, "mask_decoder.transformer", embq.expand(2, -1, -1, -1), rdpe.expand(2, -1, -1, -1), toks.float().cpu())
+    assert masks.shape == (3, 3, 4 * g, 4 * g) and iou.shape == (3, 3)
+    assert rel_err(masks.cpu().numpy(), rm.numpy()) < 0.03 and rel_err(iou.cpu().numpy(), ri.numpy()) < 0.03
+    assert q.shape == (2, 7, 256) and k.shape == (2, g * g, 256)
+    assert rel_err(q.float().cpu().numpy(), rq.numpy()) < 0.03 and rel_err(k.float().cpu().numpy(), rk.numpy()) < 0.03

@@ -397,3 +397,55 @@ def test_c1_shapes_through_from_pretrained(dev):
                                                          max_new_tokens=4)
     assert out_ids[0].shape[0] == 1 and L < out_ids[0].shape[1] <= L + 4 and out_ids[0][0, :L].cpu().equal(ids[0])
     assert pred_masks[0].shape[1:] == orig and pred_masks[0].shape[0] == int(counts[0][0]) and torch.isfinite(pred_masks[0]).all()
+
+
+class PresetLM(nn.Module):
+    """A language model whose last-layer states are given: what model_forward reads at the [SEG]-1 positions is under the test's control."""
+
+    def __init__(self, vocab, hidden):
+        super().__init__()
+        self.embed = nn.Embedding(vocab, hidden)
+        self.states = None
+        self.config = SimpleNamespace(eos_token_id=EOS)
+
+    def get_input_embeddings(self):
+        return self.embed
+
+    def forward(self, inputs_embeds=None, attention_mask=None, labels=None, output_hidden_states=False, **kw):
+        assert self.states.shape[:2] == inputs_embeds.shape[:2], (self.states.shape, inputs_embeds.shape)
+        return SimpleNamespace(logits=None, loss=None, hidden_states=(self.states,), past_key_values=None)
+
+
+@pytest.mark.gpu
+def test_model_forward_confident_masks_vs_reference(dev):
+    """The end-to-end confident-mask fixture (tests/golden/e2e_conf_tiny.npz: the reference's own encoder -> CTP -> prompt encoder ->
+    mask decoder -> postprocess in fp32) through the TOP-LEVEL surface: walkgptForCausalLM.forward(**collate dict, inference=True)
+    with the [SEG] states of the fixture at the positions the reference reads (walkgpt.py:293-306,406-409).  north_star: 1e-3 mIoU."""
+    from tests.test_gpu_modules import _e2e_model, _iou_vs_band_gt, pixel_iou
+    from walkgpt_amd.causal_lm import walkgptForCausalLM
+    c = cases.E2ES["conf_tiny"]
+    gold = cases.load("e2e_conf_tiny")
+    g = _e2e_model(c, dev)
+    x, hid = cases.e2e_inputs(c)                                     # [1,3,S,S], [3, 64]
+    Hh = hid.shape[1]
+    lm = PresetLM(V, Hh).to(dev).bfloat16()
+    m = walkgptForCausalLM(lm, grounding=g, seg_token_idx=SEG, seg_token_num=1)
+    L = 12
+    ids = torch.randint(3, 50, (2, L), generator=torch.Generator().manual_seed(17))
+    ids[:, 1] = -200
+    seg_pos = [(0, 4), (0, 9), (1, 6)]                               # row 0 carries two [SEG]s, row 1 one: three prompts of the one image
+    states = torch.zeros(2, L + 255, Hh)
+    for k, (r, p) in enumerate(seg_pos):
+        ids[r, p] = SEG
+        states[r, 255 + p - 1] = hid[k]
+    lm.states = states.to(dev, torch.bfloat16)
+    res = m(images=x.to(dev, torch.bfloat16), images_clip=torch.zeros(1, 3, 28, 28, device=dev, dtype=torch.bfloat16), input_ids=ids.to(dev),
+            labels=ids.to(dev), attention_masks=torch.ones(2, L, dtype=torch.bool, device=dev), offset=torch.tensor([0, 2], device=dev),
+            masks_list=[torch.zeros(3, *c["original"], device=dev)], label_list=[torch.zeros(c["original"], device=dev)],
+            resize_list=[c["resize"]], clip_resize_list=[(28, 28)], inference=True)
+    assert res["batch_seg_token_counts"] == [3]
+    post = res["pred_masks"][0]
+    pix = pixel_iou(post.cpu().numpy(), gold["post"])
+    iou_h, iou_r = _iou_vs_band_gt(post, gold["post"], dev)
+    assert pix >= 1.0 - 1e-3 and pix >= pixel_iou(gold["post_bf16"], gold["post"]), pix
+    assert np.abs(iou_h - iou_r).max() <= 1e-3 and abs(iou_h.mean() - iou_r.mean()) <= 1e-3, (iou_h, iou_r)

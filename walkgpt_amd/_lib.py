@@ -87,7 +87,8 @@ _SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, []),
             "wg_gemm_pick_tile": (c_int, [c_int, c_int]),
             "wg_gemm_ln_supported": (c_int, [c_int, c_int, c_int, c_long, c_long, c_long]),
             "wg_gemm_row_partials_supported": (c_int, [c_int, c_int, c_int, c_long, c_long, c_long]),
-            "wg_gemm_pick_tile_ex": (c_int, [c_int, c_int, c_int])}
+            "wg_gemm_pick_tile_ex": (c_int, [c_int, c_int, c_int]),
+            "wg_gemm_pick_tile_mnk": (c_int, [c_int, c_int, c_int, c_int])}
 
 
 class WalkgptHipError(RuntimeError):

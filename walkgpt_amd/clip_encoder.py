@@ -205,14 +205,14 @@ class CLIPVisionTower(nn.Module):
         if t is None or t.shape[0] == want:
             return
         side = int(round((want - 1) ** 0.5))
-        if t.is_cuda:
-            state_dict[key] = resize_position_table(t.to(BF16), side).to(t.dtype)
-        else:   # a checkpoint still on the host: same arithmetic in torch (fp32 bilinear, align_corners=False), no HIP call without a GPU
-            n, D = t.shape
-            old = int(round((n - 1) ** 0.5))
-            grid = t[:-1].float().reshape(1, old, old, D).permute(0, 3, 1, 2)
-            new = torch.nn.functional.interpolate(grid, size=(side, side), mode="bilinear", align_corners=False)
-            state_dict[key] = torch.cat([new.permute(0, 2, 3, 1).reshape(side * side, D), t[-1:].float()], 0).to(t.dtype)
+        # One-time load step, the same arithmetic wherever the tensor sits: the reference interpolates the stock table in its own
+        # precision and casts afterwards (clip_encoder.py:38-55), so fp32 bilinear here and ONE rounding at the end -- a bf16 round
+        # trip through the HIP resample kernel on the GPU branch would give a checkpoint two different tables depending on its device.
+        n, D = t.shape
+        old = int(round((n - 1) ** 0.5))
+        grid = t[:-1].float().reshape(1, old, old, D).permute(0, 3, 1, 2)
+        new = torch.nn.functional.interpolate(grid, size=(side, side), mode="bilinear", align_corners=False)
+        state_dict[key] = torch.cat([new.permute(0, 2, 3, 1).reshape(side * side, D), t[-1:].float()], 0).to(t.dtype)
 
     def feature_select(self, states):
         feats = states[self.select_layer]

@@ -1079,18 +1079,21 @@ static int launch_attn_window(const AttnArgs& a, int groups, hipStream_t st) {
     constexpr int RPT = 64 / RP;
     constexpr int SP = ((S + RPT - 1) / RPT) * RPT + 1;
     const size_t lds = 2 * TILE + (size_t)NW * 32 * SP * 4 + 2 * (2 * S - 1) * HD * 2 + (size_t)NW * (HD / 16) * 1024 + (HD == 80 ? (size_t)NW * 64 * 80 : 0);
-    static int per_cu = 0;
-    if (!per_cu) {
+    static WgPerDevice once;
+    static int per_cu_of[64] = {};
+    int dev = 0;
+    if (once.first(&dev) || per_cu_of[dev & 63] == 0) {
         (void)hipFuncSetAttribute((const void*)wg_attn_window_kernel<HD, S, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)wg_attn_window_kernel<HD, S, NW>, NW * 64, lds) != hipSuccess || nb < 1) nb = 1;
-        per_cu = nb;
+        per_cu_of[dev & 63] = nb;
     }
+    const int per_cu = per_cu_of[dev & 63];
     // as many workgroups as the chip holds at once, trimmed so that every workgroup walks the same number of units (+-1) and the
     // XCD-aware unit order keeps its period
     const int total = groups * a.qchunks;
     const int period = 8 * a.qchunks;
-    const int cap = 256 * per_cu;
+    const int cap = wg_cu_count(dev) * per_cu;
     int grid = total;
     if (total > cap) {
         const int rounds = (total + cap - 1) / cap;
@@ -1115,11 +1118,9 @@ static int launch_attn_impl(const AttnArgs& a, int groups, hipStream_t st) {
         wg_set_error("attention: LDS request %zu exceeds 160 KiB", lds);
         return WG_ERR_UNSUPPORTED;
     }
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wg_attn_kernel<HD, S, NW, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    static WgPerDevice once;
+    int dev = 0;
+    if (once.first(&dev)) (void)hipFuncSetAttribute((const void*)wg_attn_kernel<HD, S, NW, KB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 #ifdef WG_ATTN_STAMP
     lds = 160 * 1024;
 #endif

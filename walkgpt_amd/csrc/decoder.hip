@@ -1013,12 +1013,11 @@ extern "C" int wg_dec_i2t_rows_bf16(const void* q, long ldq, const void* kq, con
                "dec_i2t_rows: misaligned operand");
     I2tArgs a{(const bf16*)q, ldq, (const bf16*)kq, (const bf16*)vq, (const bf16*)wo, (const bf16*)bo, (const bf16*)res, ldr, (const bf16*)res_bias, row_mod, prompt_image,
               (const bf16*)ln_g, (const bf16*)ln_b, eps, (bf16*)out, (long)P * hw, hw};
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wg_dec_i2t_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, I2_LDS);
-        attr_done = true;
-    }
+    static WgPerDevice once;
+    int dev = 0;
+    if (once.first(&dev)) (void)hipFuncSetAttribute((const void*)wg_dec_i2t_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, I2_LDS);
     const long wgs = (a.rows / 16 + I2_WAVES - 1) / I2_WAVES;
-    hipLaunchKernelGGL(wg_dec_i2t_rows_kernel, dim3((unsigned)(wgs < 256 ? wgs : 256)), dim3(64 * I2_WAVES), I2_LDS, (hipStream_t)stream, a);
+    const long cus = wg_cu_count(dev);
+    hipLaunchKernelGGL(wg_dec_i2t_rows_kernel, dim3((unsigned)(wgs < cus ? wgs : cus)), dim3(64 * I2_WAVES), I2_LDS, (hipStream_t)stream, a);
     return wg_check_launch("wg_dec_i2t_rows");
 }

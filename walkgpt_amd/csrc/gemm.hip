@@ -875,11 +875,9 @@ static int launch_tail(GemmArgs& g, hipStream_t st) {
     g.tiles_m = g.M / 128;             // the last row tile takes the M % 128 (<= 16) leftover rows
     g.tiles_n = (g.N + 127) / 128;
     constexpr int lds = 2 * (128 + 16 + 128) * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wg_gemm_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+    static WgPerDevice once;
+    int dev = 0;
+    if (once.first(&dev)) (void)hipFuncSetAttribute((const void*)wg_gemm_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL(wg_gemm_tail_kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), lds, st, g);
     return wg_check_launch("wg_gemm_bias_act_bf16(tail)");
 }
@@ -1014,11 +1012,9 @@ static int launch_tile_impl(GemmArgs& g, hipStream_t st) {
 #else
     constexpr int lds = lds_main > lds_stg ? lds_main : lds_stg;
 #endif
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wg_gemm_kernel<BM, BN, BK, STAGES, WM, WN, STAGED, PIPE, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+    static WgPerDevice once;
+    int dev = 0;
+    if (once.first(&dev)) (void)hipFuncSetAttribute((const void*)wg_gemm_kernel<BM, BN, BK, STAGES, WM, WN, STAGED, PIPE, FP8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL((wg_gemm_kernel<BM, BN, BK, STAGES, WM, WN, STAGED, PIPE, FP8>), dim3(g.tiles_m * g.tiles_n), dim3(WM * WN * 64), lds, st, g);
     return wg_check_launch(FP8 ? "wg_gemm_fp8_bias_act" : "wg_gemm_bias_act_bf16");
 }
@@ -1033,13 +1029,11 @@ static int launch_persist(GemmArgs& g, hipStream_t st) {
     constexpr int extra = (WM * WN > fit) ? (WM * WN - fit) * slab : 0;
     constexpr int lds = 2 * stage + extra;
     constexpr int per_cu = lds <= 80 * 1024 ? 2 : 1;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)wg_gemm_persist_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        attr_done = true;
-    }
+    static WgPerDevice once;
+    int dev = 0;
+    if (once.first(&dev)) (void)hipFuncSetAttribute((const void*)wg_gemm_persist_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int nwg = g.tiles_m * g.tiles_n;
-    int grid = 256 * per_cu;           // one (or two) resident workgroups per CU; a multiple of 8 keeps a workgroup on one XCD
+    int grid = wg_cu_count(dev) * per_cu;   // one (or two) resident workgroups per CU; a multiple of 8 keeps a workgroup on one XCD
     if (grid > nwg) grid = nwg;
     hipLaunchKernelGGL((wg_gemm_persist_kernel<BM, BN, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, st, g);
     return wg_check_launch("wg_gemm_bias_act_bf16(persistent)");
@@ -1441,15 +1435,13 @@ static int launch_pp_persist(GemmArgs& g, hipStream_t st) {
     // + the double-buffered bias row / LayerNorm operands, the raw partial sums of the next tile (mode 2), the row-sum exchange (STATS)
     constexpr int lds_plain = base + 2 * 512, lds_stats = base + 2 * 512 + 256 * 4 * 8, lds_ln = base + 2 * 4096, lds_lnp = base + 2 * 4096 + 5 * 2048;
     static_assert(lds_lnp <= 160 * 1024 && lds_stats <= 160 * 1024, "LDS budget of the persistent GEMM");
+    static WgPerDevice once;
     int dev = 0;
-    (void)hipGetDevice(&dev);
-    static bool attr_done[64] = {};
-    if (dev >= 0 && dev < 64 && !attr_done[dev]) {   // the attribute is per device (a process may drive several)
+    if (once.first(&dev)) {   // the attribute is per device (a process may drive several)
         (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_plain);
         (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_stats);
         (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_ln);
         (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_lnp);
-        attr_done[dev] = true;
     }
     const int nwg = g.tiles_m * g.tiles_n;
     const int cus = wg_cu_count(dev);
@@ -1511,6 +1503,12 @@ extern "C" int wg_gemm_pick_tile_ex(int M, int N, int allow_tail) {
 }
 
 extern "C" int wg_gemm_pick_tile(int M, int N) { return wg_gemm_pick_tile_ex(M, N, 0); }
+// The same choice with K in view: exactly the kernel wg_gemm_bias_act_bf16 launches for a shape whose operands qualify for the MFMA
+// path (the skinny kernel needs K % 128 == 0 and falls back to the 128x128 tiles otherwise) -- host-side accounting asks this one.
+extern "C" int wg_gemm_pick_tile_mnk(int M, int N, int K, int allow_tail) {
+    const int t = wg_gemm_pick_tile_ex(M, N, allow_tail);
+    return (t == 5 && K % 128 != 0) ? 1 : t;
+}
 
 struct GemmStatsIO {   // row statistics travelling between two persistent GEMMs (see wg_gemm_pp_persist_kernel)
     const float* ln_part = nullptr; int ln_np = 0; long ln_mpad = 0; float ln_eps = 0.f;   // consumer

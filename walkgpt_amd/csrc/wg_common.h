@@ -35,6 +35,20 @@ void wg_set_error(const char* fmt, ...);
     } while (0)
 int wg_check_launch(const char* what);
 int wg_cu_count(int device);   // compute units of a device (cached): persistent grids are sized from it, not from a constant
+// One-time setup per (call site, device): hipFuncSetAttribute and occupancy answers belong to a device, and a process may drive
+// several.  `static WgPerDevice once; int dev; if (once.first(&dev)) { ...set attributes... }`
+struct WgPerDevice {
+    bool done[64] = {};
+    bool first(int* dev_out) {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        *dev_out = d;
+        if (d < 0 || d >= 64) return true;      // out of the table: repeat the (idempotent) setup every time
+        if (done[d]) return false;
+        done[d] = true;
+        return true;
+    }
+};
 
 // ---- device helpers --------------------------------------------------------
 __device__ __forceinline__ float wg_bf2f(bf16 x) { return (float)x; }

@@ -72,7 +72,7 @@ def gemm_tile_for(M, N, K, lda, ldw, ldc, ldr, tail_tiles=False):
         return 3
     if _FORCE_TILE:
         return _FORCE_TILE
-    return _lib.lib().wg_gemm_pick_tile_ex(M, N, 1 if tail_tiles else 0)
+    return _lib.lib().wg_gemm_pick_tile_mnk(M, N, K, 1 if tail_tiles else 0)
 
 
 ROW_PARTIALS = _os.environ.get("WG_ROW_PARTIALS", "1") != "0"   # experiments: 0 = always take the row statistics in their own pass

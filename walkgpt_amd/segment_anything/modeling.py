@@ -449,6 +449,39 @@ class TwoWayAttentionBlock(nn.Module):
         if self.norm1.eps != self.norm2.eps or self.norm1.eps != self.norm3.eps or self.mlp._act_code != ops.ACT_RELU:
             raise NotImplementedError("the fused token kernels are built for SAM's decoder block (one LayerNorm eps, ReLU MLP)")
 
+    def fused_ok(self, embedding_dim, eps, d):
+        """The fused token kernels take SAM's block: 256 channels, 8 heads, MLP 2048 with ReLU, one LayerNorm eps, one attention width."""
+        return (embedding_dim == 256 and self.self_attn.num_heads == 8 and self.mlp.lin1.out_features == 2048 and self.mlp._act_code == ops.ACT_RELU
+                and self.norm1.eps == self.norm2.eps == self.norm3.eps == eps and self.cross_attn_token_to_image.internal_dim == d
+                and self.cross_attn_image_to_token.internal_dim == d)
+
+    def run_general(self, queries, keys, query_pe, key_pe, P):
+        """transformer.py:151-182 op by op (any width, head count, token count; bf16 token stream): the path for geometries the fused
+        token kernels do not take.  queries / query_pe [P, N, C] bf16; keys [1|P, hw, C]; key_pe [1, hw, C]."""
+        ln = lambda x, n: ops.layernorm(x, n.weight, n.bias, n.eps)   # noqa: E731
+        hw = keys.shape[1]
+        t2i, i2t = self.cross_attn_token_to_image, self.cross_attn_image_to_token
+        d = t2i.internal_dim
+        if self.skip_first_layer_pe:
+            queries = self.self_attn.run(queries, queries, queries, P)
+        else:
+            q = ops.add_rows(queries, query_pe)
+            queries = self.self_attn.run(q, q, queries, P, residual=queries)
+        queries = ln(queries, self.norm1)
+        wcat, rtab = _pe_folded_projection(key_pe.reshape(-1, key_pe.shape[-1]), [(t2i.k_proj, True), (t2i.v_proj, False), (i2t.q_proj, True)])
+        proj = ops.linear(keys, wcat, residual=rtab, res_row_mod=hw)          # [1|P, hw, 2d + d_i2t]
+        q = ops.add_rows(queries, query_pe)
+        qp = ops.linear(q, t2i.q_proj.weight, t2i.q_proj.bias)
+        queries = t2i.run_projected(qp, proj[..., :d], proj[..., d:2 * d], P, residual=queries)
+        queries = ln(queries, self.norm2)
+        queries = self.mlp.rows(queries, residual=queries)
+        queries = ln(queries, self.norm3)
+        q = ops.add_rows(queries, query_pe)
+        kq = ops.linear(q, i2t.k_proj.weight, i2t.k_proj.bias)
+        vq = ops.linear(queries, i2t.v_proj.weight, i2t.v_proj.bias)
+        keys = i2t.run_projected(proj[..., 2 * d:], kq, vq, P, residual=keys, res_row_mod=hw if keys.shape[0] == 1 and P > 1 else 0)
+        return queries, ln(keys, self.norm4)
+
     def run(self, queries, keys, query_pe, key_pe, P):
         """transformer.py:151-182, one block on its own (TwoWayTransformer.run_tokens merges the launch that closes a block with the one
         that opens the next).  queries / query_pe [P,6,C] fp32 (queries updated in place); keys [1|P, hw, C] bf16; key_pe [1, hw, C]."""
@@ -517,10 +550,10 @@ class TwoWayTransformer(nn.Module):
         ops.dec_heads applies in its own launch; keys [P, hw, C] bf16).
         Launch chain per block: tokens[close previous block | self attention | q] -> (previous block's image->token attention, norm4)
         -> image-side GEMM -> attention partials -> MLP partials (which first merge the partials: out_proj, norm2)."""
-        if self.embedding_dim != 256 or self.num_heads != 8 or out_tokens.shape[0] != 5 or prompts.shape[1] != 1 or self.mlp_dim != 2048:
+        if not self.fused_ok(out_tokens.shape[0], prompts.shape[1]):
             raise NotImplementedError("the fused token kernels are built for SAM's decoder geometry (256 channels, 8 heads, 5 + 1 tokens, "
-                                      "MLP 2048); got %d / %d / %d + %d / %d" % (self.embedding_dim, self.num_heads, out_tokens.shape[0],
-                                                                                prompts.shape[1], self.mlp_dim))
+                                      "MLP 2048); got %d / %d / %d + %d / %d -- MaskDecoder takes the per-op path for others"
+                                      % (self.embedding_dim, self.num_heads, out_tokens.shape[0], prompts.shape[1], self.mlp_dim))
         P = prompts.shape[0]
         dev = prompts.device
         queries = torch.empty(P, 6, self.embedding_dim, device=dev, dtype=torch.float32)
@@ -574,8 +607,37 @@ class TwoWayTransformer(nn.Module):
         wcat, rtab = self._fin_val
         return ops.linear(keys, wcat, residual=rtab, res_row_mod=keys.shape[1])
 
+    def fused_ok(self, n_out_tokens, n_prompt_tokens):
+        """SAM's decoder geometry, the one the fused token kernels are built for (anything else runs op by op: run_general)."""
+        fa = self.final_attn_token_to_image
+        eps, d = self.norm_final_attn.eps, fa.internal_dim
+        return (self.embedding_dim == 256 and self.num_heads == 8 and self.mlp_dim == 2048 and n_out_tokens == 5 and n_prompt_tokens == 1
+                and d == 128 and all(layer.fused_ok(self.embedding_dim, eps, d) for layer in self.layers))
+
+    def run_general(self, src_tokens, pe_tokens, point_embedding):
+        """transformer.py:62-106 op by op: src_tokens [1|P, hw, C] rows, pe_tokens [1, hw, C], point_embedding [P, N, C] bf16
+        -> (queries [P, N, C], keys [P, hw, C]) -- any width / head count / number of tokens."""
+        P = point_embedding.shape[0]
+        queries, keys = point_embedding, src_tokens
+        for layer in self.layers:
+            queries, keys = layer.run_general(queries, keys, point_embedding, pe_tokens, P)
+        q = ops.add_rows(queries, point_embedding)
+        fa = self.final_attn_token_to_image
+        d = fa.internal_dim
+        wcat, rtab = _pe_folded_projection(pe_tokens.reshape(-1, pe_tokens.shape[-1]), [(fa.k_proj, True), (fa.v_proj, False)])
+        proj = ops.linear(keys, wcat, residual=rtab, res_row_mod=keys.shape[1])
+        qp = ops.linear(q, fa.q_proj.weight, fa.q_proj.bias)
+        queries = fa.run_projected(qp, proj[..., :d], proj[..., d:], P, residual=queries)
+        return ops.layernorm(queries, self.norm_final_attn.weight, self.norm_final_attn.bias, self.norm_final_attn.eps), keys
+
     def forward(self, image_embedding, image_pe, point_embedding):
-        raise NotImplementedError("TwoWayTransformer is driven by MaskDecoder.predict_masks_tokens on the WalkGPT path")
+        """transformer.py:62-106 signature: image_embedding [B, C, h, w], image_pe the same shape, point_embedding [B, N, C]
+        -> (processed point_embedding [B, N, C], processed image embedding [B, hw, C]).  (MaskDecoder drives the fused kernels through
+        run_tokens for SAM's geometry; this entry runs op by op and takes any geometry.)"""
+        _check_bf16_gpu(image_embedding, "image_embedding")
+        src = ops.nchw_to_tokens(image_embedding.contiguous())
+        pe = ops.nchw_to_tokens(image_pe.to(BF16).contiguous())[:1]
+        return self.run_general(src, pe, point_embedding.to(BF16).contiguous())
 
 
 class MLP(nn.Module):
@@ -654,8 +716,9 @@ class MaskDecoder(nn.Module, _Prepared):
                                                   self.mask_tokens.weight))
         P = sparse.shape[0]
         tr = self.transformer
-        if self.num_mask_tokens != 4 or sparse.shape[1] != 1 or self.transformer_dim != 256:
-            raise NotImplementedError("the fused decoder kernels are built for 4 mask tokens + one text prompt per query (mask_decoder.py:125-132)")
+        if self.num_mask_tokens != 4 or self.transformer_dim != 256 or not tr.fused_ok(1 + self.num_mask_tokens, sparse.shape[1]) \
+                or any(m.num_layers != 3 or m.sigmoid_output for m in list(self.output_hypernetworks_mlps) + [self.iou_prediction_head]):
+            return self._predict_masks_general(src_tokens, pe_tokens, sparse, h, w, mask_slice, src_bias, prompt_image)
         if len(tr.layers) == 0 or not tr.layers[0].fused_i2t_ok(src_tokens, 6):
             if prompt_image is not None:
                 src_tokens, prompt_image = src_tokens.index_select(0, prompt_image.long()), None
@@ -667,6 +730,31 @@ class MaskDecoder(nn.Module, _Prepared):
         k0, nk = mask_slice
         masks = ops.upscale_mask(keys, p["up1_w"], self.output_upscaling[0].bias, ln1.weight, ln1.bias, ln1.eps, p["up2_w"],
                                  self.output_upscaling[3].bias, hyper, h, w, k0, nk)
+        return masks, iou[:, k0:k0 + nk]
+
+    def _predict_masks_general(self, src_tokens, pe_tokens, sparse, h, w, mask_slice, src_bias=None, prompt_image=None):
+        """mask_decoder.py:116-164 op by op, for what the fused kernels do not take: any number of sparse prompt tokens / mask tokens, other
+        head counts or MLP widths (bf16 token stream; the upscaler's last width must be 32, what wg_hyper_mask_dot multiplies)."""
+        P, C = sparse.shape[0], self.transformer_dim
+        if C // 8 != 32:
+            raise NotImplementedError("mask decoder widths other than 256 are not built (hyper_in @ upscaled runs on 32 channels)")
+        if prompt_image is not None:
+            src_tokens = src_tokens.index_select(0, prompt_image.long())
+        if src_bias is not None:
+            src_tokens = ops.add_rows(src_tokens, src_bias)
+        out_tokens = torch.cat([self.iou_token.weight, self.mask_tokens.weight], 0).to(BF16)
+        tokens = torch.cat([out_tokens.unsqueeze(0).expand(P, -1, -1), sparse.to(BF16)], dim=1).contiguous()      # :125-132
+        hs, keys = self.transformer.run_general(src_tokens, pe_tokens, tokens)
+        c1, ln1, c3 = self.output_upscaling[0], self.output_upscaling[1], self.output_upscaling[3]
+        u = ops.linear(keys.reshape(P * h * w, C), self._convt_as_gemm(c1.weight), c1.bias.repeat(4).contiguous())     # [P*hw, 4 * C/4]
+        u = ops.layernorm(u.view(P * h * w * 4, C // 4), ln1.weight, ln1.bias, ln1.eps, act=ops.ACT_GELU)
+        u = ops.linear(u, self._convt_as_gemm(c3.weight), c3.bias.repeat(4).contiguous(), act=ops.ACT_GELU)             # [P*hw*4, 4 * C/8]
+        hyper = torch.empty(P, self.num_mask_tokens, C // 8, device=u.device, dtype=BF16)
+        for i in range(self.num_mask_tokens):
+            hyper[:, i] = self.output_hypernetworks_mlps[i].rows(hs[:, 1 + i].contiguous())
+        k0, nk = mask_slice
+        masks = ops.hyper_mask_dot(u, hyper, P, h, w, k0, nk)
+        iou = self.iou_prediction_head.rows(hs[:, 0].contiguous(), out_f32=True)
         return masks, iou[:, k0:k0 + nk]
 
     def forward(self, image_embeddings, image_pe, sparse_prompt_embeddings, dense_prompt_embeddings, multimask_output):
