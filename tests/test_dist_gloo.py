@@ -53,6 +53,20 @@ def _worker(rank, world, port, q):
         ok = ok and len(got2[1]) == 0 and len(got2[0]) == 1 and bool((got2[0][0] == 7.0).all()) and got2[0][0].shape == (2, 4, 3)
         u = all_gather_masks_uniform(torch.full((2, 3, 3), float(rank)))
         ok = ok and u.shape == (4, 3, 3) and bool((u[:2] == 0).all()) and bool((u[2:] == 1).all())
+        # bf16 on the wire (2 bytes per logit): signs, hence thresholded masks, are those of the fp32 logits
+        got3 = all_gather_masks(_masks_for(rank), wire_dtype=torch.bfloat16)
+        for r in range(world):
+            want = _masks_for(r)
+            ok = ok and all(a.dtype == torch.bfloat16 and torch.equal(a, b.to(torch.bfloat16)) and torch.equal(a > 0, b > 0)
+                            for a, b in zip(got3[r], want))
+        out = torch.empty(4, 3, 3, dtype=torch.bfloat16)
+        u2 = all_gather_masks_uniform(torch.full((2, 3, 3), rank - 0.5), out=out, wire_dtype=torch.bfloat16)
+        ok = ok and u2 is out and bool((out[:2] == -0.5).all()) and bool((out[2:] == 0.5).all())
+        try:
+            all_gather_masks_uniform(torch.zeros(2, 3, 3), out=torch.empty(4, 3, 3), wire_dtype=torch.bfloat16)   # fp32 buffer, bf16 payload
+            ok = False
+        except ValueError:
+            pass
         # images sharded by rank cover the batch exactly once
         a, b = shard_range(9, rank, world)
         t = torch.zeros(9)

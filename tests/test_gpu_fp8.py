@@ -99,7 +99,7 @@ def test_sam_encoder_fp8_vs_reference_golden(dev, name):
             blk.gemm_dtype = "fp8"
         e8 = rel_err(cases.tap_embedding(enc(x).float().cpu()).numpy(), gold["out"])
     print("encoder %s: rel err vs reference fp32: bf16 GEMMs %.4f, fp8 GEMMs %.4f" % (name, e16, e8))
-    assert e8 < 0.12 and e8 < 15 * e16 + 0.02
+    assert e8 < 0.07 and e8 < 8 * e16 + 0.01           # measured 0.055 (tiny) / 0.049 (vit_h3) against 0.0085 / 0.0079 with bf16 GEMMs
 
 
 def test_masks_with_fp8_encoder_vs_oracle(dev):
@@ -146,4 +146,31 @@ def test_masks_with_fp8_encoder_vs_oracle(dev):
             i8.append(pixel_iou(out8["pred_masks"][i].cpu().numpy(), ref))
     print("thresholded masks vs the fp32 oracle (pixel IoU per image): bf16 GEMMs %s, fp8 GEMMs %s; mean delta %.4f"
           % (["%.4f" % v for v in i16], ["%.4f" % v for v in i8], float(np.mean(i16) - np.mean(i8))))
-    assert min(i8) > 0.93 and np.mean(i16) - np.mean(i8) < 0.06
+    # measured 0.9888 / 0.9978 (fp8) against 0.9972 / 0.9993 (bf16): 5e-3 of mIoU on masks where EVERY pixel is a boundary pixel; on the
+    # confident-mask case (test_gpu_modules.test_end_to_end_confident_masks_vs_reference) the same operand type stays within 3e-4
+    assert min(i8) > 0.98 and np.mean(i16) - np.mean(i8) < 0.012
+
+
+def test_clip_tower_fp8_vs_standin_golden(dev):
+    """The CLIP tower with q|k|v / out_proj / fc1 / fc2 on fp8 operands (config C5 runs both towers that way) against the stand-in's fp32
+    features, next to the bf16 path on the same golden."""
+    from types import SimpleNamespace
+    from tests.test_gpu_modules import load_into
+    from walkgpt_amd.clip_encoder import CLIPVisionTower
+    c = cases.CLIPS["tiny"]
+    gold = cases.load("clip_tiny")
+    cfg = dict(hidden_size=c["dim"], intermediate_size=4 * c["dim"], num_hidden_layers=c["layers"], num_attention_heads=c["heads"],
+               image_size=c["img"], patch_size=14, layer_norm_eps=1e-5)
+    args = SimpleNamespace(mm_vision_select_layer=c["select_layer"], pad_train_clip_images=True, resize_vision_tower=True,
+                           resize_vision_tower_size=c["img"])
+    tower = CLIPVisionTower("synthetic", args, config=cfg)
+    load_into(tower.vision_tower, cases.clip_weights(c), "", dev)
+    x, key_mask = cases.clip_inputs(c)
+    with torch.no_grad():
+        sel16, _ = tower(x.to(dev, torch.bfloat16), attention_mask=key_mask.to(dev))
+        for layer in tower.vision_tower.vision_model.encoder.layers:
+            layer.gemm_dtype = "fp8"
+        sel8, pre8 = tower(x.to(dev, torch.bfloat16), attention_mask=key_mask.to(dev))
+    e16, e8 = rel_err(sel16.float().cpu().numpy(), gold["sel"]), rel_err(sel8.float().cpu().numpy(), gold["sel"])
+    print("CLIP tower (tiny): selected features rel err vs fp32: bf16 GEMMs %.4f, fp8 GEMMs %.4f" % (e16, e8))
+    assert e8 < 0.08 and torch.isfinite(pre8[0].float()).all()

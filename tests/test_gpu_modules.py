@@ -307,6 +307,15 @@ def test_grounding_pipeline_end_to_end_vs_oracle(dev):
         gm, gs = model.decode_from_hidden_graphed(emb_t, hid, resize, orig)
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(em, gm)) and all(torch.equal(a, b) for a, b in zip(es, gs))
+    # a caller that keeps its data in the graph's own input buffers replays without staging copies, same result
+    s_emb, s_hid = model.decode_graph_inputs(emb_t, hid, resize, orig)
+    s_emb.copy_(emb_t)
+    for d_, h_ in zip(s_hid, hid):
+        d_.copy_(h_ * 0.5)
+    em, es = model.decode_from_hidden(emb_t, [h_ * 0.5 for h_ in hid], resize, orig)
+    gm, gs = model.decode_from_hidden_graphed(s_emb, s_hid, resize, orig)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(em, gm)) and all(torch.equal(a, b) for a, b in zip(es, gs))
     # new weights after the capture (load_state_dict copies in place; .to() / re-assignment would move the storage): the graph key
     # carries the identity and version of every parameter and buffer of the chain, so the stale graph is dropped and re-captured
     md = model.visual_model.mask_decoder

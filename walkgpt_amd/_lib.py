@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwalkgpt_hip.so")
+LIB_PATH = os.environ.get("WG_LIB") or os.path.join(_HERE, "libwalkgpt_hip.so")   # WG_LIB: A/B against a variant build (tools/build_variant.py)
 
 c_void_p, c_int, c_long, c_float = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float
 

@@ -75,10 +75,42 @@ class _EncoderLayer(nn.Module, _Prepared):
         return {"qkv": ops.fold_layernorm(n1.weight, n1.bias, w, b),
                 "fc1": ops.fold_layernorm(n2.weight, n2.bias, m.fc1.weight, m.fc1.bias)}
 
+    gemm_dtype = "bf16"   # "fp8": q|k|v / out_proj / fc1 / fc2 on e4m3 operands (BASELINE config C5); set through WalkGPTGrounding.set_gemm_dtype
+
+    def _build_fp8(self):
+        a, m = self.self_attn, self.mlp
+        wqkv = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).contiguous()
+        return {"qkv": ops.quantize_weight_fp8(wqkv), "bqkv": torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).contiguous(),
+                "out": ops.quantize_weight_fp8(a.out_proj.weight), "fc1": ops.quantize_weight_fp8(m.fc1.weight),
+                "fc2": ops.quantize_weight_fp8(m.fc2.weight)}
+
+    def run_fp8(self, x, key_bias):
+        """The layer on the fp8 GEMM path (as Block.rows_fp8 of the SAM encoder): both LayerNorms fused with the per-row quantisation of
+        their output; attention, the residual stream and every statistic stay bf16 / fp32."""
+        a, m = self.self_attn, self.mlp
+        key = tuple((p.data_ptr(), p._version) for p in (a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.out_proj.weight, m.fc1.weight,
+                                                         m.fc2.weight, a.q_proj.bias, a.k_proj.bias, a.v_proj.bias))
+        w = self.__dict__.get("_fp8_val")
+        if w is None or self.__dict__.get("_fp8_key") != key:
+            w = self._build_fp8()
+            self.__dict__["_fp8_val"], self.__dict__["_fp8_key"] = w, key
+        D = x.shape[-1]
+        q, s = ops.quantize_rows_fp8(x, ln=(self.layer_norm1.weight, self.layer_norm1.bias), eps=self.layer_norm1.eps)
+        qkv = ops.linear_fp8(q, s, *w["qkv"], bias=w["bqkv"])
+        o = ops.mha(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], a.num_heads, a.scale, key_bias, small=False)
+        q, s = ops.quantize_rows_fp8(o)
+        x = ops.linear_fp8(q, s, *w["out"], bias=a.out_proj.bias, residual=x)
+        q, s = ops.quantize_rows_fp8(x, ln=(self.layer_norm2.weight, self.layer_norm2.bias), eps=self.layer_norm2.eps)
+        h = ops.linear_fp8(q, s, *w["fc1"], bias=m.fc1.bias, act=ops.ACT_QUICK_GELU)
+        q, s = ops.quantize_rows_fp8(h)
+        return ops.linear_fp8(q, s, *w["fc2"], bias=m.fc2.bias, residual=x)
+
     def run(self, x, key_bias, tail_tiles=False):
         """HF CLIPEncoderLayer: pre-LN attention + pre-LN quick-GELU MLP, both residual.  x [B, L, D].
         Both LayerNorms are folded into the GEMM behind them (ops.ln_linear).  tail_tiles: let the M = B*1025 GEMMs use the
         tail-absorbing tiles (faster when nothing else shares the GPU, slower under stream overlap)."""
+        if self.gemm_dtype == "fp8":
+            return self.run_fp8(x, key_bias)
         a = self.self_attn
         p = self._prep_get(self._build)
         D = x.shape[-1]

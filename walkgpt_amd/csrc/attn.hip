@@ -590,6 +590,10 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
 #endif
         WG_STAMP(4);
     };
+#if defined(WG_ATTN_PRIO) && WG_ATTN_PRIO
+    // experiment (MI355X_MICROARCH.md, Two waves per SIMD, item 4): one static s_setprio 1 for the second-dispatched half of the workgroup
+    if (NW >= 8 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     if constexpr (HALF_LAST) {
         for (int t = 0; t + 1 < nt; ++t) tile(t, std::false_type());
         tile(nt - 1, std::true_type());

@@ -155,6 +155,32 @@ __device__ __forceinline__ void wg_load_residual(u32x4* rres, __amdgpu_buffer_rs
 
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
+// Experiment knobs of the persistent 256x256 kernel (diagnostic builds only, tools/build_variant.py): cache policy bits of its output
+// stores and of its operand loads (gfx950 aux: 1 = sc0, 2 = nt, 16 = sc1).  Default 0 = the plain policy.
+#ifndef WG_GEMM_C_AUX
+#define WG_GEMM_C_AUX 0
+#endif
+#ifndef WG_GEMM_A_AUX
+#define WG_GEMM_A_AUX 0
+#endif
+#ifndef WG_GEMM_W_AUX
+#define WG_GEMM_W_AUX 0
+#endif
+// WG_GEMM_AGPR (persistent kernel): 1 = accumulators in AGPRs, 2 = accumulators and both operand fragments in AGPRs (hipcc by itself
+// keeps every MFMA operand in arch VGPRs; tools/micro/coexec_probe.hip measures the same MFMA stream 10 / 15 % faster this way)
+#ifndef WG_GEMM_AGPR
+#define WG_GEMM_AGPR 0
+#endif
+__device__ __forceinline__ void wg_mfma16_acc(f32x4& acc, bf16x8 a, bf16x8 b) {
+#if WG_GEMM_AGPR == 1
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+#elif WG_GEMM_AGPR == 2
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(a), "a"(b));
+#else
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+#endif
+}
+
 // FP8 = true: the same kernel on e4m3 (OCP) operands.  A K slab is still 128 bytes per row -- 128 fp8 values instead of 64 bf16 -- so
 // staging, swizzle, barriers and the ping-pong schedule are unchanged; a fragment is the 32 contiguous bytes k = 32*fq .. 32*fq+31
 // of its row (two 16-byte chunks) and ONE block-scaled MFMA 16x16x128 (v_mfma_scale_f32_16x16x128_f8f6f4, both block scales 1.0 =
@@ -1128,10 +1154,10 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
         for (int u = 0; u < 2; ++u) {
             if (which < 2) {
                 const int i = which * 2 + u;
-                __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcW[i] + k0), WG_LDS_PTR(ldsW + (i * RPR + wave * RPI) * ROWB), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcW[i] + k0), WG_LDS_PTR(ldsW + (i * RPR + wave * RPI) * ROWB), 16, 0, WG_GEMM_W_AUX);
             } else {
                 const int i = (which - 2) + 2 * u;
-                __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcA[i] + k0), WG_LDS_PTR(ldsA + (i * RPR + wave * RPI) * ROWB), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcA[i] + k0), WG_LDS_PTR(ldsA + (i * RPR + wave * RPI) * ROWB), 16, 0, WG_GEMM_A_AUX);
             }
         }
     };
@@ -1283,7 +1309,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
-                            acc[4 * sc + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf2[j >> 1][j & 1][ks], af[i][ks], acc[4 * sc + i][j], 0, 0, 0);
+                            wg_mfma16_acc(acc[4 * sc + i][j], wf2[j >> 1][j & 1][ks], af[i][ks]);
                 }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
@@ -1402,7 +1428,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                 const int n = nbase + (el % CH) * 8;
                 const int off0 = n < g.N ? ((cm0 + wm * WTM + half * 64 + el / CH) * (int)g.ldc + n) * 2 : (int)0x80000000;
 #pragma unroll
-                for (int it = 0; it < NIT; ++it) __builtin_amdgcn_raw_buffer_store_b128(t[it], crs, off0 + it * RPSl * (int)g.ldc * 2, 0, 0);
+                for (int it = 0; it < NIT; ++it) __builtin_amdgcn_raw_buffer_store_b128(t[it], crs, off0 + it * RPSl * (int)g.ldc * 2, 0, WG_GEMM_C_AUX);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -1429,6 +1455,8 @@ static int launch_pp_persist(GemmArgs& g, hipStream_t st) {
         const long panel = 256L * g.K * 2, wbytes = (long)g.N * g.K * 2;
         const int cb = (int)((3L << 19) / (panel > 0 ? panel : 1));
         g.col_block = (wbytes > (3L << 20) && cb >= 2 && cb < g.tiles_n) ? cb : 0;
+        static const char* force = getenv("WG_GEMM_COLBLOCK");      // experiments: tile order override (0 = row-major)
+        if (force && *force) g.col_block = atoi(force);
     }
     constexpr int stage = 512 * 128, slab = 64 * (64 * 2 + 16);
     constexpr int base = 2 * stage + (8 - stage / slab) * slab;

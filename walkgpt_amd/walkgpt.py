@@ -121,13 +121,18 @@ class WalkGPTGrounding(nn.Module):
             p.requires_grad = True
         self.__dict__.pop("_decode_graphs", None)      # captured decode graphs hold the old modules' addresses
 
-    def set_gemm_dtype(self, dtype):
+    def set_gemm_dtype(self, dtype, clip=True):
         """"bf16" (default) or "fp8": operand type of the qkv / proj / MLP GEMMs of the SAM encoder blocks (BASELINE config C5; needs
-        block widths that are multiples of 128: ViT-B / L / H are).  Attention, LayerNorm statistics and the residual stream stay bf16 / fp32."""
+        block widths that are multiples of 128: ViT-B / L / H are) and, with clip=True, of the CLIP tower's layers.  Attention, LayerNorm
+        statistics and the residual stream stay bf16 / fp32."""
         if dtype not in ("bf16", "fp8"):
             raise ValueError("gemm dtype must be 'bf16' or 'fp8'")
         for blk in self.visual_model.image_encoder.blocks:
             blk.gemm_dtype = dtype
+        tower = self.get_vision_tower()
+        if tower is not None and clip:
+            for layer in tower.vision_tower.vision_model.encoder.layers:
+                layer.gemm_dtype = dtype
 
     # -- walkgpt.py:241-258 -----------------------------------------------------------------------------------------
     def get_visual_embs(self, pixel_values):
@@ -265,10 +270,28 @@ class WalkGPTGrounding(nn.Module):
                 out = self.decode_from_hidden(s_emb, s_hid, resize_list, original_size_list)
             ent = graphs[key] = (g, s_emb, s_all, out, wkey)
         g, s_emb, s_all, out, _ = ent
-        s_emb.copy_(emb_tokens)
-        torch.cat(list(seg_hidden), 0, out=s_all)
+        # staging copies into the graph's static inputs -- skipped for an input that IS the static buffer (callers that keep their
+        # data in the buffers `decode_graph_inputs` hands out: the two copies are 9 of a one-image decode's ~220 microseconds)
+        if emb_tokens.data_ptr() != s_emb.data_ptr():
+            s_emb.copy_(emb_tokens)
+        off, in_place = 0, True
+        for h in seg_hidden:
+            in_place = in_place and h.is_contiguous() and h.data_ptr() == s_all.data_ptr() + off * s_all.stride(0) * s_all.element_size()
+            off += int(h.shape[0])
+        if not in_place:
+            torch.cat(list(seg_hidden), 0, out=s_all)
         g.replay()
         return out
+
+    def decode_graph_inputs(self, emb_tokens, seg_hidden, resize_list, original_size_list):
+        """The static input buffers of the captured decode graph for this signature (capturing it if needed), as
+        (emb_tokens-like, [seg_hidden-like ...]) views: a caller that writes its embedding / [SEG] states straight into them and passes
+        them back to decode_from_hidden_graphed replays without staging copies."""
+        self.decode_from_hidden_graphed(emb_tokens, seg_hidden, resize_list, original_size_list)
+        key = (tuple(emb_tokens.shape), tuple(tuple(h.shape) for h in seg_hidden), tuple(map(tuple, resize_list)),
+               tuple(map(tuple, original_size_list)), str(emb_tokens.device), seg_hidden[0].dtype if seg_hidden else None)
+        _, s_emb, s_all, _, _ = self._decode_graphs[key]
+        return s_emb, list(torch.split(s_all, [int(h.shape[0]) for h in seg_hidden], 0))
 
     def decode_from_hidden(self, emb_tokens, seg_hidden: Sequence[torch.Tensor], resize_list, original_size_list):
         """seg_hidden[i] [T_i, H_llm]: last-layer LLM states at the positions preceding each [SEG] (walkgpt.py:406-447;
