@@ -516,14 +516,14 @@ def main():
                 "algorithmic_bytes_per_launch": round(byt / n_l)}
     # HBM traffic of the dominant kernel from the committed PMC passes -- only when they profiled THIS configuration
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
             pmc = json.load(f)
         same = pmc.get("config") == {"batch": B, "sam": args.sam, "seg_tokens": T, "with_msqp": bool(args.with_msqp), "dtype": args.dtype,
                                      "world": 1}
         key = [k for k in pmc["kernels"] if dom in PMC_PREFIX and k.startswith(PMC_PREFIX[dom])]
         if same and key:
             roofline["traffic"] = pmc["kernels"][key[0]]["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes of this command, avg per launch)"
+            roofline["traffic_source"] = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes of this command, avg per launch)"
     except (OSError, KeyError, ValueError):
         pass
 
