@@ -89,3 +89,36 @@ def test_clip_vit_l_448_calibrated_against_reference_bf16(dev):
     for k, (e_hip, e_ref16) in cal.items():
         assert e_hip <= 1.03 * e_ref16, (k, e_hip, e_ref16)
     assert cal["sel"][0] < 0.013 and cal["h0"][0] < 0.005
+
+
+def test_c3_workload_at_its_own_batch(dev):
+    """BASELINE config C3 on its own workload: bs = 32 at 448 x 448, SAM ViT-H (the reference's default, model/walkgpt.py:128) + MSQP at
+    H_llm = 4096 + CTP + T = 14 [SEG] tokens per image -> masks.  One pass of the whole grounding step (what bench.py --config C3 times),
+    checked through properties that need no full-size reference: shapes, finiteness, determinism, and image 5 of the batch against the
+    same image run alone (other tilings: M = 131072 rows of the persistent GEMMs against 4096)."""
+    from walkgpt_amd.walkgpt import WalkGPTGrounding
+    B, T, Hl = 32, 14, 4096
+    torch.manual_seed(0)
+    model = WalkGPTGrounding(sam="vit_h", llm_hidden=Hl, with_clip=False).to(dev).bfloat16()
+    enc = model.visual_model.image_encoder
+    with torch.no_grad():                                            # zero-initialised by default (image_encoder.py:71-74,232-233)
+        enc.pos_embed.normal_(0, 0.02)
+        for blk in enc.blocks:
+            blk.attn.rel_pos_h.normal_(0, 0.02)
+            blk.attn.rel_pos_w.normal_(0, 0.02)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, 3, 1024, 1024, generator=g).to(dev, torch.bfloat16)
+    hid = [torch.randn(T, Hl, generator=g).to(dev, torch.bfloat16) for _ in range(B)]
+    sizes, orig = [(1024, 1024)] * B, [(448, 448)] * B
+    with torch.no_grad():
+        out = model(x, None, hid, sizes, orig)
+        again = model(x, None, hid, sizes, orig)
+        one = model(x[5:6], None, hid[5:6], sizes[:1], orig[:1])
+    assert len(out["pred_masks"]) == B and out["visual_tokens"].shape == (B, 36, Hl)
+    for i in (0, 5, 31):
+        m = out["pred_masks"][i]
+        assert m.shape == (T, 448, 448) and torch.isfinite(m).all() and out["mask_scores"][i].shape == (T,)
+        assert torch.equal(m, again["pred_masks"][i])
+    e = rel_err(out["pred_masks"][5].float().cpu().numpy(), one["pred_masks"][0].float().cpu().numpy())
+    assert e < 0.05, e
+    assert rel_err(out["pred_masks"][5].float().cpu().numpy(), out["pred_masks"][0].float().cpu().numpy()) > 0.1   # distinct images, distinct masks

@@ -119,14 +119,24 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     constexpr int NTG = GRID ? (S + RPT - 1) / RPT : 0;   // key tiles per window
     constexpr int SP = GRID ? NTG * RPT + 1 : 1;          // relh table row (fp32 words, odd => conflict-free)
     constexpr int NRW = GRID ? RP / 2 : 1;                // width-bias registers per lane
+    // STAG (experiment, -DWG_ATTN_STAGGER; MI355X_MICROARCH.md, Two waves per SIMD, item 9): the eight-wave kernels run waves w and w + 4 of a
+    // SIMD through the same program with one barrier per tile, i.e. in lockstep -- both on the matrix pipe, then both on the vector ALU.  Here
+    // waves 4-7 carry the P.V MFMAs of a tile over the barrier into the next block, so that their matrix work sits beside the other half's
+    // exponentials and vice versa.  V tiles then live for two blocks: a ring of three V buffers next to the two K buffers.
+#if defined(WG_ATTN_STAGGER) && WG_ATTN_STAGGER
+    constexpr bool STAG = (NW == 8);
+#else
+    constexpr bool STAG = false;
+#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* kv = smem;                                  // [2 buffers][K tile | V tile]
-    float* tab = (float*)(smem + 2 * TILE2);          // grid: per-wave rel table; plain: key bias row
+    char* kv = smem;                                  // [2 buffers][K tile | V tile]      (STAG: [2][K tile] | [3][V tile])
+    float* tab = (float*)(smem + 2 * TILE2 + (STAG ? TILEV : 0));   // grid: per-wave rel table; plain: key bias row
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql_lane = lane & 31, hi = lane >> 5;
+    const bool late = STAG && wave >= NW / 2;
 
     // ---- decode the block id -> (batch, window, head, q chunk) ------------------------------------------------
     int bid = blockIdx.x;
@@ -246,8 +256,8 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     const unsigned strideK = (unsigned)((GRID ? (long)RPT * a.Hg : 64L) * a.ldk);
     const unsigned strideV = (unsigned)((GRID ? (long)RPT * a.Hg : 64L) * a.ldv);
     // tile t of K (or V) -> buffer `buf`; per operand the tiles must be staged in order 0, 1, 2, ... (running pointers)
-    auto stage = [&](int t, int buf, bool isV) __attribute__((always_inline)) {
-        char* dst = kv + buf * TILE2 + (isV ? TILE : 0);
+    auto stage = [&](int t, int buf, bool isV, int vslot = 0) __attribute__((always_inline)) {
+        char* dst = STAG ? (isV ? kv + 2 * TILE + vslot * TILEV : kv + buf * TILE) : kv + buf * TILE2 + (isV ? TILE : 0);
         const int lim = klim0 - t * (GRID ? RPT : 64);
         const int o = isV ? 1 : 0;
         const int cpr = (isV ? ROWBV : ROWB) / 16, ninst = isV ? NINSTV : NINSTK;
@@ -471,7 +481,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     {
         const int g = lane >> 4, i16 = lane & 15;
         const int rq = i16 >> 2, cp = i16 & 3;
-        const unsigned vbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem) + (unsigned)TILE;
+        const unsigned vbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem) + (unsigned)(STAG ? 2 * TILE : TILE);
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
             const int col = 32 * d + 16 * (g & 1) + 4 * cp;
@@ -483,7 +493,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     // the two transposed reads that feed P.V MFMA g = ks*DB + d (the offset must be an immediate: switch on the unrolled ks)
     auto vt_pair = [&](int g, int buf) __attribute__((always_inline)) {
         const int ks = g / DB, d = g % DB;
-        const unsigned ad = vt_ad[d] + (unsigned)(buf * TILE2);
+        const unsigned ad = vt_ad[d] + (unsigned)(buf * (STAG ? TILEV : TILE2));   // STAG: buf = slot of the V ring
 #if defined(WG_ATTN_ABL) && WG_ATTN_ABL == 7
         vt[ks][d][0] = (u32x2){ad, ad}; vt[ks][d][1] = (u32x2){ad, ad};   // ablation build: no V^T reads
         return;
@@ -523,11 +533,12 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         // a wave without a single query (the last chunk of a ragged query count: CLIP's 1025 = 32 blocks + 1 leaves three such waves in
         // every ninth workgroup): it stages its share of the K / V tiles and keeps the barriers, nothing else -- its SIMD time goes to
         // the other workgroups of the CU
-        for (int t = 0; t < nt; ++t) {
+        for (int t = 0, vn = 1; t < nt; ++t) {
             if (t + 1 < nt) {
                 stage(t + 1, (t & 1) ^ 1, false);
-                stage(t + 1, (t & 1) ^ 1, true);
+                stage(t + 1, (t & 1) ^ 1, true, vn);
             }
+            vn = vn == 2 ? 0 : vn + 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -535,6 +546,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     }
 #endif
     constexpr bool HALF_LAST = GRID && RPT > 1 && (S % RPT) != 0 && (S % RPT) * RP <= 32;
+    static_assert(!(STAG && HALF_LAST), "the staggered loop is written for the whole-tile form only");
     auto tile = [&](int t, auto half_c) __attribute__((always_inline)) {
         constexpr bool HALF = decltype(half_c)::value;
         constexpr int NE = HALF ? 16 : 32;           // score elements per lane that can hold a key
@@ -600,16 +612,29 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     } else {
         // (the same loop written out: instantiating it through the generic lambda above shifts hipcc's register allocation and one
         // head_dim-128 variant starts to spill)
+        int vcur = 0, vprev = 2;                       // STAG: ring slots of V(t) and V(t - 1)
         for (int t = 0; t < nt; ++t) {
             const int buf = t & 1;
+            const int vnext = vcur == 2 ? 0 : vcur + 1;
             WG_STAMP(0);
             if (t + 1 < nt) {
                 stage(t + 1, buf ^ 1, false);
-                stage(t + 1, buf ^ 1, true);
+                stage(t + 1, buf ^ 1, true, vnext);
+            }
+            if constexpr (STAG) {
+                if (late && t > 0) {   // P.V of the PREVIOUS tile, carried over the barrier: beside the other half's S^T / exponentials
+    #pragma unroll
+                    for (int g = 0; g < NPV; ++g) vt_pair(g, vprev);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                    for (int g = 0; g < NPV; ++g) pv_one(g);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             bias_begin(t);
     #pragma unroll
-            for (int g = 0; g < NQK; ++g) qk_read(kv + buf * TILE2, g);
+            for (int g = 0; g < NQK; ++g) qk_read(STAG ? kv + buf * TILE : kv + buf * TILE2, g);
     #pragma unroll
             for (int g = 0; g < NQK; ++g) qk_one(sa, g);
             // V^T fragments: inline-asm reads (invisible to hipcc's wait insertion), issued as early as the registers allow so that
@@ -622,16 +647,20 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
                 for (int i = 0; i < RPT; ++i) asm volatile("" : "+v"(rh[i]));
             }
             if constexpr (EARLY_VT) {
+                if (!late) {
     #pragma unroll
-                for (int g = 0; g < NPV; ++g) vt_pair(g, buf);
+                    for (int g = 0; g < NPV; ++g) vt_pair(g, STAG ? vcur : buf);
+                }
             }
             float mt = NEG_BIG;
             if (ragged && t + 1 == nt) bias_max(sa, t, 0, 32, mt, true);
             else bias_max(sa, t, 0, 32, mt, false);
             const float off = bias_end(mt);
             if constexpr (!EARLY_VT) {
+                if (!late) {
     #pragma unroll
-                for (int g = 0; g < NPV; ++g) vt_pair(g, buf);
+                    for (int g = 0; g < NPV; ++g) vt_pair(g, STAG ? vcur : buf);
+                }
             }
             WG_STAMP(1);
             probs(sa, off, 0, 32);
@@ -639,14 +668,28 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
             // O^T += V^T . P^T  (operands of the asm reads above: wait for them here, fenced from the MFMAs)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
+            if (!late) {
     #pragma unroll
-            for (int g = 0; g < NPV; ++g) pv_one(g);
+                for (int g = 0; g < NPV; ++g) pv_one(g);
+            }
+            vprev = vcur;
+            vcur = vnext;
             WG_STAMP(3);
     #if !(defined(WG_ATTN_ABL) && WG_ATTN_ABL == 5)   // (ablation build 5: no per-tile wait / barrier -- wrong results, timing only)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
     #endif
             WG_STAMP(4);
+        }
+        if constexpr (STAG) {
+            if (late && nt > 0) {   // the last tile's P.V (its V tile still sits in its ring slot: nothing was staged after it)
+    #pragma unroll
+                for (int g = 0; g < NPV; ++g) vt_pair(g, vprev);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int g = 0; g < NPV; ++g) pv_one(g);
+            }
         }
     }
 
@@ -1116,6 +1159,9 @@ static int launch_attn_impl(const AttnArgs& a, int groups, hipStream_t st) {
     constexpr int RPT = 64 / RP;
     constexpr int SP = S > 0 ? ((S + RPT - 1) / RPT) * RPT + 1 : 1;
     size_t lds = 2 * TILE;
+#if defined(WG_ATTN_STAGGER) && WG_ATTN_STAGGER
+    if (NW == 8) lds += 64 * ((HD == 80) ? 192 : 2 * (HD == 16 ? 32 : HD));   // the third V buffer of the staggered loop
+#endif
     if (S > 0) lds += (size_t)NW * 32 * SP * 4;
     else lds += (size_t)((a.Lk + 63) / 64) * 64 * 4;
     if (lds > 160 * 1024) {
