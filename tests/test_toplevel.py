@@ -449,3 +449,84 @@ def test_model_forward_confident_masks_vs_reference(dev):
     iou_h, iou_r = _iou_vs_band_gt(post, gold["post"], dev)
     assert pix >= 1.0 - 1e-3 and pix >= pixel_iou(gold["post_bf16"], gold["post"]), pix
     assert np.abs(iou_h - iou_r).max() <= 1e-3 and abs(iou_h.mean() - iou_r.mean()) <= 1e-3, (iou_h, iou_r)
+
+
+@pytest.mark.gpu
+def test_reference_validate_loop_on_the_adapter(dev):
+    """The body of the reference's `validate()` (evaluation_walkgpt.py:877-982) on the adapter: `model(**input_dict)` with the collate
+    dict in inference layout -> `pred_masks[0] > 0` against `gt_masks[0]` -> per-mask intersection / union (utils/utils.py:192-204; here
+    wg_mask_iou_f32, thresholding fused) -> the loop's gIoU / cIoU accumulators; plus the text side of the loop,
+    `generate(images=<projected SAM tokens>, ...)` as `generate_predictions_from_questions` calls it (:443-475, :569-577).  The numbers
+    are held to what the same loop gives on the REFERENCE's masks of the confident end-to-end fixture (its modules in fp32)."""
+    from tests.test_gpu_modules import _e2e_model
+    from walkgpt_amd import ops
+    from walkgpt_amd.causal_lm import walkgptForCausalLM
+    c = cases.E2ES["conf_tiny"]
+    gold = cases.load("e2e_conf_tiny")
+    g = _e2e_model(c, dev)
+    x, hid = cases.e2e_inputs(c)
+    Hh, T = hid.shape[1], hid.shape[0]
+    lm = PresetLM(V, Hh).to(dev).bfloat16()
+    model = walkgptForCausalLM(lm, grounding=g, seg_token_idx=SEG, seg_token_num=1).eval()
+    L = 12
+    ref_post = torch.from_numpy(gold["post"])
+    gt = (ref_post > 0).float()
+    gt[:, 60:90, :] = 1.0 - gt[:, 60:90, :]                           # a ground truth the masks do not match exactly
+    gt[:, :, :4] = 255.0                                              # an ignore band (utils/utils.py:197-199)
+
+    def batch():
+        ids = torch.randint(3, 50, (T, L), generator=torch.Generator().manual_seed(23))
+        ids[:, 1] = -200
+        states = torch.zeros(T, L + 255, Hh)
+        for r in range(T):                                            # one [SEG] per prompt row, as PAVEValDataset builds them
+            ids[r, 5 + r] = SEG
+            states[r, 255 + 5 + r - 1] = hid[r]
+        lm.states = states.to(dev, torch.bfloat16)
+        return dict(images=x.to(dev), images_clip=torch.zeros(1, 3, 28, 28, device=dev), input_ids=ids.to(dev), labels=ids.to(dev),
+                    attention_masks=torch.ones(T, L, dtype=torch.bool, device=dev), offset=torch.tensor([0, T], device=dev),
+                    masks_list=[gt.to(dev)], label_list=[torch.zeros(c["original"], device=dev)], resize_list=[c["resize"]],
+                    clip_resize_list=[(28, 28)], inference=True, image_paths=["synthetic.png"], questions_list=[["q"] * T])
+
+    num_classes = 2
+    acc = {k: torch.zeros(num_classes, dtype=torch.float64) for k in ("inter", "union", "giou_sum", "giou_count")}
+    ref = {k: torch.zeros(num_classes, dtype=torch.float64) for k in acc}
+
+    def accumulate(a, inter, union):                                  # evaluation_walkgpt.py:944-955
+        for inter_i, union_i in zip(inter.double().cpu(), union.double().cpu()):
+            a["inter"] += inter_i
+            a["union"] += union_i
+            gs = inter_i / (union_i + 1e-5)
+            gs[union_i == 0] += 1.0
+            a["giou_sum"] += gs
+            a["giou_count"] += 1.0
+
+    for _ in range(2):                                                # two "batches" of the loader
+        input_dict = batch()
+        input_dict["images"] = input_dict["images"].bfloat16()        # :908-910
+        input_dict["images_clip"] = input_dict["images_clip"].bfloat16()
+        with torch.no_grad():
+            output_dict = model(**input_dict)
+        pred_masks = output_dict["pred_masks"]
+        assert len(pred_masks) == 1
+        masks_list = output_dict["gt_masks"][0]
+        i_h, u_h, _ = ops.mask_iou(pred_masks[0].float().contiguous(), masks_list.float().contiguous())
+        accumulate(acc, i_h, u_h)
+        i_r, u_r, _ = ops.mask_iou(ref_post.to(dev).contiguous(), masks_list.float().contiguous())
+        accumulate(ref, i_r, u_r)
+        # the text side of the loop: projected SAM tokens as the visual input of generate()
+        toks = model.get_model().out_mm_projector(model.get_visual_embs(input_dict["images"]).flatten(2).transpose(1, 2).contiguous())
+        lm.states = None
+        lm.forward = lambda inputs_embeds=None, **kw: SimpleNamespace(                      # a language model that always answers EOS
+            logits=torch.nn.functional.one_hot(torch.full(inputs_embeds.shape[:2], EOS, device=dev), V).float(), loss=None,
+            hidden_states=(inputs_embeds,), past_key_values=None)
+        out = model.generate(images=toks.expand(T, -1, -1).contiguous(), input_ids=input_dict["input_ids"],
+                             attention_mask=input_dict["attention_masks"], max_new_tokens=8, num_beams=1, return_dict_in_generate=True,
+                             clip_resize_list=[(28, 28)] * T)
+        assert out.sequences.shape == (T, L + 1) and bool((out.sequences[:, -1] == EOS).all())
+        del lm.forward
+    giou = (acc["giou_sum"] / (acc["giou_count"] + 1e-10))[1].item()
+    ciou = (acc["inter"] / (acc["union"] + 1e-10))[1].item()
+    giou_r = (ref["giou_sum"] / (ref["giou_count"] + 1e-10))[1].item()
+    ciou_r = (ref["inter"] / (ref["union"] + 1e-10))[1].item()
+    print("validate loop on the adapter: gIoU %.5f cIoU %.5f; on the reference's masks: %.5f %.5f" % (giou, ciou, giou_r, ciou_r))
+    assert 0.5 < giou_r < 0.999 and abs(giou - giou_r) <= 1e-3 and abs(ciou - ciou_r) <= 1e-3
