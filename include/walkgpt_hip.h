@@ -158,6 +158,16 @@ int wg_layernorm_quantize_fp8(const void* x, long ldx, const void* gamma, const 
                               int M, int K, void* stream);
 int wg_gemm_fp8_bias_act(const void* Aq, long lda, const float* scale_a, const void* Wq, long ldw, const float* scale_w, const void* bias,
                          const void* residual, long ldr, int res_row_mod, void* C, long ldc, int M, int N, int K, int act, void* stream);
+/* wg_gemm_fp8_mx_bias_act: the same GEMM with OCP-MX block scales on the activation side, so that a chain of fp8 linears (the MLP of
+ * image_encoder.py:177-193 / CLIP's fc1 -> fc2) needs no quantisation pass between them.
+ *   mx_a != NULL: one E8M0 scale per 32 values of A's rows, [K/32][mx_a_pitch] bytes; inside every 128-row group row r sits at byte
+ *                 (r % 16) * 8 + r / 16 (the 8 MFMA fragments of a lane are 8 adjacent bytes).  scale_a may then be NULL (= 1.0).
+ *   mx_c != NULL: C is written as e4m3 BYTES (ldc in bytes) and its block scales (power of two at or above max|block| / 448) into mx_c
+ *                 [N/32][mx_c_pitch] in that same layout; N % 32 == 0, no residual.
+ * Pitches: bytes, multiples of 8, at least M rounded up to 256. */
+int wg_gemm_fp8_mx_bias_act(const void* Aq, long lda, const float* scale_a, const void* mx_a, long mx_a_pitch, const void* Wq, long ldw,
+                            const float* scale_w, const void* bias, const void* residual, long ldr, int res_row_mod, void* C, long ldc,
+                            void* mx_c, long mx_c_pitch, int M, int N, int K, int act, void* stream);
 
 /* mask_decoder.py:140-160 fused: `upscaled = output_upscaling(src)` (ConvT k2 s2 -> LayerNorm2d -> GELU -> ConvT k2 s2 -> GELU) and
  * `masks = hyper_in @ upscaled` in one launch; every step is local to an image token.  x [P*h*w, 256] bf16 token rows; w1 [(dy,dx,64),

@@ -101,8 +101,10 @@ class _EncoderLayer(nn.Module, _Prepared):
         q, s = ops.quantize_rows_fp8(o)
         x = ops.linear_fp8(q, s, *w["out"], bias=a.out_proj.bias, residual=x)
         q, s = ops.quantize_rows_fp8(x, ln=(self.layer_norm2.weight, self.layer_norm2.bias), eps=self.layer_norm2.eps)
-        h = ops.linear_fp8(q, s, *w["fc1"], bias=m.fc1.bias, act=ops.ACT_QUICK_GELU)
-        q, s = ops.quantize_rows_fp8(h)
+        if m.fc1.weight.shape[0] % 32 == 0:   # fc1's epilogue leaves e4m3 + MX block scales: fc2's operand, no quantisation pass between
+            q, s = ops.linear_fp8(q, s, *w["fc1"], bias=m.fc1.bias, act=ops.ACT_QUICK_GELU, mx_out=True)
+        else:
+            q, s = ops.quantize_rows_fp8(ops.linear_fp8(q, s, *w["fc1"], bias=m.fc1.bias, act=ops.ACT_QUICK_GELU))
         return ops.linear_fp8(q, s, *w["fc2"], bias=m.fc2.bias, residual=x)
 
     def run(self, x, key_bias, tail_tiles=False):

@@ -135,8 +135,11 @@ class Block(nn.Module, _Prepared):
         q, s = ops.quantize_rows_fp8(o)
         x = ops.linear_fp8(q, s, *w["proj"], bias=a.proj.bias, residual=x)
         q, s = ops.quantize_rows_fp8(x, ln=(self.norm2.weight, self.norm2.bias), eps=self.norm2.eps)
-        h = ops.linear_fp8(q, s, *w["lin1"], bias=m.lin1.bias, act=m._act_code)
-        q, s = ops.quantize_rows_fp8(h)
+        # lin1's epilogue leaves its GELU output as e4m3 + MX block scales: lin2 reads that pair directly, no quantisation pass between
+        if m.lin1.weight.shape[0] % 32 == 0:
+            q, s = ops.linear_fp8(q, s, *w["lin1"], bias=m.lin1.bias, act=m._act_code, mx_out=True)
+        else:
+            q, s = ops.quantize_rows_fp8(ops.linear_fp8(q, s, *w["lin1"], bias=m.lin1.bias, act=m._act_code))
         return ops.linear_fp8(q, s, *w["lin2"], bias=m.lin2.bias, residual=x)
 
     def rows(self, x, B, grid):
