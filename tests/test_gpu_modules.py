@@ -470,8 +470,9 @@ def test_end_to_end_confident_masks_vs_reference(dev, name):
     assert b["pix"] >= ref16["pix"] - 2e-4 and b["pix"] >= 1.0 - 1e-3, (b["pix"], ref16["pix"])
     assert b["d_iou"] <= 1e-3 and b["d_miou"] <= 1e-3, b                                    # north_star: 1e-3 mIoU
     f = res["fp8"]
-    assert f["pix"] >= 0.997 and f["d_iou"] <= 1e-3 and f["d_miou"] <= 5e-4, f              # config C5's operand type, end to end (measured:
-    #                                                         pixel IoU 0.99810, |IoU - reference's| <= 2.8e-4 per mask, 1.2e-4 on average)
+    assert f["pix"] >= 0.997 and f["d_iou"] <= 1e-3 and f["d_miou"] <= 1e-3, f              # config C5's operand type, end to end: inside
+    #   north_star's 1e-3 (measured, MX block scales in the MLP: pixel IoU 0.99818, |IoU - reference's| <= 8.9e-4 per mask, 5.1e-4 on
+    #   average; with per-row scales throughout: 0.99810 / 2.8e-4 / 1.2e-4 -- two draws of the same e4m3 rounding noise)
 
 
 def test_decoder_takes_geometries_the_fused_kernels_do_not(dev):
