@@ -165,6 +165,20 @@ int wg_gemm_fp8_bias_act(const void* Aq, long lda, const float* scale_a, const v
  *   mx_c != NULL: C is written as e4m3 BYTES (ldc in bytes) and its block scales (power of two at or above max|block| / 448) into mx_c
  *                 [N/32][mx_c_pitch] in that same layout; N % 32 == 0, no residual.
  * Pitches: bytes, multiples of 8, at least M rounded up to 256. */
+/* wg_quantize_mx_fp8: x [M,K] bf16 -> e4m3 bytes + E8M0 block scales [K/32][pitch] (rows permuted inside `group`-row groups: 128 for an
+ * activation operand, 64 for a weight operand; the rule above).
+ * wg_gemm_mxfp8: the persistent 256x256 fp8 GEMM with block scales on BOTH operands, applied inside the MFMA:
+ *   C[M,N] bf16 = act(sum_k deq(Aq)[m,k] deq(Wq)[n,k] + bias[n]) (+ residual[m % res_row_mod]).
+ *   Optional, as in the bf16 kernel it shares loop and epilogues with (wg_gemm_lnp_bias_act_bf16 / wg_gemm_bias_act_stats_bf16):
+ *   ln_colsum != NULL: LayerNorm of A's rows folded in -- Wq = the gamma-scaled weight, ln_colsum [N] the row sums of its dequantised
+ *     values, ln_bias [N] = b + W beta, ln_part [ln_np][ln_mpad][2] the {sum, sum of squares} partials of the rows Aq was quantised
+ *     from (K = 256 ln_np); stats_part != NULL (N % 256 == 0): leaves such partials for its own output; Cq != NULL (N % 32 == 0): the
+ *     stored values once more as e4m3 [M][ldcq] + block scales c_mx [N/32][c_pitch] (the next call's A operand; C may then be NULL). */
+int wg_gemm_mxfp8(const void* Aq, long lda, const void* a_mx, long a_pitch, const void* Wq, long ldw, const void* w_mx, long w_pitch,
+                  const void* bias, const float* ln_colsum, const float* ln_bias, const float* ln_part, int ln_np, long ln_mpad, float ln_eps,
+                  const void* residual, long ldr, int res_row_mod, void* C, long ldc, void* Cq, long ldcq, void* c_mx, long c_pitch,
+                  float* stats_part, long stats_mpad, int M, int N, int K, int act, void* stream);
+int wg_quantize_mx_fp8(const void* x, long ldx, void* q, long ldq, void* mx, long pitch, int group, int M, int K, void* stream);
 int wg_gemm_fp8_mx_bias_act(const void* Aq, long lda, const float* scale_a, const void* mx_a, long mx_a_pitch, const void* Wq, long ldw,
                             const float* scale_w, const void* bias, const void* residual, long ldr, int res_row_mod, void* C, long ldc,
                             void* mx_c, long mx_c_pitch, int M, int N, int K, int act, void* stream);

@@ -147,6 +147,119 @@ def test_fp8_gemm_mx_operand_exact_on_small_integers(dev, M, N, K):
     assert torch.equal(got, exact), float((got - exact).abs().max())
 
 
+def _mx_deq(q, mx, rows, group):
+    """e4m3 bytes [rows, K] + block-scale planes -> fp32 values"""
+    K = q.shape[1]
+    e = mx[:, ops.mx_scale_index(rows, mx.device, group)].float() - 127.0          # [K/32, rows]
+    return (q.view(F8).float().view(rows, K // 32, 32) * torch.exp2(e).t()[..., None]).view(rows, K)
+
+
+@pytest.mark.parametrize("M,K,group", [(300, 128, 128), (4099, 768, 128), (520, 1280, 64)])
+def test_quantize_mx_matches_the_stated_rule(dev, M, K, group):
+    x = (torch.randn(M, K, generator=torch.Generator().manual_seed(M)) * 3).to(torch.bfloat16)
+    x[:, 32:64] *= 1e-3
+    x[7] = 0
+    q, mx = ops.quantize_mx_fp8(x.to(dev), group=group)
+    q_ref, s_ref = _mx_reference(x)
+    assert torch.equal(mx[:, ops.mx_scale_index(M, dev, group)].cpu(), s_ref)
+    assert torch.equal(q.cpu(), q_ref)
+    assert rel_err(_mx_deq(q, mx, M, group).cpu().numpy(), x.float().numpy()) < 0.04
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 264, 384), (1000, 520, 1280), (2100, 1032, 256)])
+def test_mxfp8_persistent_gemm_exact_on_small_integers(dev, M, N, K):
+    """Both operands with per-(row, block) power-of-two scales on exact integer data, on the persistent kernel (several tiles per
+    workgroup at the larger shapes): a scale byte of either side that reaches the wrong row, K block, fragment or TILE changes an integer."""
+    g = torch.Generator().manual_seed(M + N + K + 2)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float()
+    w[:, ::5] = 0.0
+    ea = torch.randint(-2, 3, (K // 32, M), generator=g)
+    ew = torch.randint(-2, 3, (K // 32, N), generator=g)
+    bias = torch.randint(-8, 9, (N,), generator=g).float()
+    res = torch.randint(-8, 9, (M, N), generator=g).float()
+    pa = torch.full((K // 32, ops.mx_pitch(M)), 255, dtype=torch.uint8)              # rows past M / N: NaN scales, must never reach the output
+    pa[:, ops.mx_scale_index(M)] = (ea + 127).to(torch.uint8)
+    pw = torch.full((K // 32, ops.mx_pitch(N)), 255, dtype=torch.uint8)
+    pw[:, ops.mx_scale_index(N, group=64)] = (ew + 127).to(torch.uint8)
+    out = ops.linear_mxfp8((_q(a).to(dev), pa.to(dev)), {"q": _q(w).to(dev), "mx": pw.to(dev)}, bias=bias.to(dev, torch.bfloat16),
+                           residual=res.to(dev, torch.bfloat16))
+    a_deq = a * torch.exp2(ea.float()).t().repeat_interleave(32, dim=1)
+    w_deq = w * torch.exp2(ew.float()).t().repeat_interleave(32, dim=1)
+    ref = (a_deq.double() @ w_deq.double().t()).float() + bias
+    exact = (ref.to(torch.bfloat16).float() + res).to(torch.bfloat16).float()         # bf16 result, then the residual added in bf16
+    got = out.float().cpu()
+    assert torch.equal(got, exact), float((got - exact).abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,act", [(4096, 768, 768, 0), (1025, 3072, 768, 1), (8200, 1024, 4096, 2)])
+def test_mxfp8_persistent_linear_vs_fp32(dev, M, N, K, act):
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(torch.bfloat16)
+    r = torch.randn(M, N, generator=g).to(torch.bfloat16)
+    xq, xm = ops.quantize_mx_fp8(x.to(dev))
+    wd = ops.mx_weight(w.to(dev))
+    wq, wm = wd["q"], wd["mx"]
+    out = ops.linear_mxfp8((xq, xm), wd, bias=b.to(dev), act=act, residual=r.to(dev)).float().cpu()
+    fn = {0: lambda t: t, 1: torch.nn.functional.gelu, 2: lambda t: t * torch.sigmoid(1.702 * t)}[act]
+    same = fn(_mx_deq(xq, xm, M, 128).cpu() @ _mx_deq(wq, wm, N, 64).cpu().t() + b.float()) + r.float()
+    assert rel_err(out.numpy(), same.numpy()) < 4e-3
+    full = fn(x.float() @ w.float().t() + b.float()) + r.float()
+    e = rel_err(out.numpy(), full.numpy())
+    print("mxfp8 linear M=%d N=%d K=%d: rel err vs unquantised fp32 %.4f" % (M, N, K, e))
+    assert e < 0.05
+
+
+@pytest.mark.parametrize("M,D,H", [(4099, 768, 3072), (8200, 1280, 5120), (700, 256, 512)])
+def test_mxfp8_transformer_block_chain(dev, M, D, H):
+    """The GEMM chain of a transformer block on the persistent MX kernel, no pass between the GEMMs:
+       proj (+ residual; leaves bf16 x, its e4m3 + block-scale form and its rows' partial sums)
+       -> LayerNorm folded into lin1 (+ GELU; only the e4m3 form of the hidden layer is written) -> lin2 (+ residual, same by-products).
+    Every by-product against its definition, the chain against fp32."""
+    g = torch.Generator().manual_seed(M)
+    o = torch.randn(M, D, generator=g).to(torch.bfloat16)                       # attention output
+    x0 = (torch.randn(M, D, generator=g) * 2 + 0.5).to(torch.bfloat16)          # residual stream (non-zero mean: the fold's cancellation)
+    wp = (torch.randn(D, D, generator=g) / D ** 0.5).to(torch.bfloat16)
+    w1 = (torch.randn(H, D, generator=g) / D ** 0.5).to(torch.bfloat16)
+    w2 = (torch.randn(D, H, generator=g) / H ** 0.5).to(torch.bfloat16)
+    bp, b1, b2 = (torch.randn(n, generator=g).to(torch.bfloat16) for n in (D, H, D))
+    gam = (1 + 0.2 * torch.randn(D, generator=g)).to(torch.bfloat16)
+    bet = (0.2 * torch.randn(D, generator=g)).to(torch.bfloat16)
+    eps = 1e-6
+    x1 = ops.linear_mxfp8(ops.quantize_mx_fp8(o.to(dev)), ops.mx_weight(wp.to(dev)), bias=bp.to(dev), residual=x0.to(dev), mx_out=True, row_partials=True)
+    # by-products of the producer: MX form and partial sums of exactly the bf16 values it stored
+    q_ref, s_ref = _mx_reference(x1.cpu())
+    xq, xm = x1._wg_mx
+    assert torch.equal(xm[:, ops.mx_scale_index(M, dev)].cpu(), s_ref) and torch.equal(xq.cpu(), q_ref)
+    part = x1._wg_row_partials[0].cpu()[:, :M]                                   # [D / 256, M, 2]
+    tiles = x1.float().cpu().view(M, D // 256, 256)
+    assert torch.allclose(part[..., 0].t(), tiles.sum(-1), rtol=1e-5, atol=1e-3)
+    assert torch.allclose(part[..., 1].t(), (tiles * tiles).sum(-1), rtol=1e-5, atol=1e-3)
+    # LayerNorm folded into lin1, GELU, e4m3-only output
+    fold = ops.fold_layernorm_mx(gam.to(dev), bet.to(dev), w1.to(dev), b1.to(dev))
+    hq, hm = ops.linear_mxfp8(x1, fold, act=1, ln_eps=eps, mx_out=True, bf16_out=False)
+    xf = x1.float().cpu()
+    mean, var = xf.mean(1, keepdim=True), xf.var(1, unbiased=False, keepdim=True)
+    rstd = (var + eps).rsqrt()
+    xd = _mx_deq(xq, xm, M, 128).cpu()
+    wgd = _mx_deq(fold["q"], fold["mx"], H, 64).cpu()
+    h_same = torch.nn.functional.gelu(rstd * (xd @ wgd.t() - mean * fold["colsum"].cpu()[None]) + fold["bias_f32"].cpu()[None])
+    hd = _mx_deq(hq, hm, M, 128).cpu()
+    assert rel_err(hd.numpy(), h_same.numpy()) < 0.03                             # one e4m3 rounding of the result
+    h_full = torch.nn.functional.gelu(torch.nn.functional.layer_norm(xf, (D,), gam.float(), bet.float(), eps) @ w1.float().t() + b1.float())
+    e_h = rel_err(hd.numpy(), h_full.numpy())
+    # lin2 back onto the residual stream
+    x2 = ops.linear_mxfp8((hq, hm), ops.mx_weight(w2.to(dev)), bias=b2.to(dev), residual=x1, mx_out=True, row_partials=True)
+    y_full = h_full @ w2.float().t() + b2.float() + xf
+    e_y = rel_err(x2.float().cpu().numpy(), y_full.numpy())
+    print("mxfp8 block chain M=%d D=%d H=%d: hidden layer rel err vs fp32 %.4f, block output %.4f" % (M, D, H, e_h, e_y))
+    assert e_h < 0.06 and e_y < 0.03
+    q2, s2 = _mx_reference(x2.cpu())
+    assert torch.equal(x2._wg_mx[1][:, ops.mx_scale_index(M, dev)].cpu(), s2) and torch.equal(x2._wg_mx[0].cpu(), q2)
+
+
 def test_fp8_mlp_chain_without_a_quantise_pass(dev):
     """lin1 (GELU, MX output) -> lin2 (MX operand): the chain the encoders run, against fp32 on the unquantised operands next to the
     per-row-scale path it replaces (block scales are the finer of the two)."""

@@ -27,3 +27,18 @@ for (M, D, H) in [(32768, 1280, 5120), (32768, 768, 3072), (8200, 1024, 4096)]:
     e = t(lambda: ops.linear_fp8(mq, ms, w2q, w2s, bias=b2, residual=x))
     print("M=%d D=%d H=%d: lin1 bf16-out %.1f us (%.0f TF/s) | lin1 mx-out %.1f us (%.0f) | quantise %.1f us | lin2 row %.1f us (%.0f) | lin2 mx %.1f us (%.0f)"
           % (M, D, H, a, f1 / a / 1e6, b, f1 / b / 1e6, c, d, f2 / d / 1e6, e, f2 / e / 1e6), flush=True)
+
+# persistent MX GEMM (block scales on both operands) against the tile kernel, ViT-H / ViT-B / CLIP shapes
+print("persistent mxfp8 vs tile fp8 (no activation, residual on the square / down projections)")
+for (M, N, K, res) in [(32768, 3840, 1280, 0), (32768, 1280, 1280, 1), (32768, 5120, 1280, 0), (32768, 1280, 5120, 1),
+                       (32768, 2304, 768, 0), (32768, 768, 768, 1), (32768, 3072, 768, 0), (32768, 768, 3072, 1),
+                       (8200, 3072, 1024, 0), (8200, 1024, 1024, 1), (8200, 4096, 1024, 0), (8200, 1024, 4096, 1)]:
+    x = torch.randn(M, K, device=dev).bfloat16(); w = (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device=dev).bfloat16(); r = torch.randn(M, N, device=dev).bfloat16() if res else None
+    xq, xs = ops.quantize_rows_fp8(x); wq, ws = ops.quantize_weight_fp8(w)
+    xq2, xm = ops.quantize_mx_fp8(x); wd = ops.mx_weight(w)
+    fl = 2.0 * M * N * K
+    a = t(lambda: ops.linear_fp8(xq, xs, wq, ws, bias=b, residual=r))
+    c = t(lambda: ops.linear_mxfp8((xq2, xm), wd, bias=b, residual=r))
+    d = t(lambda: ops.linear(x, w, b, residual=r))
+    print("M=%d N=%d K=%d: tile fp8 %.1f us (%.0f TF/s) | persistent mxfp8 %.1f us (%.0f TF/s) | bf16 %.1f us (%.0f)" % (M, N, K, a, fl / a / 1e6, c, fl / c / 1e6, d, fl / d / 1e6), flush=True)

@@ -46,6 +46,11 @@ struct GemmArgs {
     unsigned char* mx_c = nullptr;         // fp8 kernel, MX result: C is written as e4m3 bytes (ldc in bytes) with its block scales in the same
     long mx_c_pitch = 0;                   //   layout [N/32][mx_c_pitch] -- the next GEMM's mx_a
     unsigned mx_c_bytes = 0;
+    const unsigned char* mx_w = nullptr;   // persistent fp8 kernel: the weights' block scales, [K/32][mx_w_pitch], rows of a 64-row group at
+    long mx_w_pitch = 0;                   //   (row % 16) * 4 + row / 16 (a lane's 4 column fragments = one dword)
+    void* Cq = nullptr;                    // persistent fp8 kernel: the stored values once more as e4m3 bytes [M][ldcq] with block scales mx_c
+    long ldcq = 0;                         //   (the next fp8 GEMM's A operand); C itself may then be null (c_bytes 0: its stores are dropped)
+    unsigned cq_bytes = 0;
     const bf16* sk_gamma;        // skinny kernel only: LayerNorm(A) applied to the rows on their way into the MFMA (gamma, beta [K], eps)
     const bf16* sk_beta;
     float sk_eps;
@@ -371,19 +376,19 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
         // cluster 0 starts -- the loop's own counted wait in its first M half-phase covers them
         WG_TSTAMP(0);
         // MX operand (fp8): the 8 block scales of this lane's A fragments for K block 4*kt + fq are 8 adjacent bytes, one dword per
-        // cluster.  Each dword is fetched one M half-phase before the one that precedes its MFMAs (raw asm loads: the counted waits are
-        // the only synchronisation; the register of cluster c is dead from the end of its C half-phase).  Without MX both hold E8M0
-        // 127 = 1.0.
-        unsigned sa0 = 0x7F7F7F7Fu, sa1 = 0x7F7F7F7Fu;
+        // cluster.  Each dword is fetched one M half-phase before the one that precedes its MFMAs.  Plain loads, so that hipcc itself
+        // orders every use (and every register copy it makes) behind the data's arrival -- as raw asm loads under the counted waits
+        // alone, a compiler-made copy of the destination register ran ahead of the wait.  Its own waits come out no stricter than the
+        // counted ones (memory operations retire in issue order).  Without MX both hold E8M0 127 = 1.0.
+        unsigned sa0 = 0x7F7F7F7Fu, sa1 = 0x7F7F7F7Fu, sa0_next = 0x7F7F7F7Fu;
         const unsigned sw1 = 0x7F7F7F7Fu;                        // the weights' block scale: 1.0 (their scale is per output channel, fp32)
         const bool mxa = FP8 && g.mx_a != nullptr;
         const unsigned char* sab = g.mx_a;                       // wave-uniform: advances by four scale planes per slab
         const long sa_step = 4 * g.mx_a_pitch;
-        const int sa_off = fq * (int)g.mx_a_pitch + m0 + wm * WTM + fr * 8;
-        if (mxa) asm volatile("global_load_dword %0, %1, %2" : "=v"(sa0) : "v"(sa_off), "s"(sab) : "memory");
+        const unsigned sa_off = (unsigned)(fq * (int)g.mx_a_pitch + m0 + wm * WTM + fr * 8);
+        if (mxa) sa0_next = *(const unsigned*)(sab + sa_off);
         piece(0, 0); piece(0, 1); piece(0, 2); piece(0, 3);
         wg_wait_vmcnt<2>();
-        asm volatile("" : "+v"(sa0));
         __builtin_amdgcn_s_barrier();
         WG_TSTAMP(1);
         if (grp == 1) __builtin_amdgcn_s_barrier();
@@ -403,10 +408,12 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
                     else piece(kt + 1, 3);
                 }
                 if (mxa) {
-                    if (sc == 0) asm volatile("global_load_dword %0, %1, %2 offset:4" : "=v"(sa1) : "v"(sa_off), "s"(sab) : "memory");
-                    else if (more) {
+                    if (sc == 0) {
+                        sa0 = sa0_next;
+                        sa1 = *(const unsigned*)(sab + sa_off + 4);
+                    } else if (more) {
                         sab += sa_step;
-                        asm volatile("global_load_dword %0, %1, %2" : "=v"(sa0) : "v"(sa_off), "s"(sab) : "memory");
+                        sa0_next = *(const unsigned*)(sab + sa_off);
                     }
                 }
                 // sc 0: the late A rows of THIS slab (sent in the previous slab's sc 1) must be in before sc 1 reads them;
@@ -415,11 +422,9 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
                 if (sc == 0) {
                     if (more) { if (mxa) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); }
                     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    asm volatile("" : "+v"(sa0));
                 } else {
                     if (more) { if (mxa) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); }
                     else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    asm volatile("" : "+v"(sa1));
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 WG_GSTAMP(1);
@@ -1190,6 +1195,18 @@ __device__ __forceinline__ void wg_stats_combine(const float* spart, int tid, fl
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, o2), srs, tid >= 256 ? (int)0x80000000 : (row_off + r) * 8, 0, 0);
 }
 
+// One block-scaled fp8 MFMA with both operands' E8M0 scales taken from byte J of `sw` (SrcA = weights) and byte I of `sa` (SrcB =
+// activations).  Volatile asm: see wg_gemm_kernel (the builtin's cluster gets sunk out of its half-phase).
+template <int I, int J>
+__device__ __forceinline__ void wg_mx_mfma(f32x4& acc, const i32x8& w8, const i32x8& a8, unsigned sw, unsigned sa) {
+    asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 op_sel:[%5,%6,0] op_sel_hi:[%7,%8,0]"
+                 : "+v"(acc) : "v"(w8), "v"(a8), "v"(sw), "v"(sa), "n"(J & 1), "n"(I & 1), "n"(J >> 1), "n"(I >> 1));
+}
+__device__ __forceinline__ i32x8 wg_i32x8_of(bf16x8 lo, bf16x8 hi) {
+    const u32x4 a = __builtin_bit_cast(u32x4, lo), b = __builtin_bit_cast(u32x4, hi);
+    return (i32x8){(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Persistent 256x256 tiles with the two-cluster ping-pong loop of wg_gemm_kernel (bf16 output, staged epilogue).
 // Tile-level stamps on the K = 768 shapes put 5 % of a tile's life into the first-slab latency and ~6 % into waiting for
@@ -1211,16 +1228,20 @@ __device__ __forceinline__ void wg_stats_combine(const float* spart, int tid, fl
 //     the sums are taken from the packed registers that feed a slab's stores (two v_dot2c per bf16 pair) while the residual
 //     registers are free, cross the waves through 8 KiB of LDS, and leave as ONE 8-byte store per row and tile behind the next
 //     tile's first barrier.
-template <int LNMODE, bool STATS>
+//   * FP8: e4m3 operands with OCP-MX block scales on BOTH sides (GemmArgs::mx_a, mx_w), applied by the MFMA itself -- the
+//     accumulators come out dequantised and every epilogue above runs unchanged.  The scale bytes of a slab travel like its operands:
+//     by LDS-DMA with the early pieces of slab kt+1 (7 operations stay in flight at the first counted wait instead of 6).
+template <int LNMODE, bool STATS, bool FP8 = false>
 __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) {
     constexpr bool LN = LNMODE != 0;
-    constexpr bool FP8 = false;   // (the fp8 operands of wg_gemm_kernel<..., FP8 = true> share this loop's source; bf16 only here)
     constexpr int BM = 256, BN = 256, BK = 64, WN = 4;
     constexpr int WTM = 128, WTN = 64, FJ = 4;
     constexpr int ROWB = 128, STAGE = (BM + BN) * ROWB, RPI = 8, RPR = 64;   // RPR: rows per LDS-DMA round of the 8 waves
     constexpr int SROW = WTN * 2 + 16, CH = 8, RPS = 8;
     constexpr int NIT = 64 / RPS;                        // store instructions per 64-row slab
-    constexpr int NSTORE = (WTM / 64) * NIT;             // ... per wave per tile
+    // ... per wave per tile.  FP8: + the same rows as e4m3 (8 bytes per lane) and two scale dwords per slab, issued whether or not an MX
+    // copy was asked for (null descriptors drop them): the tile loop's counted waits need a fixed number of operations per tile
+    constexpr int NSTORE = (WTM / 64) * NIT + (FP8 ? (WTM / 64) * (NIT + 2) : 0);
     constexpr int SLAB = 64 * SROW;
     constexpr int FIT = STAGE / SLAB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1231,6 +1252,13 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
     const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 15, fq = lane >> 4;
     const int grp = wm;
+    // the lane id, re-derived where the tile loop needs it outside the main loop (two VALU instructions) instead of being kept in a
+    // register across it: every instance sits at the 256-register limit
+    auto lane_now = [&]() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
     char* stg = wave < FIT ? smem + STAGE + wave * SLAB : smem + 2 * STAGE + (wave - FIT) * SLAB;
     char* biasbuf = smem + 2 * STAGE + SLAB;   // [2][256] bf16, double-buffered by tile parity
 
@@ -1247,10 +1275,11 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
     const bf16* srcA[4];
     const bf16* srcW[4];
     auto set_sources = [&](int m0, int n0) {
+        const int ln = FP8 ? lane_now() : lane;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = i * RPR + wave * RPI + (lane >> 3);
-            const int c = (lane & 7) ^ wg_swz<BK>(r);
+            const int r = i * RPR + wave * RPI + (ln >> 3);
+            const int c = (ln & 7) ^ wg_swz<BK>(r);
             int ga = m0 + r, gw = n0 + r;
             ga = ga < g.M ? ga : g.M - 1;
             gw = gw < g.N ? gw : g.N - 1;
@@ -1279,7 +1308,21 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
     // stats[] right behind the tile's first barrier, many barriers before the next DMA into it).  STATS: + part[256][4][2] f32.
     char* const rawbuf = biasbuf + 2 * EPIB;
     float* const spart = (float*)(biasbuf + 2 * EPIB);
+    // FP8: the block scales of a slab -- 4 planes x 256 rows of A, 4 planes x 256 rows of W, one byte each -- ride the operands' LDS-DMA
+    // pipeline: one more 4-byte-per-lane DMA per wave and slab (waves 0-3: A plane `wave`, waves 4-7: W plane `wave - 4`) into
+    // mxbuf[slab parity][2 KiB], sent with the early pieces, read back as one dword per cluster (A) / per slab (W) in the M half-phases.
+    // (As raw global loads into registers under the counted waits, hipcc's own copies of the destination registers ran ahead of the
+    // data; as plain loads it drained the whole queue -- vmcnt(0) -- at every loop edge.)
+    char* const mxbuf = biasbuf + 2 * EPIB + (LNMODE == 2 ? 5 * 2048 : 0) + (STATS ? 256 * 4 * 8 : 0);
+    // (addresses: wave-uniform base + lane * 4, the lane id re-derived where it is needed -- nothing of this may stay in a VGPR across the
+    // main loop: the bf16 instances already sit at the 256-register limit, and a spilled register's reload is a VMEM operation that makes
+    // hipcc drain the whole queue)
+    auto scale_piece = [&](int tm0, int tn0, int kt) {
+        const unsigned char* ub = wave < 4 ? g.mx_a + (long)(4 * kt + wave) * g.mx_a_pitch + tm0 : g.mx_w + (long)(4 * kt + wave - 4) * g.mx_w_pitch + tn0;
+        __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(ub + (unsigned)(lane_now() * 4)), WG_LDS_PTR(mxbuf + (kt & 1) * 2048 + wave * 256), 4, 0, 0);
+    };
     auto first_slab = [&](int m0, int n0, int par) {
+        const int lane = FP8 ? lane_now() : (tid & 63);   // (shadows the kernel's: see lane_now)
         if (LN) {
             if (wave == 0) {
                 int n = n0 + lane * 4;
@@ -1312,10 +1355,13 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
             n = n + 8 <= g.N ? n : 0;             // columns past N are never stored
             __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(g.bias + n), WG_LDS_PTR(biasbuf + par * 512), 16, 0, 0);
         }
+        if constexpr (FP8) scale_piece(m0, n0, 0);
         piece(0, 0); piece(0, 1); piece(0, 2); piece(0, 3);
     };
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.c_bytes, WG_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.R, 0, g.r_bytes, WG_RSRC_FLAGS);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(g.Cq, 0, g.cq_bytes, WG_RSRC_FLAGS);
+    [[maybe_unused]] const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)g.mx_c, 0, g.mx_c_bytes, WG_RSRC_FLAGS);
     int sp_off = 0;    // STATS: row index (tile column * mpad + first row) of the tile whose row sums sit in spart
 
     int v = blockIdx.x;
@@ -1334,6 +1380,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
 #pragma unroll
             for (int j = 0; j < FJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
         bf16x8 af[4][2], wf2[2][2][2];
+        [[maybe_unused]] unsigned sb = 0x7F7F7F7Fu, swc = 0x7F7F7F7Fu;   // FP8: the clusters' A scales (byte i = fragment i) / the slab's W scales (byte j)
         auto read_a = [&](const char* ldsA, int ci) {
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -1358,7 +1405,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
         if constexpr (LNMODE == 2) {
             // this tile's row statistics from the partial sums that arrived with its first slab:  mean = S / K,
             // var = Q / K - mean^2 (fp32 sums of bf16 values; |mean| stays within a few sigma on a residual stream), rstd = (var + eps)^-1/2
-            int ct = tid;
+            int ct = FP8 ? wave * 64 + lane_now() : tid;
             asm volatile("" : "+v"(ct));
             if (ct < 256) {
                 float S = 0.f, Q = 0.f;
@@ -1367,7 +1414,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                     const f32x2 v = *(const f32x2*)(rawbuf + p * 2048 + ct * 8);
                     S += v.x; Q += v.y;
                 }
-                const float invk = 1.0f / (float)g.K;
+                const float invk = 1.0f / (float)(FP8 ? 2 * g.K : g.K);     // (fp8: g.K counts byte pairs)
                 const float mean = S * invk;
                 const float var = fmaxf(Q * invk - mean * mean, 0.f);
                 *(f32x2*)(biasbuf + par * EPIB + 2048 + ct * 8) = (f32x2){mean, __builtin_amdgcn_rsqf(var + g.ln_eps)};
@@ -1375,7 +1422,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
         }
         if constexpr (STATS) {
             // the previous tile's row sums: the four column waves' shares meet here (their LDS writes are behind the barrier above)
-            if (stores_in_flight) wg_stats_combine(spart, tid, g.stats_part, g.tiles_n * g.stats_mpad, sp_off);
+            if (stores_in_flight) wg_stats_combine(spart, FP8 ? wave * 64 + lane_now() : tid, g.stats_part, g.tiles_n * g.stats_mpad, sp_off);
         }
         if (grp == 1) __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nk; ++kt) {
@@ -1390,30 +1437,40 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                     if (sc == 0) { piece(kt + 1, 0); piece(kt + 1, 1); piece(kt + 1, 2); }
                     else piece(kt + 1, 3);
                 }
+                if constexpr (FP8) {
+                    const char* mxs = mxbuf + (kt & 1) * 2048;
+                    const int ol = lane_now();
+                    sb = *(const unsigned*)(mxs + (ol >> 4) * 256 + wm * WTM + (ol & 15) * 8 + 4 * sc);
+                    if (sc == 0) {
+                        swc = *(const unsigned*)(mxs + 1024 + (ol >> 4) * 256 + wn * WTN + (ol & 15) * 4);
+                        if (more) scale_piece(m0, n0, kt + 1);
+                    }
+                }
                 if (sc == 0) {
                     // late A rows of this slab must be in.  In slab 0 they are (first-slab wait above) and the queue may still hold
                     // the previous tile's stores in front of the six pieces just sent: do not wait for those here.
                     if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                     else if (kt == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    else if (FP8) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory");
                     else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
                 } else {
-                    if (more) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_s_setprio(1);
                 if constexpr (FP8) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const u32x4 a0 = __builtin_bit_cast(u32x4, af[i][0]), a1 = __builtin_bit_cast(u32x4, af[i][1]);
-                        const i32x8 a8 = {(int)a0[0], (int)a0[1], (int)a0[2], (int)a0[3], (int)a1[0], (int)a1[1], (int)a1[2], (int)a1[3]};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const u32x4 w0 = __builtin_bit_cast(u32x4, wf2[j >> 1][j & 1][0]), w1 = __builtin_bit_cast(u32x4, wf2[j >> 1][j & 1][1]);
-                            const i32x8 w8 = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
-                            acc[4 * sc + i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(w8, a8, acc[4 * sc + i][j], 0, 0, 0, 0x7F7F7F7F, 0, 0x7F7F7F7F);
-                        }
-                    }
+                    const i32x8 w0 = wg_i32x8_of(wf2[0][0][0], wf2[0][0][1]), w1 = wg_i32x8_of(wf2[0][1][0], wf2[0][1][1]);
+                    const i32x8 w2 = wg_i32x8_of(wf2[1][0][0], wf2[1][0][1]), w3 = wg_i32x8_of(wf2[1][1][0], wf2[1][1][1]);
+#define WG_MX_ROW(I)                                                                                                          \
+    {                                                                                                                         \
+        const i32x8 a8 = wg_i32x8_of(af[I][0], af[I][1]);                                                                     \
+        wg_mx_mfma<I, 0>(acc[4 * sc + I][0], w0, a8, swc, sb); wg_mx_mfma<I, 1>(acc[4 * sc + I][1], w1, a8, swc, sb);         \
+        wg_mx_mfma<I, 2>(acc[4 * sc + I][2], w2, a8, swc, sb); wg_mx_mfma<I, 3>(acc[4 * sc + I][3], w3, a8, swc, sb);         \
+    }
+                    WG_MX_ROW(0) WG_MX_ROW(1) WG_MX_ROW(2) WG_MX_ROW(3)
+#undef WG_MX_ROW
                 } else {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks)
@@ -1437,6 +1494,11 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
         // opaque copies of the lane coordinates: keeps hipcc from hoisting the epilogue's tile-invariant address arithmetic
         // out of the tile loop, where it would stay live across the main loop
         int el = lane, efr = fr, efq = fq;
+        if constexpr (FP8) {
+            el = lane_now();
+            efr = el & 15;
+            efq = el >> 4;
+        }
         asm volatile("" : "+v"(el), "+v"(efr), "+v"(efq));
         float bv[FJ][4];
         if (!LN) {
@@ -1536,11 +1598,61 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                             *(f32x2*)(spart + ((wm * WTM + half * 64 + it * RPSl + (el >> 3)) * 4 + wn) * 2) = (f32x2){sv, qv};
                     }
                 }
+                // FP8, MX copy: the final values go back into the wave's slab (same 16 bytes this lane took them from) and are turned into
+                // e4m3 + block scales one row segment at a time AFTER the bf16 stores, when their 32 registers are free -- done from the
+                // registers in the store loop this cost 16-86 spilled registers, and a spill's reload is a VMEM operation the counted
+                // waits do not know about.
+                [[maybe_unused]] const bool mxc = FP8 && g.mx_c != nullptr;
+                if constexpr (FP8) {
+                    if (mxc) {
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) *(u32x4*)(stg + (it * RPSl + el / CH) * SROW + (el % CH) * 16) = t[it];
+                    }
+                }
                 if (HAS_R && half + 1 < WTM / 64) wg_load_residual<CH, NIT>(rres, rrs, (int)g.ldr, g.res_mod, cm0 + wm * WTM + (half + 1) * 64, nbase, el);
                 const int n = nbase + (el % CH) * 8;
                 const int off0 = n < g.N ? ((cm0 + wm * WTM + half * 64 + el / CH) * (int)g.ldc + n) * 2 : (int)0x80000000;
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) __builtin_amdgcn_raw_buffer_store_b128(t[it], crs, off0 + it * RPSl * (int)g.ldc * 2, 0, WG_GEMM_C_AUX);
+                if constexpr (FP8) {
+                    // one E8M0 scale per (row, 32 columns): the rule and the scale layout of wg_flush_slab_mx; the four lanes of a quad
+                    // hold one block of a row.  Without an MX copy the same stores leave with null descriptors (fixed count per tile).
+                    const int qoff0 = n < g.N ? (cm0 + wm * WTM + half * 64 + el / CH) * (int)g.ldcq + n : (int)0x80000000;
+                    unsigned se = 0, so = 0;
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        u32x2 q = {0u, 0u};
+                        if (mxc) {
+                            const u32x4 tv = *(const u32x4*)(stg + (it * RPSl + el / CH) * SROW + (el % CH) * 16);
+                            float am = 0x1p-100f;
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                am = fmaxf(am, fmaxf(fabsf(__builtin_bit_cast(float, tv[k] << 16)), fabsf(__builtin_bit_cast(float, tv[k] & 0xFFFF0000u))));
+                            am = fmaxf(am, WG_DPP(am, 0xB1));
+                            am = fmaxf(am, WG_DPP(am, 0x4E));
+                            const unsigned bits = __builtin_bit_cast(unsigned, am * (1.0f / 448.0f));
+                            unsigned e8 = (bits >> 23) + ((bits & 0x7FFFFFu) ? 1u : 0u);
+                            e8 = e8 > 253u ? 253u : e8;
+                            const float inv = __builtin_bit_cast(float, (254u - e8) << 23);
+#define WG_LO(k) (__builtin_bit_cast(float, tv[k] << 16) * inv)
+#define WG_HI(k) (__builtin_bit_cast(float, tv[k] & 0xFFFF0000u) * inv)
+                            int lo = 0, hi = 0;
+                            lo = __builtin_amdgcn_cvt_pk_fp8_f32(WG_LO(0), WG_HI(0), lo, false);
+                            lo = __builtin_amdgcn_cvt_pk_fp8_f32(WG_LO(1), WG_HI(1), lo, true);
+                            hi = __builtin_amdgcn_cvt_pk_fp8_f32(WG_LO(2), WG_HI(2), hi, false);
+                            hi = __builtin_amdgcn_cvt_pk_fp8_f32(WG_LO(3), WG_HI(3), hi, true);
+#undef WG_LO
+#undef WG_HI
+                            q = (u32x2){(unsigned)lo, (unsigned)hi};
+                            if (it & 1) so |= e8 << (8 * (it >> 1));
+                            else se |= e8 << (8 * (it >> 1));
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b64(q, qrs, qoff0 + it * RPSl * (int)g.ldcq, 0, 0);
+                    }
+                    const int soff = (n < g.N && (el & 3) == 0) ? (n >> 5) * (int)g.mx_c_pitch + cm0 + wm * WTM + (el / CH) * 8 + 4 * half : (int)0x80000000;
+                    __builtin_amdgcn_raw_buffer_store_b32(se, srs, soff, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(so, srs, soff + 64, 0, 0);
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
             }
@@ -1556,7 +1668,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
     }
     if constexpr (STATS) {   // the last tile's row sums
         __syncthreads();
-        wg_stats_combine(spart, tid, g.stats_part, g.tiles_n * g.stats_mpad, sp_off);
+        wg_stats_combine(spart, FP8 ? wave * 64 + lane_now() : tid, g.stats_part, g.tiles_n * g.stats_mpad, sp_off);
     }
 }
 
@@ -1574,7 +1686,7 @@ static int launch_pp_persist(GemmArgs& g, hipStream_t st) {
     constexpr int base = 2 * stage + (8 - stage / slab) * slab;
     // + the double-buffered bias row / LayerNorm operands, the raw partial sums of the next tile (mode 2), the row-sum exchange (STATS)
     constexpr int lds_plain = base + 2 * 512, lds_stats = base + 2 * 512 + 256 * 4 * 8, lds_ln = base + 2 * 4096, lds_lnp = base + 2 * 4096 + 5 * 2048;
-    static_assert(lds_lnp <= 160 * 1024 && lds_stats <= 160 * 1024, "LDS budget of the persistent GEMM");
+    static_assert(lds_lnp + 4096 <= 160 * 1024 && lds_stats + 4096 <= 160 * 1024, "LDS budget of the persistent GEMM");
     static WgPerDevice once;
     int dev = 0;
     if (once.first(&dev)) {   // the attribute is per device (a process may drive several)
@@ -1582,11 +1694,18 @@ static int launch_pp_persist(GemmArgs& g, hipStream_t st) {
         (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_stats);
         (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_ln);
         (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_lnp);
+        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_plain + 4096);
+        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_stats + 4096);
+        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_lnp + 4096);
     }
     const int nwg = g.tiles_m * g.tiles_n;
     const int cus = wg_cu_count(dev);
     const int grid = nwg < cus ? nwg : cus;   // one resident workgroup per CU; a multiple of 8 keeps a workgroup's tiles on one XCD
-    if (g.ln_part) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<2, false>), dim3(grid), dim3(512), lds_lnp, st, g);
+    if (g.mx_w) {   // fp8 operands with MX block scales: the same three epilogue flavours (4 KiB more LDS for the slabs' scale bytes)
+        if (g.ln_part) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<2, false, true>), dim3(grid), dim3(512), lds_lnp + 4096, st, g);
+        else if (g.stats_part) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<0, true, true>), dim3(grid), dim3(512), lds_stats + 4096, st, g);
+        else hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<0, false, true>), dim3(grid), dim3(512), lds_plain + 4096, st, g);
+    } else if (g.ln_part) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<2, false>), dim3(grid), dim3(512), lds_lnp, st, g);
     else if (g.ln_stats) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<1, false>), dim3(grid), dim3(512), lds_ln, st, g);
     else if (g.stats_part) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<0, true>), dim3(grid), dim3(512), lds_stats, st, g);
     else hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<0, false>), dim3(grid), dim3(512), lds_plain, st, g);
@@ -1820,6 +1939,63 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
 // Aq [M,K] and Wq [N,K] are e4m3 bytes, K-contiguous, produced by wg_quantize_rows_fp8 (activations: per call; weights: once).
 // Runs the 256x256 ping-pong kernel with block-scaled MFMAs (see wg_gemm_kernel<..., FP8 = true>); K % 128 == 0 (one 128-byte slab),
 // leading dimensions multiples of 16 bytes.
+// Persistent 256x256 fp8 GEMM with OCP-MX block scales on both operands (wg_gemm_pp_persist_kernel<.., FP8 = true>):
+//   C[M,N] bf16 = act(sum_k deq(Aq)[m,k] deq(Wq)[n,k] + bias[n]) (+ residual),  deq(x)[r,k] = e4m3(x[r,k]) * 2^(mx[k / 32][pos(r)] - 127).
+// Aq [M,K], Wq [N,K] e4m3 bytes; a_mx [K/32][a_pitch] in the 128-row-group layout of GemmArgs::mx_a, w_mx [K/32][w_pitch] in the
+// 64-row-group layout of GemmArgs::mx_w (both written by wg_quantize_mx_fp8 or by a producing GEMM's epilogue).  Optional, as in the
+// bf16 kernel it shares its loop and epilogues with:
+//   * LayerNorm of A's rows folded in (ln_colsum != null): Wq holds the gamma-scaled weight, ln_colsum [N] the row sums of its
+//     DEQUANTISED values, ln_bias [N] = b + W beta (fp32; `bias` unused), ln_part [ln_np][ln_mpad][2] the {sum, sum of squares} partials
+//     of the rows of the bf16 tensor Aq was quantised from (left by the GEMM that produced it); K = ln_np * 256;
+//   * stats_part != null (N % 256 == 0): this GEMM leaves those partials for its own output;
+//   * Cq != null (N % 32 == 0): the stored values once more as e4m3 [M][ldcq] + block scales c_mx [N/32][c_pitch] -- the A operand of
+//     the next call; C may then be null (MLP hidden layer: only the fp8 form is ever read).
+extern "C" int wg_gemm_mxfp8(const void* Aq, long lda, const void* a_mx, long a_pitch, const void* Wq, long ldw, const void* w_mx, long w_pitch,
+                             const void* bias, const float* ln_colsum, const float* ln_bias, const float* ln_part, int ln_np, long ln_mpad,
+                             float ln_eps, const void* residual, long ldr, int res_row_mod, void* C, long ldc, void* Cq, long ldcq, void* c_mx,
+                             long c_pitch, float* stats_part, long stats_mpad, int M, int N, int K, int act, void* stream) {
+    WG_REQUIRE(Aq && Wq && (C || Cq) && a_mx && w_mx, "gemm_mxfp8: null operand");
+    WG_REQUIRE(M > 0 && N > 0 && K > 0 && K % 128 == 0, "gemm_mxfp8: K = %d must be a positive multiple of 128", K);
+    WG_REQUIRE(act >= 0 && act <= 3, "gemm_mxfp8: bad activation %d", act);
+    WG_REQUIRE(lda >= K && ldw >= K && (!C || ldc >= N) && lda % 16 == 0 && ldw % 16 == 0, "gemm_mxfp8: leading dimensions must cover the row and be multiples of 16");
+    WG_REQUIRE(N % 8 == 0 && ldc % 8 == 0 && (!residual || (ldr >= N && ldr % 8 == 0)), "gemm_mxfp8: N, ldc, ldr must be multiples of 8");
+    WG_REQUIRE((((uintptr_t)Aq | (uintptr_t)Wq | (uintptr_t)C) & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0) &&
+                   (!residual || ((uintptr_t)residual & 15) == 0) && (((uintptr_t)a_mx | (uintptr_t)w_mx) & 3) == 0, "gemm_mxfp8: misaligned operand");
+    WG_REQUIRE((long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31), "gemm_mxfp8: operand larger than 2 GiB");
+    const long mpad = ((long)M + 255) / 256 * 256, npad = ((long)N + 255) / 256 * 256;
+    WG_REQUIRE(a_pitch >= mpad && a_pitch % 4 == 0 && w_pitch >= npad && w_pitch % 4 == 0 && (K / 32) * a_pitch < (1L << 31) && (K / 32) * w_pitch < (1L << 31),
+               "gemm_mxfp8: scale pitches must be multiples of 4 covering M, N rounded up to 256 (%ld, %ld)", mpad, npad);
+    WG_REQUIRE(!ln_colsum || (ln_bias && ln_part && ln_np >= 1 && ln_np <= 5 && ln_np * 256 == K && ln_mpad % 256 == 0 && ln_mpad >= M && N % 4 == 0 &&
+                              (((uintptr_t)ln_colsum | (uintptr_t)ln_bias | (uintptr_t)ln_part) & 15) == 0),
+               "gemm_mxfp8: folded LayerNorm needs colsum, bias, partial sums in K / 256 = %d planes of a multiple-of-256 pitch covering M", K / 256);
+    WG_REQUIRE(!stats_part || (N % 256 == 0 && stats_mpad % 256 == 0 && stats_mpad >= M && !ln_colsum), "gemm_mxfp8: row partials need N %% 256 == 0 and a pitch covering M (not together with a folded LayerNorm)");
+    WG_REQUIRE(!Cq || (c_mx && N % 32 == 0 && ldcq >= N && ldcq % 8 == 0 && c_pitch >= mpad && c_pitch % 4 == 0 && ((uintptr_t)Cq & 7) == 0 && ((uintptr_t)c_mx & 3) == 0),
+               "gemm_mxfp8: the fp8 copy needs N %% 32 == 0, ldcq %% 8 == 0 and a scale pitch covering %ld rows", mpad);
+    GemmArgs g;
+    g.A = (const bf16*)Aq; g.lda = lda / 2; g.W = (const bf16*)Wq; g.ldw = ldw / 2;      // the kernel counts 2-byte elements: byte PAIRS
+    g.bias = (const bf16*)bias; g.R = (const bf16*)residual; g.ldr = ldr; g.res_mod = res_row_mod;
+    g.C = C; g.ldc = C ? ldc : 0; g.M = M; g.N = N; g.K = K / 2; g.act = act; g.out_f32 = 0;
+    g.tiles_m = g.tiles_n = 0;
+    g.col_block = 0;
+    g.ln_stats = nullptr; g.ln_s = ln_colsum; g.ln_b = ln_bias;
+    g.ln_part = ln_colsum ? ln_part : nullptr; g.ln_np = ln_np; g.ln_mpad = ln_mpad; g.ln_eps = ln_eps;
+    g.stats_part = stats_part; g.stats_mpad = stats_mpad;
+    g.scale_a = g.scale_w = nullptr;
+    g.mx_a = (const unsigned char*)a_mx; g.mx_a_pitch = a_pitch; g.mx_w = (const unsigned char*)w_mx; g.mx_w_pitch = w_pitch;
+    g.Cq = Cq; g.ldcq = ldcq; g.mx_c = (unsigned char*)(Cq ? c_mx : nullptr); g.mx_c_pitch = c_pitch;
+    g.sk_gamma = g.sk_beta = nullptr; g.sk_eps = 0.f; g.sk_tiled = 0;
+    const long cb = C ? ((long)(M - 1) * ldc + N) * 2 : 0;
+    const long rrows = res_row_mod > 0 ? (res_row_mod < M ? res_row_mod : M) : M;
+    const long rb = residual ? ((rrows - 1) * ldr + N) * 2 : 0;
+    const long qb = Cq ? (long)(M - 1) * ldcq + N : 0, sb = Cq ? (long)(N / 32) * c_pitch : 0;
+    WG_REQUIRE(cb < (1L << 31) && rb < (1L << 31) && qb < (1L << 31) && sb < (1L << 31), "gemm_mxfp8: output larger than 2 GiB");
+    g.c_bytes = (unsigned)cb;
+    g.r_bytes = (unsigned)rb;
+    g.cq_bytes = (unsigned)qb;
+    g.mx_c_bytes = (unsigned)sb;
+    return launch_pp_persist(g, (hipStream_t)stream);
+}
+
 extern "C" int wg_gemm_fp8_mx_bias_act(const void* Aq, long lda, const float* scale_a, const void* mx_a, long mx_a_pitch, const void* Wq,
                                        long ldw, const float* scale_w, const void* bias, const void* residual, long ldr, int res_row_mod,
                                        void* C, long ldc, void* mx_c, long mx_c_pitch, int M, int N, int K, int act, void* stream);

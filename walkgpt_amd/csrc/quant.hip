@@ -99,7 +99,58 @@ int launch(bool ln, const void* x, long ldx, const void* gamma, const void* beta
     return wg_check_launch("wg_quantize_rows_fp8");
 }
 
+// x [M,K] bf16 -> e4m3 bytes [M,K] + one E8M0 scale per (row, 32 columns): the power of two at or above max|block| / 448 (the rule of
+// the GEMM epilogue's MX output, gemm.hip wg_flush_slab_mx).  Scale planes [K/32][pitch]; inside every `group`-row group (128: the A
+// side of the MX GEMMs, 8 MFMA fragments per lane; 64: the W side, 4 fragments) row r sits at (r % 16) * (group / 16) + r / 16.
+// A lane takes 8 adjacent columns of a row, four lanes one block, 16 rows per 256-thread workgroup pass; HBM-bound (3 bytes / value).
+__global__ __launch_bounds__(256) void wg_quantize_mx_kernel(const bf16* x, long ldx, unsigned char* q, long ldq, unsigned char* mx, long pitch,
+                                                             int group, int M, int K) {
+    const int cpr = K / 8;                                  // 8-column pieces per row
+    const long total = (long)M * cpr;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int row = (int)(idx / cpr), c = (int)(idx % cpr) * 8;
+        const bf16x8 t = *(const bf16x8*)(x + (long)row * ldx + c);
+        float v[8];
+        float am = 0x1p-100f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = (float)t[e];
+            am = fmaxf(am, fabsf(v[e]));
+        }
+        am = fmaxf(am, WG_DPP(am, 0xB1));                   // K % 32 == 0: the four lanes of a block are one aligned quad, all active
+        am = fmaxf(am, WG_DPP(am, 0x4E));
+        const unsigned bits = __builtin_bit_cast(unsigned, am * (1.0f / E4M3_MAX));
+        unsigned e8 = (bits >> 23) + ((bits & 0x7FFFFFu) ? 1u : 0u);
+        e8 = e8 > 253u ? 253u : e8;
+        const float inv = __builtin_bit_cast(float, (254u - e8) << 23);
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
+        *(u32x2*)(q + (long)row * ldq + c) = (u32x2){(unsigned)lo, (unsigned)hi};
+        if ((c & 31) == 0) {
+            const int r = row % group;
+            mx[(long)(c >> 5) * pitch + (row - r) + (r % 16) * (group / 16) + r / 16] = (unsigned char)e8;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int wg_quantize_mx_fp8(const void* x, long ldx, void* q, long ldq, void* mx, long pitch, int group, int M, int K, void* stream) {
+    WG_REQUIRE(x && q && mx, "quantize_mx: null operand");
+    WG_REQUIRE(M > 0 && K > 0 && K % 32 == 0 && (group == 64 || group == 128), "quantize_mx: K = %d must be a multiple of 32, group 64 or 128", K);
+    WG_REQUIRE(ldx % 8 == 0 && ldq % 8 == 0 && ldx >= K && ldq >= K, "quantize_mx: leading dimensions must be multiples of 8 covering the row");
+    WG_REQUIRE(pitch >= ((long)M + group - 1) / group * group, "quantize_mx: scale pitch %ld does not cover %d rows in groups of %d", pitch, M, group);
+    WG_REQUIRE((((uintptr_t)x & 15) | ((uintptr_t)q & 7)) == 0, "quantize_mx: misaligned operand");
+    const long total = (long)M * (K / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(wg_quantize_mx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, (unsigned char*)q, ldq,
+                       (unsigned char*)mx, pitch, group, M, K);
+    return wg_check_launch("wg_quantize_mx_fp8");
+}
 
 extern "C" int wg_quantize_rows_fp8(const void* x, long ldx, void* q, long ldq, float* scale, int M, int K, void* stream) {
     return launch(false, x, ldx, nullptr, nullptr, 0.f, q, ldq, scale, M, K, stream);

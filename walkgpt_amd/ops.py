@@ -399,12 +399,111 @@ def mx_pitch(M):
     return (M + 255) // 256 * 256
 
 
-def mx_scale_index(M, device=None):
-    """Position of row m inside a block-scale plane (include/walkgpt_hip.h: wg_gemm_fp8_mx_bias_act): rows of a 128-row group are
-    permuted to (r % 16) * 8 + r // 16.  For tests and tools; the kernels never materialise it."""
+def mx_scale_index(M, device=None, group=128):
+    """Position of row m inside a block-scale plane (include/walkgpt_hip.h: wg_gemm_fp8_mx_bias_act): rows of a `group`-row group are
+    permuted to (r % 16) * (group / 16) + r // 16 (128: activations, 64: weights).  For tests and tools; the kernels never materialise it."""
     m = torch.arange(M, device=device)
-    r = m % 128
-    return (m - r) + (r % 16) * 8 + r // 16
+    r = m % group
+    return (m - r) + (r % 16) * (group // 16) + r // 16
+
+
+def quantize_mx_fp8(x, group=128):
+    """x [..., K] bf16 -> (e4m3 bytes uint8 [..., K], E8M0 block scales uint8 [K / 32, mx_pitch(rows)]): OCP-MX, one power-of-two scale per
+    (row, 32 columns).  group=128: an activation operand of linear_mxfp8 / linear_fp8; group=64: its weight operand (once per weight)."""
+    _need_gpu(x)
+    assert x.dtype == _BF16
+    M, K, ldx = _rows(x)
+    q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    mx = torch.empty(K // 32, mx_pitch(M), device=x.device, dtype=torch.uint8)
+    rc = _lib.lib().wg_quantize_mx_fp8(x.data_ptr(), ldx, q.data_ptr(), K, mx.data_ptr(), mx.shape[1], group, M, K, _stream())
+    _lib.check(rc, "wg_quantize_mx_fp8")
+    return q, mx
+
+
+def mx_dequantize(q, mx, group=128):
+    """(e4m3 bytes [rows, K], block scales [K / 32, pitch]) -> fp32 values (host-side helper: weight folds, tests)."""
+    rows, K = q.shape
+    e = mx[:, mx_scale_index(rows, mx.device, group)].float() - 127.0          # [K/32, rows]
+    return (q.view(torch.float8_e4m3fn).float().view(rows, K // 32, 32) * torch.exp2(e).t()[..., None]).view(rows, K)
+
+
+def mx_weight(weight):
+    """nn.Linear weight [N, K] bf16 -> {"q", "mx"}: the W operand of linear_mxfp8 (once per weight set)."""
+    q, mx = quantize_mx_fp8(weight.contiguous(), group=64)
+    return {"q": q, "mx": mx}
+
+
+def fold_layernorm_mx(gamma, beta, weight, bias):
+    """fold_layernorm for the fp8 path: Wg = W gamma quantised to e4m3 with MX block scales, s = row sums of the DEQUANTISED Wg (so the
+    mean term cancels exactly what the block-scaled MFMA accumulates), b' = b + W beta (fp32, from the unquantised weight)."""
+    wf = weight.float()
+    q, mx = quantize_mx_fp8((wf * gamma.float()[None, :]).to(_BF16).contiguous(), group=64)
+    b = wf @ beta.float()
+    if bias is not None:
+        b = b + bias.float()
+    return {"q": q, "mx": mx, "colsum": mx_dequantize(q, mx, 64).sum(1).contiguous(), "bias_f32": b.contiguous()}
+
+
+def linear_mxfp8(x, w, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out=None, ln_eps=None, mx_out=False, bf16_out=True,
+                 row_partials=False):
+    """act(dequant(x) @ dequant(w).T + bias) (+ residual) on the persistent fp8 GEMM with MX block scales on both operands.
+    x: (xq uint8 [..., K], x_mx) from quantize_mx_fp8 / an earlier call's mx_out -- or, with ln_eps set, the bf16 tensor such a call
+       returned (it carries its fp8 form and its rows' partial sums): LayerNorm(x) is then folded in and w = fold_layernorm_mx(...);
+    w: mx_weight(...) / fold_layernorm_mx(...).
+    mx_out: the result also leaves as e4m3 + block scales (attached to the returned tensor as ._wg_mx; with bf16_out=False ONLY so, and
+    the pair is what is returned); row_partials: its rows' {sum, sum of squares} partials are attached as ._wg_row_partials (N % 256 == 0)."""
+    ln = None
+    if ln_eps is not None:
+        xt = x
+        rp, xm = getattr(xt, "_wg_row_partials", None), getattr(xt, "_wg_mx", None)
+        assert rp is not None and xm is not None and rp[2] == xt._version, "linear_mxfp8(ln_eps=...): x must come from a call with mx_out and row_partials"
+        x = xm
+        ln = (rp[0], rp[1])
+    xq, x_mx = x
+    wq, w_mx = w["q"], w["mx"]
+    _need_gpu(xq, x_mx, wq, w_mx, bias, residual, out)
+    assert xq.dtype == torch.uint8 and wq.dtype == torch.uint8 and xq.is_contiguous() and wq.is_contiguous()
+    assert x_mx.dtype == torch.uint8 and w_mx.dtype == torch.uint8 and x_mx.is_contiguous() and w_mx.is_contiguous()
+    K = xq.shape[-1]
+    M = xq.numel() // K
+    N = wq.shape[0]
+    assert wq.shape[1] == K and x_mx.shape[0] == K // 32 and w_mx.shape[0] == K // 32
+    dev = xq.device
+    assert bf16_out or mx_out
+    if out is None and bf16_out:
+        out = torch.empty(xq.shape[:-1] + (N,), device=dev, dtype=_BF16)
+    ldc = _rows(out)[2] if out is not None else 0
+    ldr = 0
+    if residual is not None:
+        assert residual.dtype == _BF16
+        _, _, ldr = _rows(residual)
+    cq = cmx = part = None
+    if mx_out:
+        cq = torch.empty(xq.shape[:-1] + (N,), device=dev, dtype=torch.uint8)
+        cmx = torch.empty(N // 32, mx_pitch(M), device=dev, dtype=torch.uint8)
+    if row_partials:
+        assert N % 256 == 0 and ln is None
+        part = torch.empty(N // 256, mx_pitch(M), 2, device=dev, dtype=torch.float32)
+    ev = _timed(21, M, N, K)
+    if ev is not None:
+        ev[0].record()
+    rc = _lib.lib().wg_gemm_mxfp8(xq.data_ptr(), K, x_mx.data_ptr(), x_mx.shape[1], wq.data_ptr(), K, w_mx.data_ptr(), w_mx.shape[1],
+                                  None if ln is not None else _ptr(bias),
+                                  w["colsum"].data_ptr() if ln is not None else None, w["bias_f32"].data_ptr() if ln is not None else None,
+                                  ln[0].data_ptr() if ln is not None else None, ln[0].shape[0] if ln is not None else 0,
+                                  ln[1] if ln is not None else 0, float(ln_eps) if ln is not None else 0.0,
+                                  _ptr(residual), ldr, res_row_mod, _ptr(out), ldc, _ptr(cq), N, _ptr(cmx), cmx.shape[1] if mx_out else 0,
+                                  _ptr(part), part.shape[1] if row_partials else 0, M, N, K, act, _stream())
+    if ev is not None:
+        ev[1].record()
+    _lib.check(rc, "wg_gemm_mxfp8")
+    if not bf16_out:
+        return cq, cmx
+    if mx_out:
+        out._wg_mx = (cq, cmx)
+    if row_partials:
+        out._wg_row_partials = (part, part.shape[1], out._version, M, N)
+    return out
 
 
 def linear_fp8(xq, x_scale, wq, w_scale, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out=None, mx_out=False):
