@@ -178,7 +178,8 @@ int wg_gemm_mxfp8(const void* Aq, long lda, const void* a_mx, long a_pitch, cons
                   const void* bias, const float* ln_colsum, const float* ln_bias, const float* ln_part, int ln_np, long ln_mpad, float ln_eps,
                   const void* residual, long ldr, int res_row_mod, void* C, long ldc, void* Cq, long ldcq, void* c_mx, long c_pitch,
                   float* stats_part, long stats_mpad, int M, int N, int K, int act, void* stream);
-int wg_quantize_mx_fp8(const void* x, long ldx, void* q, long ldq, void* mx, long pitch, int group, int M, int K, void* stream);
+int wg_quantize_mx_fp8(const void* x, long ldx, void* q, long ldq, void* mx, long pitch, int group, int M, int K, float* part, long part_mpad,
+                       void* stream);   /* part != NULL (K % 256 == 0): + the rows' {sum, sum of squares} per 256-column tile, [K/256][part_mpad][2] */
 int wg_gemm_fp8_mx_bias_act(const void* Aq, long lda, const float* scale_a, const void* mx_a, long mx_a_pitch, const void* Wq, long ldw,
                             const float* scale_w, const void* bias, const void* residual, long ldr, int res_row_mod, void* C, long ldc,
                             void* mx_c, long mx_c_pitch, int M, int N, int K, int act, void* stream);

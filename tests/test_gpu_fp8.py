@@ -164,6 +164,15 @@ def test_quantize_mx_matches_the_stated_rule(dev, M, K, group):
     assert torch.equal(mx[:, ops.mx_scale_index(M, dev, group)].cpu(), s_ref)
     assert torch.equal(q.cpu(), q_ref)
     assert rel_err(_mx_deq(q, mx, M, group).cpu().numpy(), x.float().numpy()) < 0.04
+    if K % 256 == 0:                                       # the chain-entry form: the same pass also leaves the rows' partial sums
+        xd = x.to(dev)
+        q2, mx2 = ops.quantize_mx_fp8(xd, group=group, row_partials=True)
+        idx = ops.mx_scale_index(M, dev, group)
+        assert torch.equal(q2, q) and torch.equal(mx2[:, idx], mx[:, idx])
+        part = xd._wg_row_partials[0].cpu()[:, :M]
+        tiles = x.float().view(M, K // 256, 256)
+        assert torch.allclose(part[..., 0].t(), tiles.sum(-1), rtol=1e-5, atol=1e-3)
+        assert torch.allclose(part[..., 1].t(), (tiles * tiles).sum(-1), rtol=1e-5, atol=1e-3)
 
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 264, 384), (1000, 520, 1280), (2100, 1032, 256)])

@@ -84,10 +84,31 @@ class _EncoderLayer(nn.Module, _Prepared):
                 "out": ops.quantize_weight_fp8(a.out_proj.weight), "fc1": ops.quantize_weight_fp8(m.fc1.weight),
                 "fc2": ops.quantize_weight_fp8(m.fc2.weight)}
 
-    def run_fp8(self, x, key_bias):
-        """The layer on the fp8 GEMM path (as Block.rows_fp8 of the SAM encoder): both LayerNorms fused with the per-row quantisation of
-        their output; attention, the residual stream and every statistic stay bf16 / fp32."""
+    def _build_mx(self):
+        a, n1, n2, m = self.self_attn, self.layer_norm1, self.layer_norm2, self.mlp
+        w = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight], 0).contiguous()
+        b = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias], 0).contiguous()
+        return {"qkv": ops.fold_layernorm_mx(n1.weight, n1.bias, w, b), "out": ops.mx_weight(a.out_proj.weight),
+                "fc1": ops.fold_layernorm_mx(n2.weight, n2.bias, m.fc1.weight, m.fc1.bias), "fc2": ops.mx_weight(m.fc2.weight)}
+
+    def run_mx(self, x, key_bias):
+        """The layer as one MX chain on the persistent fp8 GEMM (as Block.rows_mx of the SAM encoder)."""
         a, m = self.self_attn, self.mlp
+        w = self._prep_get(self._build_mx, slot="_mx")
+        D = x.shape[-1]
+        qkv = ops.linear_mxfp8(x, w["qkv"], ln_eps=self.layer_norm1.eps)
+        o = ops.mha(qkv[..., :D], qkv[..., D:2 * D], qkv[..., 2 * D:], a.num_heads, a.scale, key_bias, small=False)
+        x = ops.linear_mxfp8(ops.quantize_mx_fp8(o), w["out"], bias=a.out_proj.bias, residual=x, mx_out=True, row_partials=True)
+        h = ops.linear_mxfp8(x, w["fc1"], act=ops.ACT_QUICK_GELU, ln_eps=self.layer_norm2.eps, mx_out=True, bf16_out=False)
+        return ops.linear_mxfp8(h, w["fc2"], bias=m.fc2.bias, residual=x, mx_out=True, row_partials=True)
+
+    def run_fp8(self, x, key_bias):
+        """The layer on the fp8 GEMM path (as Block.rows_fp8 of the SAM encoder): the MX chain where the widths allow it and the input
+        carries its rows' partial sums; otherwise per-row activation scales with both LayerNorms fused into the quantisation of their
+        output.  Attention, the residual stream and every statistic stay bf16 / fp32."""
+        a, m = self.self_attn, self.mlp
+        if ops.mx_chain_ok(x.shape[-1], m.fc1.weight.shape[0]) and ops.mx_prepare_rows(x):
+            return self.run_mx(x, key_bias)
         key = tuple((p.data_ptr(), p._version) for p in (a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.out_proj.weight, m.fc1.weight,
                                                          m.fc2.weight, a.q_proj.bias, a.k_proj.bias, a.v_proj.bias))
         w = self.__dict__.get("_fp8_val")

@@ -103,8 +103,10 @@ int launch(bool ln, const void* x, long ldx, const void* gamma, const void* beta
 // the GEMM epilogue's MX output, gemm.hip wg_flush_slab_mx).  Scale planes [K/32][pitch]; inside every `group`-row group (128: the A
 // side of the MX GEMMs, 8 MFMA fragments per lane; 64: the W side, 4 fragments) row r sits at (r % 16) * (group / 16) + r / 16.
 // A lane takes 8 adjacent columns of a row, four lanes one block, 16 rows per 256-thread workgroup pass; HBM-bound (3 bytes / value).
+// part != null (K % 256 == 0): also the rows' {sum, sum of squares} per 256-column tile, [K/256][part_mpad][2] fp32 -- the partial sums a
+// GEMM with a folded LayerNorm reads (gemm.hip LNMODE 2), for a tensor no GEMM epilogue produced them for (the chain's entry).
 __global__ __launch_bounds__(256) void wg_quantize_mx_kernel(const bf16* x, long ldx, unsigned char* q, long ldq, unsigned char* mx, long pitch,
-                                                             int group, int M, int K) {
+                                                             int group, int M, int K, float* part, long part_mpad) {
     const int cpr = K / 8;                                  // 8-column pieces per row
     const long total = (long)M * cpr;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -116,6 +118,22 @@ __global__ __launch_bounds__(256) void wg_quantize_mx_kernel(const bf16* x, long
         for (int e = 0; e < 8; ++e) {
             v[e] = (float)t[e];
             am = fmaxf(am, fabsf(v[e]));
+        }
+        if (part) {                                         // 32 lanes = one 256-column tile of one row (K % 256 == 0: never a partial half-wave)
+            float sv = 0.f, qv = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                sv += v[e];
+                qv += v[e] * v[e];
+            }
+            sv += WG_DPP(sv, 0xB1); qv += WG_DPP(qv, 0xB1);
+            sv += WG_DPP(sv, 0x4E); qv += WG_DPP(qv, 0x4E);
+            sv += WG_DPP(sv, 0x124); qv += WG_DPP(qv, 0x124);
+            sv += WG_DPP(sv, 0x128); qv += WG_DPP(qv, 0x128);
+            float a, b;
+            wg_permlane_swap<0>(sv, a, b); sv = a + b;
+            wg_permlane_swap<0>(qv, a, b); qv = a + b;
+            if ((threadIdx.x & 31) == 0) *(f32x2*)(part + 2 * ((long)(c >> 8) * part_mpad + row)) = (f32x2){sv, qv};
         }
         am = fmaxf(am, WG_DPP(am, 0xB1));                   // K % 32 == 0: the four lanes of a block are one aligned quad, all active
         am = fmaxf(am, WG_DPP(am, 0x4E));
@@ -138,8 +156,10 @@ __global__ __launch_bounds__(256) void wg_quantize_mx_kernel(const bf16* x, long
 
 }  // namespace
 
-extern "C" int wg_quantize_mx_fp8(const void* x, long ldx, void* q, long ldq, void* mx, long pitch, int group, int M, int K, void* stream) {
+extern "C" int wg_quantize_mx_fp8(const void* x, long ldx, void* q, long ldq, void* mx, long pitch, int group, int M, int K, float* part,
+                                  long part_mpad, void* stream) {
     WG_REQUIRE(x && q && mx, "quantize_mx: null operand");
+    WG_REQUIRE(!part || (K % 256 == 0 && part_mpad >= M && ((uintptr_t)part & 7) == 0), "quantize_mx: row partials need K %% 256 == 0 and a pitch covering M");
     WG_REQUIRE(M > 0 && K > 0 && K % 32 == 0 && (group == 64 || group == 128), "quantize_mx: K = %d must be a multiple of 32, group 64 or 128", K);
     WG_REQUIRE(ldx % 8 == 0 && ldq % 8 == 0 && ldx >= K && ldq >= K, "quantize_mx: leading dimensions must be multiples of 8 covering the row");
     WG_REQUIRE(pitch >= ((long)M + group - 1) / group * group, "quantize_mx: scale pitch %ld does not cover %d rows in groups of %d", pitch, M, group);
@@ -148,7 +168,7 @@ extern "C" int wg_quantize_mx_fp8(const void* x, long ldx, void* q, long ldq, vo
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(wg_quantize_mx_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, (unsigned char*)q, ldq,
-                       (unsigned char*)mx, pitch, group, M, K);
+                       (unsigned char*)mx, pitch, group, M, K, part, part_mpad);
     return wg_check_launch("wg_quantize_mx_fp8");
 }
 

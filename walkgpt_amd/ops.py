@@ -407,16 +407,21 @@ def mx_scale_index(M, device=None, group=128):
     return (m - r) + (r % 16) * (group // 16) + r // 16
 
 
-def quantize_mx_fp8(x, group=128):
+def quantize_mx_fp8(x, group=128, row_partials=False):
     """x [..., K] bf16 -> (e4m3 bytes uint8 [..., K], E8M0 block scales uint8 [K / 32, mx_pitch(rows)]): OCP-MX, one power-of-two scale per
-    (row, 32 columns).  group=128: an activation operand of linear_mxfp8 / linear_fp8; group=64: its weight operand (once per weight)."""
+    (row, 32 columns).  group=128: an activation operand of linear_mxfp8 / linear_fp8; group=64: its weight operand (once per weight).
+    row_partials (K % 256 == 0): the same pass also attaches x's row partial sums (x._wg_row_partials), as a GEMM epilogue would have."""
     _need_gpu(x)
     assert x.dtype == _BF16
     M, K, ldx = _rows(x)
     q = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
     mx = torch.empty(K // 32, mx_pitch(M), device=x.device, dtype=torch.uint8)
-    rc = _lib.lib().wg_quantize_mx_fp8(x.data_ptr(), ldx, q.data_ptr(), K, mx.data_ptr(), mx.shape[1], group, M, K, _stream())
+    part = torch.empty(K // 256, mx_pitch(M), 2, device=x.device, dtype=torch.float32) if row_partials else None
+    rc = _lib.lib().wg_quantize_mx_fp8(x.data_ptr(), ldx, q.data_ptr(), K, mx.data_ptr(), mx.shape[1], group, M, K, _ptr(part),
+                                       part.shape[1] if row_partials else 0, _stream())
     _lib.check(rc, "wg_quantize_mx_fp8")
+    if row_partials:
+        x._wg_row_partials = (part, part.shape[1], x._version, M, K)
     return q, mx
 
 
@@ -442,6 +447,23 @@ def fold_layernorm_mx(gamma, beta, weight, bias):
     if bias is not None:
         b = b + bias.float()
     return {"q": q, "mx": mx, "colsum": mx_dequantize(q, mx, 64).sum(1).contiguous(), "bias_f32": b.contiguous()}
+
+
+def mx_chain_ok(D, hidden):
+    """Can a transformer block of width D / MLP width `hidden` run its four linears as one MX chain on the persistent fp8 GEMM?  (LayerNorm
+    fold: the row statistics arrive as D / 256 partial planes, at most 5; fp8 copies need whole 32-column blocks.)"""
+    return D % 256 == 0 and D <= 1280 and hidden % 32 == 0 and hidden % 128 == 0
+
+
+def mx_prepare_rows(x):
+    """Give a bf16 activation tensor [.., D] (D % 256 == 0) the by-products an MX-chain consumer (linear_mxfp8(ln_eps=...)) expects: its
+    e4m3 + block-scale form and its rows' partial sums.  Inside the chain the producing GEMM's epilogue leaves both; at the chain's
+    entry one quantisation pass makes what is missing."""
+    rp = getattr(x, "_wg_row_partials", None)
+    have_rp = rp is not None and rp[2] == x._version
+    if getattr(x, "_wg_mx", None) is None or not have_rp:
+        x._wg_mx = quantize_mx_fp8(x, row_partials=not have_rp)
+    return True
 
 
 def linear_mxfp8(x, w, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out=None, ln_eps=None, mx_out=False, bf16_out=True,

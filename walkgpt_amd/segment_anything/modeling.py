@@ -25,16 +25,16 @@ BF16 = torch.bfloat16
 class _Prepared:
     """Derived (re-laid / concatenated / bf16) kernel operands, rebuilt after any parameter change."""
 
-    def _prep_get(self, build, deps=None):
+    def _prep_get(self, build, deps=None, slot=""):
         """deps: the tensors `build` reads (default: every parameter below this module -- pass them explicitly where the module
-        tree is large, the key is recomputed on every forward)."""
+        tree is large, the key is recomputed on every forward).  slot: a second, independently keyed set on the same module."""
         if deps is None:
             deps = self.parameters(recurse=True)
         key = tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in deps if p is not None)
-        if getattr(self, "_prep_key", None) != key:
-            object.__setattr__(self, "_prep_val", build())
-            object.__setattr__(self, "_prep_key", key)
-        return self._prep_val
+        if getattr(self, "_prep_key" + slot, None) != key:
+            object.__setattr__(self, "_prep_val" + slot, build())
+            object.__setattr__(self, "_prep_key" + slot, key)
+        return getattr(self, "_prep_val" + slot)
 
 
 def _check_bf16_gpu(t, what):
@@ -119,10 +119,34 @@ class Block(nn.Module, _Prepared):
         return {k: ops.quantize_weight_fp8(w) for k, w in (("qkv", a.qkv.weight), ("proj", a.proj.weight), ("lin1", m.lin1.weight),
                                                            ("lin2", m.lin2.weight))}
 
-    def rows_fp8(self, x, B, grid):
-        """The block on the fp8 GEMM path: both LayerNorms are fused with the per-row quantisation of their output; attention, the
-        residual stream and every statistic stay bf16 / fp32."""
+    def _build_mx(self):
         a, m = self.attn, self.mlp
+        return {"qkv": ops.fold_layernorm_mx(self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias), "proj": ops.mx_weight(a.proj.weight),
+                "lin1": ops.fold_layernorm_mx(self.norm2.weight, self.norm2.bias, m.lin1.weight, m.lin1.bias), "lin2": ops.mx_weight(m.lin2.weight)}
+
+    def rows_mx(self, x, B, grid):
+        """The block as one MX chain on the persistent fp8 GEMM (ops.linear_mxfp8): e4m3 operands with a power-of-two scale per 32
+        values on both sides; both LayerNorms folded into the GEMM behind them from the partial sums the GEMM in front left; the
+        residual GEMMs (proj, lin2) leave the stream as bf16 AND as the next GEMM's e4m3 operand; the MLP's hidden layer only ever
+        exists as e4m3.  The one quantisation pass left per block is the attention output's.  Attention, the residual stream and every
+        statistic stay bf16 / fp32."""
+        a, m = self.attn, self.mlp
+        w = self._prep_get(self._build_mx, (self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, self.norm2.weight,
+                                            self.norm2.bias, m.lin1.weight, m.lin1.bias, m.lin2.weight), slot="_mx")
+        qkv = ops.linear_mxfp8(x, w["qkv"], ln_eps=self.norm1.eps)
+        window = self.window_size if self.window_size > 0 else grid
+        o = ops.sam_attention(qkv, a.qkv.bias, a.rel_pos_h, a.rel_pos_w, B, grid, window, a.num_heads)
+        x = ops.linear_mxfp8(ops.quantize_mx_fp8(o), w["proj"], bias=a.proj.bias, residual=x, mx_out=True, row_partials=True)
+        h = ops.linear_mxfp8(x, w["lin1"], act=m._act_code, ln_eps=self.norm2.eps, mx_out=True, bf16_out=False)
+        return ops.linear_mxfp8(h, w["lin2"], bias=m.lin2.bias, residual=x, mx_out=True, row_partials=True)
+
+    def rows_fp8(self, x, B, grid):
+        """The block on the fp8 GEMM path.  Widths the persistent MX kernel takes run as rows_mx; the rest (and a block whose input
+        carries no row partial sums) with per-row activation scales: both LayerNorms fused with the per-row quantisation of their
+        output, the MLP's hidden layer handed over as e4m3 + MX block scales."""
+        a, m = self.attn, self.mlp
+        if ops.mx_chain_ok(x.shape[-1], m.lin1.weight.shape[0]) and ops.mx_prepare_rows(x):
+            return self.rows_mx(x, B, grid)
         w = self.__dict__.get("_fp8_val")
         key = tuple((p.data_ptr(), p._version) for p in (a.qkv.weight, a.proj.weight, m.lin1.weight, m.lin2.weight))
         if w is None or self.__dict__.get("_fp8_key") != key:
