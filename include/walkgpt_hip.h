@@ -158,15 +158,10 @@ int wg_layernorm_quantize_fp8(const void* x, long ldx, const void* gamma, const 
                               int M, int K, void* stream);
 int wg_gemm_fp8_bias_act(const void* Aq, long lda, const float* scale_a, const void* Wq, long ldw, const float* scale_w, const void* bias,
                          const void* residual, long ldr, int res_row_mod, void* C, long ldc, int M, int N, int K, int act, void* stream);
-/* wg_gemm_fp8_mx_bias_act: the same GEMM with OCP-MX block scales on the activation side, so that a chain of fp8 linears (the MLP of
- * image_encoder.py:177-193 / CLIP's fc1 -> fc2) needs no quantisation pass between them.
- *   mx_a != NULL: one E8M0 scale per 32 values of A's rows, [K/32][mx_a_pitch] bytes; inside every 128-row group row r sits at byte
- *                 (r % 16) * 8 + r / 16 (the 8 MFMA fragments of a lane are 8 adjacent bytes).  scale_a may then be NULL (= 1.0).
- *   mx_c != NULL: C is written as e4m3 BYTES (ldc in bytes) and its block scales (power of two at or above max|block| / 448) into mx_c
- *                 [N/32][mx_c_pitch] in that same layout; N % 32 == 0, no residual.
- * Pitches: bytes, multiples of 8, at least M rounded up to 256. */
 /* wg_quantize_mx_fp8: x [M,K] bf16 -> e4m3 bytes + E8M0 block scales [K/32][pitch] (rows permuted inside `group`-row groups: 128 for an
- * activation operand, 64 for a weight operand; the rule above).
+ * activation operand, 64 for a weight operand).  The scale of a block is the power of two at or above max|block| / 448 (E8M0 byte =
+ * 127 + exponent; no value saturates); inside a 128-row group row r sits at byte (r % 16) * 8 + r / 16 of its plane, inside a 64-row
+ * group at (r % 16) * 4 + r / 16: the 8 (4) MFMA fragments of a lane are adjacent bytes.
  * wg_gemm_mxfp8: the persistent 256x256 fp8 GEMM with block scales on BOTH operands, applied inside the MFMA:
  *   C[M,N] bf16 = act(sum_k deq(Aq)[m,k] deq(Wq)[n,k] + bias[n]) (+ residual[m % res_row_mod]).
  *   Optional, as in the bf16 kernel it shares loop and epilogues with (wg_gemm_lnp_bias_act_bf16 / wg_gemm_bias_act_stats_bf16):
@@ -180,9 +175,6 @@ int wg_gemm_mxfp8(const void* Aq, long lda, const void* a_mx, long a_pitch, cons
                   float* stats_part, long stats_mpad, int M, int N, int K, int act, void* stream);
 int wg_quantize_mx_fp8(const void* x, long ldx, void* q, long ldq, void* mx, long pitch, int group, int M, int K, float* part, long part_mpad,
                        void* stream);   /* part != NULL (K % 256 == 0): + the rows' {sum, sum of squares} per 256-column tile, [K/256][part_mpad][2] */
-int wg_gemm_fp8_mx_bias_act(const void* Aq, long lda, const float* scale_a, const void* mx_a, long mx_a_pitch, const void* Wq, long ldw,
-                            const float* scale_w, const void* bias, const void* residual, long ldr, int res_row_mod, void* C, long ldc,
-                            void* mx_c, long mx_c_pitch, int M, int N, int K, int act, void* stream);
 
 /* mask_decoder.py:140-160 fused: `upscaled = output_upscaling(src)` (ConvT k2 s2 -> LayerNorm2d -> GELU -> ConvT k2 s2 -> GELU) and
  * `masks = hyper_in @ upscaled` in one launch; every step is local to an image token.  x [P*h*w, 256] bf16 token rows; w1 [(dy,dx,64),

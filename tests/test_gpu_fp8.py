@@ -96,57 +96,6 @@ def _mx_reference(h):
     return q, (e + 127).to(torch.uint8).t().contiguous()
 
 
-def _mx_unpermute(scales, M):
-    """block-scale planes [nblk, pitch] (rows permuted inside 128-row groups) -> [nblk, M] in row order"""
-    return scales[:, ops.mx_scale_index(M, scales.device)]
-
-
-@pytest.mark.parametrize("M,N,K,act", [(256, 256, 128, 1), (700, 1056, 384, 2), (4099, 3072, 768, 1), (520, 96, 128, 0)])
-def test_fp8_gemm_mx_output_is_the_quantised_bf16_output(dev, M, N, K, act):
-    """mx_out=True writes exactly what quantising the bf16 result block-wise would give: bytes and E8M0 scales bit for bit, scale planes in
-    the permuted row order the consuming GEMM reads."""
-    g = torch.Generator().manual_seed(M + N)
-    x = torch.randn(M, K, generator=g).to(torch.bfloat16)
-    x[:, :64] *= 30.0                                      # blocks of very different magnitude along the row
-    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
-    w[32:64] *= 1e-3
-    w[64:96] = 0.0                                         # an all-zero block (bias 0 there as well): scale at its floor, bytes zero
-    b = torch.randn(N, generator=g).to(torch.bfloat16)
-    b[32:96] = 0.0
-    xq, xs = ops.quantize_rows_fp8(x.to(dev))
-    wq, ws = ops.quantize_weight_fp8(w.to(dev))
-    h = ops.linear_fp8(xq, xs, wq, ws, bias=b.to(dev), act=act)
-    q, sc = ops.linear_fp8(xq, xs, wq, ws, bias=b.to(dev), act=act, mx_out=True)
-    assert q.shape == (M, N) and sc.shape == (N // 32, ops.mx_pitch(M))
-    q_ref, s_ref = _mx_reference(h.cpu())
-    got_s = _mx_unpermute(sc, M).cpu()
-    assert torch.equal(got_s, s_ref), (got_s.int() - s_ref.int()).abs().max()
-    assert torch.equal(q.cpu(), q_ref), (q.cpu() != q_ref).float().mean()
-    assert int(q.cpu()[:, 64:96].max()) == 0 and int(got_s[2].max()) == 19      # 2^-100 / 448 rounded up to a power of two: 2^-108
-
-
-@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 264, 384), (1000, 520, 1280)])
-def test_fp8_gemm_mx_operand_exact_on_small_integers(dev, M, N, K):
-    """Block scales on the activation side, exact data: integers in [-3, 3] times a power of two that differs per (row, 32-column block).
-    A scale byte that reaches the wrong row, K block or MFMA fragment changes an integer."""
-    g = torch.Generator().manual_seed(M + N + K + 1)
-    a = torch.randint(-3, 4, (M, K), generator=g).float()
-    w = torch.randint(-3, 4, (N, K), generator=g).float()
-    w[:, ::5] = 0.0
-    e = torch.randint(-3, 4, (K // 32, M), generator=g)                                # exponent of block kb of row m
-    e[:, 0] = 0
-    sw = (torch.arange(N) % 3 + 1).float() * 0.5
-    bias = torch.randint(-8, 9, (N,), generator=g).float()
-    planes = torch.full((K // 32, ops.mx_pitch(M)), 255, dtype=torch.uint8)            # rows past M: NaN scales, must never reach the output
-    planes[:, ops.mx_scale_index(M)] = (e + 127).to(torch.uint8)
-    out = ops.linear_fp8(_q(a).to(dev), planes.to(dev), _q(w).to(dev), sw.to(dev), bias=bias.to(dev, torch.bfloat16))
-    a_deq = a * torch.exp2(e.float()).t().repeat_interleave(32, dim=1)
-    ref = (a_deq.double() @ w.double().t()).float() * sw[None, :] + bias
-    got = out.float().cpu()
-    exact = ref.to(torch.bfloat16).float()
-    assert torch.equal(got, exact), float((got - exact).abs().max())
-
-
 def _mx_deq(q, mx, rows, group):
     """e4m3 bytes [rows, K] + block-scale planes -> fp32 values"""
     K = q.shape[1]
@@ -267,36 +216,6 @@ def test_mxfp8_transformer_block_chain(dev, M, D, H):
     assert e_h < 0.06 and e_y < 0.03
     q2, s2 = _mx_reference(x2.cpu())
     assert torch.equal(x2._wg_mx[1][:, ops.mx_scale_index(M, dev)].cpu(), s2) and torch.equal(x2._wg_mx[0].cpu(), q2)
-
-
-def test_fp8_mlp_chain_without_a_quantise_pass(dev):
-    """lin1 (GELU, MX output) -> lin2 (MX operand): the chain the encoders run, against fp32 on the unquantised operands next to the
-    per-row-scale path it replaces (block scales are the finer of the two)."""
-    M, D, H = 4099, 768, 3072
-    g = torch.Generator().manual_seed(21)
-    x = torch.randn(M, D, generator=g).to(torch.bfloat16)
-    w1 = (torch.randn(H, D, generator=g) / D ** 0.5).to(torch.bfloat16)
-    w2 = (torch.randn(D, H, generator=g) / H ** 0.5).to(torch.bfloat16)
-    b1 = torch.randn(H, generator=g).to(torch.bfloat16)
-    b2 = torch.randn(D, generator=g).to(torch.bfloat16)
-    r = torch.randn(M, D, generator=g).to(torch.bfloat16)
-    xq, xs = ops.quantize_rows_fp8(x.to(dev))
-    w1q, w1s = ops.quantize_weight_fp8(w1.to(dev))
-    w2q, w2s = ops.quantize_weight_fp8(w2.to(dev))
-    hq, hs = ops.linear_fp8(xq, xs, w1q, w1s, bias=b1.to(dev), act=1, mx_out=True)
-    y_mx = ops.linear_fp8(hq, hs, w2q, w2s, bias=b2.to(dev), residual=r.to(dev)).float().cpu()
-    h = ops.linear_fp8(xq, xs, w1q, w1s, bias=b1.to(dev), act=1)
-    hq2, hs2 = ops.quantize_rows_fp8(h)
-    y_row = ops.linear_fp8(hq2, hs2, w2q, w2s, bias=b2.to(dev), residual=r.to(dev)).float().cpu()
-    # same operands in fp32: the dequantised MX activations against the dequantised weights
-    hd = hq.cpu().view(F8).float().view(M, H // 32, 32) * torch.exp2(_mx_unpermute(hs, M).cpu().float() - 127).t()[..., None]
-    w2d = w2q.cpu().view(F8).float() * w2s.cpu()[:, None]
-    y_same = hd.view(M, H) @ w2d.t() + b2.float() + r.float()
-    assert rel_err(y_mx.numpy(), y_same.numpy()) < 4e-3
-    full = torch.nn.functional.gelu(x.float() @ w1.float().t() + b1.float()) @ w2.float().t() + b2.float() + r.float()
-    e_mx, e_row = rel_err(y_mx.numpy(), full.numpy()), rel_err(y_row.numpy(), full.numpy())
-    print("fp8 MLP chain: rel err vs fp32  MX block scales %.4f, per-row scales + quantise pass %.4f" % (e_mx, e_row))
-    assert e_mx < 0.03 and e_mx < 1.1 * e_row
 
 
 @pytest.mark.parametrize("name", ["tiny", "vit_h3"])

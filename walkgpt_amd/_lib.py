@@ -42,8 +42,6 @@ SIGNATURES = {
     "wg_layernorm_quantize_fp8": [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_long, c_void_p, c_int, c_int, c_void_p],
     "wg_gemm_fp8_bias_act": [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p, c_long,
                              c_int, c_int, c_int, c_int, c_void_p],
-    "wg_gemm_fp8_mx_bias_act": [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_long, c_int,
-                                c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p],
     "wg_gemm_mxfp8": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_long,
                       c_float, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long,
                       c_int, c_int, c_int, c_int, c_void_p],

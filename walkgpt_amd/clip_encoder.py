@@ -103,9 +103,9 @@ class _EncoderLayer(nn.Module, _Prepared):
         return ops.linear_mxfp8(h, w["fc2"], bias=m.fc2.bias, residual=x, mx_out=True, row_partials=True)
 
     def run_fp8(self, x, key_bias):
-        """The layer on the fp8 GEMM path (as Block.rows_fp8 of the SAM encoder): the MX chain where the widths allow it and the input
-        carries its rows' partial sums; otherwise per-row activation scales with both LayerNorms fused into the quantisation of their
-        output.  Attention, the residual stream and every statistic stay bf16 / fp32."""
+        """The layer on the fp8 GEMM path (as Block.rows_fp8 of the SAM encoder): the MX chain where the widths allow it, otherwise per-row
+        activation scales with both LayerNorms fused into the quantisation of their output.  Attention, the residual stream and every
+        statistic stay bf16 / fp32."""
         a, m = self.self_attn, self.mlp
         if ops.mx_chain_ok(x.shape[-1], m.fc1.weight.shape[0]) and ops.mx_prepare_rows(x):
             return self.run_mx(x, key_bias)
@@ -122,10 +122,7 @@ class _EncoderLayer(nn.Module, _Prepared):
         q, s = ops.quantize_rows_fp8(o)
         x = ops.linear_fp8(q, s, *w["out"], bias=a.out_proj.bias, residual=x)
         q, s = ops.quantize_rows_fp8(x, ln=(self.layer_norm2.weight, self.layer_norm2.bias), eps=self.layer_norm2.eps)
-        if m.fc1.weight.shape[0] % 32 == 0:   # fc1's epilogue leaves e4m3 + MX block scales: fc2's operand, no quantisation pass between
-            q, s = ops.linear_fp8(q, s, *w["fc1"], bias=m.fc1.bias, act=ops.ACT_QUICK_GELU, mx_out=True)
-        else:
-            q, s = ops.quantize_rows_fp8(ops.linear_fp8(q, s, *w["fc1"], bias=m.fc1.bias, act=ops.ACT_QUICK_GELU))
+        q, s = ops.quantize_rows_fp8(ops.linear_fp8(q, s, *w["fc1"], bias=m.fc1.bias, act=ops.ACT_QUICK_GELU))
         return ops.linear_fp8(q, s, *w["fc2"], bias=m.fc2.bias, residual=x)
 
     def run(self, x, key_bias, tail_tiles=False):

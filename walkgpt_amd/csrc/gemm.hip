@@ -41,10 +41,10 @@ struct GemmArgs {
     unsigned c_bytes, r_bytes;   // extents of C and R for the staged epilogue's buffer descriptors (0: not addressable in 32 bits)
     const float* scale_a;        // fp8 operands (wg_gemm_fp8_bias_act): per-row scale of A [M] and per-output-channel scale of W [N];
     const float* scale_w;        //   A, W then point at e4m3 bytes and lda / ldw / K count PAIRS of bytes (see the entry point)
-    const unsigned char* mx_a = nullptr;   // fp8 kernel, MX operand: E8M0 scale of every 32-value block of A's rows, [K/32][mx_a_pitch] bytes, the
-    long mx_a_pitch = 0;                   //   rows of a 128-row group permuted to (row % 16) * 8 + row / 16 (a lane's 8 fragments = 8 adjacent bytes)
-    unsigned char* mx_c = nullptr;         // fp8 kernel, MX result: C is written as e4m3 bytes (ldc in bytes) with its block scales in the same
-    long mx_c_pitch = 0;                   //   layout [N/32][mx_c_pitch] -- the next GEMM's mx_a
+    const unsigned char* mx_a = nullptr;   // persistent fp8 kernel, MX operand: E8M0 scale of every 32-value block of A's rows, [K/32][mx_a_pitch]
+    long mx_a_pitch = 0;                   //   bytes, the rows of a 128-row group permuted to (row % 16) * 8 + row / 16 (a lane's 8 fragments = 8 adjacent bytes)
+    unsigned char* mx_c = nullptr;         // ... and the block scales of its e4m3 output copy Cq (below), same layout [N/32][mx_c_pitch]: the next
+    long mx_c_pitch = 0;                   //   GEMM's mx_a
     unsigned mx_c_bytes = 0;
     const unsigned char* mx_w = nullptr;   // persistent fp8 kernel: the weights' block scales, [K/32][mx_w_pitch], rows of a 64-row group at
     long mx_w_pitch = 0;                   //   (row % 16) * 4 + row / 16 (a lane's 4 column fragments = one dword)
@@ -163,52 +163,6 @@ __device__ __forceinline__ void wg_load_residual(u32x4* rres, __amdgpu_buffer_rs
     }
 }
 
-// MX flavour of the flush: the slab's bf16 values leave as e4m3 with one E8M0 scale per (row, 32 columns).  A lane holds 8 adjacent
-// columns of a row and the four lanes of a quad one block, so the block maximum is two quad DPP steps; the scale is the power of two
-// at or above max / 448 (no value saturates).  Scale bytes: rows r and r+16, .. of a 128-row group are adjacent (GemmArgs::mx_a), which
-// makes the 4 scales a lane collects over the even (odd) iterations of a 64-row slab one aligned dword.
-template <int SROW, int CH, int NIT>
-__device__ __forceinline__ void wg_flush_slab_mx(const char* stg, __amdgpu_buffer_rsrc_t qrs, __amdgpu_buffer_rsrc_t srs, int ldc, int N, int row0,
-                                                 int nbase, int el, int pitch, int group_row0, int half) {
-    static_assert(CH == 8 && NIT == 8, "written for 64-column wave tiles: 8 lanes x 8 columns per row, 8 rows per instruction");
-    constexpr int RPS = 64 / CH;
-    u32x2 t[NIT];
-    unsigned se = 0, so = 0;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const bf16x8 o = *(const bf16x8*)(stg + (it * RPS + el / CH) * SROW + (el % CH) * 16);
-        float v[8];
-        float am = 0x1p-100f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v[e] = (float)o[e];
-            am = fmaxf(am, fabsf(v[e]));
-        }
-        am = fmaxf(am, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, am), 0xB1, 0xF, 0xF, true)));   // quad_perm [1,0,3,2]
-        am = fmaxf(am, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, am), 0x4E, 0xF, 0xF, true)));   // quad_perm [2,3,0,1]
-        const unsigned bits = __builtin_bit_cast(unsigned, am * (1.0f / 448.0f));
-        unsigned e8 = (bits >> 23) + ((bits & 0x7FFFFFu) ? 1u : 0u);
-        e8 = e8 > 253u ? 253u : e8;
-        const float inv = __builtin_bit_cast(float, (254u - e8) << 23);
-        int lo = 0, hi = 0;
-        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[0] * inv, v[1] * inv, lo, false);
-        lo = __builtin_amdgcn_cvt_pk_fp8_f32(v[2] * inv, v[3] * inv, lo, true);
-        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[4] * inv, v[5] * inv, hi, false);
-        hi = __builtin_amdgcn_cvt_pk_fp8_f32(v[6] * inv, v[7] * inv, hi, true);
-        t[it] = (u32x2){(unsigned)lo, (unsigned)hi};
-        asm volatile("" : "+v"(t[it]));
-        if (it & 1) so |= e8 << (8 * (it >> 1));
-        else se |= e8 << (8 * (it >> 1));
-    }
-    const int n = nbase + (el % CH) * 8;
-    const int off0 = n < N ? (row0 + el / CH) * ldc + n : (int)0x80000000;
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) __builtin_amdgcn_raw_buffer_store_b64(t[it], qrs, off0 + it * RPS * ldc, 0, 0);
-    const int soff = (n < N && (el & 3) == 0) ? (n >> 5) * pitch + group_row0 + (el / CH) * 8 + 4 * half : (int)0x80000000;
-    __builtin_amdgcn_raw_buffer_store_b32(se, srs, soff, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b32(so, srs, soff + 64, 0, 0);
-}
-
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 // Experiment knobs of the persistent 256x256 kernel (diagnostic builds only, tools/build_variant.py): cache policy bits of its output
@@ -242,9 +196,9 @@ __device__ __forceinline__ void wg_mfma16_acc(f32x4& acc, bf16x8 a, bf16x8 b) {
 // and k = 64+16*fq .. 64+16*fq+15 of its row -- the K order of v_mfma_scale_f32_16x16x128_f8f6f4's operand registers, measured with
 // per-block scales (tools/micro/mx_dbg.py: with 32 contiguous bytes per lane half of every block took the scale of another one):
 // lane group q supplies the E8M0 scale of K block q = k 32q .. 32q+31.  ONE such MFMA replaces the two bf16 16x16x32 steps of a
-// slab at the same matrix-pipe time for twice the K.  The weights' block scale is 1.0 (E8M0 127; their scale is per output
-// channel, fp32, applied to the accumulators before the epilogue like the per-row scale of A); A's block scales are 1.0 or the MX
-// scales a producing GEMM left (GemmArgs::mx_a).
+// slab at the same matrix-pipe time for twice the K.  Here both block scales are 1.0 (E8M0 127): the operands carry fp32 scales per
+// row (A) and per output channel (W), applied to the accumulators before the epilogue.  The persistent kernel
+// (wg_gemm_pp_persist_kernel<.., FP8>) feeds real MX block scales to the same instruction.
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool STAGED, int PIPE, bool FP8 = false>
 __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 : 2)) void wg_gemm_kernel(GemmArgs g) {
     static_assert(PIPE == 0 || (PIPE == 2 && BK == 64 && STAGES == 2), "the ping-pong schedule is written for two 64-deep slabs");
@@ -375,18 +329,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
         // first slab in the order the loop consumes it; its late A rows (the two youngest pieces) may still be in flight when
         // cluster 0 starts -- the loop's own counted wait in its first M half-phase covers them
         WG_TSTAMP(0);
-        // MX operand (fp8): the 8 block scales of this lane's A fragments for K block 4*kt + fq are 8 adjacent bytes, one dword per
-        // cluster.  Each dword is fetched one M half-phase before the one that precedes its MFMAs.  Plain loads, so that hipcc itself
-        // orders every use (and every register copy it makes) behind the data's arrival -- as raw asm loads under the counted waits
-        // alone, a compiler-made copy of the destination register ran ahead of the wait.  Its own waits come out no stricter than the
-        // counted ones (memory operations retire in issue order).  Without MX both hold E8M0 127 = 1.0.
-        unsigned sa0 = 0x7F7F7F7Fu, sa1 = 0x7F7F7F7Fu, sa0_next = 0x7F7F7F7Fu;
-        const unsigned sw1 = 0x7F7F7F7Fu;                        // the weights' block scale: 1.0 (their scale is per output channel, fp32)
-        const bool mxa = FP8 && g.mx_a != nullptr;
-        const unsigned char* sab = g.mx_a;                       // wave-uniform: advances by four scale planes per slab
-        const long sa_step = 4 * g.mx_a_pitch;
-        const unsigned sa_off = (unsigned)(fq * (int)g.mx_a_pitch + m0 + wm * WTM + fr * 8);
-        if (mxa) sa0_next = *(const unsigned*)(sab + sa_off);
+        const unsigned sw1 = 0x7F7F7F7Fu;   // both operands' block scales: 1.0 (E8M0 127); the fp32 per-row / per-channel scales follow in the epilogue
         piece(0, 0); piece(0, 1); piece(0, 2); piece(0, 3);
         wg_wait_vmcnt<2>();
         __builtin_amdgcn_s_barrier();
@@ -407,25 +350,10 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
                     if (sc == 0) { piece(kt + 1, 0); piece(kt + 1, 1); piece(kt + 1, 2); }
                     else piece(kt + 1, 3);
                 }
-                if (mxa) {
-                    if (sc == 0) {
-                        sa0 = sa0_next;
-                        sa1 = *(const unsigned*)(sab + sa_off + 4);
-                    } else if (more) {
-                        sab += sa_step;
-                        sa0_next = *(const unsigned*)(sab + sa_off);
-                    }
-                }
                 // sc 0: the late A rows of THIS slab (sent in the previous slab's sc 1) must be in before sc 1 reads them;
                 // sc 1: everything of slab kt+1 except the two pieces just sent must be in before its sc 0
-                // (with MX scales one more load is in flight at either point: cluster 1's dword of this slab / cluster 0's of the next)
-                if (sc == 0) {
-                    if (more) { if (mxa) asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); }
-                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                } else {
-                    if (more) { if (mxa) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); }
-                    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                }
+                if (sc == 0) { if (more) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+                else { if (more) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
                 __builtin_amdgcn_sched_barrier(0);
                 WG_GSTAMP(1);
                 __builtin_amdgcn_s_barrier();
@@ -441,16 +369,9 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
                         for (int j = 0; j < 4; ++j) {
                             const u32x4 w0 = __builtin_bit_cast(u32x4, wf2[j >> 1][j & 1][0]), w1 = __builtin_bit_cast(u32x4, wf2[j >> 1][j & 1][1]);
                             const i32x8 w8 = {(int)w0[0], (int)w0[1], (int)w0[2], (int)w0[3], (int)w1[0], (int)w1[1], (int)w1[2], (int)w1[3]};
-                            // Operand order: weights as SrcA, activations as SrcB -> their block scale is scale_b, byte i of the dword
-                            // (op_sel[1] + 2 * op_sel_hi[1]).  Volatile asm, not the builtin: as a pure value the builtin's cluster 0 was
-                            // sunk by hipcc below cluster 1's M half-phase (both clusters back to back, reads uncovered).
-                            const unsigned sb = sc == 0 ? sa0 : sa1;
-#define WG_MXM(SEL) asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %4 " SEL : "+v"(acc[4 * sc + i][j]) : "v"(w8), "v"(a8), "v"(sw1), "v"(sb))
-                            if (i == 0) WG_MXM("op_sel_hi:[0,0,0]");
-                            else if (i == 1) WG_MXM("op_sel:[0,1,0] op_sel_hi:[0,0,0]");
-                            else if (i == 2) WG_MXM("op_sel_hi:[0,1,0]");
-                            else WG_MXM("op_sel:[0,1,0] op_sel_hi:[0,1,0]");
-#undef WG_MXM
+                            // Volatile asm, not the builtin: as a pure value the builtin's cluster 0 was sunk by hipcc below cluster 1's M
+                            // half-phase (both clusters back to back, their reads uncovered).
+                            asm volatile("v_mfma_scale_f32_16x16x128_f8f6f4 %0, %1, %2, %0, %3, %3" : "+v"(acc[4 * sc + i][j]) : "v"(w8), "v"(a8), "v"(sw1));
                         }
                     }
                 } else {
@@ -537,7 +458,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
 #pragma unroll
         for (int i = 0; i < FI; ++i) {
             const int m = m0 + wm * WTM + i * 16 + fr;
-            const float sa = g.scale_a ? g.scale_a[m < g.M ? m : g.M - 1] : 1.0f;
+            const float sa = g.scale_a[m < g.M ? m : g.M - 1];
 #pragma unroll
             for (int j = 0; j < FJ; ++j)
 #pragma unroll
@@ -568,28 +489,6 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
         // One straight-line copy of the rest per (residual? yes/no): with the residual handled by `if (g.R)` inside a common
         // body, hipcc cannot tell at the control-flow joins that no load is pending and guards the second slab's stores with
         // `s_waitcnt vmcnt(0)` -- which waits for the first slab's stores to be acknowledged.
-        if constexpr (FP8) {
-            if (g.mx_c) {   // e4m3 output + block scales (no residual): the operand of the next fp8 GEMM
-                const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.c_bytes, WG_RSRC_FLAGS);
-                const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc((void*)g.mx_c, 0, g.mx_c_bytes, WG_RSRC_FLAGS);
-#pragma unroll
-                for (int half = 0; half < WTM / 64; ++half) {
-                    WG_ACT_SWITCH(g.act,
-                        _Pragma("unroll") for (int i = 0; i < 4; ++i) {
-                            _Pragma("unroll") for (int j = 0; j < FJ; ++j)
-                                *(bf16x4*)(stg + (i * 16 + fr) * SROW + (j * 16 + fq * 4) * 2) = wg_epi_pack<ACT>(acc[half * 4 + i][j], bv[j]);
-                        })
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();
-                    wg_flush_slab_mx<SROW, CH, 64 / RPI>(stg, qrs, srs, (int)g.ldc, g.N, m0 + wm * WTM + half * 64, nbase, lane, (int)g.mx_c_pitch,
-                                                         m0 + wm * WTM, half);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_wave_barrier();
-                }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                return;
-            }
-        }
         const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.c_bytes, WG_RSRC_FLAGS);
         const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.R, 0, g.r_bytes, WG_RSRC_FLAGS);
         auto finish = [&](auto has_r) __attribute__((always_inline)) {
@@ -1615,8 +1514,10 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
 #pragma unroll
                 for (int it = 0; it < NIT; ++it) __builtin_amdgcn_raw_buffer_store_b128(t[it], crs, off0 + it * RPSl * (int)g.ldc * 2, 0, WG_GEMM_C_AUX);
                 if constexpr (FP8) {
-                    // one E8M0 scale per (row, 32 columns): the rule and the scale layout of wg_flush_slab_mx; the four lanes of a quad
-                    // hold one block of a row.  Without an MX copy the same stores leave with null descriptors (fixed count per tile).
+                    // one E8M0 scale per (row, 32 columns): the power of two at or above max|block| / 448 (no value saturates), byte
+                    // 127 + its exponent; the four lanes of a quad hold one block of a row.  Scale bytes: rows r, r+16, .. of a 128-row
+                    // group are adjacent (GemmArgs::mx_a), which makes the 4 scales a lane collects over the even (odd) iterations of a
+                    // 64-row slab one aligned dword.  Without an MX copy the same stores leave with null descriptors (fixed count per tile).
                     const int qoff0 = n < g.N ? (cm0 + wm * WTM + half * 64 + el / CH) * (int)g.ldcq + n : (int)0x80000000;
                     unsigned se = 0, so = 0;
 #pragma unroll
@@ -1936,9 +1837,6 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
 // ---------------------------------------------------------------------------------------------------------------------
 // fp8 (OCP e4m3) GEMM with per-row / per-output-channel scales (BASELINE config C5):
 //     C[M,N] (bf16) = act( scale_a[m] scale_w[n] sum_k Aq[m,k] Wq[n,k] + bias[n] ) (+ R)
-// Aq [M,K] and Wq [N,K] are e4m3 bytes, K-contiguous, produced by wg_quantize_rows_fp8 (activations: per call; weights: once).
-// Runs the 256x256 ping-pong kernel with block-scaled MFMAs (see wg_gemm_kernel<..., FP8 = true>); K % 128 == 0 (one 128-byte slab),
-// leading dimensions multiples of 16 bytes.
 // Persistent 256x256 fp8 GEMM with OCP-MX block scales on both operands (wg_gemm_pp_persist_kernel<.., FP8 = true>):
 //   C[M,N] bf16 = act(sum_k deq(Aq)[m,k] deq(Wq)[n,k] + bias[n]) (+ residual),  deq(x)[r,k] = e4m3(x[r,k]) * 2^(mx[k / 32][pos(r)] - 127).
 // Aq [M,K], Wq [N,K] e4m3 bytes; a_mx [K/32][a_pitch] in the 128-row-group layout of GemmArgs::mx_a, w_mx [K/32][w_pitch] in the
@@ -1996,29 +1894,15 @@ extern "C" int wg_gemm_mxfp8(const void* Aq, long lda, const void* a_mx, long a_
     return launch_pp_persist(g, (hipStream_t)stream);
 }
 
-extern "C" int wg_gemm_fp8_mx_bias_act(const void* Aq, long lda, const float* scale_a, const void* mx_a, long mx_a_pitch, const void* Wq,
-                                       long ldw, const float* scale_w, const void* bias, const void* residual, long ldr, int res_row_mod,
-                                       void* C, long ldc, void* mx_c, long mx_c_pitch, int M, int N, int K, int act, void* stream);
+// fp8 GEMM with per-row (A) and per-output-channel (W) fp32 scales, for widths the MX kernel above does not take (and as the form a
+// caller with its own row quantisation binds).
+// Aq [M,K] and Wq [N,K] are e4m3 bytes, K-contiguous, produced by wg_quantize_rows_fp8 (activations: per call; weights: once).
+// Runs the 256x256 ping-pong kernel with block-scaled MFMAs (see wg_gemm_kernel<..., FP8 = true>); K % 128 == 0 (one 128-byte slab),
+// leading dimensions multiples of 16 bytes.
 extern "C" int wg_gemm_fp8_bias_act(const void* Aq, long lda, const float* scale_a, const void* Wq, long ldw, const float* scale_w,
                                     const void* bias, const void* residual, long ldr, int res_row_mod, void* C, long ldc, int M, int N,
                                     int K, int act, void* stream) {
-    WG_REQUIRE(scale_a, "gemm_fp8: null operand");
-    return wg_gemm_fp8_mx_bias_act(Aq, lda, scale_a, nullptr, 0, Wq, ldw, scale_w, bias, residual, ldr, res_row_mod, C, ldc, nullptr, 0, M, N, K, act, stream);
-}
-
-// The same with MX block scales on the activation side (OCP MX: one E8M0 scale per 32 values of a row).
-//   mx_a  != null: A's scales, [K/32][mx_a_pitch] bytes in the layout GemmArgs::mx_a describes (scale_a may then be null = 1.0);
-//   mx_c  != null: C is written as e4m3 BYTES (ldc in bytes, N % 32 == 0, no residual) with its block scales into mx_c in that same
-//                  layout: the operand pair of the next wg_gemm_fp8_mx_bias_act, with no quantisation pass in between.
-// Pitches are in bytes, multiples of 8 and at least M rounded up to 256 (whole tiles write / read their rows).
-extern "C" int wg_gemm_fp8_mx_bias_act(const void* Aq, long lda, const float* scale_a, const void* mx_a, long mx_a_pitch, const void* Wq,
-                                       long ldw, const float* scale_w, const void* bias, const void* residual, long ldr, int res_row_mod,
-                                       void* C, long ldc, void* mx_c, long mx_c_pitch, int M, int N, int K, int act, void* stream) {
-    WG_REQUIRE(Aq && Wq && C && (scale_a || mx_a) && scale_w, "gemm_fp8: null operand");
-    const long mpad = ((long)M + 255) / 256 * 256;
-    WG_REQUIRE(!mx_a || (mx_a_pitch >= mpad && mx_a_pitch % 8 == 0 && ((uintptr_t)mx_a & 7) == 0), "gemm_fp8: A block-scale pitch %ld must be a multiple of 8 covering %ld rows", mx_a_pitch, mpad);
-    WG_REQUIRE(!mx_c || (mx_c_pitch >= mpad && mx_c_pitch % 8 == 0 && ((uintptr_t)mx_c & 7) == 0 && N % 32 == 0 && !residual),
-               "gemm_fp8: block-scaled output needs N %% 32 == 0, no residual and a scale pitch that is a multiple of 8 covering %ld rows", mpad);
+    WG_REQUIRE(Aq && Wq && C && scale_a && scale_w, "gemm_fp8: null operand");
     WG_REQUIRE(M > 0 && N > 0 && K > 0 && K % 128 == 0, "gemm_fp8: K = %d must be a positive multiple of 128", K);
     WG_REQUIRE(act >= 0 && act <= 3, "gemm_fp8: bad activation %d", act);
     WG_REQUIRE(lda >= K && ldw >= K && ldc >= N && lda % 16 == 0 && ldw % 16 == 0, "gemm_fp8: leading dimensions must cover the row and be multiples of 16");
@@ -2036,15 +1920,11 @@ extern "C" int wg_gemm_fp8_mx_bias_act(const void* Aq, long lda, const float* sc
     g.ln_stats = nullptr; g.ln_s = nullptr; g.ln_b = nullptr;
     g.ln_part = nullptr; g.ln_np = 0; g.ln_mpad = 0; g.ln_eps = 0.f; g.stats_part = nullptr; g.stats_mpad = 0;
     g.scale_a = scale_a; g.scale_w = scale_w;
-    g.mx_a = (const unsigned char*)mx_a; g.mx_a_pitch = mx_a_pitch;
-    g.mx_c = (unsigned char*)mx_c; g.mx_c_pitch = mx_c_pitch;
     g.sk_gamma = g.sk_beta = nullptr; g.sk_eps = 0.f; g.sk_tiled = 0;
-    const long cb = ((long)(M - 1) * ldc + N) * (mx_c ? 1 : 2);
+    const long cb = ((long)(M - 1) * ldc + N) * 2;
     const long rrows = res_row_mod > 0 ? (res_row_mod < M ? res_row_mod : M) : M;
     const long rb = residual ? ((rrows - 1) * ldr + N) * 2 : 0;
-    const long sb = mx_c ? (long)(N / 32) * mx_c_pitch : 0;
-    WG_REQUIRE(cb < (1L << 31) && rb < (1L << 31) && sb < (1L << 31), "gemm_fp8: output larger than 2 GiB");
-    g.mx_c_bytes = (unsigned)sb;
+    WG_REQUIRE(cb < (1L << 31) && rb < (1L << 31), "gemm_fp8: output larger than 2 GiB");
     g.c_bytes = (unsigned)cb;
     g.r_bytes = (unsigned)rb;
     return launch_tile_impl<256, 256, 64, 2, 2, 4, true, 2, true>(g, (hipStream_t)stream);

@@ -400,7 +400,7 @@ def mx_pitch(M):
 
 
 def mx_scale_index(M, device=None, group=128):
-    """Position of row m inside a block-scale plane (include/walkgpt_hip.h: wg_gemm_fp8_mx_bias_act): rows of a `group`-row group are
+    """Position of row m inside a block-scale plane (include/walkgpt_hip.h: wg_gemm_mxfp8): rows of a `group`-row group are
     permuted to (r % 16) * (group / 16) + r // 16 (128: activations, 64: weights).  For tests and tools; the kernels never materialise it."""
     m = torch.arange(M, device=device)
     r = m % group
@@ -409,7 +409,7 @@ def mx_scale_index(M, device=None, group=128):
 
 def quantize_mx_fp8(x, group=128, row_partials=False):
     """x [..., K] bf16 -> (e4m3 bytes uint8 [..., K], E8M0 block scales uint8 [K / 32, mx_pitch(rows)]): OCP-MX, one power-of-two scale per
-    (row, 32 columns).  group=128: an activation operand of linear_mxfp8 / linear_fp8; group=64: its weight operand (once per weight).
+    (row, 32 columns).  group=128: an activation operand of linear_mxfp8; group=64: its weight operand (once per weight).
     row_partials (K % 256 == 0): the same pass also attaches x's row partial sums (x._wg_row_partials), as a GEMM epilogue would have."""
     _need_gpu(x)
     assert x.dtype == _BF16
@@ -528,28 +528,16 @@ def linear_mxfp8(x, w, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, ou
     return out
 
 
-def linear_fp8(xq, x_scale, wq, w_scale, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out=None, mx_out=False):
-    """act(dequant(xq) @ dequant(wq).T + bias) (+ residual) -> bf16.  xq [..., K] uint8 (e4m3), wq [N, K].
-    x_scale: fp32 per-row scales [rows], or the uint8 MX block scales [K / 32, mx_pitch(rows)] an earlier call returned.
-    mx_out=True: the result leaves as (e4m3 bytes [..., N], block scales uint8 [N / 32, mx_pitch(rows)]) -- the (xq, x_scale) of the
-    next call, no quantisation pass in between (N % 32 == 0, no residual)."""
+def linear_fp8(xq, x_scale, wq, w_scale, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out=None):
+    """act(dequant(xq) @ dequant(wq).T + bias) (+ residual) -> bf16.  xq [..., K] uint8 (e4m3) with per-row scales, wq [N, K] with
+    per-output-channel scales (quantize_rows_fp8 / quantize_weight_fp8).  The form for widths the MX chain (linear_mxfp8) does not take."""
     _need_gpu(xq, x_scale, wq, w_scale, bias, residual, out)
     assert xq.dtype == torch.uint8 and wq.dtype == torch.uint8 and xq.is_contiguous() and wq.is_contiguous()
     K = xq.shape[-1]
     M = xq.numel() // K
     N = wq.shape[0]
-    assert wq.shape[1] == K and w_scale.numel() == N
-    mx_in = x_scale.dtype == torch.uint8
-    if mx_in:
-        assert x_scale.dim() == 2 and x_scale.shape[0] == K // 32 and x_scale.shape[1] >= mx_pitch(M) and x_scale.is_contiguous()
-    else:
-        assert x_scale.dtype == torch.float32 and x_scale.numel() == M
-    out_scale = None
-    if mx_out:
-        assert residual is None and N % 32 == 0 and out is None
-        out = torch.empty(xq.shape[:-1] + (N,), device=xq.device, dtype=torch.uint8)
-        out_scale = torch.empty(N // 32, mx_pitch(M), device=xq.device, dtype=torch.uint8)
-    elif out is None:
+    assert wq.shape[1] == K and x_scale.numel() == M and w_scale.numel() == N
+    if out is None:
         out = torch.empty(xq.shape[:-1] + (N,), device=xq.device, dtype=_BF16)
     _, _, ldc = _rows(out)
     ldr = 0
@@ -559,14 +547,12 @@ def linear_fp8(xq, x_scale, wq, w_scale, bias=None, act=ACT_NONE, residual=None,
     ev = _timed(20, M, N, K)
     if ev is not None:
         ev[0].record()
-    rc = _lib.lib().wg_gemm_fp8_mx_bias_act(xq.data_ptr(), K, None if mx_in else x_scale.data_ptr(), x_scale.data_ptr() if mx_in else None,
-                                            x_scale.shape[1] if mx_in else 0, wq.data_ptr(), K, w_scale.data_ptr(), _ptr(bias), _ptr(residual),
-                                            ldr, res_row_mod, out.data_ptr(), ldc, _ptr(out_scale), out_scale.shape[1] if mx_out else 0,
-                                            M, N, K, act, _stream())
+    rc = _lib.lib().wg_gemm_fp8_bias_act(xq.data_ptr(), K, x_scale.data_ptr(), wq.data_ptr(), K, w_scale.data_ptr(), _ptr(bias),
+                                         _ptr(residual), ldr, res_row_mod, out.data_ptr(), ldc, M, N, K, act, _stream())
     if ev is not None:
         ev[1].record()
-    _lib.check(rc, "wg_gemm_fp8_mx_bias_act")
-    return (out, out_scale) if mx_out else out
+    _lib.check(rc, "wg_gemm_fp8_bias_act")
+    return out
 
 
 def tile_weight(w, k_slices=1):

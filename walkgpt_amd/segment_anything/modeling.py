@@ -141,9 +141,8 @@ class Block(nn.Module, _Prepared):
         return ops.linear_mxfp8(h, w["lin2"], bias=m.lin2.bias, residual=x, mx_out=True, row_partials=True)
 
     def rows_fp8(self, x, B, grid):
-        """The block on the fp8 GEMM path.  Widths the persistent MX kernel takes run as rows_mx; the rest (and a block whose input
-        carries no row partial sums) with per-row activation scales: both LayerNorms fused with the per-row quantisation of their
-        output, the MLP's hidden layer handed over as e4m3 + MX block scales."""
+        """The block on the fp8 GEMM path.  Widths the persistent MX kernel takes run as rows_mx; the rest
+        with per-row activation scales: both LayerNorms fused with the per-row quantisation of their output."""
         a, m = self.attn, self.mlp
         if ops.mx_chain_ok(x.shape[-1], m.lin1.weight.shape[0]) and ops.mx_prepare_rows(x):
             return self.rows_mx(x, B, grid)
@@ -159,11 +158,7 @@ class Block(nn.Module, _Prepared):
         q, s = ops.quantize_rows_fp8(o)
         x = ops.linear_fp8(q, s, *w["proj"], bias=a.proj.bias, residual=x)
         q, s = ops.quantize_rows_fp8(x, ln=(self.norm2.weight, self.norm2.bias), eps=self.norm2.eps)
-        # lin1's epilogue leaves its GELU output as e4m3 + MX block scales: lin2 reads that pair directly, no quantisation pass between
-        if m.lin1.weight.shape[0] % 32 == 0:
-            q, s = ops.linear_fp8(q, s, *w["lin1"], bias=m.lin1.bias, act=m._act_code, mx_out=True)
-        else:
-            q, s = ops.quantize_rows_fp8(ops.linear_fp8(q, s, *w["lin1"], bias=m.lin1.bias, act=m._act_code))
+        q, s = ops.quantize_rows_fp8(ops.linear_fp8(q, s, *w["lin1"], bias=m.lin1.bias, act=m._act_code))
         return ops.linear_fp8(q, s, *w["lin2"], bias=m.lin2.bias, residual=x)
 
     def rows(self, x, B, grid):
