@@ -331,12 +331,17 @@ def probe_launch(args, rank, local_rank, world):
 KERNEL_NAMES = {1: "wg_gemm_kernel<128,128,64,2,2,2>", 2: "wg_gemm_kernel<256,256,64,2,2,4>", 3: "wg_gemm_rowwave_kernel", 5: "wg_gemm_skinny_kernel",
                 11: "wg_gemm_persist_kernel<128,128,2,2>", 12: "wg_gemm_kernel<128,128 tail (+16 rows)>",
                 14: "wg_gemm_kernel<256,256,64,2,2,4,ping-pong>",
-                16: "wg_gemm_pp_persist_kernel<0, false> (256x256 tiles, ping-pong, persistent)",
-                17: "wg_gemm_pp_persist_kernel<2, false> (256x256 tiles, ping-pong, persistent, LayerNorm folded in, row statistics from the producing GEMM's partial sums)",
-                18: "wg_gemm_pp_persist_kernel<0, true> (256x256 tiles, ping-pong, persistent, leaves the row sums of its output)",
-                20: "wg_gemm_fp8_kernel (256x256 tiles, block-scaled fp8 MFMA)"}
-PMC_PREFIX = {16: "wg_gemm_pp_persist_kernel<0, false>", 17: "wg_gemm_pp_persist_kernel<2, false>", 18: "wg_gemm_pp_persist_kernel<0, true>",
-              20: "wg_gemm_fp8_kernel"}
+                16: "wg_gemm_pp_persist_kernel<0, false, false> (256x256 tiles, ping-pong, persistent)",
+                17: "wg_gemm_pp_persist_kernel<2, false, false> (256x256 tiles, ping-pong, persistent, LayerNorm folded in, row statistics from the producing GEMM's partial sums)",
+                18: "wg_gemm_pp_persist_kernel<0, true, false> (256x256 tiles, ping-pong, persistent, leaves the row sums of its output)",
+                20: "wg_gemm_kernel<256, 256, 64, 2, 2, 4, true, 2, true> (256x256 tiles, fp8 MFMA, per-row / per-channel scales)",
+                21: "wg_gemm_pp_persist_kernel<0, false, true> (256x256 tiles, ping-pong, persistent, fp8 with MX block scales on both operands)",
+                22: "wg_gemm_pp_persist_kernel<2, false, true> (persistent fp8 MX, LayerNorm folded in from the producing GEMM's partial sums)",
+                23: "wg_gemm_pp_persist_kernel<0, true, true> (persistent fp8 MX, leaves its output's row sums and e4m3 + block-scale copy)"}
+PMC_PREFIX = {16: "wg_gemm_pp_persist_kernel<0, false, false>", 17: "wg_gemm_pp_persist_kernel<2, false, false>", 18: "wg_gemm_pp_persist_kernel<0, true, false>",
+              20: "wg_gemm_kernel<256, 256, 64, 2, 2, 4, true, 2, true>", 21: "wg_gemm_pp_persist_kernel<0, false, true>",
+              22: "wg_gemm_pp_persist_kernel<2, false, true>", 23: "wg_gemm_pp_persist_kernel<0, true, true>"}
+FP8_KERNELS = (20, 21, 22, 23)
 
 
 def main():
@@ -497,11 +502,11 @@ def main():
         d[0] += 1
         d[1] += 2.0 * M * N * K
         d[2] += e0.elapsed_time(e1) * 1e-3
-        d[3] += (1.0 if kid == 20 else 2.0) * (M * K + N * K) + 2.0 * M * N   # operands (1 B fp8 / 2 B bf16) + bf16 output
+        d[3] += (1.0 if kid in FP8_KERNELS else 2.0) * (M * K + N * K) + 2.0 * M * N   # operands (1 B fp8 / 2 B bf16) + bf16 output
     dom = max(per_kernel, key=lambda k: per_kernel[k][2])
     n_l, fl, sec, byt = per_kernel[dom]
     achieved_tf = fl / sec / 1e12
-    peak = PEAK_TF["fp8" if dom == 20 else "bf16"]
+    peak = PEAK_TF["fp8" if dom in FP8_KERNELS else "bf16"]
     gf_clip = GF_CLIP_L_448 if not args.clip_skip_unused_layer else GF_CLIP_L_448 - (GF_CLIP_L_448 - 0.6) / 24.0   # (0.6 GF: patch embedding)
     gf_step = B * (gf_clip + GF_SAM[args.sam] + (GF_MSQP if args.with_msqp else 0.0) + T * (GF_DECODE_PER_TOKEN + GF_CTP_PER_TOKEN))
     roofline = {"bound": "mfma", "kernel": KERNEL_NAMES.get(dom, str(dom)),

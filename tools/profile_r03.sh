@@ -16,7 +16,7 @@ echo c3 done
 $P --kernel-trace --stats -d gpurun_out/p3_c5 -o s -- python3 bench.py --config C5 --dtype fp8 --steps 2 --warmup 1 --steps-only > gpurun_out/p3_c5.log 2>&1
 $P --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY -d gpurun_out/p3_c5sq -o s -- python3 bench.py --config C5 --dtype fp8 --steps 2 --warmup 1 --steps-only --single-stream > gpurun_out/p3_c5sq.log 2>&1
 echo c5 done
-tail -2 gpurun_out/p3_stats.log gpurun_out/p3_c3.log gpurun_out/p3_c5.log
+for f in gpurun_out/p3_stats.log gpurun_out/p3_c3.log gpurun_out/p3_c5.log; do tail -n 2 "$f"; done
 
 # Back in the build container: gpurun_out/ -> the tracked summaries
 #   python tools/summarize_prof.py r03 --stats gpurun_out/p3_stats --fetch gpurun_out/p3_fetch --write gpurun_out/p3_write --sq gpurun_out/p3_sq \

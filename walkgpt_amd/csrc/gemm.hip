@@ -1665,8 +1665,18 @@ extern "C" int wg_gemm_pick_tile_ex(int M, int N, int allow_tail) {
 extern "C" int wg_gemm_pick_tile(int M, int N) { return wg_gemm_pick_tile_ex(M, N, 0); }
 // The same choice with K in view: exactly the kernel wg_gemm_bias_act_bf16 launches for a shape whose operands qualify for the MFMA
 // path (the skinny kernel needs K % 128 == 0 and falls back to the 128x128 tiles otherwise) -- host-side accounting asks this one.
+// A few dozen rows (MSQP's query tokens x batch: M = 32..96 at 1024 / 4096 columns): the 128x128 tiles put ONE workgroup per 128
+// columns and walk K in a single chain (14 us at K = 1024, 40 us at K = 4096, whatever M <= 128 is); the skinny kernel spreads the same
+// weights over (M / 16) x (N / 16) workgroups: 5 us + ~6.6 ns per workgroup and 1024 of K (tools/micro/skinny_bench.py under rocprofv3).
+static bool wg_skinny_wins(int M, int N, int K) {
+    if (M > 128 || N % 16 != 0 || K % 128 != 0) return false;
+    const double kk = K / 1024.0;
+    const double blocks = (double)((M + 15) / 16) * (N / 16);
+    return 4.5 + (K >= 2048 ? 5.0 : 0.0) + blocks * kk * 0.0066 < 14.0 * (kk < 1.0 ? 1.0 : kk);
+}
 extern "C" int wg_gemm_pick_tile_mnk(int M, int N, int K, int allow_tail) {
     const int t = wg_gemm_pick_tile_ex(M, N, allow_tail);
+    if (t == 1 && wg_skinny_wins(M, N, K)) return 5;
     return (t == 5 && K % 128 != 0) ? 1 : t;
 }
 
@@ -1794,7 +1804,7 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
         return wg_check_launch("wg_gemm_bias_act_bf16(rowwave)");
     }
     int tile = tile_hint;
-    if (tile <= 0) tile = wg_gemm_pick_tile(M, N);
+    if (tile <= 0) tile = wg_gemm_pick_tile_mnk(M, N, K, 0);
     const bool can_stage = !out_f32 && N % 8 == 0 && ldc % 8 == 0 && g.c_bytes != 0 &&
                            (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0 && g.r_bytes != 0));
     const bool small_ops = (long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31);

@@ -506,7 +506,7 @@ def linear_mxfp8(x, w, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, ou
     if row_partials:
         assert N % 256 == 0 and ln is None
         part = torch.empty(N // 256, mx_pitch(M), 2, device=dev, dtype=torch.float32)
-    ev = _timed(21, M, N, K)
+    ev = _timed(22 if ln is not None else (23 if row_partials else 21), M, N, K)   # (ids: bench.py KERNEL_NAMES)
     if ev is not None:
         ev[0].record()
     rc = _lib.lib().wg_gemm_mxfp8(xq.data_ptr(), K, x_mx.data_ptr(), x_mx.shape[1], wq.data_ptr(), K, w_mx.data_ptr(), w_mx.shape[1],
