@@ -322,6 +322,18 @@ int wg_ctp_tail_bf16(const void* x, long ldx, const void* gamma, const void* bet
 /* [n, p*p, C] -> bilinear(align_corners=False) -> [n, t*t, C] (llava_arch.py:252-259; clip_encoder.py:47-49). */
 int wg_resample_tokens_bf16(const void* x, void* y, int n, int p, int t, int C, void* stream);
 
+/* ---- backward passes of the trainable grounding head (train_walkgpt.py:347-350: mask decoder, text_hidden_fcs, projector; the reference
+ * obtains them from torch autograd over nn.Linear / nn.LayerNorm / nn.GELU / nn.ReLU ...).  A Linear's gradients are GEMMs on transposed
+ * copies (wg_gemm_bias_act_bf16); these are the pieces that are not:
+ * wg_colsum_f32:          out[c] += sum_r x[r][c]   (bias gradient; fp32, the caller zeroes `out`)
+ * wg_act_bf16 / _bwd:     y = act(x); dx = dy * act'(x)  (act codes of the GEMM epilogue: 1 erf-GELU, 2 quick-GELU, 3 ReLU)
+ * wg_layernorm_bwd_bf16:  dx [M,C] bf16, dgamma / dbeta [C] fp32 (+=) of y = LayerNorm(x) gamma + beta, C <= 4096 */
+int wg_colsum_f32(const void* x, long ldx, float* out, int R, int C, void* stream);
+int wg_act_bf16(const void* x, void* y, long n, int act, void* stream);
+int wg_act_bwd_bf16(const void* x, const void* dy, void* dx, long n, int act, void* stream);
+int wg_layernorm_bwd_bf16(const void* x, long ldx, const void* gamma, const void* dy, long lddy, void* dx, long lddx, float* dgamma,
+                          float* dbeta, int M, int C, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,10 @@ SIGNATURES = {
                       c_float, c_void_p, c_long, c_int, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_void_p, c_long,
                       c_int, c_int, c_int, c_int, c_void_p],
     "wg_quantize_mx_fp8": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_long, c_int, c_int, c_int, c_void_p, c_long, c_void_p],
+    "wg_colsum_f32": [c_void_p, c_long, c_void_p, c_int, c_int, c_void_p],
+    "wg_act_bf16": [c_void_p, c_void_p, c_long, c_int, c_void_p],
+    "wg_act_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
+    "wg_layernorm_bwd_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "wg_upscale_mask_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_dec_tokens_f32": [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
