@@ -333,6 +333,26 @@ int wg_act_bf16(const void* x, void* y, long n, int act, void* stream);
 int wg_act_bwd_bf16(const void* x, const void* dy, void* dx, long n, int act, void* stream);
 int wg_layernorm_bwd_bf16(const void* x, long ldx, const void* gamma, const void* dy, long lddy, void* dx, long lddx, float* dgamma,
                           float* dbeta, int M, int C, float eps, void* stream);
+/* wg_l2norm_scale_bf16 / _bwd: y = x / max(|x|, eps) * exp(log_temp), the tail of CalibratedTextProjector behind its LayerNorm and type
+ *   embedding (utils_walkgpt.py:325-327) as a separate operator, and its backward (dx bf16; dlog_temp fp32 +=).  C <= 512.
+ * wg_attn_bwd_bf16: gradients of o = softmax(scale q k^T) v per (batch, head) for the head's small attentions (two-way transformer,
+ *   transformer.py:185-240; CrossAttnBlock / TinyCrossAttn, utils_walkgpt.py:163-185,330-357): q [B,Lq,D], k / v [B,Lk,D], o / dout [B,Lq,D]
+ *   contiguous bf16, min(Lq, Lk) <= 16, head_dim % 8 == 0, <= 128.  The long side's gradients are written as bf16, the short side's
+ *   accumulated into zeroed fp32 buffers; wg_attn_bwd_short_side: 1 = keys short (dq bf16, dk / dv fp32), 0 = queries short (dk / dv
+ *   bf16, dq fp32), -1 = unsupported.  stats: B * heads * Lq * 2 floats of workspace.
+ * wg_postprocess_masks_bwd_f32: adjoint of wg_postprocess_masks_f32 (d loss / d low-res logits +=, zeroed by the caller).
+ * wg_mask_losses_bwd_f32: d(g_bce sigmoid_ce_loss + g_dice dice_loss) / d logits (utils_walkgpt.py:76-120); workspace
+ *   wg_mask_stats_workspace_floats(N, hw) + 2 N floats. */
+int wg_l2norm_scale_bf16(const void* x, const void* log_temp, void* y, int M, int C, float eps, void* stream);
+int wg_l2norm_scale_bwd_bf16(const void* x, const void* dy, const void* log_temp, void* dx, float* dlog_temp, int M, int C, float eps, void* stream);
+int wg_attn_bwd_short_side(int Lq, int Lk);
+int wg_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* dout, void* dq_bf16, void* dk_bf16, void* dv_bf16,
+                     float* dq_f32, float* dk_f32, float* dv_f32, float* stats, int B, int heads, int head_dim, int Lq, int Lk, float scale,
+                     void* stream);
+int wg_postprocess_masks_bwd_f32(const float* dout, float* dlow, int N, int low_h, int low_w, int img_size, int in_h, int in_w, int out_h,
+                                 int out_w, void* stream);
+int wg_mask_losses_bwd_f32(const float* pred_logits, const float* targets, float* dpred, float* workspace, long workspace_floats, int N, long hw,
+                           float g_bce, float g_dice, float dice_scale, float dice_eps, void* stream);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,12 @@ SIGNATURES = {
     "wg_act_bf16": [c_void_p, c_void_p, c_long, c_int, c_void_p],
     "wg_act_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     "wg_layernorm_bwd_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "wg_l2norm_scale_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "wg_l2norm_scale_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "wg_attn_bwd_short_side": [c_int, c_int],
+    "wg_attn_bwd_bf16": [c_void_p] * 12 + [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "wg_postprocess_masks_bwd_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "wg_mask_losses_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_float, c_float, c_float, c_void_p],
     "wg_upscale_mask_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_dec_tokens_f32": [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

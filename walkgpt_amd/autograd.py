@@ -134,3 +134,157 @@ def activation(x, act):
 def layernorm(x, gamma, beta, eps):
     ops._need_gpu(x, gamma, beta)
     return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+class _AddRow(torch.autograd.Function):
+    """x [..., C] + vec [C] (a type / positional embedding broadcast over the rows; ops.add_rows).  d vec = column sums of dy."""
+
+    @staticmethod
+    def forward(ctx, x, vec):
+        with torch.no_grad():
+            return ops.add_rows(x.contiguous(), vec.reshape(1, -1).contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        C = dy.shape[-1]
+        dv = colsum(dy.contiguous().view(-1, C)).to(dy.dtype) if ctx.needs_input_grad[1] else None
+        return dy, dv
+
+
+class _L2NormScale(torch.autograd.Function):
+    """y = x / max(|x|, eps) * exp(log_temp) (utils_walkgpt.py:325-327): wg_l2norm_scale_bf16 / _bwd."""
+
+    @staticmethod
+    def forward(ctx, x, log_temp, eps):
+        x = x.contiguous()
+        ctx.save_for_backward(x, log_temp)
+        ctx.eps = eps
+        C = x.shape[-1]
+        y = torch.empty_like(x)
+        _lib.check(_lib.lib().wg_l2norm_scale_bf16(x.data_ptr(), log_temp.data_ptr(), y.data_ptr(), x.numel() // C, C, float(eps), ops._stream()),
+                   "wg_l2norm_scale_bf16")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, log_temp = ctx.saved_tensors
+        C = x.shape[-1]
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dt = torch.zeros(1, device=x.device, dtype=torch.float32)
+        rc = _lib.lib().wg_l2norm_scale_bwd_bf16(x.data_ptr(), dy.data_ptr(), log_temp.data_ptr(), dx.data_ptr(), dt.data_ptr(), x.numel() // C, C,
+                                                 float(ctx.eps), ops._stream())
+        _lib.check(rc, "wg_l2norm_scale_bwd_bf16")
+        return dx, dt.to(log_temp.dtype).view(log_temp.shape), None
+
+
+class _Attention(torch.autograd.Function):
+    """o = softmax(scale q k^T) v per head (ops.mha); backward wg_attn_bwd_bf16 (one side of every trainable attention has <= 16 rows)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads, scale):
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        with torch.no_grad():
+            o = ops.mha(q, k, v, heads, scale)
+        ctx.save_for_backward(q, k, v, o)
+        ctx.heads, ctx.scale = heads, scale
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o = ctx.saved_tensors
+        B, Lq, D = q.shape
+        Lk = k.shape[1]
+        H = ctx.heads
+        L = _lib.lib()
+        side = L.wg_attn_bwd_short_side(Lq, Lk)
+        if side < 0:
+            raise NotImplementedError("attention backward: one side must have at most 16 rows (Lq = %d, Lk = %d)" % (Lq, Lk))
+        dev = q.device
+        do = do.contiguous()
+        stats = torch.empty(B * H * Lq * 2, device=dev, dtype=torch.float32)
+        if side == 1:      # few keys
+            dq = torch.empty_like(q)
+            dk32, dv32 = torch.zeros(B, Lk, D, device=dev), torch.zeros(B, Lk, D, device=dev)
+            args = (dq.data_ptr(), None, None, None, dk32.data_ptr(), dv32.data_ptr())
+        else:              # few queries
+            dk, dv = torch.empty_like(k), torch.empty_like(v)
+            dq32 = torch.zeros(B, Lq, D, device=dev)
+            args = (None, dk.data_ptr(), dv.data_ptr(), dq32.data_ptr(), None, None)
+        rc = L.wg_attn_bwd_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), *args, stats.data_ptr(), B, H, D // H, Lq, Lk,
+                                float(ctx.scale), ops._stream())
+        _lib.check(rc, "wg_attn_bwd_bf16")
+        if side == 1:
+            return dq, dk32.to(BF16), dv32.to(BF16), None, None
+        return dq32.to(BF16), dk, dv, None, None
+
+
+class _Postprocess(torch.autograd.Function):
+    """Sam.postprocess_masks (ops.postprocess_masks); backward: its adjoint (wg_postprocess_masks_bwd_f32)."""
+
+    @staticmethod
+    def forward(ctx, low_res, img_size, input_size, original_size):
+        ctx.geom = (tuple(low_res.shape), int(img_size), (int(input_size[0]), int(input_size[1])), (int(original_size[0]), int(original_size[1])))
+        with torch.no_grad():
+            return ops.postprocess_masks(low_res.contiguous(), img_size, input_size, original_size)
+
+    @staticmethod
+    def backward(ctx, dout):
+        shape, img, (ih, iw), (oh, ow) = ctx.geom
+        N, C, lh, lw = shape
+        dout = dout.contiguous().float()
+        dlow = torch.zeros(shape, device=dout.device, dtype=torch.float32)
+        rc = _lib.lib().wg_postprocess_masks_bwd_f32(dout.data_ptr(), dlow.data_ptr(), N * C, lh, lw, img, ih, iw, oh, ow, ops._stream())
+        _lib.check(rc, "wg_postprocess_masks_bwd_f32")
+        return dlow, None, None, None
+
+
+class _MaskLosses(torch.autograd.Function):
+    """(sigmoid_ce_loss, dice_loss) of utils_walkgpt.py:76-120 (ops.mask_losses); backward wg_mask_losses_bwd_f32."""
+
+    @staticmethod
+    def forward(ctx, pred_logits, targets, num_masks, dice_scale, dice_eps):
+        pred_logits, targets = pred_logits.contiguous(), targets.contiguous()
+        ctx.save_for_backward(pred_logits, targets)
+        ctx.cfg = (float(num_masks), float(dice_scale), float(dice_eps))
+        with torch.no_grad():
+            return ops.mask_losses(pred_logits, targets, num_masks, dice_scale, dice_eps)
+
+    @staticmethod
+    def backward(ctx, g_bce, g_dice):
+        pred, tgt = ctx.saved_tensors
+        num_masks, scale, eps = ctx.cfg
+        N = pred.shape[0]
+        hw = pred.numel() // N
+        L = _lib.lib()
+        nws = L.wg_mask_stats_workspace_floats(N, hw) + 2 * N
+        ws = torch.empty(nws, device=pred.device, dtype=torch.float32)
+        dpred = torch.empty_like(pred)
+        k = 1.0 / (num_masks + 1e-8)
+        gb = float(g_bce) * k if g_bce is not None else 0.0          # (one host read of two scalars per step)
+        gd = float(g_dice) * k if g_dice is not None else 0.0
+        rc = L.wg_mask_losses_bwd_f32(pred.data_ptr(), tgt.data_ptr(), dpred.data_ptr(), ws.data_ptr(), nws, N, hw, gb, gd, scale, eps, ops._stream())
+        _lib.check(rc, "wg_mask_losses_bwd_f32")
+        return dpred, None, None, None, None
+
+
+def add_row(x, vec):
+    return _AddRow.apply(x, vec)
+
+
+def l2norm_scale(x, log_temp, eps=1e-12):
+    return _L2NormScale.apply(x, log_temp, eps)
+
+
+def attention(q, k, v, heads, scale):
+    """Differentiable ops.mha: q [B, Lq, D], k / v [B, Lk, D] bf16."""
+    return _Attention.apply(q, k, v, heads, scale)
+
+
+def postprocess_masks(low_res, img_size, input_size, original_size):
+    return _Postprocess.apply(low_res, img_size, input_size, original_size)
+
+
+def mask_losses(pred_logits, targets, num_masks, dice_scale=1000.0, dice_eps=1e-6):
+    """-> (sigmoid_ce_loss, dice_loss), differentiable in pred_logits (fp32 [N, H, W])."""
+    return _MaskLosses.apply(pred_logits, targets, num_masks, dice_scale, dice_eps)

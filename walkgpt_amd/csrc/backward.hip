@@ -154,7 +154,269 @@ __global__ __launch_bounds__(256) void wg_layernorm_bwd_kernel(const bf16* x, lo
     }
 }
 
+// ---- y = x / max(|x|, eps) * exp(t): the tail of CalibratedTextProjector behind its LayerNorm and type embedding (utils_walkgpt.py:325-327:
+// F.normalize(dim=-1, eps 1e-12) * log_temp.exp()).  One wave per row, C <= 512.
+//   forward:  y = x e^t / n,  n = max(|x|, eps)
+//   backward: dx = e^t / n (dy - xh (xh . dy)),  xh = x / n   (for |x| >= eps);   dt += sum_rows dy . y
+template <bool BWD>
+__global__ __launch_bounds__(256) void wg_l2norm_scale_kernel(const bf16* x, const bf16* dy, const bf16* log_temp, bf16* out, float* dtemp, int M, int C,
+                                                              float eps) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int d = lane * 8;
+    const bool on = d < C;
+    float v[8], g[8];
+    float n2 = 0.f, dot = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = g[e] = 0.f;
+    if (on) {
+        const bf16x8 t = *(const bf16x8*)(x + (long)m * C + d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[e] = (float)t[e]; n2 += v[e] * v[e]; }
+        if (BWD) {
+            const bf16x8 u = *(const bf16x8*)(dy + (long)m * C + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { g[e] = (float)u[e]; dot += g[e] * v[e]; }
+        }
+    }
+    const float nrm = fmaxf(sqrtf(wg_wave_sum(n2)), eps);
+    const float et = __expf((float)log_temp[0]), k = et / nrm;
+    if (BWD) {
+        dot = wg_wave_sum(dot);                               // x . dy
+        if (lane == 0) atomicAdd(dtemp, dot * k);             // dy . y
+        const float c = dot / (nrm * nrm);
+        if (on) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)(k * (g[e] - v[e] * c));
+            *(bf16x8*)(out + (long)m * C + d) = o;
+        }
+    } else if (on) {
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)(v[e] * k);
+        *(bf16x8*)(out + (long)m * C + d) = o;
+    }
+}
+
+// ---- attention backward for the head's small attentions ---------------------------------------------------------------------------------------
+// o = softmax(scale q k^T) v per (batch, head); q [B, Lq, D], k / v [B, Lk, D], D = H * hd, all contiguous bf16.  The trainable attentions
+// (two-way transformer: 6 tokens <-> 4096 image tokens, transformer.py:185-240; MSQP's CrossAttnBlock: 4..12 queries, utils_walkgpt.py:163-185;
+// TinyCrossAttn: 1 query) always have ONE short side (<= 16 rows).  A lane owns a row of the LONG side and keeps its 16 scores in registers:
+//   BYQ  (few keys):    lane = query i.  softmax over its <= 16 keys locally; dq_i written directly; dk / dv are sums over lanes (wave
+//                       reduction -> LDS -> one fp32 atomic per element and workgroup).
+//   BYKEY (few queries): lane = key j.  The softmax runs over ALL keys: log-sum-exp and D_i = dO_i . O_i of every query come from a pre-pass
+//                       (wg_attn_rowstats_kernel); dk_j / dv_j written directly; dq is the sum over lanes.
+// fp32 arithmetic; the short side's rows sit in LDS as fp32.
+constexpr int ATT_S = 16;     // rows of the short side
+constexpr int ATT_HD = 128;   // head dim limit
+
+__global__ __launch_bounds__(256) void wg_attn_rowstats_kernel(const bf16* q, const bf16* k, const bf16* o, const bf16* dout, float* stats, int H, int hd,
+                                                               int Lq, int Lk, float scale) {
+    // one workgroup per (batch*head, query): stats[.][0] = log sum_j exp(s_ij), stats[.][1] = dO_i . O_i
+    __shared__ float qs[ATT_HD];
+    __shared__ float red[4];
+    const int i = blockIdx.x, bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int D = H * hd;
+    const long qoff = ((long)b * Lq + i) * D + h * hd;
+    if (threadIdx.x < hd) qs[threadIdx.x] = (float)q[qoff + threadIdx.x];
+    __syncthreads();
+    float m = -3.0e38f, l = 0.f;
+    for (int j = threadIdx.x; j < Lk; j += 256) {
+        const bf16* kr = k + ((long)b * Lk + j) * D + h * hd;
+        float s = 0.f;
+        for (int d = 0; d < hd; d += 8) {
+            const bf16x8 t = *(const bf16x8*)(kr + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += qs[d + e] * (float)t[e];
+        }
+        s *= scale;
+        const float mn = fmaxf(m, s);
+        l = l * __expf(m - mn) + __expf(s - mn);
+        m = mn;
+    }
+    // combine (m, l) over the workgroup
+    const float wm = wg_wave_max(m);
+    l = wg_wave_sum(l * __expf(m - wm));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = wm;
+    __syncthreads();
+    const float gm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = l * __expf(wm - gm);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float lt = red[0] + red[1] + red[2] + red[3];
+        float dsum = 0.f;
+        for (int d = 0; d < hd; ++d) dsum += (float)dout[qoff + d] * (float)o[qoff + d];
+        stats[((long)bh * Lq + i) * 2 + 0] = gm + __logf(lt);
+        stats[((long)bh * Lq + i) * 2 + 1] = dsum;
+    }
+}
+
+// a: the long side's rows this workgroup's lanes own (queries for BYQ, keys for BYKEY); s_*: the short side
+template <bool BYKEY>
+__global__ __launch_bounds__(256) void wg_attn_bwd_kernel(const bf16* q, const bf16* k, const bf16* v, const bf16* dout, const float* stats, bf16* dlong_a,
+                                                          bf16* dlong_b, float* dshort_a, float* dshort_b, int H, int hd, int Lq, int Lk, float scale) {
+    // BYQ:   dlong_a = dq (bf16, direct);           dshort_a = dk, dshort_b = dv (fp32, atomics)
+    // BYKEY: dlong_a = dk, dlong_b = dv (direct);    dshort_a = dq (fp32, atomics)
+    __shared__ float s_a[ATT_S][ATT_HD];      // BYQ: K rows          BYKEY: Q rows
+    __shared__ float s_b[ATT_S][ATT_HD];      // BYQ: V rows          BYKEY: dO rows
+    __shared__ float acc_a[ATT_S][ATT_HD];    // BYQ: dK              BYKEY: dQ
+    __shared__ float acc_b[BYKEY ? 1 : ATT_S][BYKEY ? 1 : ATT_HD];   // BYQ: dV
+    __shared__ float s_st[ATT_S][2];
+    const int bh = blockIdx.y, b = bh / H, h = bh % H, D = H * hd;
+    const int Ll = BYKEY ? Lk : Lq, Ls = BYKEY ? Lq : Lk;
+    const int lane = threadIdx.x & 63;
+    const bf16* sa_src = BYKEY ? q : k;
+    const bf16* sb_src = BYKEY ? dout : v;
+    for (int t = threadIdx.x; t < Ls * hd; t += 256) {
+        const int r = t / hd, d = t % hd;
+        const long off = ((long)b * Ls + r) * D + h * hd + d;
+        s_a[r][d] = (float)sa_src[off];
+        s_b[r][d] = (float)sb_src[off];
+        acc_a[r][d] = 0.f;
+        if (!BYKEY) acc_b[r][d] = 0.f;
+    }
+    if (BYKEY && threadIdx.x < Ls * 2) s_st[threadIdx.x >> 1][threadIdx.x & 1] = stats[((long)bh * Lq + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)];
+    __syncthreads();
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const bool on = row < Ll;
+    const int rr = on ? row : Ll - 1;
+    const long loff = ((long)b * Ll + rr) * D + h * hd;
+    // BYQ: la = q_i, lb = dO_i;   BYKEY: la = k_j, lb = v_j
+    const bf16* la = (BYKEY ? k : q) + loff;
+    const bf16* lb = (BYKEY ? v : dout) + loff;
+    float sc[ATT_S], dp[ATT_S];
+#pragma unroll
+    for (int r = 0; r < ATT_S; ++r) sc[r] = dp[r] = 0.f;
+    for (int d = 0; d < hd; d += 8) {
+        const bf16x8 ta = *(const bf16x8*)(la + d), tb = *(const bf16x8*)(lb + d);
+#pragma unroll
+        for (int r = 0; r < ATT_S; ++r) {
+            if (r < Ls) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (BYKEY) {               // s_ij = q_i . k_j ;  dp_ij = dO_i . v_j
+                        sc[r] += s_a[r][d + e] * (float)ta[e];
+                        dp[r] += s_b[r][d + e] * (float)tb[e];
+                    } else {                   // s_ij = q_i . k_j ;  dp_ij = dO_i . v_j
+                        sc[r] += (float)ta[e] * s_a[r][d + e];
+                        dp[r] += (float)tb[e] * s_b[r][d + e];
+                    }
+                }
+            }
+        }
+    }
+    float pr[ATT_S], ds[ATT_S];
+    if (BYKEY) {
+#pragma unroll
+        for (int r = 0; r < ATT_S; ++r) {
+            pr[r] = (r < Ls && on) ? __expf(sc[r] * scale - s_st[r][0]) : 0.f;
+            ds[r] = pr[r] * (dp[r] - (r < Ls ? s_st[r][1] : 0.f)) * scale;
+        }
+    } else {
+        float m = -3.0e38f, l = 0.f, dsum = 0.f;
+#pragma unroll
+        for (int r = 0; r < ATT_S; ++r)
+            if (r < Ls) m = fmaxf(m, sc[r] * scale);
+#pragma unroll
+        for (int r = 0; r < ATT_S; ++r) {
+            pr[r] = r < Ls ? __expf(sc[r] * scale - m) : 0.f;
+            l += pr[r];
+        }
+        const float il = on ? 1.0f / l : 0.f;
+#pragma unroll
+        for (int r = 0; r < ATT_S; ++r) { pr[r] *= il; dsum += pr[r] * dp[r]; }
+#pragma unroll
+        for (int r = 0; r < ATT_S; ++r) ds[r] = pr[r] * (dp[r] - dsum) * scale;
+    }
+    // second sweep over the head dim: the long side's own gradient (direct) and the short side's (reduced over the lanes)
+    for (int d = 0; d < hd; d += 8) {
+        const bf16x8 ta = *(const bf16x8*)(la + d), tb = *(const bf16x8*)(lb + d);
+        float o1[8], o2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o1[e] = o2[e] = 0.f;
+#pragma unroll
+        for (int r = 0; r < ATT_S; ++r) {
+            if (r < Ls) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (BYKEY) {
+                        o1[e] += ds[r] * s_a[r][d + e];          // dk_j = sum_i ds_ij q_i
+                        o2[e] += pr[r] * s_b[r][d + e];          // dv_j = sum_i p_ij dO_i
+                        const float c = wg_wave_sum(ds[r] * (float)ta[e]);      // dq_i += sum_j ds_ij k_j
+                        if (lane == 0) atomicAdd(&acc_a[r][d + e], c);
+                    } else {
+                        o1[e] += ds[r] * s_a[r][d + e];          // dq_i = sum_j ds_ij k_j
+                        const float c1 = wg_wave_sum(ds[r] * (float)ta[e]);     // dk_j += sum_i ds_ij q_i
+                        const float c2 = wg_wave_sum(pr[r] * (float)tb[e]);     // dv_j += sum_i p_ij dO_i
+                        if (lane == 0) { atomicAdd(&acc_a[r][d + e], c1); atomicAdd(&acc_b[r][d + e], c2); }
+                    }
+                }
+            }
+        }
+        if (on) {
+            bf16x8 w1, w2;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { w1[e] = (bf16)o1[e]; w2[e] = (bf16)o2[e]; }
+            *(bf16x8*)(dlong_a + loff + d) = w1;
+            if (BYKEY) *(bf16x8*)(dlong_b + loff + d) = w2;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < Ls * hd; t += 256) {
+        const int r = t / hd, d = t % hd;
+        const long off = ((long)b * Ls + r) * D + h * hd + d;
+        atomicAdd(dshort_a + off, acc_a[r][d]);
+        if (!BYKEY) atomicAdd(dshort_b + off, acc_b[r][d]);
+    }
+}
+
 }  // namespace
+
+extern "C" int wg_l2norm_scale_bf16(const void* x, const void* log_temp, void* y, int M, int C, float eps, void* stream) {
+    WG_REQUIRE(x && log_temp && y && M > 0 && C > 0 && C % 8 == 0 && C <= 512, "l2norm_scale: C = %d must be a multiple of 8, at most 512", C);
+    hipLaunchKernelGGL(wg_l2norm_scale_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, nullptr, (const bf16*)log_temp,
+                       (bf16*)y, nullptr, M, C, eps);
+    return wg_check_launch("wg_l2norm_scale_bf16");
+}
+
+extern "C" int wg_l2norm_scale_bwd_bf16(const void* x, const void* dy, const void* log_temp, void* dx, float* dlog_temp, int M, int C, float eps,
+                                        void* stream) {
+    WG_REQUIRE(x && dy && log_temp && dx && dlog_temp && M > 0 && C > 0 && C % 8 == 0 && C <= 512, "l2norm_scale_bwd: C = %d must be a multiple of 8, at most 512", C);
+    hipLaunchKernelGGL(wg_l2norm_scale_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy,
+                       (const bf16*)log_temp, (bf16*)dx, dlog_temp, M, C, eps);
+    return wg_check_launch("wg_l2norm_scale_bwd_bf16");
+}
+
+// q [B,Lq,D], k / v [B,Lk,D], o / dout [B,Lq,D] contiguous bf16 (D = heads * head_dim); min(Lq, Lk) <= 16, head_dim % 8 == 0, <= 128.
+// dq / dk / dv: bf16 for the long side(s) written directly, fp32 (+=, zeroed by the caller) for the short side: the caller passes BOTH forms
+// for every gradient and reads the one that applies (wg_attn_bwd_short_side tells which side is short).
+// stats: workspace of B * heads * Lq * 2 floats (used when the queries are the short side).
+extern "C" int wg_attn_bwd_short_side(int Lq, int Lk) { return Lk <= ATT_S ? 1 : (Lq <= ATT_S ? 0 : -1); }   // 1: keys short, 0: queries short
+
+extern "C" int wg_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* dout, void* dq_bf16, void* dk_bf16, void* dv_bf16,
+                                float* dq_f32, float* dk_f32, float* dv_f32, float* stats, int B, int heads, int head_dim, int Lq, int Lk, float scale,
+                                void* stream) {
+    WG_REQUIRE(q && k && v && o && dout && stats, "attn_bwd: null operand");
+    WG_REQUIRE(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && head_dim % 8 == 0 && head_dim <= ATT_HD, "attn_bwd: head_dim = %d must be a multiple of 8, at most %d", head_dim, ATT_HD);
+    const int side = wg_attn_bwd_short_side(Lq, Lk);
+    WG_REQUIRE(side >= 0, "attn_bwd: one side must have at most %d rows (Lq = %d, Lk = %d)", ATT_S, Lq, Lk);
+    hipStream_t st = (hipStream_t)stream;
+    if (side == 1) {   // few keys: a lane per query
+        WG_REQUIRE(dq_bf16 && dk_f32 && dv_f32, "attn_bwd: dq (bf16), dk / dv (fp32) outputs");
+        hipLaunchKernelGGL(wg_attn_bwd_kernel<false>, dim3((Lq + 255) / 256, B * heads), dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v,
+                           (const bf16*)dout, stats, (bf16*)dq_bf16, nullptr, dk_f32, dv_f32, heads, head_dim, Lq, Lk, scale);
+    } else {           // few queries: a lane per key, softmax statistics first
+        WG_REQUIRE(dk_bf16 && dv_bf16 && dq_f32, "attn_bwd: dk / dv (bf16), dq (fp32) outputs");
+        hipLaunchKernelGGL(wg_attn_rowstats_kernel, dim3(Lq, B * heads), dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)o, (const bf16*)dout,
+                           stats, heads, head_dim, Lq, Lk, scale);
+        hipLaunchKernelGGL(wg_attn_bwd_kernel<true>, dim3((Lk + 255) / 256, B * heads), dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v,
+                           (const bf16*)dout, stats, (bf16*)dk_bf16, (bf16*)dv_bf16, dq_f32, nullptr, heads, head_dim, Lq, Lk, scale);
+    }
+    return wg_check_launch("wg_attn_bwd_bf16");
+}
 
 extern "C" int wg_colsum_f32(const void* x, long ldx, float* out, int R, int C, void* stream) {
     WG_REQUIRE(x && out && R > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, "colsum: x [R, C] bf16 with C %% 8 == 0, 16-byte rows");

@@ -324,6 +324,48 @@ __global__ __launch_bounds__(256) void wg_postprocess_kernel(const float* low, f
     }
 }
 
+// Adjoint of the two resamples (training: d loss / d low-res logits from d loss / d masks): every output pixel scatters its gradient to the 16
+// low-res taps it was blended from, with the weights the forward pass used (same index rule).  fp32 atomics; dlow zeroed by the caller.
+__global__ __launch_bounds__(256) void wg_postprocess_bwd_kernel(const float* dout, float* dlow, int N, int lh, int lw, int img, int in_h, int in_w,
+                                                                 int out_h, int out_w) {
+    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y, n = blockIdx.z;
+    if (ox >= out_w) return;
+    const float g = dout[((long)n * out_h + oy) * out_w + ox];
+    if (g == 0.f) return;
+    const float s1y = (float)lh / (float)img, s1x = (float)lw / (float)img;
+    const float s2y = (float)in_h / (float)out_h, s2x = (float)in_w / (float)out_w;
+    float* m = dlow + (long)n * lh * lw;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    wg_src_index(oy, s2y, in_h, y0, y1, ly);
+    wg_src_index(ox, s2x, in_w, x0, x1, lx);
+    int ya[2][2], xa[2][2];
+    float lya[2], lxa[2];
+    wg_src_index(y0, s1y, lh, ya[0][0], ya[0][1], lya[0]);
+    wg_src_index(y1, s1y, lh, ya[1][0], ya[1][1], lya[1]);
+    wg_src_index(x0, s1x, lw, xa[0][0], xa[0][1], lxa[0]);
+    wg_src_index(x1, s1x, lw, xa[1][0], xa[1][1], lxa[1]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float w2 = g * (j ? ly : 1.f - ly) * (i ? lx : 1.f - lx);
+            atomicAdd(m + ya[j][0] * lw + xa[i][0], w2 * (1.f - lya[j]) * (1.f - lxa[i]));
+            atomicAdd(m + ya[j][0] * lw + xa[i][1], w2 * (1.f - lya[j]) * lxa[i]);
+            atomicAdd(m + ya[j][1] * lw + xa[i][0], w2 * lya[j] * (1.f - lxa[i]));
+            atomicAdd(m + ya[j][1] * lw + xa[i][1], w2 * lya[j] * lxa[i]);
+        }
+}
+
+extern "C" int wg_postprocess_masks_bwd_f32(const float* dout, float* dlow, int N, int low_h, int low_w, int img_size, int in_h, int in_w, int out_h,
+                                            int out_w, void* stream) {
+    WG_REQUIRE(dout && dlow && N > 0 && low_h > 0 && low_w > 0 && img_size > 0 && in_h > 0 && in_w > 0 && in_h <= img_size && in_w <= img_size &&
+                   out_h > 0 && out_w > 0, "postprocess_bwd: bad arguments");
+    hipLaunchKernelGGL(wg_postprocess_bwd_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)N), dim3(256), 0, (hipStream_t)stream,
+                       dout, dlow, N, low_h, low_w, img_size, in_h, in_w, out_h, out_w);
+    return wg_check_launch("wg_postprocess_masks_bwd_f32");
+}
+
 extern "C" int wg_postprocess_masks_f32(const float* low_res, float* out, int N, int low_h, int low_w, int img_size,
                                         int in_h, int in_w, int out_h, int out_w, void* stream) {
     WG_REQUIRE(low_res && out && N > 0 && low_h > 0 && low_w > 0 && img_size > 0, "postprocess: bad arguments");
@@ -473,9 +515,12 @@ __global__ __launch_bounds__(64) void wg_mask_stats_final_kernel(const float* ws
             const float i0 = a[0], i1 = a[3], o0 = a[0] + a[1], o1 = a[2] + a[3], t0 = a[0] + a[2], t1 = a[1] + a[3];
             float* o = out + (long)n * 6;
             o[0] = i0; o[1] = i1; o[2] = o0 + t0 - i0; o[3] = o1 + t1 - i1; o[4] = t0; o[5] = t1;
-        } else {           // [mean bce, dice loss] of this mask
+        } else if (MODE == 1) {   // [mean bce, dice loss] of this mask
             out[(long)n * 2 + 0] = a[0] / (float)hw;
             out[(long)n * 2 + 1] = 1.0f - (2.0f * a[1] / scale + eps) / (a[2] / scale + a[3] / scale + eps);
+        } else {                  // MODE 2 (loss backward): the dice loss's numerator and denominator
+            out[(long)n * 2 + 0] = 2.0f * a[1] / scale + eps;
+            out[(long)n * 2 + 1] = a[2] / scale + a[3] / scale + eps;
         }
     }
 }
@@ -507,6 +552,36 @@ extern "C" int wg_mask_losses_f32(const float* pred_logits, const float* targets
     hipLaunchKernelGGL(wg_mask_stats_final_kernel<1>, dim3(N), dim3(64), 0, (hipStream_t)stream, workspace, out2, (int)nblk, hw,
                        dice_scale, dice_eps);
     return wg_check_launch("wg_mask_losses_f32");
+}
+
+// d(g_bce * sigmoid_ce_loss + g_dice * dice_loss) / d logits (utils_walkgpt.py:76-120; g_* already carry the 1 / (num_masks + 1e-8) of the final
+// mean and the upstream gradient).  Per mask: bce_mean' = (s - y) / hw;  dice = 1 - num / den, num = 2 sum(s y) / scale + eps,
+// den = (sum s + sum y) / scale + eps:  d dice / d s_i = (num - 2 y_i den) / (scale den^2),  ds / dx = s (1 - s).
+__global__ __launch_bounds__(256) void wg_mask_losses_bwd_kernel(const float* pred, const float* gt, const float* numden, float* dpred, long hw, float g_bce,
+                                                                 float g_dice, float scale) {
+    const int n = blockIdx.y;
+    const float num = numden[(long)n * 2], den = numden[(long)n * 2 + 1];
+    const float kb = g_bce / (float)hw, kd = g_dice / (scale * den * den);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
+        const float x = pred[(long)n * hw + i], y = gt[(long)n * hw + i];
+        const float sg = 1.0f / (1.0f + __expf(-x));
+        dpred[(long)n * hw + i] = kb * (sg - y) + kd * (num - 2.0f * y * den) * sg * (1.0f - sg);
+    }
+}
+
+extern "C" int wg_mask_losses_bwd_f32(const float* pred_logits, const float* targets, float* dpred, float* workspace, long workspace_floats, int N, long hw,
+                                      float g_bce, float g_dice, float dice_scale, float dice_eps, void* stream) {
+    WG_REQUIRE(pred_logits && targets && dpred && workspace && N > 0 && hw > 0, "mask_losses_bwd: bad arguments");
+    const long nblk = wg_mask_stats_blocks(hw);
+    WG_REQUIRE(workspace_floats >= (long)N * nblk * 4 + 2L * N, "mask_losses_bwd: workspace too small (need %ld floats)", (long)N * nblk * 4 + 2L * N);
+    float* numden = workspace + (long)N * nblk * 4;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(wg_mask_stats_partial_kernel<1>, dim3((unsigned)nblk, N), dim3(256), 0, st, pred_logits, targets, workspace, hw, (int)nblk, 0.f);
+    hipLaunchKernelGGL(wg_mask_stats_final_kernel<2>, dim3(N), dim3(64), 0, st, workspace, numden, (int)nblk, hw, dice_scale, dice_eps);
+    long gx = (hw + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(wg_mask_losses_bwd_kernel, dim3((unsigned)gx, N), dim3(256), 0, st, pred_logits, targets, numden, dpred, hw, g_bce, g_dice, dice_scale);
+    return wg_check_launch("wg_mask_losses_bwd_f32");
 }
 
 
