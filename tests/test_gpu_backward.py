@@ -126,5 +126,104 @@ def test_postprocess_and_mask_losses_backward(dev, N, inp, orig):
     den = (s / 1000).sum(-1) + (t / 1000).sum(-1)
     dice_r = (1 - (num + 1e-6) / (den + 1e-6)).sum() / (N + 1e-8)
     (2.0 * bce_r + 0.5 * dice_r).backward()
-    assert abs(float(bce) - float(bce_r)) < 1e-5 and abs(float(dice) - float(dice_r)) < 1e-5
+    assert abs(float(bce.detach()) - float(bce_r.detach())) < 1e-5 and abs(float(dice.detach()) - float(dice_r.detach())) < 1e-5
     assert rel(lh.grad, lr.grad) < 1e-4, rel(lh.grad, lr.grad)
+
+
+def test_ctp_training_path_vs_oracle_autograd(dev):
+    """CalibratedTextProjector through walkgpt_amd.train_head.ctp_forward: output and every gradient (hidden states, all parameters) against
+    torch autograd over the oracle's restatement on the same bf16-rounded weights."""
+    from oracle import projectors as oproj
+    from walkgpt_amd import train_head
+    from walkgpt_amd.utils_walkgpt import CalibratedTextProjector
+    H = 512
+    ctp = CalibratedTextProjector(H, 256)
+    g = torch.Generator().manual_seed(5)
+    with torch.no_grad():
+        for p in ctp.parameters():
+            p.copy_((torch.randn(p.shape, generator=g) * (0.3 if p.dim() == 1 else p.shape[-1] ** -0.5)).to(torch.bfloat16).float())
+        ctp.net[0].weight.add_(1.0)
+        ctp.net[4].weight.add_(1.0)
+    ctp = ctp.to(dev).bfloat16()
+    x = torch.randn(9, H, generator=g).to(torch.bfloat16)
+    dy = torch.randn(9, 256, generator=g).to(torch.bfloat16)
+    xh = _leaf(x, dev)
+    y = train_head.ctp_forward(ctp, xh)
+    y.backward(dy.to(dev))
+    wr = {k: v.detach().float().cpu().requires_grad_(True) for k, v in ctp.state_dict().items()}
+    xr = x.float().requires_grad_(True)
+    yr = oproj.ctp(wr, xr).reshape(9, 256)          # (text_type is [1, 1, 256]: the oracle's output carries that leading 1)
+    yr.backward(dy.float())
+    assert rel(y, yr) < 1e-2
+    assert rel(xh.grad, xr.grad) < 3e-2, rel(xh.grad, xr.grad)
+    for k, p in ctp.named_parameters():
+        assert rel(p.grad, wr[k].grad) < 4e-2, (k, rel(p.grad, wr[k].grad))
+
+
+def test_mask_decoder_training_path_vs_oracle_autograd(dev):
+    """[SEG] embeddings -> prompt encoder -> MaskDecoder -> postprocess -> sigmoid-CE + dice loss through walkgpt_amd.train_head, one
+    image with three prompts: the loss, its gradient on the incoming embeddings and on EVERY decoder parameter against torch autograd over the
+    oracle's restatement (fp32, same bf16-rounded weights and inputs)."""
+    from oracle import sam as osam
+    from tests.golden import cases
+    from tests.test_gpu_modules import load_into
+    from walkgpt_amd import train_head
+    from walkgpt_amd.segment_anything import modeling as M
+    c = cases.DECODERS["g32"]
+    g = c["grid"]
+    sam = M._build_sam(128, 1, 2, [0], image_size=g * 16)
+    w = cases.decoder_case_weights(c)
+    load_into(sam.prompt_encoder, w, "prompt_encoder.", dev, strict=False)
+    load_into(sam.mask_decoder, w, "mask_decoder.", dev)
+    sam.prompt_encoder.pe_layer.positional_encoding_gaussian_matrix.data = w["prompt_encoder.pe_layer.positional_encoding_gaussian_matrix"].to(dev)
+    sam.to(dev)
+    emb, text = cases.decoder_inputs(c)                                   # [1,256,g,g], [3,1,256]
+    embq, textq = emb.to(torch.bfloat16), text.to(torch.bfloat16)
+    inp, orig = (g * 16, g * 16 * 3 // 4), (200, 150)
+    tgt = (torch.rand(3, orig[0], orig[1], generator=torch.Generator().manual_seed(2)) > 0.5).float()
+
+    class _G:      # the two attributes train_head.decode reads from a WalkGPTGrounding
+        visual_model = sam
+    th = _leaf(textq[:, 0], dev)
+    emb_tokens = embq.flatten(2).transpose(1, 2).contiguous().to(dev)     # [1, hw, 256] channels-last rows
+    masks = train_head.decode(_G, emb_tokens, [th], [inp], [orig])[0]
+    bce, dice = ag.mask_losses(masks.contiguous(), tgt.to(dev), 3)
+    loss = 2.0 * bce + 0.5 * dice
+    loss.backward()
+
+    def oracle_run(dt):
+        wq = {k: v.detach().to(dt).clone().requires_grad_(k.startswith("mask_decoder.")) for k, v in w.items()}
+        tr = textq.detach().to(dt).clone().requires_grad_(True)
+        rdpe = osam.dense_pe({k: v.float() for k, v in w.items()}, (g, g)).to(dt)      # (the positional encoding is fp32 arithmetic in every run)
+        rsp, rdense = osam.prompt_encoder_text(wq, tr, (g, g))
+        rm, _ = osam.mask_decoder(wq, embq.to(dt), rdpe, rsp, rdense, multimask_output=False)
+        rfull = osam.postprocess_masks(rm.float(), g * 16, inp, orig)[:, 0]
+        F = torch.nn.functional
+        bce_r = F.binary_cross_entropy_with_logits(rfull, tgt, reduction="none").flatten(1, 2).mean(1).sum() / (3 + 1e-8)
+        sgm, t = rfull.sigmoid().flatten(1, 2), tgt.flatten(1, 2)
+        dice_r = (1 - (2 * (sgm / 1000 * t).sum(-1) + 1e-6) / ((sgm / 1000).sum(-1) + (t / 1000).sum(-1) + 1e-6)).sum() / (3 + 1e-8)
+        loss_r = 2.0 * bce_r + 0.5 * dice_r
+        loss_r.backward()
+        return loss_r, rfull, tr.grad[:, 0], {k[len("mask_decoder."):]: v.grad for k, v in wq.items() if k.startswith("mask_decoder.")}
+
+    loss_r, rfull, gt32, gw32 = oracle_run(torch.float32)
+    _, _, gt16, gw16 = oracle_run(torch.bfloat16)          # the same graph in bf16 on the CPU: what bf16 autograd itself costs
+    e_hip, e_16 = rel(th.grad, gt32), rel(gt16, gt32)
+    print("decoder training path: loss %.5f (oracle %.5f); mask logits rel err %.4f; d loss / d [SEG] embedding rel err HIP %.4f, oracle in bf16 %.4f"
+          % (float(loss.detach()), float(loss_r.detach()), rel(masks, rfull), e_hip, e_16))
+    assert abs(float(loss.detach()) - float(loss_r.detach())) < 2e-2 * abs(float(loss_r.detach())) and rel(masks, rfull) < 3e-2
+    assert e_hip < max(1.5 * e_16, 0.05), (e_hip, e_16)
+    worst, worst16 = ("", 0.0), 0.0
+    for k, p in sam.mask_decoder.named_parameters():
+        if p.grad is None:   # not on the loss's path (IoU head; the hypernetworks of the masks multimask_output=False does not return)
+            assert gw32[k] is None or float(gw32[k].abs().max()) == 0.0, k
+            continue
+        e, e16 = rel(p.grad, gw32[k]), rel(gw16[k], gw32[k])
+        if e16 > 1.0:      # a gradient that is exactly zero in exact arithmetic (a key bias shifts every score of a softmax row alike): rounding noise only
+            assert float(p.grad.float().norm()) <= 10.0 * float(gw16[k].float().norm()) + 1e-5, k
+            continue
+        worst16 = max(worst16, e16)
+        if e > worst[1]:
+            worst = (k, e)
+        assert e < max(2.0 * e16, 0.06), (k, e, e16)
+    print("decoder parameter gradients: worst rel err HIP %.4f (%s); oracle in bf16, worst %.4f" % (worst[1], worst[0], worst16))

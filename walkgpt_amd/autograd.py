@@ -26,10 +26,21 @@ def _pad_rows(t, mult=64):
     return out
 
 
+def _dense2d(t, C):
+    """[..., C] -> [rows, C] with strides exactly (C, 1) (torch calls a [rows, 1] tensor contiguous whatever its last stride is; the C-ABI
+    takes leading dimensions literally)."""
+    t = t.reshape(-1, C)
+    if not t.is_contiguous():
+        t = t.contiguous()
+    if t.stride() != (C, 1):
+        t = t.as_strided(t.shape, (C, 1))
+    return t
+
+
 def transpose2d(t):
     """[R, C] bf16 contiguous -> [C, R] (wg_tokens_to_nchw_bf16 with one batch)."""
     R, C = t.shape
-    return ops.tokens_to_nchw(t.contiguous(), 1, R, C).view(C, R)
+    return _dense2d(ops.tokens_to_nchw(_dense2d(t, C), 1, R, C).view(C, R), R)
 
 
 def colsum(t):
@@ -50,18 +61,19 @@ class _Linear(torch.autograd.Function):
     reduction dimension padded to whole slabs; dW accumulated and returned in fp32 -> parameter dtype), db = column sums of dY."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, out_f32=False):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         with torch.no_grad():
-            return ops.linear(x.contiguous(), weight, bias)
+            y = ops.linear(_dense2d(x, weight.shape[1]), _dense2d(weight, weight.shape[1]), bias, out_f32=out_f32)
+            return y.view(x.shape[:-1] + (weight.shape[0],))
 
     @staticmethod
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         N, K = weight.shape
-        dy2 = dy.contiguous().view(-1, N)
-        x2 = x.contiguous().view(-1, K)
+        dy2 = _dense2d(dy.to(BF16), N)
+        x2 = _dense2d(x, K)
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = ops.linear(dy2, transpose2d(weight.detach())).view(x.shape)                     # [M, N] @ [N, K]
@@ -70,7 +82,7 @@ class _Linear(torch.autograd.Function):
             dw = ops.linear(dyt, xt, out_f32=True).to(weight.dtype)                              # [N, K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = colsum(dy2).to(weight.dtype)
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 class _Act(torch.autograd.Function):
@@ -120,10 +132,10 @@ class _LayerNorm(torch.autograd.Function):
         return dx, dg.to(gamma.dtype), db.to(gamma.dtype), None
 
 
-def linear(x, weight, bias=None, act=ops.ACT_NONE):
-    """Differentiable ops.linear (+ a separate activation operator when one is asked for)."""
+def linear(x, weight, bias=None, act=ops.ACT_NONE, out_f32=False):
+    """Differentiable ops.linear (+ a separate activation operator when one is asked for).  out_f32: fp32 result (no activation)."""
     ops._need_gpu(x, weight, bias)
-    y = _Linear.apply(x, weight, bias)
+    y = _Linear.apply(x, weight, bias, out_f32)
     return y if act == ops.ACT_NONE else _Act.apply(y, act)
 
 

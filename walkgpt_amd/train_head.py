@@ -1,0 +1,144 @@
+"""Training path of the grounding head: CalibratedTextProjector -> prompt encoder (text branch) -> MaskDecoder -> Sam.postprocess_masks ->
+mask losses, composed from the differentiable HIP operators of walkgpt_amd.autograd so that `loss.backward()` reaches the parameters
+train_walkgpt.py:347-350 leaves trainable (mask_decoder.*, text_hidden_fcs.*) and the LLM hidden states the [SEG] rows came from.
+
+Reference structure restated operator by operator: utils_walkgpt.py:302-327 (CTP), prompt_encoder.py:149-186 (text branch),
+mask_decoder.py:116-164, transformer.py:62-240, sam.py:137-172, utils_walkgpt.py:76-120; the per-image loop of model/walkgpt.py:716-737.
+Inference uses the fused kernels (segment_anything.modeling); this is what they decompose into when gradients are asked for.  Tensor
+re-arrangements (concatenation, broadcast, pixel shuffle, residual adds) are torch views / elementwise adds on the bf16 tensors; every
+GEMM, LayerNorm, activation, attention, resample and loss -- forward and backward -- is a HIP kernel.
+"""
+import math
+
+import torch
+
+from . import autograd as ag
+from . import ops
+
+BF16 = torch.bfloat16
+
+
+def _ln(x, n):
+    return ag.layernorm(x, n.weight, n.bias, n.eps)
+
+
+def _lin(x, layer, act=ops.ACT_NONE):
+    return ag.linear(x, layer.weight, layer.bias, act)
+
+
+def ctp_forward(ctp, x):
+    """CalibratedTextProjector.forward (utils_walkgpt.py:316-327) on [M, H_llm] bf16 rows."""
+    if ctp.use_residual:
+        raise NotImplementedError("use_residual=True is never configured by WalkGPT (walkgpt.py:115-123)")
+    net = ctp.net
+    y = _lin(_ln(x.contiguous(), net[0]), net[1], ops.ACT_GELU)
+    y = _lin(y, net[3])
+    y = ag.add_row(_ln(y, net[4]), ctp.text_type.reshape(-1))
+    return ag.l2norm_scale(y, ctp.log_temp, 1e-12)
+
+
+def _attention(att, q, k, v):
+    """transformer.py:185-240: projections, per-head softmax(q k^T / sqrt(d)) v, out_proj.  q [P, Nq, C], k / v [P, Nk, C]."""
+    qp, kp, vp = _lin(q, att.q_proj), _lin(k, att.k_proj), _lin(v, att.v_proj)
+    hd = att.internal_dim // att.num_heads
+    o = ag.attention(qp, kp, vp, att.num_heads, 1.0 / math.sqrt(hd))
+    return _lin(o, att.out_proj)
+
+
+def _two_way_block(blk, queries, keys, query_pe, key_pe):
+    """transformer.py:151-182."""
+    if blk.skip_first_layer_pe:
+        queries = _attention(blk.self_attn, queries, queries, queries)
+    else:
+        q = queries + query_pe
+        queries = queries + _attention(blk.self_attn, q, q, queries)
+    queries = _ln(queries, blk.norm1)
+    q, k = queries + query_pe, keys + key_pe
+    queries = _ln(queries + _attention(blk.cross_attn_token_to_image, q, k, keys), blk.norm2)
+    h = _lin(_lin(queries, blk.mlp.lin1, blk.mlp._act_code), blk.mlp.lin2)
+    queries = _ln(queries + h, blk.norm3)
+    q, k = queries + query_pe, keys + key_pe
+    keys = _ln(keys + _attention(blk.cross_attn_image_to_token, k, q, queries), blk.norm4)
+    return queries, keys
+
+
+def _two_way_transformer(tr, src_tokens, pos_tokens, point_embedding):
+    """transformer.py:62-106 on channels-last rows: src_tokens / pos_tokens [P, hw, C], point_embedding [P, Nt, C]."""
+    queries, keys = point_embedding, src_tokens
+    for blk in tr.layers:
+        queries, keys = _two_way_block(blk, queries, keys, point_embedding, pos_tokens)
+    q, k = queries + point_embedding, keys + pos_tokens
+    queries = _ln(queries + _attention(tr.final_attn_token_to_image, q, k, keys), tr.norm_final_attn)
+    return queries, keys
+
+
+def _mlp3(mlp, x):
+    """mask_decoder.py:167-188 (ReLU between layers, no sigmoid on WalkGPT's path)."""
+    n = len(mlp.layers)
+    for i, layer in enumerate(mlp.layers):
+        x = _lin(x, layer, ops.ACT_RELU if i < n - 1 else ops.ACT_NONE)
+    if mlp.sigmoid_output:
+        raise NotImplementedError("sigmoid_output heads are not on WalkGPT's path")
+    return x
+
+
+def _convt2x2_rows(x_rows, conv, P, h, w):
+    """ConvTranspose2d(k=2, s=2) on channels-last rows [P*h*w, Cin] -> [P*2h*2w, Cout]: a per-pixel GEMM whose output columns are
+    (dy, dx, c_out), then the pixel shuffle (a view + one copy)."""
+    cout = conv.weight.shape[1]
+    wg = conv.weight.permute(2, 3, 1, 0).reshape(-1, conv.weight.shape[0])        # [(dy, dx, Cout), Cin]
+    y = ag.linear(x_rows, wg.contiguous(), conv.bias.repeat(4))
+    y = y.view(P, h, w, 2, 2, cout).permute(0, 1, 3, 2, 4, 5).reshape(P * 2 * h * 2 * w, cout)
+    return y
+
+
+def decoder_forward(dec, src_tokens, pos_tokens, sparse, dense_vec, h, w, mask_slice=(0, 1)):
+    """MaskDecoder.predict_masks (mask_decoder.py:116-164) for P prompts.
+    src_tokens [P, hw, C] (each prompt's image embedding, channels-last rows), pos_tokens [1 or P, hw, C], sparse [P, n, C],
+    dense_vec [C] (the no-mask embedding, the same at every pixel: prompt_encoder.py:181-184).
+    -> (low-res mask logits fp32 [P, k, 4h, 4w], iou predictions [P, k])."""
+    P = sparse.shape[0]
+    C = dec.transformer_dim
+    out_tokens = torch.cat([dec.iou_token.weight, dec.mask_tokens.weight], 0).unsqueeze(0).expand(P, -1, -1)
+    tokens = torch.cat([out_tokens, sparse], 1).contiguous()
+    src = ag.add_row(src_tokens.contiguous(), dense_vec)
+    pos = pos_tokens.expand(P, -1, -1)
+    hs, keys = _two_way_transformer(dec.transformer, src, pos, tokens)
+    nm = dec.num_mask_tokens
+    iou_out, mask_out = hs[:, 0], hs[:, 1:1 + nm]
+    up = _convt2x2_rows(keys.reshape(P * h * w, C), dec.output_upscaling[0], P, h, w)
+    n1 = dec.output_upscaling[1]
+    up = ag.activation(ag.layernorm(up, n1.weight, n1.bias, n1.eps), ops.ACT_GELU)
+    up = ag.activation(_convt2x2_rows(up, dec.output_upscaling[3], P, 2 * h, 2 * w), ops.ACT_GELU)      # [P*4h*4w, C/8]
+    hyper = torch.stack([_mlp3(dec.output_hypernetworks_mlps[i], mask_out[:, i].contiguous()) for i in range(nm)], 1)   # [P, nm, C/8]
+    k0, k1 = mask_slice[0], mask_slice[0] + mask_slice[1]
+    up = up.view(P, 16 * h * w, -1)
+    masks = []
+    for p in range(P):   # masks_p = hyper_in_p @ upscaled_p: a GEMM per prompt (its weights are the prompt's own hypernetwork output)
+        m = ag.linear(up[p], hyper[p, k0:k1].contiguous(), None, out_f32=True)                       # [16hw, k] fp32 logits
+        masks.append(m.t().reshape(k1 - k0, 4 * h, 4 * w))
+    iou = _mlp3(dec.iou_prediction_head, iou_out.contiguous())
+    return torch.stack(masks, 0), iou[:, k0:k1]
+
+
+def decode(grounding, emb_tokens, pred_embeddings, resize_list, original_size_list, multimask_output=False):
+    """WalkGPTGrounding.decode with gradients: emb_tokens [B, hw, 256] (frozen SAM embedding), pred_embeddings[i] [T_i, 256] (CTP output).
+    -> pred_masks[i] fp32 [T_i, H0, W0] (logits), differentiable in pred_embeddings and the decoder's parameters."""
+    vm = grounding.visual_model
+    h, w = vm.prompt_encoder.image_embedding_size
+    pe = vm.prompt_encoder.dense_pe_tokens().unsqueeze(0).to(BF16)
+    no_mask = vm.prompt_encoder.no_mask_embed.weight.reshape(-1)
+    dec = vm.mask_decoder
+    sl = (1, dec.num_mask_tokens - 1) if multimask_output else (0, 1)
+    out = []
+    for i, pred in enumerate(pred_embeddings):
+        T = int(pred.shape[0])
+        H0, W0 = original_size_list[i]
+        if T == 0:
+            out.append(torch.zeros(0, H0, W0, device=emb_tokens.device))
+            continue
+        src = emb_tokens[i:i + 1].expand(T, -1, -1)
+        low_res, _ = decoder_forward(dec, src, pe, pred.unsqueeze(1), no_mask, h, w, sl)
+        full = ag.postprocess_masks(low_res.contiguous(), vm.image_encoder.img_size, resize_list[i], original_size_list[i])
+        out.append(full[:, 0])
+    return out
