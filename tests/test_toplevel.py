@@ -243,6 +243,68 @@ def test_model_forward_collate_dict_vs_oracle(dev):
 
 
 @pytest.mark.gpu
+def test_model_forward_trains_the_grounding_head(dev):
+    """train_walkgpt.py's step on the adapter: `enable_head_training()`, forward(**collate dict) with gradients on, `loss.backward()`.  The
+    loss dict equals the no-gradient forward's; text_hidden_fcs.*, mask_decoder.* and the language model's parameters receive finite
+    gradients; the frozen parts (SAM encoders, MSQP in this round) receive none; a plain SGD step on the head lowers the mask loss."""
+    m, lm, weights = _build(dev)
+    c = weights["c"]
+    x = cases.sam_encoder_input(c)
+    L = 12
+    ids = torch.randint(3, 50, (3, L), generator=torch.Generator().manual_seed(9))
+    ids[:, 1] = -200
+    ids[0, 5] = SEG; ids[0, 9] = SEG
+    ids[1, 7] = SEG
+    ids[2, 4] = SEG; ids[2, 6] = SEG; ids[2, 10] = SEG
+    offset = torch.tensor([0, 2, 3])
+    resize, orig = [(512, 384), (400, 512)], [(200, 150), (75, 96)]
+    gt = [(torch.rand(3, *o, generator=torch.Generator().manual_seed(i)) > 0.5).float().to(dev) for i, o in enumerate(orig)]
+    batch = dict(images=x.to(dev, torch.bfloat16), images_clip=torch.zeros(2, 3, 28, 28, device=dev, dtype=torch.bfloat16),
+                 input_ids=ids.to(dev), labels=ids.to(dev), attention_masks=torch.ones(3, L, dtype=torch.bool, device=dev), offset=offset.to(dev),
+                 masks_list=gt, label_list=[torch.zeros(orig[0], device=dev), torch.zeros(orig[1], device=dev)], resize_list=resize,
+                 clip_resize_list=[(28, 28)] * 2, inference=False)
+    base = m(**batch)                                                   # head training off: the no-gradient forward
+    assert not base["loss"].requires_grad
+    for p in m.model.visual_model.parameters():                        # model/walkgpt.py:83-91: SAM frozen, its mask decoder trainable
+        p.requires_grad_(False)
+    for p in m.model.visual_model.mask_decoder.parameters():
+        p.requires_grad_(True)
+    m.enable_head_training()
+    out = m(**batch)
+    assert out["loss"].requires_grad
+    for k in ("ce_loss", "mask_bce_loss", "mask_dice_loss"):
+        assert abs(float(out[k].detach()) - float(base[k])) < 2e-2 * abs(float(base[k])) + 1e-4, (k, float(out[k].detach()), float(base[k]))
+    out["loss"].backward()
+    head = [(k, p) for k, p in m.model.named_parameters() if k.startswith("text_hidden_fcs.") or ".mask_decoder." in k]
+    got = [k for k, p in head if p.grad is not None]
+    assert len(got) > 0.8 * len(head), (len(got), len(head))            # (all but the IoU head and the hypernetworks of the masks not returned)
+    assert all(torch.isfinite(p.grad).all() for _, p in head if p.grad is not None)
+    zero = [k for k, p in head if p.grad is not None and "k_proj.bias" not in k and float(p.grad.float().abs().max()) == 0]
+    # exactly zero, as in the reference: the hypernetworks of the masks multimask_output=False does not return
+    assert all(".output_hypernetworks_mlps." in k and ".output_hypernetworks_mlps.0." not in k for k in zero), zero
+    assert lm.head.weight.grad is not None and lm.wq[0].grad is not None and torch.isfinite(lm.wq[0].grad).all()   # the LLM learns from both losses
+    frozen = [p for k, p in m.model.named_parameters() if ".image_encoder." in k or ".prompt_encoder." in k or k.startswith("out_mm_projector.")]
+    assert frozen and all(p.grad is None for p in frozen)
+    # a few descent steps on the head only, fp32 master weights behind the bf16 parameters (a bf16 parameter does not register a step of a
+    # fraction of a percent): the mask loss goes down
+    before = float(out["mask_loss"].detach())
+    train_p = [p for _, p in head if p.grad is not None and float(p.grad.float().abs().mean()) > 0]
+    master = [p.detach().float().clone() for p in train_p]
+    for _ in range(6):
+        with torch.no_grad():
+            for p, w32 in zip(train_p, master):
+                g = p.grad.float()
+                w32 -= 0.002 * w32.abs().mean() / (g.abs().mean() + 1e-30) * g
+                p.copy_(w32.to(p.dtype))
+                p.grad = None
+        step = m(**batch)
+        step["mask_loss"].backward()
+    after = float(step["mask_loss"].detach())
+    print("head training, 6 steps: mask loss %.5f -> %.5f" % (before, after))
+    assert after < before
+
+
+@pytest.mark.gpu
 def test_evaluate_signature_and_masks_vs_oracle(dev):
     from oracle import splice as osplice
     L0 = 8

@@ -362,45 +362,78 @@ class walkgptForCausalLM(nn.Module):  # noqa: N801  (the reference's class name)
         return ops.linear(x, mp[2].weight, mp[2].bias)
 
     # -- walkgpt.py:267-605 ------------------------------------------------------------------------------------------------------------
-    @torch.no_grad()
+    head_training = False
+
+    def enable_head_training(self, on: bool = True):
+        """Training of the grounding head (train_walkgpt.py:347-350): with this on, `model_forward(inference=False)` called with gradients
+        enabled runs CTP, the mask decoder, postprocess and the mask losses through walkgpt_amd.train_head (differentiable HIP operators),
+        so `loss.backward()` fills `.grad` of text_hidden_fcs.*, visual_model.mask_decoder.* and -- through the [SEG] hidden states and the
+        language-model loss -- of whatever the caller left trainable in the language model.  Frozen here as in the reference: SAM's image and
+        prompt encoders, the vision tower.  Not differentiated yet (their forward values still enter the loss): the MSQP tokens spliced into
+        the language model's input and the InfoNCE term."""
+        self.head_training = bool(on)
+        return self
+
     def model_forward(self, images, images_clip, input_ids, labels, attention_masks, offset, masks_list: List[torch.Tensor],
                       label_list: List[torch.Tensor], resize_list: List[tuple], inference: bool = False, clip_resize_list=None,
                       decode_masks: bool = True, **kwargs):
-        batch_size = images.shape[0]
-        assert batch_size == len(offset) - 1
-        seg_token_mask = self._seg_token_mask(input_ids, pad_right=True)
-        if inference:
-            assert images_clip.shape[0] == 1, "inference branch assumes one image"
-        off = [int(v) for v in offset]
-        # SAM encoder once for the batch, MSQP on all images at once (the reference calls it image by image: :364-378)
-        emb_tokens = self.model.get_visual_emb_tokens(images)                        # [B, hw, 256] channels-last rows
-        tokens_proj = self.model.out_mm_projector(emb_tokens)                         # [B, 36, H]
-        row_img = torch.tensor([i for i in range(batch_size) for _ in range(off[i + 1] - off[i])], device=images.device)
-        if inference:
-            row_img = torch.zeros(input_ids.shape[0], dtype=torch.long, device=images.device)
-        sam_tokens = tokens_proj.index_select(0, row_img)                             # one row of image tokens per text row
-        sam_tokens_256 = emb_tokens.index_select(0, row_img)
-        attn, embeds, new_labels, _ = self._llm_inputs(input_ids, attention_masks, None if inference else labels, sam_tokens)
+        train = bool(self.head_training and torch.is_grad_enabled() and not inference)
+        if not train:
+            with torch.no_grad():
+                return self._model_forward(images, images_clip, input_ids, labels, attention_masks, offset, masks_list, label_list, resize_list,
+                                           inference, clip_resize_list, decode_masks, False)
+        return self._model_forward(images, images_clip, input_ids, labels, attention_masks, offset, masks_list, label_list, resize_list, inference,
+                                   clip_resize_list, decode_masks, True)
+
+    def _model_forward(self, images, images_clip, input_ids, labels, attention_masks, offset, masks_list, label_list, resize_list, inference,
+                       clip_resize_list, decode_masks, train):
+        from . import autograd as ag
+        from . import train_head
+        with torch.no_grad():                  # SAM encoder, MSQP, the splice: no gradients in either mode
+            batch_size = images.shape[0]
+            assert batch_size == len(offset) - 1
+            seg_token_mask = self._seg_token_mask(input_ids, pad_right=True)
+            if inference:
+                assert images_clip.shape[0] == 1, "inference branch assumes one image"
+            off = [int(v) for v in offset]
+            # SAM encoder once for the batch, MSQP on all images at once (the reference calls it image by image: :364-378)
+            emb_tokens = self.model.get_visual_emb_tokens(images)                        # [B, hw, 256] channels-last rows
+            tokens_proj = self.model.out_mm_projector(emb_tokens)                         # [B, 36, H]
+            row_img = torch.tensor([i for i in range(batch_size) for _ in range(off[i + 1] - off[i])], device=images.device)
+            if inference:
+                row_img = torch.zeros(input_ids.shape[0], dtype=torch.long, device=images.device)
+            sam_tokens = tokens_proj.index_select(0, row_img)                             # one row of image tokens per text row
+            sam_tokens_256 = emb_tokens.index_select(0, row_img)
+            attn, embeds, new_labels, _ = self._llm_inputs(input_ids, attention_masks, None if inference else labels, sam_tokens)
+
         output = self.llm(inputs_embeds=embeds, attention_mask=attn, labels=new_labels, output_hidden_states=True)
         last_hidden = output.hidden_states[-1]
         assert len(self.model.text_hidden_fcs) == 1
         # CTP is a per-token map: projecting the gathered [SEG] rows equals projecting the sequence and gathering (:406-409)
         assert seg_token_mask.shape[1] == last_hidden.shape[1], (seg_token_mask.shape, last_hidden.shape)
         seg_hidden = last_hidden[seg_token_mask]
-        pred_embeddings = self.model.text_hidden_fcs[0](seg_hidden.to(BF16)) if seg_hidden.shape[0] else seg_hidden.new_zeros(0, 256, dtype=BF16)
-        pred_embeddings_nce = pred_embeddings
+        ctp = self.model.text_hidden_fcs[0]
+        if seg_hidden.shape[0] == 0:
+            pred_embeddings = seg_hidden.new_zeros(0, 256, dtype=BF16)
+        else:
+            pred_embeddings = train_head.ctp_forward(ctp, seg_hidden.to(BF16)) if train else ctp(seg_hidden.to(BF16))
+        pred_embeddings_nce = pred_embeddings.detach()
         seg_token_counts = seg_token_mask.int().sum(-1)
         pred_list, batch_seg_token_counts = self._queries_per_image(pred_embeddings, seg_token_counts, off, inference)
         # region-alignment InfoNCE (:449-473)
         seg_row_ids = torch.repeat_interleave(torch.arange(sam_tokens_256.size(0), device=images.device), seg_token_counts)
         loss_nce = torch.zeros((), device=images.device)
         if seg_row_ids.numel() > 0 and not inference:
-            loss_nce = infonce_loss(pred_embeddings_nce, sam_tokens_256, seg_row_ids, self.model.tiny_xattn, temperature=self.nce_tau,
-                                    top_k=self.nce_topk, exclude_same_row=sam_tokens_256.size(0) > 1, normalize=True)
+            with torch.no_grad():              # (forward value only: enable_head_training)
+                loss_nce = infonce_loss(pred_embeddings_nce, sam_tokens_256, seg_row_ids, self.model.tiny_xattn, temperature=self.nce_tau,
+                                        top_k=self.nce_topk, exclude_same_row=sam_tokens_256.size(0) > 1, normalize=True)
         pred_masks, mask_scores = [], []
         if decode_masks:   # from SAM's embedding, evaluate()'s wiring (:713-737); the released loop (:511-543) decodes from LLM tokens and raises
             sizes = [tuple(l.shape[-2:]) for l in label_list]
-            pred_masks, mask_scores = self.model.decode(emb_tokens[:1] if inference else emb_tokens, pred_list, resize_list, sizes)
+            if train:
+                pred_masks = train_head.decode(self.model, emb_tokens, pred_list, resize_list, sizes)
+            else:
+                pred_masks, mask_scores = self.model.decode(emb_tokens[:1] if inference else emb_tokens, pred_list, resize_list, sizes)
         if inference:
             return {"pred_masks": pred_masks, "gt_masks": masks_list, "batch_seg_token_counts": batch_seg_token_counts,
                     "mask_scores": mask_scores}
@@ -412,7 +445,8 @@ class walkgptForCausalLM(nn.Module):  # noqa: N801  (the reference's class name)
             assert gt_mask.shape[0] == pred_mask.shape[0], "gt_mask.shape: {}, pred_mask.shape: {}".format(gt_mask.shape, pred_mask.shape)
             if gt_mask.shape[0] == 0:
                 continue
-            bce, dice = ops.mask_losses(pred_mask.float().contiguous(), gt_mask.float().contiguous(), num_masks=gt_mask.shape[0])
+            bce, dice = (ag.mask_losses if train else ops.mask_losses)(pred_mask.float().contiguous(), gt_mask.float().contiguous(),
+                                                                      num_masks=gt_mask.shape[0])
             mask_bce_loss = mask_bce_loss + bce * gt_mask.shape[0]
             mask_dice_loss = mask_dice_loss + dice * gt_mask.shape[0]
             num_masks += gt_mask.shape[0]
