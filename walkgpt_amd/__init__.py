@@ -6,6 +6,9 @@
   clip_encoder.py       CLIP ViT-L/14 tower behind the reference's CLIPVisionTower surface
   utils_walkgpt.py      MSQP and CTP behind the reference's class names
   walkgpt.py            the evaluate()-style composition
+  causal_lm.py          walkgptForCausalLM: the reference's top-level surface around an injected / built language model
+  autograd.py           differentiable forms of the head's operators (HIP forward + HIP backward in torch.autograd.Function)
+  train_head.py         the trainable grounding head (CTP, mask decoder, postprocess, mask losses) composed from them
   synth.py              deterministic synthetic weights / inputs (tests, golden vectors, bench)
 There is no CPU path in this package; the CPU oracle lives in /oracle and is test infrastructure only.
 """
