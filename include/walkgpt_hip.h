@@ -353,6 +353,19 @@ int wg_postprocess_masks_bwd_f32(const float* dout, float* dlow, int N, int low_
                                  int out_w, void* stream);
 int wg_mask_losses_bwd_f32(const float* pred_logits, const float* targets, float* dpred, float* workspace, long workspace_floats, int N, long hw,
                            float g_bce, float g_dice, float dice_scale, float dice_eps, void* stream);
+/* MSQP's pooling / gate (utils_walkgpt.py:195-217,256-257) and the way back from the language model's input embeddings (the splice of
+ * llava_arch.py:265-518 and the resample of :252-259) to the projector's tokens and to embed_tokens (both in train_walkgpt.py's trainable_list):
+ *   wg_avgpool_tokens_bwd_bf16 / wg_mean_tokens_bwd_bf16: dx of wg_avgpool_tokens_bf16 / wg_mean_tokens_bf16
+ *   wg_sigmoid_gate_bwd_bf16: dx (bf16) and dlogit [rows] (fp32) of y = x * sigmoid(logit)
+ *   wg_resample_tokens_bwd_f32: adjoint of wg_resample_tokens_bf16, += into fp32 [n, p*p, C] (zeroed by the caller)
+ *   wg_splice_multimodal_bwd_bf16: gradient rows of the spliced embeddings [rows, L+T-1, H] -> image features [rows, T, H] (bf16) and, when
+ *     dtable != NULL, += into the embedding table's gradient [V, H] (fp32); img_pos as wg_splice_multimodal_bf16 left it */
+int wg_avgpool_tokens_bwd_bf16(const void* dy, void* dx, int B, int H, int W, int C, int s, void* stream);
+int wg_mean_tokens_bwd_bf16(const void* dy, void* dx, int B, int L, int C, void* stream);
+int wg_sigmoid_gate_bwd_bf16(const void* x, const float* logit, const void* dy, void* dx, float* dlogit, long rows, int C, void* stream);
+int wg_resample_tokens_bwd_f32(const void* dy, float* dx, int n, int p, int t, int C, void* stream);
+int wg_splice_multimodal_bwd_bf16(const long* ids, const int* img_pos, const void* dembeds, void* dimage_features, float* dtable, int rows, int L,
+                                  int T, int H, int V, void* stream);
 
 #ifdef __cplusplus
 }

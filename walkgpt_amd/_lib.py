@@ -56,6 +56,11 @@ SIGNATURES = {
     "wg_attn_bwd_bf16": [c_void_p] * 12 + [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "wg_postprocess_masks_bwd_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_mask_losses_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_float, c_float, c_float, c_void_p],
+    "wg_avgpool_tokens_bwd_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "wg_mean_tokens_bwd_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
+    "wg_sigmoid_gate_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
+    "wg_resample_tokens_bwd_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "wg_splice_multimodal_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_upscale_mask_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_dec_tokens_f32": [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

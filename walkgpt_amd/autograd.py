@@ -300,3 +300,133 @@ def postprocess_masks(low_res, img_size, input_size, original_size):
 def mask_losses(pred_logits, targets, num_masks, dice_scale=1000.0, dice_eps=1e-6):
     """-> (sigmoid_ce_loss, dice_loss), differentiable in pred_logits (fp32 [N, H, W])."""
     return _MaskLosses.apply(pred_logits, targets, num_masks, dice_scale, dice_eps)
+
+
+class _AvgPool(torch.autograd.Function):
+    """MSQP's _pool_grid_tokens (utils_walkgpt.py:195-201; ops.avgpool_tokens) and its backward."""
+
+    @staticmethod
+    def forward(ctx, x, B, H, W, s):
+        ctx.geom = (B, H, W, x.shape[-1], s)
+        with torch.no_grad():
+            return ops.avgpool_tokens(x.contiguous(), B, H, W, s)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C, s = ctx.geom
+        dy = dy.contiguous()
+        dx = torch.empty(B, H * W, C, device=dy.device, dtype=BF16)
+        _lib.check(_lib.lib().wg_avgpool_tokens_bwd_bf16(dy.data_ptr(), dx.data_ptr(), B, H, W, C, s, ops._stream()), "wg_avgpool_tokens_bwd_bf16")
+        return dx, None, None, None, None
+
+
+class _MeanTokens(torch.autograd.Function):
+    """MSQP's _global_token (utils_walkgpt.py:256-257; ops.mean_tokens): [B, L, C] -> [B, 1, C]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        with torch.no_grad():
+            return ops.mean_tokens(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, L, C = ctx.shape
+        dy = dy.contiguous()
+        dx = torch.empty(B, L, C, device=dy.device, dtype=BF16)
+        _lib.check(_lib.lib().wg_mean_tokens_bwd_bf16(dy.data_ptr(), dx.data_ptr(), B, L, C, ops._stream()), "wg_mean_tokens_bwd_bf16")
+        return dx
+
+
+class _Gate(torch.autograd.Function):
+    """SegAwareGate's tail y = x * sigmoid(logit) (utils_walkgpt.py:213-217; ops.sigmoid_gate); logit fp32 [rows, 1]."""
+
+    @staticmethod
+    def forward(ctx, x, logit):
+        x, logit = x.contiguous(), logit.contiguous()
+        ctx.save_for_backward(x, logit)
+        with torch.no_grad():
+            return ops.sigmoid_gate(x, logit)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, logit = ctx.saved_tensors
+        C = x.shape[-1]
+        rows = x.numel() // C
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dl = torch.empty(logit.shape, device=x.device, dtype=torch.float32)
+        rc = _lib.lib().wg_sigmoid_gate_bwd_bf16(x.data_ptr(), logit.data_ptr(), dy.data_ptr(), dx.data_ptr(), dl.data_ptr(), rows, C, ops._stream())
+        _lib.check(rc, "wg_sigmoid_gate_bwd_bf16")
+        return dx, dl
+
+
+class _Resample(torch.autograd.Function):
+    """The token resample in front of the splice (llava_arch.py:252-259; ops.resample_tokens) and its adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, target):
+        ctx.shape, ctx.target = tuple(x.shape), target
+        with torch.no_grad():
+            return ops.resample_tokens(x.contiguous(), target)
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, pp, C = ctx.shape
+        p = int(round(pp ** 0.5))
+        dy = dy.contiguous()
+        dx = torch.zeros(n, pp, C, device=dy.device, dtype=torch.float32)
+        _lib.check(_lib.lib().wg_resample_tokens_bwd_f32(dy.data_ptr(), dx.data_ptr(), n, p, ctx.target, C, ops._stream()), "wg_resample_tokens_bwd_f32")
+        return dx.to(BF16), None
+
+
+class _Splice(torch.autograd.Function):
+    """prepare_inputs_labels_for_multimodal (llava_arch.py:265-518; llava_splice) as a function of the image features and of
+    embed_tokens.weight: the gradient of the spliced embeddings goes back to both (wg_splice_multimodal_bwd_bf16)."""
+
+    @staticmethod
+    def forward(ctx, image_features, embed_weight, input_ids, attention_mask, labels, vit_attention_mask, seg_token_idx, aux):
+        from . import llava_splice
+        with torch.no_grad():
+            mask, embeds, lab, seg, pos = llava_splice.prepare_inputs_labels_for_multimodal(
+                input_ids, attention_mask, labels, image_features, embed_weight, vit_attention_mask, seg_token_idx, return_positions=True)
+        aux.extend([mask, lab, seg])
+        ctx.save_for_backward(input_ids.contiguous(), pos)
+        ctx.geom = (tuple(image_features.shape), tuple(embed_weight.shape), embed_weight.dtype)
+        return embeds
+
+    @staticmethod
+    def backward(ctx, dembeds):
+        ids, pos = ctx.saved_tensors
+        (rows, T, H), (V, _), wdtype = ctx.geom
+        L = ids.shape[1]
+        dembeds = dembeds.contiguous().to(BF16)
+        dimg = torch.empty(rows, T, H, device=dembeds.device, dtype=BF16)
+        dtab = torch.zeros(V, H, device=dembeds.device, dtype=torch.float32) if ctx.needs_input_grad[1] else None
+        rc = _lib.lib().wg_splice_multimodal_bwd_bf16(ids.data_ptr(), pos.data_ptr(), dembeds.data_ptr(), dimg.data_ptr(), ops._ptr(dtab) or None, rows, L,
+                                                      T, H, V, ops._stream())
+        _lib.check(rc, "wg_splice_multimodal_bwd_bf16")
+        return dimg, (dtab.to(wdtype) if dtab is not None else None), None, None, None, None, None, None
+
+
+def avgpool_tokens(x, B, H, W, s):
+    return _AvgPool.apply(x, B, H, W, s)
+
+
+def mean_tokens(x):
+    return _MeanTokens.apply(x)
+
+
+def sigmoid_gate(x, logit):
+    return _Gate.apply(x, logit)
+
+
+def resample_tokens(x, target=16):
+    return _Resample.apply(x, target)
+
+
+def splice(input_ids, attention_mask, labels, image_features, embed_weight, vit_attention_mask=None, seg_token_idx=None):
+    """Differentiable llava_splice.prepare_inputs_labels_for_multimodal -> (attention_mask, embeds, labels, seg_mask)."""
+    aux = []
+    embeds = _Splice.apply(image_features, embed_weight, input_ids, attention_mask, labels, vit_attention_mask, seg_token_idx, aux)
+    return aux[0], embeds, aux[1], aux[2]

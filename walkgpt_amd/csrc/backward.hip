@@ -11,7 +11,10 @@
 //   wg_attn_bwd_f32          dq, dk, dv of softmax(scale q k^T) v for the decoder's / projector's small attentions
 //   wg_hyper_mask_dot_bwd    gradients of masks = hyper_in @ upscaled (mask_decoder.py:150-160)
 //   wg_postprocess_bwd_f32   adjoint of the two bilinear resamples of Sam.postprocess_masks (sam.py:137-172)
-//   wg_mask_losses_bwd_f32   d(sigmoid_ce_loss + dice_loss)/d logits (utils_walkgpt.py:76-120)
+//   wg_mask_losses_bwd_f32   d(sigmoid_ce_loss + dice_loss)/d logits (utils_walkgpt.py:76-120)          (the last two live in misc.hip)
+//   wg_avgpool_tokens_bwd / wg_mean_tokens_bwd / wg_sigmoid_gate_bwd        MSQP's pooling and gate (utils_walkgpt.py:195-217,256-257)
+//   wg_resample_tokens_bwd_f32, wg_splice_multimodal_bwd_bf16                the path from the language model's input embeddings back to the
+//                            projector's tokens and to embed_tokens (llava_arch.py:252-259, :265-518)
 // All HBM-bound row or element kernels: fp32 arithmetic, bf16 activations, fp32 accumulation of parameter gradients (atomics).
 #include "wg_common.h"
 
@@ -373,7 +376,155 @@ __global__ __launch_bounds__(256) void wg_attn_bwd_kernel(const bf16* q, const b
     }
 }
 
+// ---- MSQP pieces (utils_walkgpt.py:195-217,256-257) and the path from the language model's input back to the projector ------------------------
+// avg-pool s x s over the token grid: dx[b, y, x, :] = dy[b, y / s, x / s, :] / s^2
+__global__ __launch_bounds__(256) void wg_avgpool_bwd_kernel(const bf16* dy, bf16* dx, int B, int H, int W, int C, int s) {
+    const int Ho = H / s, Wo = W / s, cpr = C / 8;
+    const long total = (long)B * H * W * cpr;
+    const float inv = 1.0f / (float)(s * s);
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cpr) * 8;
+        const long t = i / cpr;
+        const int x = (int)(t % W), y = (int)((t / W) % H), b = (int)(t / ((long)W * H));
+        bf16x8 o;
+        if (y / s < Ho && x / s < Wo) {
+            const bf16x8 g = *(const bf16x8*)(dy + (((long)b * Ho + y / s) * Wo + x / s) * C + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)g[e] * inv);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (bf16)0.f;
+        }
+        *(bf16x8*)(dx + t * C + c) = o;
+    }
+}
+// mean over the L tokens: dx[b, r, :] = dy[b, :] / L
+__global__ __launch_bounds__(256) void wg_mean_tokens_bwd_kernel(const bf16* dy, bf16* dx, int B, int L, int C) {
+    const int cpr = C / 8;
+    const long total = (long)B * L * cpr;
+    const float inv = 1.0f / (float)L;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cpr) * 8;
+        const long t = i / cpr;
+        const int b = (int)(t / L);
+        const bf16x8 g = *(const bf16x8*)(dy + (long)b * C + c);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)((float)g[e] * inv);
+        *(bf16x8*)(dx + t * C + c) = o;
+    }
+}
+// y = x sigmoid(l):  dx = dy sigmoid(l),  dl[r] = sigmoid'(l) sum_c dy x   (a wave per row)
+__global__ __launch_bounds__(256) void wg_gate_bwd_kernel(const bf16* x, const float* logit, const bf16* dy, bf16* dx, float* dlogit, long rows, int C) {
+    const int lane = threadIdx.x & 63;
+    for (long r = (long)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (long)gridDim.x * 4) {
+        const float g = 1.0f / (1.0f + __expf(-logit[r]));
+        float dot = 0.f;
+        for (int c = lane * 8; c < C; c += 512) {
+            const bf16x8 v = *(const bf16x8*)(x + r * C + c), d = *(const bf16x8*)(dy + r * C + c);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { dot += (float)v[e] * (float)d[e]; o[e] = (bf16)((float)d[e] * g); }
+            *(bf16x8*)(dx + r * C + c) = o;
+        }
+        dot = wg_wave_sum(dot);
+        if (lane == 0) dlogit[r] = dot * g * (1.0f - g);
+    }
+}
+// adjoint of the token resample (llava_arch.py:252-259; projector.hip wg_resample_kernel): [n, t*t, C] -> += into fp32 [n, p*p, C]
+__global__ __launch_bounds__(256) void wg_resample_bwd_kernel(const bf16* dy, float* dx, int n, int p, int t, int C) {
+    const int cpr = C / 8;
+    const long total = (long)n * t * t * cpr;
+    const float sc = (float)p / (float)t;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cpr) * 8;
+        const long cell = i / cpr;
+        const int ox = (int)(cell % t), oy = (int)((cell / t) % t), b = (int)(cell / ((long)t * t));
+        float sy = __fsub_rn(__fmul_rn(sc, (float)oy + 0.5f), 0.5f), sx = __fsub_rn(__fmul_rn(sc, (float)ox + 0.5f), 0.5f);
+        sy = sy < 0.f ? 0.f : sy;
+        sx = sx < 0.f ? 0.f : sx;
+        int y0 = (int)sy, x0 = (int)sx;
+        y0 = y0 < p - 1 ? y0 : p - 1;
+        x0 = x0 < p - 1 ? x0 : p - 1;
+        const int y1 = y0 + (y0 < p - 1 ? 1 : 0), x1 = x0 + (x0 < p - 1 ? 1 : 0);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const bf16x8 g = *(const bf16x8*)(dy + cell * C + c);
+        float* base = dx + (long)b * p * p * C + c;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = (float)g[e];
+            atomicAdd(base + (long)(y0 * p + x0) * C + e, v * (1.f - ly) * (1.f - lx));
+            atomicAdd(base + (long)(y0 * p + x1) * C + e, v * (1.f - ly) * lx);
+            atomicAdd(base + (long)(y1 * p + x0) * C + e, v * ly * (1.f - lx));
+            atomicAdd(base + (long)(y1 * p + x1) * C + e, v * ly * lx);
+        }
+    }
+}
+// adjoint of the multimodal splice (splice.hip wg_splice_gather_kernel): a workgroup per spliced token sends its gradient row to the image
+// feature it was copied from (bf16, one writer) or adds it to its embedding row (fp32 atomics: a token id occurs many times)
+__global__ __launch_bounds__(256) void wg_splice_bwd_kernel(const long* ids, const int* img_pos, const bf16* dembeds, bf16* dimg, float* dtable, int L, int T,
+                                                            int H, int V) {
+    const int Lo = L + T - 1;
+    const int r = blockIdx.x / Lo, j = blockIdx.x % Lo;
+    const int s = img_pos[r];
+    const bool is_img = j >= s && j < s + T;
+    const bf16* src = dembeds + ((long)r * Lo + j) * H;
+    if (is_img) {
+        bf16* dst = dimg + ((long)r * T + (j - s)) * H;
+        for (int d = threadIdx.x * 8; d < H; d += 2048) *(bf16x8*)(dst + d) = *(const bf16x8*)(src + d);
+    } else if (dtable) {
+        const int i = j < s ? j : j - T + 1;
+        const long id = ids[(long)r * L + i];
+        if (id < 0 || id >= V) return;
+        float* dst = dtable + id * H;
+        for (int d = threadIdx.x * 8; d < H; d += 2048) {
+            const bf16x8 g = *(const bf16x8*)(src + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(dst + d + e, (float)g[e]);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int wg_avgpool_tokens_bwd_bf16(const void* dy, void* dx, int B, int H, int W, int C, int s, void* stream) {
+    WG_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C % 8 == 0 && s > 0 && H % s == 0 && W % s == 0, "avgpool_bwd: bad arguments");
+    const long total = (long)B * H * W * (C / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(wg_avgpool_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (bf16*)dx, B, H, W, C, s);
+    return wg_check_launch("wg_avgpool_tokens_bwd_bf16");
+}
+
+extern "C" int wg_mean_tokens_bwd_bf16(const void* dy, void* dx, int B, int L, int C, void* stream) {
+    WG_REQUIRE(dy && dx && B > 0 && L > 0 && C % 8 == 0, "mean_tokens_bwd: bad arguments");
+    const long total = (long)B * L * (C / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(wg_mean_tokens_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, (bf16*)dx, B, L, C);
+    return wg_check_launch("wg_mean_tokens_bwd_bf16");
+}
+
+extern "C" int wg_sigmoid_gate_bwd_bf16(const void* x, const float* logit, const void* dy, void* dx, float* dlogit, long rows, int C, void* stream) {
+    WG_REQUIRE(x && logit && dy && dx && dlogit && rows > 0 && C % 8 == 0, "sigmoid_gate_bwd: bad arguments");
+    const int blocks = (int)((rows + 3) / 4 < 4096 ? (rows + 3) / 4 : 4096);
+    hipLaunchKernelGGL(wg_gate_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, logit, (const bf16*)dy, (bf16*)dx, dlogit, rows, C);
+    return wg_check_launch("wg_sigmoid_gate_bwd_bf16");
+}
+
+extern "C" int wg_resample_tokens_bwd_f32(const void* dy, float* dx, int n, int p, int t, int C, void* stream) {
+    WG_REQUIRE(dy && dx && n > 0 && p > 0 && t > 0 && C % 8 == 0, "resample_tokens_bwd: bad arguments");
+    const long total = (long)n * t * t * (C / 8);
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(wg_resample_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)dy, dx, n, p, t, C);
+    return wg_check_launch("wg_resample_tokens_bwd_f32");
+}
+
+extern "C" int wg_splice_multimodal_bwd_bf16(const long* ids, const int* img_pos, const void* dembeds, void* dimage_features, float* dtable, int rows,
+                                             int L, int T, int H, int V, void* stream) {
+    WG_REQUIRE(ids && img_pos && dembeds && dimage_features && rows > 0 && L > 0 && T > 0 && V > 0 && H > 0 && H % 8 == 0, "splice_bwd: bad arguments");
+    hipLaunchKernelGGL(wg_splice_bwd_kernel, dim3((unsigned)(rows * (L + T - 1))), dim3(256), 0, (hipStream_t)stream, ids, img_pos, (const bf16*)dembeds,
+                       (bf16*)dimage_features, dtable, L, T, H, V);
+    return wg_check_launch("wg_splice_multimodal_bwd_bf16");
+}
 
 extern "C" int wg_l2norm_scale_bf16(const void* x, const void* log_temp, void* y, int M, int C, float eps, void* stream) {
     WG_REQUIRE(x && log_temp && y && M > 0 && C > 0 && C % 8 == 0 && C <= 512, "l2norm_scale: C = %d must be a multiple of 8, at most 512", C);

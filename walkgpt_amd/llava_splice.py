@@ -17,7 +17,7 @@ IGNORE_INDEX = -100
 
 
 def prepare_inputs_labels_for_multimodal(input_ids, attention_mask, labels, image_features, embed_weight, vit_attention_mask=None,
-                                         seg_token_idx=None):
+                                         seg_token_idx=None, return_positions=False):
     """input_ids [rows,L] int64, attention_mask [rows,L] bool or None, labels [rows,L] int64 or None, image_features
     [rows,T,H] bf16, embed_weight [V,H] bf16 (the LLM's embed_tokens.weight), vit_attention_mask [rows,T] or None,
     seg_token_idx int / list of ints or None.
@@ -60,4 +60,6 @@ def prepare_inputs_labels_for_multimodal(input_ids, attention_mask, labels, imag
     text = ids[ids != IMAGE_TOKEN_INDEX]
     if bool(((text < 0) | (text >= V)).any()):
         raise IndexError("input_ids hold ids outside the embedding table")
+    if return_positions:       # (+ the placeholder position of every row: what the splice's backward needs, walkgpt_amd.autograd)
+        return mask_out, embeds, lab_out, seg_mask, pos
     return mask_out, embeds, lab_out, seg_mask

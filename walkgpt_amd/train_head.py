@@ -142,3 +142,54 @@ def decode(grounding, emb_tokens, pred_embeddings, resize_list, original_size_li
         full = ag.postprocess_masks(low_res.contiguous(), vm.image_encoder.img_size, resize_list[i], original_size_list[i])
         out.append(full[:, 0])
     return out
+
+
+def _cross_block(blk, queries, kv):
+    """CrossAttnBlock (utils_walkgpt.py:163-185): pre-LN cross attention of the query tokens to the image tokens + GELU MLP, both residual."""
+    D = queries.shape[-1]
+    a = blk.attn
+    q = ag.linear(_ln(queries, blk.q_norm), a.in_proj_weight[:D], a.in_proj_bias[:D])
+    kvp = ag.linear(_ln(kv, blk.kv_norm), a.in_proj_weight[D:], a.in_proj_bias[D:])
+    o = ag.attention(q, kvp[..., :D], kvp[..., D:], blk.nhead, 1.0 / math.sqrt(D // blk.nhead))
+    out = queries + ag.linear(o, a.out_proj.weight, a.out_proj.bias)
+    h = _lin(_lin(_ln(out, blk.ffn[0]), blk.ffn[1], ops.ACT_GELU), blk.ffn[3])
+    return out + h
+
+
+def _gate(gate, kv):
+    """SegAwareGate (utils_walkgpt.py:204-217)."""
+    h = _lin(_ln(kv, gate.net[0]), gate.net[1], ops.ACT_GELU)
+    logit = ag.linear(h, gate.net[3].weight, gate.net[3].bias, out_f32=True)
+    return ag.sigmoid_gate(kv, logit)
+
+
+def msqp_forward(proj, sam_feats, grid_size=None):
+    """MultiScaleQFormerProjector.forward (utils_walkgpt.py:220-300): sam_feats [B, L, sam_dim] bf16 -> [B, s*s, llama_dim]."""
+    B, L, _ = sam_feats.shape
+    if grid_size is None and proj.grid_size is None:
+        H = int(math.sqrt(L))
+        if H * H != L:
+            raise ValueError(f"Token length {L} is not a perfect square.")
+        W = H
+    else:
+        H, W = grid_size or proj.grid_size
+    feats = _lin(sam_feats.contiguous(), proj.sam_to_proj)
+    scales = [(proj.q_x1, proj.cross_x1, feats),
+              (proj.q_x2, proj.cross_x2, ag.avgpool_tokens(feats, B, H, W, 2)),
+              (proj.q_x4, proj.cross_x4, ag.avgpool_tokens(feats, B, H, W, 4)),
+              (proj.q_global, proj.cross_glb, ag.mean_tokens(feats))]
+    outs = []
+    for q_param, layers, kv in scales:
+        kv = _gate(proj.gate, kv)
+        q = q_param.expand(B, -1, -1)
+        for blk in layers:
+            q = _cross_block(blk, q, kv)
+        outs.append(q)
+    vis = torch.cat(outs, 1)
+    if proj.pad_to_square:
+        Q = vis.shape[1]
+        s = int(math.ceil(math.sqrt(Q))) if proj.target_square_side is None else proj.target_square_side
+        assert s * s >= Q, "target_square_side too small"
+        if s * s > Q:
+            vis = torch.cat([vis, proj.pad_token.expand(B, s * s - Q, -1)], 1)
+    return _lin(vis.contiguous(), proj.to_llama)
