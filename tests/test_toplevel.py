@@ -246,7 +246,8 @@ def test_model_forward_collate_dict_vs_oracle(dev):
 def test_model_forward_trains_the_grounding_head(dev):
     """train_walkgpt.py's step on the adapter: `enable_head_training()`, forward(**collate dict) with gradients on, `loss.backward()`.  The
     loss dict equals the no-gradient forward's; text_hidden_fcs.*, mask_decoder.* and the language model's parameters receive finite
-    gradients; the frozen parts (SAM encoders, MSQP in this round) receive none; a plain SGD step on the head lowers the mask loss."""
+    gradients, so do out_mm_projector.* and embed_tokens (through the splice); the frozen SAM encoders receive none; a few descent steps on
+    the head lower the mask loss."""
     m, lm, weights = _build(dev)
     c = weights["c"]
     x = cases.sam_encoder_input(c)
@@ -283,8 +284,11 @@ def test_model_forward_trains_the_grounding_head(dev):
     # exactly zero, as in the reference: the hypernetworks of the masks multimask_output=False does not return
     assert all(".output_hypernetworks_mlps." in k and ".output_hypernetworks_mlps.0." not in k for k in zero), zero
     assert lm.head.weight.grad is not None and lm.wq[0].grad is not None and torch.isfinite(lm.wq[0].grad).all()   # the LLM learns from both losses
-    frozen = [p for k, p in m.model.named_parameters() if ".image_encoder." in k or ".prompt_encoder." in k or k.startswith("out_mm_projector.")]
+    frozen = [p for k, p in m.model.named_parameters() if ".image_encoder." in k or ".prompt_encoder." in k]
     assert frozen and all(p.grad is None for p in frozen)
+    msqp = [(k, p) for k, p in m.model.named_parameters() if k.startswith("out_mm_projector.")]
+    assert msqp and all(p.grad is not None and torch.isfinite(p.grad).all() for _, p in msqp)        # the projector learns from the LM loss
+    assert lm.embed.weight.grad is not None and float(lm.embed.weight.grad.float().abs().max()) > 0    # embed_tokens through the splice
     # a few descent steps on the head only, fp32 master weights behind the bf16 parameters (a bf16 parameter does not register a step of a
     # fraction of a percent): the mask loss goes down
     before = float(out["mask_loss"].detach())

@@ -321,9 +321,13 @@ class walkgptForCausalLM(nn.Module):  # noqa: N801  (the reference's class name)
                                "bf16, the precision the reference's callers use (evaluation_walkgpt.py:227-231)" % w.dtype)
         return w
 
-    def _llm_inputs(self, input_ids, attention_mask, labels, image_tokens, vit_attention_mask=None):
+    def _llm_inputs(self, input_ids, attention_mask, labels, image_tokens, vit_attention_mask=None, train=False):
         """LlavaMetaForCausalLM.prepare_inputs_labels_for_multimodal on image tokens already in language space (llava_arch.py:252-259
-        resample to 16x16, :265-518 splice)."""
+        resample to 16x16, :265-518 splice).  train: the differentiable forms (gradients reach the image tokens and embed_tokens)."""
+        if train:
+            from . import autograd as ag
+            return ag.splice(input_ids, attention_mask, labels, ag.resample_tokens(image_tokens, 16), self._embed_table(),
+                             vit_attention_mask=vit_attention_mask)
         feats = ops.resample_tokens(image_tokens.contiguous(), 16)
         return prepare_inputs_labels_for_multimodal(input_ids, attention_mask, labels, feats, self._embed_table(),
                                                     vit_attention_mask=vit_attention_mask)
@@ -368,9 +372,9 @@ class walkgptForCausalLM(nn.Module):  # noqa: N801  (the reference's class name)
         """Training of the grounding head (train_walkgpt.py:347-350): with this on, `model_forward(inference=False)` called with gradients
         enabled runs CTP, the mask decoder, postprocess and the mask losses through walkgpt_amd.train_head (differentiable HIP operators),
         so `loss.backward()` fills `.grad` of text_hidden_fcs.*, visual_model.mask_decoder.* and -- through the [SEG] hidden states and the
-        language-model loss -- of whatever the caller left trainable in the language model.  Frozen here as in the reference: SAM's image and
-        prompt encoders, the vision tower.  Not differentiated yet (their forward values still enter the loss): the MSQP tokens spliced into
-        the language model's input and the InfoNCE term."""
+        language-model loss -- of whatever the caller left trainable in the language model, of out_mm_projector.* (MSQP) and of
+        embed_tokens (through the splice).  Frozen here as in the reference: SAM's image and prompt encoders, the vision tower.  Not
+        differentiated yet (its forward value still enters the loss): the InfoNCE term."""
         self.head_training = bool(on)
         return self
 
@@ -389,22 +393,25 @@ class walkgptForCausalLM(nn.Module):  # noqa: N801  (the reference's class name)
                        clip_resize_list, decode_masks, train):
         from . import autograd as ag
         from . import train_head
-        with torch.no_grad():                  # SAM encoder, MSQP, the splice: no gradients in either mode
-            batch_size = images.shape[0]
-            assert batch_size == len(offset) - 1
+        batch_size = images.shape[0]
+        assert batch_size == len(offset) - 1
+        off = [int(v) for v in offset]
+        with torch.no_grad():                  # the frozen SAM encoder and the bookkeeping: no gradients in either mode
             seg_token_mask = self._seg_token_mask(input_ids, pad_right=True)
             if inference:
                 assert images_clip.shape[0] == 1, "inference branch assumes one image"
-            off = [int(v) for v in offset]
-            # SAM encoder once for the batch, MSQP on all images at once (the reference calls it image by image: :364-378)
             emb_tokens = self.model.get_visual_emb_tokens(images)                        # [B, hw, 256] channels-last rows
-            tokens_proj = self.model.out_mm_projector(emb_tokens)                         # [B, 36, H]
             row_img = torch.tensor([i for i in range(batch_size) for _ in range(off[i + 1] - off[i])], device=images.device)
             if inference:
                 row_img = torch.zeros(input_ids.shape[0], dtype=torch.long, device=images.device)
-            sam_tokens = tokens_proj.index_select(0, row_img)                             # one row of image tokens per text row
             sam_tokens_256 = emb_tokens.index_select(0, row_img)
-            attn, embeds, new_labels, _ = self._llm_inputs(input_ids, attention_masks, None if inference else labels, sam_tokens)
+        # MSQP on all images at once (the reference calls it image by image: :364-378), resample, splice.  Training: through the
+        # differentiable operators, so that out_mm_projector.* and embed_tokens (train_walkgpt.py:347-350) get their gradients
+        proj = self.model.out_mm_projector
+        with torch.enable_grad() if train else torch.no_grad():
+            tokens_proj = train_head.msqp_forward(proj, emb_tokens) if train else proj(emb_tokens)                  # [B, 36, H]
+            sam_tokens = tokens_proj.index_select(0, row_img)                             # one row of image tokens per text row
+            attn, embeds, new_labels, _ = self._llm_inputs(input_ids, attention_masks, None if inference else labels, sam_tokens, train=train)
 
         output = self.llm(inputs_embeds=embeds, attention_mask=attn, labels=new_labels, output_hidden_states=True)
         last_hidden = output.hidden_states[-1]
