@@ -366,6 +366,17 @@ int wg_sigmoid_gate_bwd_bf16(const void* x, const float* logit, const void* dy, 
 int wg_resample_tokens_bwd_f32(const void* dy, float* dx, int n, int p, int t, int C, void* stream);
 int wg_splice_multimodal_bwd_bf16(const long* ids, const int* img_pos, const void* dembeds, void* dimage_features, float* dtable, int rows, int L,
                                   int T, int H, int V, void* stream);
+/* Region-alignment InfoNCE (utils_walkgpt.py:8-73, the top_k form WalkGPT calls: model/walkgpt.py:459-473) as differentiable pieces:
+ *   wg_topk_pool_bf16 / _bwd: v_m = sum_k softmax_k(u_m . kt_mk / sqrt(D)) kt_mk over the Kt <= 16 selected SAM tokens kt [M, Kt, D] (constants);
+ *     u [M, D] = the folded query W_k^T W_q z of TinyCrossAttn (:330-357); backward gives du.
+ *   wg_nce_tail_f32 / _bwd: pos_m = z_m . vp_m, logits_m = [pos_m, sim[m, :]] / T (the rows*N columns of m's own image masked when
+ *     exclude_same_row), loss_m = logsumexp - pos_m / T; backward (g = upstream gradient of the MEAN over m): dz (positive term), dvp, dsim. */
+int wg_topk_pool_bf16(const void* u, const void* kt, void* v, int M, int Kt, int D, void* stream);
+int wg_topk_pool_bwd_bf16(const void* u, const void* kt, const void* dv, void* du, int M, int Kt, int D, void* stream);
+int wg_nce_tail_f32(const void* z, const void* vp, const float* sim, const int* own_row, float* loss_m, float* lse_m, int M, int rows, int N, int D,
+                    float temperature, int exclude_same_row, void* stream);
+int wg_nce_tail_bwd_f32(const void* z, const void* vp, const float* sim, const int* own_row, const float* lse_m, float g, void* dz, void* dvp,
+                        float* dsim, int M, int rows, int N, int D, float temperature, int exclude_same_row, void* stream);
 
 #ifdef __cplusplus
 }

@@ -285,3 +285,44 @@ def test_msqp_splice_path_vs_oracle_autograd(dev):
         assert e < max(1.5 * e16, 0.08), (k, e, e16)
     print("MSQP -> resample -> splice: output rel err %.4f; parameter gradients worst rel err HIP %.4f (%s), oracle in bf16 %.4f (%s)"
           % (rel(embeds, emb_r), worst[1], worst[0], worst16[1], worst16[0]))
+
+
+@pytest.mark.parametrize("rows,exclude", [(3, True), (1, False)])
+def test_infonce_training_path_vs_oracle_autograd(dev, rows, exclude):
+    """Region-alignment InfoNCE (top_k = 8) through walkgpt_amd.train_head.infonce_loss: the loss and its gradients on the [SEG] embeddings and on
+    TinyCrossAttn's wq / wk against torch autograd over the oracle's restatement."""
+    from oracle import metrics as om
+    from walkgpt_amd import train_head
+    from walkgpt_amd.utils_walkgpt import TinyCrossAttn
+    g = torch.Generator().manual_seed(rows)
+    D, N, M = 256, 1024, 5
+    tx = TinyCrossAttn(D)
+    with torch.no_grad():
+        for p in tx.parameters():
+            p.copy_((torch.randn(p.shape, generator=g) * D ** -0.5).to(torch.bfloat16).float())
+    tx = tx.to(dev).bfloat16()
+    pred = torch.randn(M, D, generator=g).to(torch.bfloat16)
+    sam = torch.randn(rows, N, D, generator=g).to(torch.bfloat16)
+    ids = torch.randint(0, rows, (M,), generator=g)
+    ph = _leaf(pred, dev)
+    loss = train_head.infonce_loss(ph, sam.to(dev), ids.to(dev), tx, temperature=0.07, top_k=8, exclude_same_row=exclude)
+    loss.backward()
+
+    def oracle_run(dt):
+        w = {k: v.detach().cpu().to(dt).clone().requires_grad_(True) for k, v in tx.state_dict().items()}
+        pr = pred.detach().to(dt).clone().requires_grad_(True)
+        lr, _ = om.infonce_loss(w, pr, sam.to(dt), ids, temperature=0.07, top_k=8, exclude_same_row=exclude)
+        lr.backward()
+        return lr, pr.grad, w
+    l32, g32, w32 = oracle_run(torch.float32)
+    l16, g16, w16 = oracle_run(torch.bfloat16)
+    e, e16 = rel(ph.grad, g32), rel(g16, g32)
+    print("InfoNCE rows=%d: loss %.5f (oracle %.5f); d loss / d [SEG] embedding rel err HIP %.4f, oracle in bf16 %.4f" % (rows, float(loss.detach()), float(l32.detach()), e, e16))
+    assert abs(float(loss.detach()) - float(l32.detach())) < 2e-2 * abs(float(l32.detach()))
+    assert e < max(1.5 * e16, 0.03), (e, e16)
+    for k in ("wq.weight", "wk.weight"):
+        p = dict(tx.named_parameters())[k]
+        ek, ek16 = rel(p.grad, w32[k].grad), rel(w16[k].grad, w32[k].grad)
+        assert ek < max(1.5 * ek16, 0.05), (k, ek, ek16)
+    for k in ("wv.weight", "out.weight"):      # not on the loss's path in the top_k form
+        assert dict(tx.named_parameters())[k].grad is None and (w32[k].grad is None or float(w32[k].grad.abs().max()) == 0.0)

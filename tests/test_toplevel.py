@@ -289,6 +289,9 @@ def test_model_forward_trains_the_grounding_head(dev):
     msqp = [(k, p) for k, p in m.model.named_parameters() if k.startswith("out_mm_projector.")]
     assert msqp and all(p.grad is not None and torch.isfinite(p.grad).all() for _, p in msqp)        # the projector learns from the LM loss
     assert lm.embed.weight.grad is not None and float(lm.embed.weight.grad.float().abs().max()) > 0    # embed_tokens through the splice
+    tx = m.model.tiny_xattn                                                                            # the InfoNCE term's own parameters
+    assert tx.wq.weight.grad is not None and float(tx.wq.weight.grad.float().abs().max()) > 0 and torch.isfinite(tx.wk.weight.grad).all()
+    assert abs(float(out["nce_loss"].detach()) - float(base["nce_loss"])) < 2e-2 * abs(float(base["nce_loss"])) + 1e-4
     # a few descent steps on the head only, fp32 master weights behind the bf16 parameters (a bf16 parameter does not register a step of a
     # fraction of a percent): the mask loss goes down
     before = float(out["mask_loss"].detach())

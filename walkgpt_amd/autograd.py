@@ -430,3 +430,62 @@ def splice(input_ids, attention_mask, labels, image_features, embed_weight, vit_
     aux = []
     embeds = _Splice.apply(image_features, embed_weight, input_ids, attention_mask, labels, vit_attention_mask, seg_token_idx, aux)
     return aux[0], embeds, aux[1], aux[2]
+
+
+class _TopkPool(torch.autograd.Function):
+    """v_m = sum_k softmax_k(u_m . kt_mk / sqrt(D)) kt_mk over the top-k SAM tokens of [SEG] m (infonce_loss's refined positive,
+    utils_walkgpt.py:33-40 with TinyCrossAttn's projections folded into u); kt is a constant.  wg_topk_pool_bf16 / _bwd."""
+
+    @staticmethod
+    def forward(ctx, u, kt):
+        u, kt = u.contiguous(), kt.contiguous()
+        ctx.save_for_backward(u, kt)
+        M, Kt, D = kt.shape
+        v = torch.empty(M, D, device=u.device, dtype=BF16)
+        _lib.check(_lib.lib().wg_topk_pool_bf16(u.data_ptr(), kt.data_ptr(), v.data_ptr(), M, Kt, D, ops._stream()), "wg_topk_pool_bf16")
+        return v
+
+    @staticmethod
+    def backward(ctx, dv):
+        u, kt = ctx.saved_tensors
+        M, Kt, D = kt.shape
+        dv = dv.contiguous()
+        du = torch.empty_like(u)
+        _lib.check(_lib.lib().wg_topk_pool_bwd_bf16(u.data_ptr(), kt.data_ptr(), dv.data_ptr(), du.data_ptr(), M, Kt, D, ops._stream()), "wg_topk_pool_bwd_bf16")
+        return du, None
+
+
+class _NceTail(torch.autograd.Function):
+    """InfoNCE's cross-entropy over [positive | all SAM tokens] (utils_walkgpt.py:42-73): wg_nce_tail_f32 / _bwd."""
+
+    @staticmethod
+    def forward(ctx, z, vp, sim, own_row, rows, N, temperature, exclude):
+        z, vp, sim = z.contiguous(), vp.contiguous(), sim.contiguous()
+        M, D = z.shape
+        loss_m = torch.empty(M, device=z.device, dtype=torch.float32)
+        lse = torch.empty(M, device=z.device, dtype=torch.float32)
+        rc = _lib.lib().wg_nce_tail_f32(z.data_ptr(), vp.data_ptr(), sim.data_ptr(), own_row.data_ptr(), loss_m.data_ptr(), lse.data_ptr(), M, rows, N, D,
+                                        float(temperature), 1 if exclude else 0, ops._stream())
+        _lib.check(rc, "wg_nce_tail_f32")
+        ctx.save_for_backward(z, vp, sim, own_row, lse)
+        ctx.cfg = (rows, N, float(temperature), 1 if exclude else 0)
+        return loss_m.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        z, vp, sim, own_row, lse = ctx.saved_tensors
+        rows, N, temperature, exclude = ctx.cfg
+        M, D = z.shape
+        dz, dvp, dsim = torch.empty_like(z), torch.empty_like(vp), torch.empty_like(sim)
+        rc = _lib.lib().wg_nce_tail_bwd_f32(z.data_ptr(), vp.data_ptr(), sim.data_ptr(), own_row.data_ptr(), lse.data_ptr(), float(g), dz.data_ptr(),
+                                            dvp.data_ptr(), dsim.data_ptr(), M, rows, N, D, temperature, exclude, ops._stream())
+        _lib.check(rc, "wg_nce_tail_bwd_f32")
+        return dz, dvp, dsim, None, None, None, None, None
+
+
+def topk_pool(u, kt):
+    return _TopkPool.apply(u, kt)
+
+
+def nce_tail(z, vp, sim, own_row, rows, N, temperature, exclude_same_row):
+    return _NceTail.apply(z, vp, sim, own_row, rows, N, temperature, exclude_same_row)

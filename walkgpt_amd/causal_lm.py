@@ -373,8 +373,8 @@ class walkgptForCausalLM(nn.Module):  # noqa: N801  (the reference's class name)
         enabled runs CTP, the mask decoder, postprocess and the mask losses through walkgpt_amd.train_head (differentiable HIP operators),
         so `loss.backward()` fills `.grad` of text_hidden_fcs.*, visual_model.mask_decoder.* and -- through the [SEG] hidden states and the
         language-model loss -- of whatever the caller left trainable in the language model, of out_mm_projector.* (MSQP) and of
-        embed_tokens (through the splice).  Frozen here as in the reference: SAM's image and prompt encoders, the vision tower.  Not
-        differentiated yet (its forward value still enters the loss): the InfoNCE term."""
+        embed_tokens (through the splice), and -- through the region-alignment InfoNCE term -- of tiny_xattn.wq / wk: every entry of
+        train_walkgpt.py's trainable_list.  Frozen here as in the reference: SAM's image and prompt encoders, the vision tower."""
         self.head_training = bool(on)
         return self
 
@@ -424,14 +424,17 @@ class walkgptForCausalLM(nn.Module):  # noqa: N801  (the reference's class name)
             pred_embeddings = seg_hidden.new_zeros(0, 256, dtype=BF16)
         else:
             pred_embeddings = train_head.ctp_forward(ctp, seg_hidden.to(BF16)) if train else ctp(seg_hidden.to(BF16))
-        pred_embeddings_nce = pred_embeddings.detach()
+        pred_embeddings_nce = pred_embeddings
         seg_token_counts = seg_token_mask.int().sum(-1)
         pred_list, batch_seg_token_counts = self._queries_per_image(pred_embeddings, seg_token_counts, off, inference)
         # region-alignment InfoNCE (:449-473)
         seg_row_ids = torch.repeat_interleave(torch.arange(sam_tokens_256.size(0), device=images.device), seg_token_counts)
         loss_nce = torch.zeros((), device=images.device)
         if seg_row_ids.numel() > 0 and not inference:
-            with torch.no_grad():              # (forward value only: enable_head_training)
+            if train:
+                loss_nce = train_head.infonce_loss(pred_embeddings_nce, sam_tokens_256, seg_row_ids, self.model.tiny_xattn, temperature=self.nce_tau,
+                                                   top_k=self.nce_topk, exclude_same_row=sam_tokens_256.size(0) > 1)
+            else:
                 loss_nce = infonce_loss(pred_embeddings_nce, sam_tokens_256, seg_row_ids, self.model.tiny_xattn, temperature=self.nce_tau,
                                         top_k=self.nce_topk, exclude_same_row=sam_tokens_256.size(0) > 1, normalize=True)
         pred_masks, mask_scores = [], []

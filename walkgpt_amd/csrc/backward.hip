@@ -485,7 +485,144 @@ __global__ __launch_bounds__(256) void wg_splice_bwd_kernel(const long* ids, con
     }
 }
 
+// ---- region-alignment InfoNCE (utils_walkgpt.py:8-73, top_k form) as differentiable pieces -------------------------------------------------
+// (1) top-k pooled positive: u [M, D] (= W_k^T W_q z: the folded query of TinyCrossAttn), kt [M, Kt, D] the Kt raw SAM tokens with the largest
+//     attention weight (constants).  alpha = the attention weights renormalised over those Kt = softmax of their scores; v = sum alpha_k kt_k.
+//     A wave per row; D <= 512, Kt <= 16.  Backward: du = sum_k ds_k kt_k / sqrt(D), ds = alpha (da - sum alpha da), da_k = dv . kt_k.
+template <bool BWD>
+__global__ __launch_bounds__(256) void wg_topk_pool_kernel(const bf16* u, const bf16* kt, const bf16* dv, bf16* out, int M, int Kt, int D) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int d = lane * 8;
+    const bool on = d < D;
+    float uv[8], gv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) uv[e] = gv[e] = 0.f;
+    if (on) {
+        const bf16x8 t = *(const bf16x8*)(u + (long)m * D + d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) uv[e] = (float)t[e];
+        if (BWD) {
+            const bf16x8 g = *(const bf16x8*)(dv + (long)m * D + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gv[e] = (float)g[e];
+        }
+    }
+    const float scale = 1.0f / sqrtf((float)D);
+    float sc[16], da[16];
+    float mx = -3.0e38f;
+    for (int k = 0; k < 16; ++k) {
+        sc[k] = -3.0e38f; da[k] = 0.f;
+        if (k < Kt) {
+            float s = 0.f, a = 0.f;
+            if (on) {
+                const bf16x8 t = *(const bf16x8*)(kt + ((long)m * Kt + k) * D + d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s += uv[e] * (float)t[e]; a += gv[e] * (float)t[e]; }
+            }
+            sc[k] = wg_wave_sum(s) * scale;
+            da[k] = BWD ? wg_wave_sum(a) : 0.f;
+            mx = fmaxf(mx, sc[k]);
+        }
+    }
+    float l = 0.f;
+    for (int k = 0; k < 16; ++k) { sc[k] = k < Kt ? __expf(sc[k] - mx) : 0.f; l += sc[k]; }
+    float dsum = 0.f;
+    for (int k = 0; k < 16; ++k) { sc[k] /= l; dsum += sc[k] * da[k]; }
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (on) {
+        for (int k = 0; k < Kt; ++k) {
+            const bf16x8 t = *(const bf16x8*)(kt + ((long)m * Kt + k) * D + d);
+            const float w = BWD ? sc[k] * (da[k] - dsum) * scale : sc[k];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += w * (float)t[e];
+        }
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (bf16)o[e];
+        *(bf16x8*)(out + (long)m * D + d) = r;
+    }
+}
+
+// (2) the loss tail: pos_m = z_m . vp_m, logits_m = [pos_m, sim[m, :]] / T with the columns of m's own row masked, loss = mean_m (lse_m - pos_m / T).
+//     A workgroup per m.  Forward leaves loss_m and lse_m; backward: p_j = exp(logit_j - lse):  dsim[m, j] = g p_j / (T M),
+//     dz_m (positive term only) = g (p_0 - 1) / (T M) vp_m,  dvp_m = g (p_0 - 1) / (T M) z_m.
+template <bool BWD>
+__global__ __launch_bounds__(256) void wg_nce_tail_kernel(const bf16* z, const bf16* vp, const float* sim, const int* own_row, float* loss_m, float* lse_m,
+                                                          float g, bf16* dz, bf16* dvp, float* dsim, int M, int rows, int N, int D, float inv_t, int exclude) {
+    __shared__ float red[8];
+    const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long R = (long)rows * N;
+    float pd = 0.f;
+    for (int d = threadIdx.x; d < D; d += 256) pd += (float)z[(long)m * D + d] * (float)vp[(long)m * D + d];
+    pd = wg_wave_sum(pd);
+    if (lane == 0) red[wave] = pd;
+    __syncthreads();
+    const float pos = (red[0] + red[1] + red[2] + red[3]) * inv_t;
+    __syncthreads();
+    const long own0 = exclude ? (long)own_row[m] * N : -1, own1 = exclude ? own0 + N : -1;
+    const float* sr = sim + (long)m * R;
+    if (!BWD) {
+        float mx = pos;
+        for (long j = threadIdx.x; j < R; j += 256)
+            if (j < own0 || j >= own1) mx = fmaxf(mx, sr[j] * inv_t);
+        mx = wg_wave_max(mx);
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        __syncthreads();
+        float l = 0.f;
+        for (long j = threadIdx.x; j < R; j += 256)
+            if (j < own0 || j >= own1) l += __expf(sr[j] * inv_t - mx);
+        l = wg_wave_sum(l);
+        if (lane == 0) red[wave] = l;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float lse = mx + __logf(red[0] + red[1] + red[2] + red[3] + __expf(pos - mx));
+            lse_m[m] = lse;
+            loss_m[m] = lse - pos;
+        }
+    } else {
+        const float lse = lse_m[m], k = g * inv_t / (float)M;
+        for (long j = threadIdx.x; j < R; j += 256) dsim[(long)m * R + j] = (j < own0 || j >= own1) ? k * __expf(sr[j] * inv_t - lse) : 0.f;
+        const float c = k * (__expf(pos - lse) - 1.0f);
+        for (int d = threadIdx.x; d < D; d += 256) {
+            dz[(long)m * D + d] = (bf16)(c * (float)vp[(long)m * D + d]);
+            dvp[(long)m * D + d] = (bf16)(c * (float)z[(long)m * D + d]);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int wg_topk_pool_bf16(const void* u, const void* kt, void* v, int M, int Kt, int D, void* stream) {
+    WG_REQUIRE(u && kt && v && M > 0 && Kt > 0 && Kt <= 16 && D % 8 == 0 && D <= 512, "topk_pool: Kt <= 16, D <= 512");
+    hipLaunchKernelGGL(wg_topk_pool_kernel<false>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (const bf16*)kt, nullptr, (bf16*)v, M, Kt, D);
+    return wg_check_launch("wg_topk_pool_bf16");
+}
+
+extern "C" int wg_topk_pool_bwd_bf16(const void* u, const void* kt, const void* dv, void* du, int M, int Kt, int D, void* stream) {
+    WG_REQUIRE(u && kt && dv && du && M > 0 && Kt > 0 && Kt <= 16 && D % 8 == 0 && D <= 512, "topk_pool_bwd: Kt <= 16, D <= 512");
+    hipLaunchKernelGGL(wg_topk_pool_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (const bf16*)kt, (const bf16*)dv, (bf16*)du, M, Kt, D);
+    return wg_check_launch("wg_topk_pool_bwd_bf16");
+}
+
+extern "C" int wg_nce_tail_f32(const void* z, const void* vp, const float* sim, const int* own_row, float* loss_m, float* lse_m, int M, int rows, int N, int D,
+                               float temperature, int exclude_same_row, void* stream) {
+    WG_REQUIRE(z && vp && sim && own_row && loss_m && lse_m && M > 0 && rows > 0 && N > 0 && D > 0 && temperature > 0.f, "nce_tail: bad arguments");
+    hipLaunchKernelGGL(wg_nce_tail_kernel<false>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, (const bf16*)vp, sim, own_row, loss_m, lse_m, 0.f,
+                       nullptr, nullptr, nullptr, M, rows, N, D, 1.0f / temperature, exclude_same_row);
+    return wg_check_launch("wg_nce_tail_f32");
+}
+
+extern "C" int wg_nce_tail_bwd_f32(const void* z, const void* vp, const float* sim, const int* own_row, const float* lse_m, float g, void* dz, void* dvp,
+                                   float* dsim, int M, int rows, int N, int D, float temperature, int exclude_same_row, void* stream) {
+    WG_REQUIRE(z && vp && sim && own_row && lse_m && dz && dvp && dsim && M > 0 && rows > 0 && N > 0 && D > 0 && temperature > 0.f, "nce_tail_bwd: bad arguments");
+    hipLaunchKernelGGL(wg_nce_tail_kernel<true>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, (const bf16*)vp, sim, own_row, nullptr,
+                       (float*)lse_m, g, (bf16*)dz, (bf16*)dvp, dsim, M, rows, N, D, 1.0f / temperature, exclude_same_row);
+    return wg_check_launch("wg_nce_tail_bwd_f32");
+}
 
 extern "C" int wg_avgpool_tokens_bwd_bf16(const void* dy, void* dx, int B, int H, int W, int C, int s, void* stream) {
     WG_REQUIRE(dy && dx && B > 0 && H > 0 && W > 0 && C % 8 == 0 && s > 0 && H % s == 0 && W % s == 0, "avgpool_bwd: bad arguments");
