@@ -21,14 +21,14 @@
 namespace {
 
 // ---- column sums ----------------------------------------------------------------------------------------------------------------------
-// x [R, C] bf16 -> out[C] += sum over rows (fp32; the caller zeroes out).  A workgroup takes 64 rows x 512 columns: lane = 8 columns.
+// x [R, C] bf16 -> out[C] += sum over rows (fp32; the caller zeroes out).  A workgroup takes 256 rows x 512 columns: lane = 8 columns.
 __global__ __launch_bounds__(256) void wg_colsum_kernel(const bf16* x, long ldx, float* out, int R, int C) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = blockIdx.x * 512 + lane * 8;
     if (c >= C) return;
     float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int r0 = blockIdx.y * 64;
-    const int r1 = r0 + 64 < R ? r0 + 64 : R;
+    const int r0 = blockIdx.y * 256;
+    const int r1 = r0 + 256 < R ? r0 + 256 : R;
     for (int r = r0 + wave; r < r1; r += 4) {
         const bf16x8 t = *(const bf16x8*)(x + (long)r * ldx + c);
 #pragma unroll
@@ -708,7 +708,7 @@ extern "C" int wg_attn_bwd_bf16(const void* q, const void* k, const void* v, con
 
 extern "C" int wg_colsum_f32(const void* x, long ldx, float* out, int R, int C, void* stream) {
     WG_REQUIRE(x && out && R > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, "colsum: x [R, C] bf16 with C %% 8 == 0, 16-byte rows");
-    hipLaunchKernelGGL(wg_colsum_kernel, dim3((C + 511) / 512, (R + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, out, R, C);
+    hipLaunchKernelGGL(wg_colsum_kernel, dim3((C + 511) / 512, (R + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, out, R, C);
     return wg_check_launch("wg_colsum_f32");
 }
 
@@ -735,8 +735,10 @@ extern "C" int wg_layernorm_bwd_bf16(const void* x, long ldx, const void* gamma,
     WG_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= LNB_CH * 512 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0,
                "layernorm_bwd: C = %d must be a multiple of 8, at most %d", C, LNB_CH * 512);
     WG_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0, "layernorm_bwd: misaligned operand");
-    int blocks = (M + 3) / 4;
-    if (blocks > 512) blocks = 512;
+    // ~16 rows per wave: every wave ends with 2 C atomics, so few waves with many rows each (4096 rows of 256: 1 M atomics on 512 addresses
+    // took 122 us with one or two rows per wave)
+    int blocks = (M + 63) / 64;
+    if (blocks > 256) blocks = 256;
     hipLaunchKernelGGL(wg_layernorm_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, (const bf16*)gamma, (const bf16*)dy,
                        lddy, (bf16*)dx, lddx, dgamma, dbeta, M, C, eps);
     return wg_check_launch("wg_layernorm_bwd_bf16");

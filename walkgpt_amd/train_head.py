@@ -130,17 +130,29 @@ def decode(grounding, emb_tokens, pred_embeddings, resize_list, original_size_li
     no_mask = vm.prompt_encoder.no_mask_embed.weight.reshape(-1)
     dec = vm.mask_decoder
     sl = (1, dec.num_mask_tokens - 1) if multimask_output else (0, 1)
-    out = []
-    for i, pred in enumerate(pred_embeddings):
-        T = int(pred.shape[0])
-        H0, W0 = original_size_list[i]
-        if T == 0:
-            out.append(torch.zeros(0, H0, W0, device=emb_tokens.device))
-            continue
-        src = emb_tokens[i:i + 1].expand(T, -1, -1)
-        low_res, _ = decoder_forward(dec, src, pe, pred.unsqueeze(1), no_mask, h, w, sl)
-        full = ag.postprocess_masks(low_res.contiguous(), vm.image_encoder.img_size, resize_list[i], original_size_list[i])
-        out.append(full[:, 0])
+    counts = [int(p.shape[0]) for p in pred_embeddings]
+    P = sum(counts)
+    dev = emb_tokens.device
+    out = [None] * len(counts)
+    if P > 0:
+        # every prompt of every image in ONE decoder pass (prompt p attends to the embedding of its own image), as WalkGPTGrounding.decode does
+        pimg = torch.tensor([i for i, c in enumerate(counts) for _ in range(c)], device=dev)
+        src = emb_tokens.index_select(0, pimg)
+        sparse = torch.cat([p for p in pred_embeddings if p.shape[0]], 0).unsqueeze(1)
+        low_res, _ = decoder_forward(dec, src, pe, sparse, no_mask, h, w, sl)
+        same = len(set(zip(map(tuple, resize_list), map(tuple, original_size_list)))) == 1
+        if same:
+            full = ag.postprocess_masks(low_res.contiguous(), vm.image_encoder.img_size, resize_list[0], original_size_list[0])[:, 0]
+        off = 0
+        for i, c in enumerate(counts):
+            if c:
+                out[i] = full[off:off + c] if same else ag.postprocess_masks(low_res[off:off + c].contiguous(), vm.image_encoder.img_size, resize_list[i],
+                                                                             original_size_list[i])[:, 0]
+            off += c
+    for i, c in enumerate(counts):
+        if c == 0:
+            H0, W0 = original_size_list[i]
+            out[i] = torch.zeros(0, H0, W0, device=dev)
     return out
 
 
