@@ -507,6 +507,23 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     };
     // exponentials, row sum and bf16 packing of score elements [e0, e1)
     auto probs = [&](const f32x16* st, float off, int e0, int e1) __attribute__((always_inline)) {
+#if defined(WG_ATTN_PACKED) && WG_ATTN_PACKED
+        // experiment (-DWG_ATTN_PACKED=1): scale-and-offset and the row sum on float pairs (v_pk_fma_f32 / v_pk_add_f32: half the issue slots of
+        // the 32 fma + 32 add per tile); the sum runs as two partial sums that meet once per tile
+        f32x2 l2 = {0.f, 0.f};
+        const f32x2 sc2v = {sc2, sc2}, offv = {off, off};
+#pragma unroll
+        for (int e = e0; e < e1; e += 2) {
+            const int kb = e >> 4, r = e & 15;
+            f32x2 x = {st[kb][r], st[kb][r + 1]};
+            x = RAW ? x * sc2v - offv : x - offv;
+            const f32x2 p = {wg_exp2(x.x), wg_exp2(x.y)};
+            l2 += p;
+            pf[kb * 2 + (r >> 3)][r & 7] = (bf16)p.x;
+            pf[kb * 2 + (r >> 3)][(r & 7) + 1] = (bf16)p.y;
+        }
+        l_run += l2.x + l2.y;
+#else
 #pragma unroll
         for (int e = e0; e < e1; ++e) {
             const int kb = e >> 4, r = e & 15;
@@ -514,6 +531,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
             l_run += p;
             pf[kb * 2 + (r >> 3)][r & 7] = (bf16)p;
         }
+#endif
     };
     auto pv_one = [&](int g) __attribute__((always_inline)) {
         const int ks = g / DB, d = g % DB;
