@@ -190,3 +190,29 @@ def test_loaded_position_table_is_resized_once_in_fp32(name):
     tower.vision_tower.load_state_dict(sd, strict=True)
     got = tower.vision_tower.vision_model.embeddings.position_embedding.weight
     assert got.shape == (c["new_side"] ** 2 + 1, c["dim"]) and np.array_equal(got.detach().numpy(), gold["table"])
+
+
+def test_mx_scale_plane_layout_host_side():
+    """Host-side helpers of the fp8 MX chain (no GPU): the row permutation inside a scale plane is a bijection of every 128- / 64-row group
+    that puts rows r, r + 16, .. next to each other (the 8 / 4 MFMA fragments of a lane); the pitch covers whole 256-row tiles; dequantisation
+    applies 2^(byte - 127) per (row, 32 columns)."""
+    import torch
+    from walkgpt_amd import ops
+    for group in (128, 64):
+        M = 3 * group + 37
+        idx = ops.mx_scale_index(M, group=group)
+        assert idx.shape == (M,) and len(set(idx.tolist())) == M
+        full = ops.mx_scale_index(4 * group, group=group)
+        assert sorted(full.tolist()) == list(range(4 * group))                      # a permutation of every whole group
+        per = group // 16
+        for r in (0, 5, group + 3):
+            assert [int(full[r + 16 * k]) for k in range(per)] == list(range(int(full[r]), int(full[r]) + per))
+    assert ops.mx_pitch(1) == 256 and ops.mx_pitch(256) == 256 and ops.mx_pitch(257) == 512
+    assert ops.mx_chain_ok(1280, 5120) and ops.mx_chain_ok(768, 3072) and not ops.mx_chain_ok(192, 768) and not ops.mx_chain_ok(1536, 6144)
+    # dequantisation on a hand-built operand
+    M, K = 130, 64
+    q = torch.tensor([0x38], dtype=torch.uint8).repeat(M, K)                           # e4m3 0x38 = 1.0
+    mx = torch.full((K // 32, ops.mx_pitch(M)), 127, dtype=torch.uint8)
+    mx[1, ops.mx_scale_index(M)[129]] = 130                                             # row 129, columns 32..63: x 8
+    d = ops.mx_dequantize(q, mx)
+    assert d.shape == (M, K) and float(d[129, 40]) == 8.0 and float(d[129, 3]) == 1.0 and float(d[0, 40]) == 1.0
