@@ -520,17 +520,18 @@ def main():
                 "e2e_peak": PEAK_TF["bf16"], "e2e_frac": round(gf_step / ms_per_step / PEAK_TF["bf16"], 4),
                 "algorithmic_bytes_per_launch": round(byt / n_l)}
     # HBM traffic of the dominant kernel from the committed PMC passes -- only when they profiled THIS configuration
-    try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as f:
-            pmc = json.load(f)
-        same = pmc.get("config") == {"batch": B, "sam": args.sam, "seg_tokens": T, "with_msqp": bool(args.with_msqp), "dtype": args.dtype,
-                                     "world": 1}
-        key = [k for k in pmc["kernels"] if dom in PMC_PREFIX and k.startswith(PMC_PREFIX[dom])]
-        if same and key:
-            roofline["traffic"] = pmc["kernels"][key[0]]["hbm_bytes_per_launch"]
-            roofline["traffic_source"] = "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes of this command, avg per launch)"
-    except (OSError, KeyError, ValueError):
-        pass
+    for pmc_file in ("r03_pmc_traffic.json", "r03_c5_fp8_pmc_traffic.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
+                pmc = json.load(f)
+            same = pmc.get("config") == {"batch": B, "sam": args.sam, "seg_tokens": T, "with_msqp": bool(args.with_msqp), "dtype": args.dtype,
+                                         "world": 1}
+            key = [k for k in pmc["kernels"] if dom in PMC_PREFIX and k.startswith(PMC_PREFIX[dom])]
+            if same and key:
+                roofline["traffic"] = pmc["kernels"][key[0]]["hbm_bytes_per_launch"]
+                roofline["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes of this command, avg per launch)" % pmc_file
+        except (OSError, KeyError, ValueError):
+            pass
 
     out = {"metric": "images/sec", "value": round(images_per_s, 2), "unit": "images/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
