@@ -62,6 +62,40 @@ def test_clip_vit_l_448_full_size_batch_of_8(dev):
     assert rel_err(pre8[0][3].float().cpu().numpy(), ref_pre[0][0].numpy()) < 0.03
 
 
+def test_clip_vit_l_448_fp8_mx_chain_full_size(dev):
+    """The CLIP tower at its real size with the MX chain (D = 1024: four partial planes per LayerNorm fold, M = 2 x 1025 rows: ragged row tiles
+    and key-masked attention in front of the quantisation pass): against the bf16 path on the same weights and, one image, the fp32 oracle."""
+    from types import SimpleNamespace
+    from oracle import clip as oclip
+    cfg = dict(CLIP_VIT_L_14, image_size=448)
+    c = dict(dim=1024, heads=16, layers=24, img=448, seed=43)
+    args = SimpleNamespace(mm_vision_select_layer=-2, pad_train_clip_images=True, resize_vision_tower=True, resize_vision_tower_size=448)
+    tower = CLIPVisionTower("synthetic", args, config=cfg)
+    w = cases.clip_weights(c)
+    load_into(tower.vision_tower, w, "", dev)
+    x = torch.from_numpy(synth.normal(8, "input.images_clip8", (8, 3, 448, 448)))[:2]
+    sizes = [(448, 448), (300, 448)]
+    xd = x.to(dev, torch.bfloat16)
+    km = patch_key_mask(xd, sizes)
+    layers = tower.vision_tower.vision_model.encoder.layers
+    with torch.no_grad():
+        sel16, _ = tower(xd, attention_mask=km)
+        for l in layers:
+            l.gemm_dtype = "fp8"
+        sel8, _ = tower(xd, attention_mask=km)
+        sel8b, _ = tower(xd, attention_mask=km)
+        for l in layers:
+            l.gemm_dtype = "bf16"
+    assert torch.equal(sel8, sel8b) and torch.isfinite(sel8.float()).all()
+    wq = {k: v.bfloat16().float() for k, v in w.items()}
+    with torch.no_grad():
+        ref_sel, _ = oclip.clip_tower(wq, x[1:2].bfloat16().float(), oclip.patch_key_mask(1, (448, 448), [sizes[1]]))
+    e16 = rel_err(sel16[1].float().cpu().numpy(), ref_sel[0].numpy())
+    e8 = rel_err(sel8[1].float().cpu().numpy(), ref_sel[0].numpy())
+    print("CLIP ViT-L/14 @ 448, selected features vs the fp32 oracle: bf16 GEMMs %.4f, fp8 MX chain %.4f" % (e16, e8))
+    assert e16 < 0.03 and e8 < 0.12
+
+
 def test_sam_vit_h_full_geometry_batch_of_4(dev):
     """Config C3's encoder at its full geometry (the reference's default, model/walkgpt.py:128: D = 1280, 32 blocks, 16 heads of 80,
     global attention at 7/15/23/31) on a batch of four: finite, deterministic, batch-independent, image-dependent.  The arithmetic of
