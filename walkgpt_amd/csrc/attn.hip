@@ -371,6 +371,17 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
     float m_run = NEG_BIG;
     float l_run = 0.f;   // running softmax denominator (this lane's half of the keys)
+#if defined(WG_ATTN_MFMA_SUM) && WG_ATTN_MFMA_SUM
+    // experiment (-DWG_ATTN_MFMA_SUM=1): the denominator from the matrix pipe -- one more P.V-shaped MFMA per k-step with an all-ones A operand
+    // leaves sum_k P[q][k] (both lane halves' keys) in every row of osum: 4 MFMAs per tile instead of 32 v_add_f32, and no cross-half sum at the end
+    constexpr bool MSUM = true;
+    f32x16 osum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) osum[r] = 0.f;
+    const bf16x8 ones8 = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
+#else
+    constexpr bool MSUM = false;
+#endif
     const float sc2 = a.scale * LOG2E;
 
     // ---- main loop ---------------------------------------------------------------------------------------------------------------
@@ -467,6 +478,10 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
             const float alpha = wg_exp2(m_run - m_new);
             m_run = m_new;
             l_run *= alpha;
+#if defined(WG_ATTN_MFMA_SUM) && WG_ATTN_MFMA_SUM
+#pragma unroll
+            for (int r = 0; r < 16; ++r) osum[r] *= alpha;
+#endif
 #pragma unroll
             for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -528,7 +543,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         for (int e = e0; e < e1; ++e) {
             const int kb = e >> 4, r = e & 15;
             const float p = RAW ? wg_exp2(st[kb][r] * sc2 - off) : wg_exp2(st[kb][r] - off);
-            l_run += p;
+            if (!MSUM) l_run += p;
             pf[kb * 2 + (r >> 3)][r & 7] = (bf16)p;
         }
 #endif
@@ -542,6 +557,9 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         return;
 #endif
         ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], ot[d], 0, 0, 0);
+#if defined(WG_ATTN_MFMA_SUM) && WG_ATTN_MFMA_SUM
+        if (d == 0) osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf[ks], osum, 0, 0, 0);
+#endif
     };
 
     // Windows whose last tile holds keys in its first key block only (S = 14 at four padded rows per tile: rows 12, 13 | 14, 15): the dead
@@ -733,6 +751,9 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
             const float pl = wg_exp2(sv - m_new);
             m_run = m_new;
             l_run = l_run * alpha + (hi == 0 ? pl : 0.f);              // (the two lane halves' sums are added below)
+#if defined(WG_ATTN_MFMA_SUM) && WG_ATTN_MFMA_SUM
+            osum[0] = osum[0] * alpha + pl;                            // (osum already holds both halves)
+#endif
             const bf16* vp = a.V + krow * a.ldv + hcol + 4 * hi;
 #pragma unroll
             for (int d = 0; d < DB; ++d)
@@ -746,7 +767,11 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         }
     }
     // ---- epilogue: O = O^T / l, 8-byte stores ---------------------------------------------------------------------------
+#if defined(WG_ATTN_MFMA_SUM) && WG_ATTN_MFMA_SUM
+    const float l_tot = osum[0];
+#else
     const float l_tot = wg_xor32_sum(l_run);
+#endif
     if (qvalid) {
         const float inv = 1.0f / l_tot;
         long orow;
