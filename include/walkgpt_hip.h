@@ -327,12 +327,12 @@ int wg_resample_tokens_bf16(const void* x, void* y, int n, int p, int t, int C, 
  * copies (wg_gemm_bias_act_bf16); these are the pieces that are not:
  * wg_colsum_f32:          out[c] += sum_r x[r][c]   (bias gradient; fp32, the caller zeroes `out`)
  * wg_act_bf16 / _bwd:     y = act(x); dx = dy * act'(x)  (act codes of the GEMM epilogue: 1 erf-GELU, 2 quick-GELU, 3 ReLU)
- * wg_layernorm_bwd_bf16:  dx [M,C] bf16, dgamma / dbeta [C] fp32 (+=) of y = LayerNorm(x) gamma + beta, C <= 4096 */
+ * wg_layernorm_bwd_bf16:  dx [M,C] bf16, dgamma / dbeta [C] fp32 (+=) of y = LayerNorm(x) gamma + beta */
 int wg_colsum_f32(const void* x, long ldx, float* out, int R, int C, void* stream);
 int wg_act_bf16(const void* x, void* y, long n, int act, void* stream);
 int wg_act_bwd_bf16(const void* x, const void* dy, void* dx, long n, int act, void* stream);
 int wg_layernorm_bwd_bf16(const void* x, long ldx, const void* gamma, const void* dy, long lddy, void* dx, long lddx, float* dgamma,
-                          float* dbeta, int M, int C, float eps, void* stream);
+                          float* dbeta, float* row_stats, int M, int C, float eps, void* stream);   /* row_stats: 2 M floats, needed when C > 4096 */
 /* wg_l2norm_scale_bf16 / _bwd: y = x / max(|x|, eps) * exp(log_temp), the tail of CalibratedTextProjector behind its LayerNorm and type
  *   embedding (utils_walkgpt.py:325-327) as a separate operator, and its backward (dx bf16; dlog_temp fp32 +=).  C <= 512.
  * wg_attn_bwd_bf16: gradients of o = softmax(scale q k^T) v per (batch, head) for the head's small attentions (two-way transformer,

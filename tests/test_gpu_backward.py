@@ -52,7 +52,7 @@ def test_activation_backward(dev, act):
     assert rel(y, yr) < 4e-3 and rel(xh.grad, xr.grad) < 5e-3
 
 
-@pytest.mark.parametrize("M,C,eps", [(300, 256, 1e-5), (4099, 1280, 1e-6), (33, 4096, 1e-5)])
+@pytest.mark.parametrize("M,C,eps", [(300, 256, 1e-5), (4099, 1280, 1e-6), (33, 4096, 1e-5), (77, 5120, 1e-5)])
 def test_layernorm_backward(dev, M, C, eps):
     g = torch.Generator().manual_seed(C)
     x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(torch.bfloat16)

@@ -49,7 +49,7 @@ SIGNATURES = {
     "wg_colsum_f32": [c_void_p, c_long, c_void_p, c_int, c_int, c_void_p],
     "wg_act_bf16": [c_void_p, c_void_p, c_long, c_int, c_void_p],
     "wg_act_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
-    "wg_layernorm_bwd_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "wg_layernorm_bwd_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "wg_l2norm_scale_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "wg_l2norm_scale_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "wg_attn_bwd_short_side": [c_int, c_int],

@@ -126,8 +126,9 @@ class _LayerNorm(torch.autograd.Function):
         dx = torch.empty_like(x)
         dg = torch.zeros(C, device=x.device, dtype=torch.float32)
         db = torch.zeros(C, device=x.device, dtype=torch.float32)
+        ws = torch.empty(2 * M, device=x.device, dtype=torch.float32) if C > 4096 else None      # (wide rows: {mean, rstd} between the two kernels)
         rc = _lib.lib().wg_layernorm_bwd_bf16(x.data_ptr(), C, gamma.data_ptr(), dy.data_ptr(), C, dx.data_ptr(), C, dg.data_ptr(), db.data_ptr(),
-                                              M, C, float(ctx.eps), ops._stream())
+                                              ops._ptr(ws) or None, M, C, float(ctx.eps), ops._stream())
         _lib.check(rc, "wg_layernorm_bwd_bf16")
         return dx, dg.to(gamma.dtype), db.to(gamma.dtype), None
 

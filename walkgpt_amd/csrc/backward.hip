@@ -157,6 +157,76 @@ __global__ __launch_bounds__(256) void wg_layernorm_bwd_kernel(const bf16* x, lo
     }
 }
 
+// Rows wider than 4096 (a 13B language model's 5120 in front of CTP): the same gradients without the row or the column partials in
+// registers -- dx from three passes over the row (L2-resident), {mean, rstd} left per row; dgamma / dbeta by a column-sum kernel over
+// dy * xhat and dy.
+__global__ __launch_bounds__(256) void wg_layernorm_bwd_wide_dx_kernel(const bf16* x, long ldx, const bf16* gamma, const bf16* dy, long lddy, bf16* dx,
+                                                                       long lddx, float* stats, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const bf16* xr = x + (long)m * ldx;
+    const bf16* gr = dy + (long)m * lddy;
+    const float invc = 1.0f / (float)C;
+    float s = 0.f;
+    for (int d = lane * 8; d < C; d += 512) {
+        const bf16x8 t = *(const bf16x8*)(xr + d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)t[e];
+    }
+    const float mean = wg_wave_sum(s) * invc;
+    float q = 0.f;
+    for (int d = lane * 8; d < C; d += 512) {
+        const bf16x8 t = *(const bf16x8*)(xr + d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float v = (float)t[e] - mean; q += v * v; }
+    }
+    const float rstd = 1.0f / sqrtf(wg_wave_sum(q) * invc + eps);
+    float sg = 0.f, sgx = 0.f;
+    for (int d = lane * 8; d < C; d += 512) {
+        const bf16x8 t = *(const bf16x8*)(xr + d), g = *(const bf16x8*)(gr + d), gm = *(const bf16x8*)(gamma + d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gg = (float)g[e] * (float)gm[e];
+            sg += gg;
+            sgx += gg * ((float)t[e] - mean) * rstd;
+        }
+    }
+    const float mg = wg_wave_sum(sg) * invc, mgx = wg_wave_sum(sgx) * invc;
+    bf16* dr = dx + (long)m * lddx;
+    for (int d = lane * 8; d < C; d += 512) {
+        const bf16x8 t = *(const bf16x8*)(xr + d), g = *(const bf16x8*)(gr + d), gm = *(const bf16x8*)(gamma + d);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)(rstd * ((float)g[e] * (float)gm[e] - mg - ((float)t[e] - mean) * rstd * mgx));
+        *(bf16x8*)(dr + d) = o;
+    }
+    if (lane == 0) { stats[2 * (long)m] = mean; stats[2 * (long)m + 1] = rstd; }
+}
+__global__ __launch_bounds__(256) void wg_layernorm_bwd_wide_cols_kernel(const bf16* x, long ldx, const bf16* dy, long lddy, const float* stats, float* dgamma,
+                                                                         float* dbeta, int M, int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 512 + lane * 8;
+    if (c >= C) return;
+    float ag[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ab[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int r0 = blockIdx.y * 256;
+    const int r1 = r0 + 256 < M ? r0 + 256 : M;
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const bf16x8 t = *(const bf16x8*)(x + (long)r * ldx + c), g = *(const bf16x8*)(dy + (long)r * lddy + c);
+        const float mean = stats[2 * (long)r], rstd = stats[2 * (long)r + 1];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ag[e] += (float)g[e] * ((float)t[e] - mean) * rstd;
+            ab[e] += (float)g[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        atomicAdd(dgamma + c + e, ag[e]);
+        atomicAdd(dbeta + c + e, ab[e]);
+    }
+}
+
 // ---- y = x / max(|x|, eps) * exp(t): the tail of CalibratedTextProjector behind its LayerNorm and type embedding (utils_walkgpt.py:325-327:
 // F.normalize(dim=-1, eps 1e-12) * log_temp.exp()).  One wave per row, C <= 512.
 //   forward:  y = x e^t / n,  n = max(|x|, eps)
@@ -730,11 +800,18 @@ extern "C" int wg_act_bwd_bf16(const void* x, const void* dy, void* dx, long n, 
 }
 
 extern "C" int wg_layernorm_bwd_bf16(const void* x, long ldx, const void* gamma, const void* dy, long lddy, void* dx, long lddx, float* dgamma,
-                                     float* dbeta, int M, int C, float eps, void* stream) {
+                                     float* dbeta, float* row_stats, int M, int C, float eps, void* stream) {
     WG_REQUIRE(x && gamma && dy && dx && dgamma && dbeta, "layernorm_bwd: null operand");
-    WG_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= LNB_CH * 512 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0,
-               "layernorm_bwd: C = %d must be a multiple of 8, at most %d", C, LNB_CH * 512);
+    WG_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0, "layernorm_bwd: C = %d must be a multiple of 8", C);
     WG_REQUIRE((((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0, "layernorm_bwd: misaligned operand");
+    if (C > LNB_CH * 512) {   // wide rows: `row_stats` (2 M floats of workspace) is required
+        WG_REQUIRE(row_stats, "layernorm_bwd: rows wider than %d need the row_stats workspace (2 * M floats)", LNB_CH * 512);
+        hipLaunchKernelGGL(wg_layernorm_bwd_wide_dx_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, (const bf16*)gamma,
+                           (const bf16*)dy, lddy, (bf16*)dx, lddx, row_stats, M, C, eps);
+        hipLaunchKernelGGL(wg_layernorm_bwd_wide_cols_kernel, dim3((C + 511) / 512, (M + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx,
+                           (const bf16*)dy, lddy, row_stats, dgamma, dbeta, M, C);
+        return wg_check_launch("wg_layernorm_bwd_bf16(wide)");
+    }
     // ~16 rows per wave: every wave ends with 2 C atomics, so few waves with many rows each (4096 rows of 256: 1 M atomics on 512 addresses
     // took 122 us with one or two rows per wave)
     int blocks = (M + 63) / 64;
