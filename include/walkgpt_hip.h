@@ -371,6 +371,10 @@ int wg_splice_multimodal_bwd_bf16(const long* ids, const int* img_pos, const voi
  *     u [M, D] = the folded query W_k^T W_q z of TinyCrossAttn (:330-357); backward gives du.
  *   wg_nce_tail_f32 / _bwd: pos_m = z_m . vp_m, logits_m = [pos_m, sim[m, :]] / T (the rows*N columns of m's own image masked when
  *     exclude_same_row), loss_m = logsumexp - pos_m / T; backward (g = upstream gradient of the MEAN over m): dz (positive term), dvp, dsim. */
+/* masks = hyper_in @ upscaled (mask_decoder.py:150-160) on channels-last rows for all prompts at once, and its gradients (training path):
+ *   up [P, HW, 32] bf16, hyper [P, K <= 4, 32] bf16 -> masks [P, K, HW] fp32;  backward: dup [P, HW, 32] bf16, dhyper [P, K, 32] fp32 (+=). */
+int wg_hyper_rows_f32(const void* up, const void* hyper, float* masks, int P, int HW, int C, int K, void* stream);
+int wg_hyper_rows_bwd_f32(const void* up, const void* hyper, const float* dmasks, void* dup, float* dhyper, int P, int HW, int C, int K, void* stream);
 int wg_topk_pool_bf16(const void* u, const void* kt, void* v, int M, int Kt, int D, void* stream);
 int wg_topk_pool_bwd_bf16(const void* u, const void* kt, const void* dv, void* du, int M, int Kt, int D, void* stream);
 int wg_nce_tail_f32(const void* z, const void* vp, const float* sim, const int* own_row, float* loss_m, float* lse_m, int M, int rows, int N, int D,

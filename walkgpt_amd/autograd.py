@@ -490,3 +490,34 @@ def topk_pool(u, kt):
 
 def nce_tail(z, vp, sim, own_row, rows, N, temperature, exclude_same_row):
     return _NceTail.apply(z, vp, sim, own_row, rows, N, temperature, exclude_same_row)
+
+
+class _HyperRows(torch.autograd.Function):
+    """masks = hyper_in @ upscaled (mask_decoder.py:150-160) for all prompts at once on channels-last rows: wg_hyper_rows_f32 / _bwd_f32."""
+
+    @staticmethod
+    def forward(ctx, up, hyper):
+        up, hyper = up.contiguous(), hyper.contiguous()
+        ctx.save_for_backward(up, hyper)
+        P, HW, C = up.shape
+        K = hyper.shape[1]
+        masks = torch.empty(P, K, HW, device=up.device, dtype=torch.float32)
+        _lib.check(_lib.lib().wg_hyper_rows_f32(up.data_ptr(), hyper.data_ptr(), masks.data_ptr(), P, HW, C, K, ops._stream()), "wg_hyper_rows_f32")
+        return masks
+
+    @staticmethod
+    def backward(ctx, dm):
+        up, hyper = ctx.saved_tensors
+        P, HW, C = up.shape
+        K = hyper.shape[1]
+        dm = dm.contiguous().float()
+        dup = torch.empty_like(up)
+        dh = torch.zeros(P, K, C, device=up.device, dtype=torch.float32)
+        rc = _lib.lib().wg_hyper_rows_bwd_f32(up.data_ptr(), hyper.data_ptr(), dm.data_ptr(), dup.data_ptr(), dh.data_ptr(), P, HW, C, K, ops._stream())
+        _lib.check(rc, "wg_hyper_rows_bwd_f32")
+        return dup, dh.to(hyper.dtype)
+
+
+def hyper_rows(up, hyper):
+    """up [P, HW, 32] bf16, hyper [P, K <= 4, 32] bf16 -> masks [P, K, HW] fp32, differentiable in both."""
+    return _HyperRows.apply(up, hyper)

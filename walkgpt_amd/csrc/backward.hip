@@ -664,7 +664,99 @@ __global__ __launch_bounds__(256) void wg_nce_tail_kernel(const bf16* z, const b
     }
 }
 
+// ---- masks = hyper_in @ upscaled (mask_decoder.py:150-160) on channels-last rows, all prompts in one launch, and its gradients ------------------
+// up [P, HW, C] bf16 (C = 32: the upscaled embedding, one row per output pixel), hyper [P, K, C] bf16 (K <= 4 mask tokens' hypernetwork outputs)
+// -> masks [P, K, HW] fp32.  A thread per pixel, the prompt's K hyper rows in LDS.
+// Backward: dup[p, x, :] = sum_k dm[p, k, x] hyper[p, k, :];  dhyper[p, k, :] += sum_x dm[p, k, x] up[p, x, :] (workgroup partials -> fp32 atomics).
+constexpr int HM_C = 32, HM_K = 4;
+template <int MODE>   // 0 forward, 1 backward
+__global__ __launch_bounds__(256) void wg_hyper_rows_kernel(const bf16* up, const bf16* hyper, const float* dm, float* masks, bf16* dup, float* dhyper, int HW,
+                                                            int K) {
+    __shared__ float hs[HM_K][HM_C];
+    __shared__ float red[4][HM_K][HM_C];
+    const int p = blockIdx.y;
+    if (threadIdx.x < K * HM_C) hs[threadIdx.x / HM_C][threadIdx.x % HM_C] = (float)hyper[((long)p * K) * HM_C + threadIdx.x];
+    __syncthreads();
+    float acc[HM_K][HM_C];
+    if (MODE == 1) {
+#pragma unroll
+        for (int k = 0; k < HM_K; ++k)
+#pragma unroll
+            for (int c = 0; c < HM_C; ++c) acc[k][c] = 0.f;
+    }
+    for (int x = blockIdx.x * 256 + threadIdx.x; x < HW; x += gridDim.x * 256) {
+        float u[HM_C];
+        const bf16* ur = up + ((long)p * HW + x) * HM_C;
+#pragma unroll
+        for (int c = 0; c < HM_C; c += 8) {
+            const bf16x8 t = *(const bf16x8*)(ur + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) u[c + e] = (float)t[e];
+        }
+        if (MODE == 0) {
+            for (int k = 0; k < K; ++k) {
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < HM_C; ++c) d += u[c] * hs[k][c];
+                masks[((long)p * K + k) * HW + x] = d;
+            }
+        } else {
+            float g[HM_K];
+#pragma unroll
+            for (int k = 0; k < HM_K; ++k) g[k] = k < K ? dm[((long)p * K + k) * HW + x] : 0.f;
+            bf16* dr = dup + ((long)p * HW + x) * HM_C;
+#pragma unroll
+            for (int c = 0; c < HM_C; c += 8) {
+                bf16x8 o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int k = 0; k < HM_K; ++k) d += g[k] * hs[k][c + e];
+                    o[e] = (bf16)d;
+                }
+                *(bf16x8*)(dr + c) = o;
+            }
+#pragma unroll
+            for (int k = 0; k < HM_K; ++k)
+#pragma unroll
+                for (int c = 0; c < HM_C; ++c) acc[k][c] += g[k] * u[c];
+        }
+    }
+    if (MODE == 1) {
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < HM_K; ++k)
+#pragma unroll
+            for (int c = 0; c < HM_C; ++c) {
+                const float v = wg_wave_sum(acc[k][c]);
+                if (lane == 0) red[wave][k][c] = v;
+            }
+        __syncthreads();
+        if (threadIdx.x < K * HM_C) {
+            const int k = threadIdx.x / HM_C, c = threadIdx.x % HM_C;
+            atomicAdd(dhyper + ((long)p * K + k) * HM_C + c, red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c]);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int wg_hyper_rows_f32(const void* up, const void* hyper, float* masks, int P, int HW, int C, int K, void* stream) {
+    WG_REQUIRE(up && hyper && masks && P > 0 && HW > 0 && C == HM_C && K > 0 && K <= HM_K, "hyper_rows: C must be %d, K <= %d", HM_C, HM_K);
+    int gx = (HW + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(wg_hyper_rows_kernel<0>, dim3(gx, P), dim3(256), 0, (hipStream_t)stream, (const bf16*)up, (const bf16*)hyper, nullptr, masks, nullptr, nullptr, HW, K);
+    return wg_check_launch("wg_hyper_rows_f32");
+}
+
+extern "C" int wg_hyper_rows_bwd_f32(const void* up, const void* hyper, const float* dmasks, void* dup, float* dhyper, int P, int HW, int C, int K, void* stream) {
+    WG_REQUIRE(up && hyper && dmasks && dup && dhyper && P > 0 && HW > 0 && C == HM_C && K > 0 && K <= HM_K, "hyper_rows_bwd: C must be %d, K <= %d", HM_C, HM_K);
+    int gx = (HW + 255) / 256;
+    if (gx > 64) gx = 64;
+    hipLaunchKernelGGL(wg_hyper_rows_kernel<1>, dim3(gx, P), dim3(256), 0, (hipStream_t)stream, (const bf16*)up, (const bf16*)hyper, dmasks, nullptr, (bf16*)dup, dhyper, HW, K);
+    return wg_check_launch("wg_hyper_rows_bwd_f32");
+}
 
 extern "C" int wg_topk_pool_bf16(const void* u, const void* kt, void* v, int M, int Kt, int D, void* stream) {
     WG_REQUIRE(u && kt && v && M > 0 && Kt > 0 && Kt <= 16 && D % 8 == 0 && D <= 512, "topk_pool: Kt <= 16, D <= 512");

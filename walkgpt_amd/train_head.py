@@ -113,12 +113,12 @@ def decoder_forward(dec, src_tokens, pos_tokens, sparse, dense_vec, h, w, mask_s
     hyper = torch.stack([_mlp3(dec.output_hypernetworks_mlps[i], mask_out[:, i].contiguous()) for i in range(nm)], 1)   # [P, nm, C/8]
     k0, k1 = mask_slice[0], mask_slice[0] + mask_slice[1]
     up = up.view(P, 16 * h * w, -1)
-    masks = []
-    for p in range(P):   # masks_p = hyper_in_p @ upscaled_p: a GEMM per prompt (its weights are the prompt's own hypernetwork output)
-        m = ag.linear(up[p], hyper[p, k0:k1].contiguous(), None, out_f32=True)                       # [16hw, k] fp32 logits
-        masks.append(m.t().reshape(k1 - k0, 4 * h, 4 * w))
+    if up.shape[-1] == 32 and k1 - k0 <= 4:      # every prompt's product in one launch (its weights are the prompt's own hypernetwork output)
+        masks = ag.hyper_rows(up, hyper[:, k0:k1]).view(P, k1 - k0, 4 * h, 4 * w)
+    else:                                        # other widths: a GEMM per prompt
+        masks = torch.stack([ag.linear(up[p], hyper[p, k0:k1].contiguous(), None, out_f32=True).t().reshape(k1 - k0, 4 * h, 4 * w) for p in range(P)], 0)
     iou = _mlp3(dec.iou_prediction_head, iou_out.contiguous())
-    return torch.stack(masks, 0), iou[:, k0:k1]
+    return masks, iou[:, k0:k1]
 
 
 def decode(grounding, emb_tokens, pred_embeddings, resize_list, original_size_list, multimask_output=False):
