@@ -61,7 +61,9 @@ def parse(argv=None):
     ap.add_argument("--sam", default=None, choices=sorted(GF_SAM))
     ap.add_argument("--original", type=int, default=None, help="side of the original image the masks are resampled to")
     ap.add_argument("--llm-hidden", type=int, default=4096)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="GEMM operand type of the encoder blocks")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="GEMM operand type of the SAM encoder blocks (the CLIP tower stays bf16)")
+    ap.add_argument("--fp8-clip", action="store_true", help="NOT config C5: with --dtype fp8 also run the CLIP tower's GEMMs on fp8 operands "
+                                                            "(its features, which feed the text logits, move 8 %% from fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-b8", action="store_true", help="time the CPU oracle on a batch of 8 also for the ViT-L / ViT-H encoders (minutes)")
     ap.add_argument("--no-cpu-baseline-b8", action="store_true", help="skip the B = 8 pass of the CPU baseline (default: run it once with SAM ViT-B, ~45 s)")
@@ -90,17 +92,26 @@ def config_name(args, world):
     if "C4" in match:
         return "C4" if world == 8 else "custom (C4's per-GPU share on %d GPU)" % world
     if "C5" in match:
+        if args.dtype == "fp8" and args.fp8_clip:
+            return "custom (C5 geometry, fp8 GEMMs in BOTH towers)"
         return "C5" if args.dtype == "fp8" else "C5 geometry with bf16 GEMMs"
     if match and args.dtype == "bf16":
         return match[0]
     return "custom"
 
 
+def gemm_label(args):
+    """Which towers run which operand type."""
+    if args.dtype != "fp8":
+        return "bf16"
+    return "fp8 MX (SAM encoder and CLIP tower)" if args.fp8_clip else "fp8 MX in the SAM encoder, bf16 in the CLIP tower and everywhere else"
+
+
 def workload_label(args, world):
     return ("%s: bs=%d/GPU x %d GPU, 448x448 source images (CLIP input 448^2, SAM input 1024^2), CLIP ViT-L/14 + SAM %s encoder%s + CTP + "
             "prompt encoder + mask decoder + postprocess to %dx%d, T=%d [SEG]/image, %s GEMMs, random-init weights"
             % (config_name(args, world), args.batch, world, args.sam, " + MSQP" if args.with_msqp else "", args.original, args.original,
-               args.seg_tokens, args.dtype)
+               args.seg_tokens, gemm_label(args))
             + (" [NOT the headline workload: CLIP layer 24, whose output the path discards, is not run]" if args.clip_skip_unused_layer else ""))
 
 
@@ -147,7 +158,7 @@ def build_model(args, dev):
     pe = model.visual_model.prompt_encoder.pe_layer
     pe.positional_encoding_gaussian_matrix.data = pe.positional_encoding_gaussian_matrix.data.float()
     if args.dtype == "fp8":
-        model.set_gemm_dtype("fp8")
+        model.set_gemm_dtype("fp8", clip=args.fp8_clip)
     if args.clip_skip_unused_layer:
         model.vision_tower.run_all_layers = False
     return model
@@ -519,17 +530,24 @@ def main():
                 "e2e_achieved": round(gf_step / ms_per_step, 1),  # GFLOP/ms == TFLOP/s
                 "e2e_peak": PEAK_TF["bf16"], "e2e_frac": round(gf_step / ms_per_step / PEAK_TF["bf16"], 4),
                 "algorithmic_bytes_per_launch": round(byt / n_l)}
-    # HBM traffic of the dominant kernel from the committed PMC passes -- only when they profiled THIS configuration
-    for pmc_file in ("r03_pmc_traffic.json", "r03_c5_fp8_pmc_traffic.json"):
+    # HBM traffic of the dominant kernel.  PMC counters cannot be read from inside an un-profiled process, so `traffic` (a measurement
+    # of THIS run) stays null here; what the committed rocprofv3 passes of the same command measured (tools/profile_r04.sh: --pmc
+    # FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md) is reported beside it, labelled with the
+    # commit the profile was taken at, and only when it profiled THIS configuration and this kernel.
+    for pmc_file in ("r04_pmc_traffic.json", "r04_c5_fp8_pmc_traffic.json", "r03_pmc_traffic.json", "r03_c5_fp8_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)
-            same = pmc.get("config") == {"batch": B, "sam": args.sam, "seg_tokens": T, "with_msqp": bool(args.with_msqp), "dtype": args.dtype,
-                                         "world": 1}
+            cfg = dict(pmc.get("config") or {})
+            cfg.setdefault("fp8_clip", args.dtype == "fp8" and pmc_file.startswith("r03"))   # round 3's C5 profile ran both towers in fp8
+            same = cfg == {"batch": B, "sam": args.sam, "seg_tokens": T, "with_msqp": bool(args.with_msqp), "dtype": args.dtype,
+                           "world": 1, "fp8_clip": bool(args.dtype == "fp8" and args.fp8_clip)}
             key = [k for k in pmc["kernels"] if dom in PMC_PREFIX and k.startswith(PMC_PREFIX[dom])]
-            if same and key:
-                roofline["traffic"] = pmc["kernels"][key[0]]["hbm_bytes_per_launch"]
-                roofline["traffic_source"] = "profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes of this command, avg per launch)" % pmc_file
+            if same and key and "traffic_profiled" not in roofline:
+                roofline["traffic_profiled"] = pmc["kernels"][key[0]]["hbm_bytes_per_launch"]
+                roofline["traffic_profiled_head"] = pmc.get("head", "unknown (round-3 profile, taken before this field existed)")
+                roofline["traffic_profiled_source"] = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes of this "
+                                                       "command, avg per launch; NOT measured in this run)" % pmc_file)
         except (OSError, KeyError, ValueError):
             pass
 

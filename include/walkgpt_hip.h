@@ -375,6 +375,9 @@ int wg_splice_multimodal_bwd_bf16(const long* ids, const int* img_pos, const voi
  *   up [P, HW, 32] bf16, hyper [P, K <= 4, 32] bf16 -> masks [P, K, HW] fp32;  backward: dup [P, HW, 32] bf16, dhyper [P, K, 32] fp32 (+=). */
 int wg_hyper_rows_f32(const void* up, const void* hyper, float* masks, int P, int HW, int C, int K, void* stream);
 int wg_hyper_rows_bwd_f32(const void* up, const void* hyper, const float* dmasks, void* dup, float* dhyper, int P, int HW, int C, int K, void* stream);
+/* Test support: writes `pattern` over the first 64 KiB of every compute unit's LDS (2048 workgroups; sink: one device word, or NULL).  LDS is not
+ * cleared between launches, so a kernel that reads a word it never wrote sees whatever ran before it; tests poison with NaN bits first. */
+int wg_debug_fill_lds_u32(unsigned pattern, void* sink, void* stream);
 int wg_topk_pool_bf16(const void* u, const void* kt, void* v, int M, int Kt, int D, void* stream);
 int wg_topk_pool_bwd_bf16(const void* u, const void* kt, const void* dv, void* du, int M, int Kt, int D, void* stream);
 int wg_nce_tail_f32(const void* z, const void* vp, const float* sim, const int* own_row, float* loss_m, float* lse_m, int M, int rows, int N, int D,

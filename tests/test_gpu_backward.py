@@ -326,3 +326,28 @@ def test_infonce_training_path_vs_oracle_autograd(dev, rows, exclude):
         assert ek < max(1.5 * ek16, 0.05), (k, ek, ek16)
     for k in ("wv.weight", "out.weight"):      # not on the loss's path in the top_k form
         assert dict(tx.named_parameters())[k].grad is None and (w32[k].grad is None or float(w32[k].grad.abs().max()) == 0.0)
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_hyper_rows_backward_reads_no_stale_lds(dev, K):
+    """masks = hyper_in @ upscaled with K < 4 mask tokens (the WalkGPT training path: multimask_output=False, K = 1): its backward sums
+    over all four LDS rows of the hypernetwork table with zero weights for the absent ones, so those rows must be written -- 0 * NaN
+    left by an earlier kernel would poison every mask-decoder gradient.  Every compute unit's LDS is filled with a NaN bit pattern
+    first; the gradients must come out finite and equal to autograd's."""
+    from walkgpt_amd import _lib
+    P, HW, C = 5, 1000, 32
+    g = torch.Generator().manual_seed(3)
+    up = torch.randn(P, HW, C, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
+    hy = torch.randn(P, K, C, generator=g).to(dev, torch.bfloat16).requires_grad_(True)
+    dm = torch.randn(P, K, HW, generator=g).to(dev)
+    _lib.check(_lib.lib().wg_debug_fill_lds_u32(0x7FC00000, None, ops._stream()), "wg_debug_fill_lds_u32")
+    masks = ag.hyper_rows(up, hy)
+    _lib.check(_lib.lib().wg_debug_fill_lds_u32(0x7FC00000, None, ops._stream()), "wg_debug_fill_lds_u32")
+    masks.backward(dm)
+    assert torch.isfinite(up.grad.float()).all() and torch.isfinite(hy.grad.float()).all()
+    u32, h32 = up.detach().float().requires_grad_(True), hy.detach().float().requires_grad_(True)
+    ref = torch.einsum("pkc,pxc->pkx", h32, u32)
+    ref.backward(dm)
+    assert float((masks - ref).abs().max()) < 1e-3 * float(ref.abs().max())
+    assert float((up.grad.float() - u32.grad).norm() / u32.grad.norm()) < 6e-3
+    assert float((hy.grad.float() - h32.grad).norm() / h32.grad.norm()) < 6e-3

@@ -285,8 +285,8 @@ def test_masks_with_fp8_encoder_vs_oracle(dev):
 
 
 def test_clip_tower_fp8_vs_standin_golden(dev):
-    """The CLIP tower with q|k|v / out_proj / fc1 / fc2 on fp8 operands (config C5 runs both towers that way) against the stand-in's fp32
-    features, next to the bf16 path on the same golden."""
+    """The CLIP tower with q|k|v / out_proj / fc1 / fc2 on fp8 operands (opt-in: set_gemm_dtype("fp8", clip=True); config C5 keeps the tower
+    in bf16) against the stand-in's fp32 features, next to the bf16 path on the same golden."""
     from types import SimpleNamespace
     from tests.test_gpu_modules import load_into
     from walkgpt_amd.clip_encoder import CLIPVisionTower

@@ -156,3 +156,104 @@ def test_c3_workload_at_its_own_batch(dev):
     e = rel_err(out["pred_masks"][5].float().cpu().numpy(), one["pred_masks"][0].float().cpu().numpy())
     assert e < 0.05, e
     assert rel_err(out["pred_masks"][5].float().cpu().numpy(), out["pred_masks"][0].float().cpu().numpy()) > 0.1   # distinct images, distinct masks
+
+
+def _randomise_sam_tables(enc):
+    with torch.no_grad():                                            # zero-initialised by default (image_encoder.py:71-74,232-233)
+        enc.pos_embed.normal_(0, 0.02)
+        for blk in enc.blocks:
+            blk.attn.rel_pos_h.normal_(0, 0.02)
+            blk.attn.rel_pos_w.normal_(0, 0.02)
+
+
+def test_c5_workload_at_its_own_size(dev):
+    """BASELINE config C5 on its own workload, one GPU's share: bs = 8, 1024 x 1024 originals, SAM ViT-H (32 blocks) with its qkv / proj /
+    MLP GEMMs on fp8 MX operands, the CLIP ViT-L/14 tower beside it in bf16 (north_star asks fp8 of the hi-res SAM encoder only),
+    MSQP + CTP + T = 14 [SEG] tokens per image -> masks at 1024 x 1024.  What bench.py --config C5 --dtype fp8 times, in one pass:
+    finite, deterministic, an image of the batch against the same image alone, and the fp8 masks against the bf16 path on the SAME
+    weights (thresholded agreement and logit distance, with the bounds they are held to)."""
+    from tests.test_gpu_modules import pixel_iou
+    from walkgpt_amd.walkgpt import WalkGPTGrounding
+    B, T, Hl = 8, 14, 4096
+    torch.manual_seed(0)
+    model = WalkGPTGrounding(sam="vit_h", llm_hidden=Hl, with_clip=True).to(dev).bfloat16()
+    pe = model.visual_model.prompt_encoder.pe_layer
+    pe.positional_encoding_gaussian_matrix.data = pe.positional_encoding_gaussian_matrix.data.float()
+    _randomise_sam_tables(model.visual_model.image_encoder)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, 3, 1024, 1024, generator=g).to(dev, torch.bfloat16)
+    xc = torch.randn(B, 3, 448, 448, generator=g).to(dev, torch.bfloat16)
+    hid = [torch.randn(T, Hl, generator=g).to(dev, torch.bfloat16) for _ in range(B)]
+    sizes, orig, csz = [(1024, 1024)] * B, [(1024, 1024)] * B, [(448, 448)] * B
+    with torch.no_grad():
+        ref16 = model(x, xc, hid, sizes, orig, csz)
+        m16 = [m.clone() for m in ref16["pred_masks"]]
+        f16 = ref16["clip_features"].clone()
+        model.set_gemm_dtype("fp8")                                  # SAM encoder only: the CLIP tower stays bf16
+        assert all(l.gemm_dtype == "bf16" for l in model.vision_tower.vision_tower.vision_model.encoder.layers)
+        assert all(b.gemm_dtype == "fp8" for b in model.visual_model.image_encoder.blocks)
+        out = model(x, xc, hid, sizes, orig, csz)
+        m8 = [m.clone() for m in out["pred_masks"]]
+        again = model(x, xc, hid, sizes, orig, csz)
+        one = model(x[5:6], xc[5:6], hid[5:6], sizes[:1], orig[:1], csz[:1])
+        model.set_gemm_dtype("bf16")
+    torch.cuda.synchronize()
+    assert len(m8) == B and out["visual_tokens"].shape == (B, 36, Hl) and out["clip_features"].shape == (B, 1024, 1024)
+    assert torch.equal(out["clip_features"], f16)                    # the CLIP tower is untouched by the SAM encoder's operand type
+    for i in range(B):
+        assert m8[i].shape == (T, 1024, 1024) and torch.isfinite(m8[i]).all() and out["mask_scores"][i].shape == (T,)
+        assert torch.equal(m8[i], again["pred_masks"][i])
+    e_one = rel_err(m8[5].float().cpu().numpy(), one["pred_masks"][0].float().cpu().numpy())
+    assert e_one < 0.05, e_one
+    assert rel_err(m8[5].float().cpu().numpy(), m8[0].float().cpu().numpy()) > 0.1
+    # fp8 against bf16 on the same weights.  White-noise images and random weights: the logits hover around zero, so every pixel is
+    # a boundary pixel -- the worst case for thresholded agreement (confident masks: test_gpu_modules' e2e case stays within 3e-4)
+    ious = [pixel_iou(m8[i].cpu().numpy(), m16[i].cpu().numpy()) for i in range(B)]
+    errs = [rel_err(m8[i].float().cpu().numpy(), m16[i].float().cpu().numpy()) for i in range(B)]
+    print("C5 at its own size (bs 8, ViT-H fp8 MX, T = 14, 1024^2): pixel IoU fp8 vs bf16 per image min %.4f mean %.4f; mask logits rel L2 "
+          "max %.4f; image 5 in the batch vs alone %.4f" % (min(ious), float(np.mean(ious)), max(errs), e_one))
+    assert min(ious) > 0.90 and max(errs) < 0.30
+
+
+def test_c4_per_gpu_share_at_its_own_batch(dev):
+    """BASELINE config C4's share of one GPU: bs = 32 of the C2 model (CLIP ViT-L/14 @ 448 + SAM ViT-B @ 1024 + CTP + decode, T = 1,
+    448 x 448 originals, bf16) in one pass with the CLIP tower on its side stream -- what each of the eight ranks runs before the mask
+    all-gather (tests/test_dist_gloo.py covers the exchange).  Shapes, finiteness, determinism, an image of the batch against the same
+    image alone (M = 131072 / 32800 rows of the persistent GEMMs against 4096 / 1025)."""
+    from walkgpt_amd.walkgpt import WalkGPTGrounding
+    B, T, Hl = 32, 1, 4096
+    torch.manual_seed(1)
+    model = WalkGPTGrounding(sam="vit_b", llm_hidden=Hl, with_clip=True).to(dev).bfloat16()
+    del model.out_mm_projector                                       # MSQP feeds the LLM, which C2 / C4 do not run (bench.py:build_model)
+    pe = model.visual_model.prompt_encoder.pe_layer
+    pe.positional_encoding_gaussian_matrix.data = pe.positional_encoding_gaussian_matrix.data.float()
+    _randomise_sam_tables(model.visual_model.image_encoder)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(B, 3, 1024, 1024, generator=g).to(dev, torch.bfloat16)
+    xc = torch.randn(B, 3, 448, 448, generator=g).to(dev, torch.bfloat16)
+    hid = [torch.randn(T, Hl, generator=g).to(dev, torch.bfloat16) for _ in range(B)]
+    ctp = model.text_hidden_fcs[0]
+    sizes, orig, csz = [(1024, 1024)] * B, [(448, 448)] * B, [(448, 448)] * B
+
+    def run(sl):
+        emb = model.get_visual_emb_tokens(x[sl])
+        feats, _ = model.encode_images_clip(xc[sl], csz[sl])
+        masks, scores = model.decode_from_hidden(emb, hid[sl], sizes[sl], orig[sl])
+        return feats, masks, scores
+
+    with torch.no_grad():
+        feats, masks, scores = run(slice(0, B))
+        feats2, masks2, _ = run(slice(0, B))
+        f1, m1, _ = run(slice(9, 10))
+    torch.cuda.synchronize()
+    assert feats.shape == (B, 1024, 1024) and torch.isfinite(feats.float()).all() and torch.equal(feats, feats2)
+    assert len(masks) == B
+    for i in range(B):
+        assert masks[i].shape == (T, 448, 448) and torch.isfinite(masks[i]).all() and scores[i].shape == (T,)
+        assert torch.equal(masks[i], masks2[i])
+    e_m = rel_err(masks[9].float().cpu().numpy(), m1[0].float().cpu().numpy())
+    e_f = rel_err(feats[9].float().cpu().numpy(), f1[0].float().cpu().numpy())
+    print("C4 per-GPU share (bs 32): image 9 in the batch vs alone: masks %.4f, CLIP features %.4f" % (e_m, e_f))
+    assert e_m < 0.05 and e_f < 0.02
+    assert rel_err(masks[9].float().cpu().numpy(), masks[0].float().cpu().numpy()) > 0.1
+    assert ctp is model.text_hidden_fcs[0]

@@ -98,18 +98,30 @@ class TinyLM(nn.Module):
     def __init__(self, script=None):
         super().__init__()
         g = torch.Generator().manual_seed(5)
-        self.embed = nn.Embedding(V, H)
+        self.embed_tokens = nn.Embedding(V, H)      # HF LLaMA's names: train_walkgpt.py:347-357 picks its trainable_list by substring
         self.wq = nn.ParameterList([nn.Parameter(torch.randn(H, H, generator=g) / 8) for _ in range(2)])
         self.wv = nn.ParameterList([nn.Parameter(torch.randn(H, H, generator=g) / 8) for _ in range(2)])
-        self.head = nn.Linear(H, V, bias=False)
+        self.lm_head = nn.Linear(H, V, bias=False)
         with torch.no_grad():
             self.embed.weight.copy_(torch.randn(V, H, generator=g))
             self.head.weight.copy_(torch.randn(V, H, generator=g) / 8)
         self.script = script or {}
         self.config = SimpleNamespace(eos_token_id=EOS)
 
+    @property
+    def embed(self):
+        return self.embed_tokens
+
+    @property
+    def head(self):
+        return self.lm_head
+
     def get_input_embeddings(self):
-        return self.embed
+        return self.embed_tokens
+
+    def resize_token_embeddings(self, new_num_tokens=None, **kw):
+        assert new_num_tokens in (None, V), "the toy LM keeps its vocabulary"
+        return self.embed_tokens
 
     def forward(self, inputs_embeds=None, attention_mask=None, labels=None, past_key_values=None, use_cache=False,
                 output_hidden_states=False, **kw):
@@ -264,8 +276,11 @@ def test_model_forward_trains_the_grounding_head(dev):
                  input_ids=ids.to(dev), labels=ids.to(dev), attention_masks=torch.ones(3, L, dtype=torch.bool, device=dev), offset=offset.to(dev),
                  masks_list=gt, label_list=[torch.zeros(orig[0], device=dev), torch.zeros(orig[1], device=dev)], resize_list=resize,
                  clip_resize_list=[(28, 28)] * 2, inference=False)
-    base = m(**batch)                                                   # head training off: the no-gradient forward
+    with torch.no_grad():
+        base = m(**batch)                                               # the no-gradient forward
     assert not base["loss"].requires_grad
+    m.enable_head_training(False)                                       # the opt-out: no graph even with gradients enabled
+    assert not m(**batch)["loss"].requires_grad
     for p in m.model.visual_model.parameters():                        # model/walkgpt.py:83-91: SAM frozen, its mask decoder trainable
         p.requires_grad_(False)
     for p in m.model.visual_model.mask_decoder.parameters():
@@ -309,6 +324,171 @@ def test_model_forward_trains_the_grounding_head(dev):
     after = float(step["mask_loss"].detach())
     print("head training, 6 steps: mask loss %.5f -> %.5f" % (before, after))
     assert after < before
+
+
+class _PeftStandIn(nn.Module):
+    """What train_walkgpt.py:304 / evaluation_walkgpt.py:294 get back from `peft.get_peft_model` (peft is not installed here), reduced to
+    what the scripts touch: the wrapped model sits at `.base_model.model` (so every state_dict key gains the prefix `base_model.model.`,
+    evaluation_walkgpt.py:295-305), every base parameter is frozen, calls and unknown attributes are forwarded."""
+
+    class _Tuner(nn.Module):
+        def __init__(self, model):
+            super().__init__()
+            self.model = model
+
+        def forward(self, *a, **k):
+            return self.model(*a, **k)
+
+    def __init__(self, model):
+        super().__init__()
+        for p in model.parameters():
+            p.requires_grad_(False)
+        self.base_model = _PeftStandIn._Tuner(model)
+
+    def forward(self, *a, **k):
+        return self.base_model(*a, **k)
+
+    def __getattr__(self, name):
+        try:
+            return super().__getattr__(name)
+        except AttributeError:
+            return getattr(self.base_model.model, name)
+
+    def print_trainable_parameters(self):
+        n = sum(p.numel() for p in self.parameters() if p.requires_grad)
+        print("trainable params: %d" % n)
+
+
+class _EngineStandIn:
+    """`deepspeed.initialize(...)[0]` reduced to what train_walkgpt.py:739-757 calls: the engine is callable, `backward(loss)` runs
+    autograd, `step()` applies the optimizer (bf16 engine: fp32 master weights behind the bf16 parameters) and clears the gradients."""
+
+    def __init__(self, model, model_parameters, lr):
+        self.module = model
+        self.params = [p for p in model_parameters if p.requires_grad]
+        self.master = [p.detach().float().clone() for p in self.params]
+        self.lr = lr
+
+    def train(self):
+        self.module.train()
+
+    def __call__(self, **kw):
+        return self.module(**kw)
+
+    def backward(self, loss):
+        loss.backward()
+
+    def step(self):
+        with torch.no_grad():
+            for p, w32 in zip(self.params, self.master):
+                if p.grad is not None:
+                    g = p.grad.float()
+                    w32 -= self.lr * w32.abs().mean() / (g.abs().mean() + 1e-30) * g     # scale-free step (toy optimiser)
+                    p.copy_(w32.to(p.dtype))
+                p.grad = None
+
+
+def _unwrap_model_with_attr(model, attribute):
+    """train_walkgpt.py:32-44, restated."""
+    cur = model
+    for _ in range(10):
+        if hasattr(cur, attribute):
+            return cur
+        if hasattr(cur, "module"):
+            cur = cur.module
+        elif hasattr(cur, "base_model"):
+            cur = cur.base_model
+        else:
+            break
+    return cur
+
+
+def test_head_training_is_decided_from_requires_grad():
+    """The switch train_walkgpt.py's loop relies on, without a GPU: with nothing forced, the training path is chosen exactly when one of
+    the reference's trainable modules (or the language model) holds a parameter that requires a gradient; True / False force it."""
+    m = _bare_adapter()
+    m.llm = nn.Linear(4, 4)
+    m.model = nn.Module()
+    m.model.text_hidden_fcs = nn.ModuleList([nn.Linear(4, 4)])
+    m.model.out_mm_projector = nn.Linear(4, 4)
+    m.model.visual_model = nn.Module()
+    m.model.visual_model.mask_decoder = nn.Linear(4, 4)
+    m.model.visual_model.image_encoder = nn.Linear(4, 4)
+    assert m.head_training is None and m._wants_head_training()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    assert not m._wants_head_training()
+    m.model.visual_model.image_encoder.weight.requires_grad_(True)      # not a module the path trains: still the no-gradient forward
+    assert not m._wants_head_training()
+    m.model.text_hidden_fcs[0].bias.requires_grad_(True)
+    assert m._wants_head_training()
+    assert not m.enable_head_training(False)._wants_head_training()
+    for p in m.parameters():
+        p.requires_grad_(False)
+    assert m.enable_head_training(True)._wants_head_training()
+    assert m.enable_head_training(None).head_training is None and not m._wants_head_training()
+    # the PEFT stand-in's layout is the one the reference's scripts expect
+    w = _PeftStandIn(m)
+    assert w.base_model.model is m and all(k.startswith("base_model.model.") for k in w.state_dict())
+    assert _unwrap_model_with_attr(w, "get_model") is not None and w.seg_token_num == 1
+
+
+@pytest.mark.gpu
+def test_train_walkgpt_loop_replayed_unchanged(dev):
+    """train_walkgpt.py, call by call, on the adapter WITHOUT any added line: get_peft_model (:304, stand-in: wraps at .base_model.model
+    and freezes the base), resize_token_embeddings (:307), the trainable_list loop (:347-357) over named_parameters(), deepspeed.initialize
+    (:545, stand-in engine), model.train(), `output_dict = model(**input_dict)` (:739), the .item() reads, `model.backward(loss)` (:756),
+    `model.step()` (:757).  The loss carries a graph by itself, the listed modules receive gradients, nothing else does, and the steps
+    lower the loss."""
+    m, lm, weights = _build(dev)
+    c = weights["c"]
+    model = _PeftStandIn(m)                                              # :304
+    model.print_trainable_parameters()
+    model.resize_token_embeddings(V)                                     # :307 (same size: a no-op on the toy LM)
+    trainable_list = ["lm_head", "embed_tokens", "mask_decoder", "text_hidden_fcs", "mm_projector", "out_mm_projector"]   # :347-350
+    picked = []
+    for n, p in model.named_parameters():                                # :351-357
+        if any(x in n for x in trainable_list):
+            p.requires_grad = True
+            picked.append(n)
+    assert any("lm_head" in n for n in picked) and any("embed_tokens" in n for n in picked) and any("mask_decoder" in n for n in picked)
+    assert all(n.startswith("base_model.model.") for n in picked)
+    engine = _EngineStandIn(model, model.parameters(), lr=0.002)         # :545
+    x = cases.sam_encoder_input(c)
+    L = 12
+    ids = torch.randint(3, 50, (3, L), generator=torch.Generator().manual_seed(9))
+    ids[:, 1] = -200
+    ids[0, 5] = SEG; ids[0, 9] = SEG
+    ids[1, 7] = SEG
+    ids[2, 4] = SEG; ids[2, 6] = SEG; ids[2, 10] = SEG
+    resize, orig = [(512, 384), (400, 512)], [(200, 150), (75, 96)]
+    gt = [(torch.rand(3, *o, generator=torch.Generator().manual_seed(i)) > 0.5).float().to(dev) for i, o in enumerate(orig)]
+    input_dict = dict(images=x.to(dev), images_clip=torch.zeros(2, 3, 28, 28, device=dev), input_ids=ids.to(dev), labels=ids.to(dev),
+                      attention_masks=torch.ones(3, L, dtype=torch.bool, device=dev), offset=torch.tensor([0, 2, 3], device=dev), masks_list=gt,
+                      label_list=[torch.zeros(orig[0], device=dev), torch.zeros(orig[1], device=dev)], resize_list=resize,
+                      clip_resize_list=[(28, 28)] * 2, inference=False, image_paths=["a", "b"], questions_list=None)
+    engine.train()                                                       # :716
+    losses = []
+    for _ in range(5):
+        input_dict["images"] = input_dict["images"].bfloat16()           # :734-735 (precision == "bf16")
+        input_dict["images_clip"] = input_dict["images_clip"].bfloat16()
+        output_dict = engine(**input_dict)                               # :739
+        loss = output_dict["loss"]
+        for k in ("ce_loss", "mask_bce_loss", "mask_dice_loss", "mask_loss"):
+            assert math.isfinite(output_dict[k].item())                  # :741-752
+        assert output_dict.get("nce_loss") is not None and loss.requires_grad
+        losses.append(loss.item())
+        engine.backward(loss)                                            # :756
+        if len(losses) == 1:
+            named = dict(model.named_parameters())
+            with_grad = {n for n, p in named.items() if p.grad is not None}
+            assert all(named[n].requires_grad for n in with_grad)
+            for x_ in ("lm_head", "embed_tokens", "text_hidden_fcs", "out_mm_projector", "mask_decoder.transformer"):
+                assert any(x_ in n for n in with_grad), x_
+            assert not any(".image_encoder." in n or ".prompt_encoder." in n or n.endswith(".wq.0") for n in with_grad)
+        engine.step()                                                    # :757
+    print("train_walkgpt.py loop replayed: loss %s" % ["%.4f" % v for v in losses])
+    assert losses[-1] < losses[0]
 
 
 @pytest.mark.gpu
@@ -477,8 +657,20 @@ class PresetLM(nn.Module):
         self.states = None
         self.config = SimpleNamespace(eos_token_id=EOS)
 
+    @property
+    def embed(self):
+        return self.embed_tokens
+
+    @property
+    def head(self):
+        return self.lm_head
+
     def get_input_embeddings(self):
-        return self.embed
+        return self.embed_tokens
+
+    def resize_token_embeddings(self, new_num_tokens=None, **kw):
+        assert new_num_tokens in (None, V), "the toy LM keeps its vocabulary"
+        return self.embed_tokens
 
     def forward(self, inputs_embeds=None, attention_mask=None, labels=None, output_hidden_states=False, **kw):
         assert self.states.shape[:2] == inputs_embeds.shape[:2], (self.states.shape, inputs_embeds.shape)

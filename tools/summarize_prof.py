@@ -27,6 +27,14 @@ def one(d, suffix):
     return g[0]
 
 
+def _git_head():
+    import subprocess
+    try:
+        return subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or "unknown"
+    except OSError:
+        return "unknown"
+
+
 def short(name):
     name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     return name.split("(")[0][:80]
@@ -42,6 +50,7 @@ def main():
     ap.add_argument("--sq-cmd", default=None, help="the command of the --sq pass when it differs from --cmd")
     ap.add_argument("--steps", type=int, required=True, help="full steps the profiled command ran (timed + warm-up)")
     ap.add_argument("--cmd", required=True)
+    ap.add_argument("--head", default=None, help="git commit the profiled tree was at (default: this checkout's HEAD)")
     ap.add_argument("--config", default=None, help='JSON the bench compares with its own run before it reports roofline.traffic')
     a = ap.parse_args()
     out = os.path.join(ROOT, "profiles")
@@ -72,7 +81,8 @@ def main():
         with open(os.path.join(out, a.tag + "_pmc_traffic.json"), "w") as f:
             json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; bytes = KB * 1024, FETCH_SIZE x2 "
                                "(MI355X_MICROARCH.md: gfx950 counts 128-B requests at 64 B)", "command": a.cmd,
-                       "config": json.loads(a.config) if a.config else None, "kernels": traffic}, f, indent=1, sort_keys=True)
+                       "head": a.head or _git_head(), "config": json.loads(a.config) if a.config else None, "kernels": traffic}, f, indent=1,
+                      sort_keys=True)
     # per-step work from the kernel trace itself: everything that starts between the last two SAM patch-gather launches (the first
     # kernel of a step on the main stream) is one steady-state step across all streams; what ran before the first step is one-time work
     trace = list(csv.DictReader(open(one(a.stats, "kernel_trace.csv"))))

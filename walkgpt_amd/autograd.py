@@ -197,6 +197,13 @@ class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, heads, scale):
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        if any(ctx.needs_input_grad[:3]):
+            # what the backward kernel takes, checked where the operator is CALLED (not in the middle of loss.backward())
+            hd = q.shape[-1] // heads
+            if _lib.lib().wg_attn_bwd_short_side(q.shape[1], k.shape[1]) < 0:
+                raise NotImplementedError("differentiable attention: one side must have at most 16 rows (Lq = %d, Lk = %d)" % (q.shape[1], k.shape[1]))
+            if hd > 128 or hd % 8 != 0:
+                raise NotImplementedError("differentiable attention: head_dim %d (needs a multiple of 8, at most 128)" % hd)
         with torch.no_grad():
             o = ops.mha(q, k, v, heads, scale)
         ctx.save_for_backward(q, k, v, o)

@@ -366,22 +366,34 @@ class walkgptForCausalLM(nn.Module):  # noqa: N801  (the reference's class name)
         return ops.linear(x, mp[2].weight, mp[2].bias)
 
     # -- walkgpt.py:267-605 ------------------------------------------------------------------------------------------------------------
-    head_training = False
+    head_training = None      # None: decided per call (below); True / False: forced through enable_head_training()
 
-    def enable_head_training(self, on: bool = True):
-        """Training of the grounding head (train_walkgpt.py:347-350): with this on, `model_forward(inference=False)` called with gradients
-        enabled runs CTP, the mask decoder, postprocess and the mask losses through walkgpt_amd.train_head (differentiable HIP operators),
-        so `loss.backward()` fills `.grad` of text_hidden_fcs.*, visual_model.mask_decoder.* and -- through the [SEG] hidden states and the
-        language-model loss -- of whatever the caller left trainable in the language model, of out_mm_projector.* (MSQP) and of
-        embed_tokens (through the splice), and -- through the region-alignment InfoNCE term -- of tiny_xattn.wq / wk: every entry of
-        train_walkgpt.py's trainable_list.  Frozen here as in the reference: SAM's image and prompt encoders, the vision tower."""
-        self.head_training = bool(on)
+    def enable_head_training(self, on: Optional[bool] = True):
+        """Training of the grounding head (train_walkgpt.py:347-350).  By default `model_forward(inference=False)` decides by itself: called
+        with gradients enabled while ANY parameter of text_hidden_fcs / visual_model.mask_decoder / out_mm_projector / tiny_xattn or of the
+        language model requires a gradient -- the state train_walkgpt.py:347-357 leaves the model in -- it runs CTP, the mask decoder,
+        postprocess and the mask losses through walkgpt_amd.train_head (differentiable HIP operators), so the reference loop's
+        `model.backward(loss)` (:756) fills `.grad` of text_hidden_fcs.*, visual_model.mask_decoder.* and -- through the [SEG] hidden
+        states and the language-model loss -- of whatever the caller left trainable in the language model, of out_mm_projector.* (MSQP)
+        and of embed_tokens (through the splice), and -- through the region-alignment InfoNCE term -- of tiny_xattn.wq / wk: every entry
+        of train_walkgpt.py's trainable_list.  Frozen here as in the reference: SAM's image and prompt encoders, the vision tower.
+        `enable_head_training(False)` is the opt-out (always the no-gradient forward), `True` forces the training path, `None`
+        restores the automatic choice."""
+        self.head_training = None if on is None else bool(on)
         return self
+
+    def _wants_head_training(self):
+        if self.head_training is not None:
+            return self.head_training
+        m = self.model
+        mods = [getattr(m, "text_hidden_fcs", None), getattr(m, "out_mm_projector", None), getattr(m, "tiny_xattn", None),
+                getattr(getattr(m, "visual_model", None), "mask_decoder", None), self.llm]
+        return any(p.requires_grad for mod in mods if mod is not None for p in mod.parameters())
 
     def model_forward(self, images, images_clip, input_ids, labels, attention_masks, offset, masks_list: List[torch.Tensor],
                       label_list: List[torch.Tensor], resize_list: List[tuple], inference: bool = False, clip_resize_list=None,
                       decode_masks: bool = True, **kwargs):
-        train = bool(self.head_training and torch.is_grad_enabled() and not inference)
+        train = bool(not inference and torch.is_grad_enabled() and self._wants_head_training())
         if not train:
             with torch.no_grad():
                 return self._model_forward(images, images_clip, input_ids, labels, attention_masks, offset, masks_list, label_list, resize_list,

@@ -675,7 +675,9 @@ __global__ __launch_bounds__(256) void wg_hyper_rows_kernel(const bf16* up, cons
     __shared__ float hs[HM_K][HM_C];
     __shared__ float red[4][HM_K][HM_C];
     const int p = blockIdx.y;
-    if (threadIdx.x < K * HM_C) hs[threadIdx.x / HM_C][threadIdx.x % HM_C] = (float)hyper[((long)p * K) * HM_C + threadIdx.x];
+    // every row of hs is written: the unrolled sums below run over all HM_K rows with g[k] = 0 for k >= K, and 0 * (whatever bit pattern
+    // an earlier kernel left in LDS, NaN included) must not reach dup
+    if (threadIdx.x < HM_K * HM_C) hs[threadIdx.x / HM_C][threadIdx.x % HM_C] = threadIdx.x < K * HM_C ? (float)hyper[((long)p * K) * HM_C + threadIdx.x] : 0.f;
     __syncthreads();
     float acc[HM_K][HM_C];
     if (MODE == 1) {
@@ -741,6 +743,19 @@ __global__ __launch_bounds__(256) void wg_hyper_rows_kernel(const bf16* up, cons
 }
 
 }  // namespace
+
+// Test support: leave `pattern` in the first 64 KiB of every compute unit's LDS (a kernel's LDS is not cleared between launches; tests use
+// this to prove that a kernel reads no LDS word it has not written: tests/test_gpu_backward.py poisons with a NaN pattern).
+__global__ __launch_bounds__(256) void wg_fill_lds_kernel(unsigned pattern, unsigned* sink) {
+    __shared__ unsigned buf[16384];
+    for (int i = threadIdx.x; i < 16384; i += 256) buf[i] = pattern;
+    __syncthreads();
+    if (sink && buf[(threadIdx.x * 61) & 16383] != pattern) *sink = 1;   // keeps the stores alive
+}
+extern "C" int wg_debug_fill_lds_u32(unsigned pattern, void* sink, void* stream) {
+    hipLaunchKernelGGL(wg_fill_lds_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream, pattern, (unsigned*)sink);
+    return wg_check_launch("wg_debug_fill_lds_u32");
+}
 
 extern "C" int wg_hyper_rows_f32(const void* up, const void* hyper, float* masks, int P, int HW, int C, int K, void* stream) {
     WG_REQUIRE(up && hyper && masks && P > 0 && HW > 0 && C == HM_C && K > 0 && K <= HM_K, "hyper_rows: C must be %d, K <= %d", HM_C, HM_K);

@@ -78,6 +78,15 @@ def gemm_tile_for(M, N, K, lda, ldw, ldc, ldr, tail_tiles=False):
 ROW_PARTIALS = _os.environ.get("WG_ROW_PARTIALS", "1") != "0"   # experiments: 0 = always take the row statistics in their own pass
 
 
+def _forget_sidecars(t):
+    """A caller-supplied `out=` tensor is about to be overwritten through its raw pointer (tensor._version does not move): whatever an
+    earlier producer attached to it -- row partial sums, an e4m3 + block-scale copy -- no longer describes its contents."""
+    if t is not None:
+        for a in ("_wg_row_partials", "_wg_mx"):
+            if hasattr(t, a):
+                delattr(t, a)
+
+
 def linear(x, weight, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out=None, out_f32=False, tile=0, tail_tiles=False,
            row_partials=False):
     """y = act(x @ weight.T + bias) (+ residual).  x [..., K] bf16, weight [N, K] bf16.
@@ -89,6 +98,7 @@ def linear(x, weight, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, out
     M, K, lda = _rows(x)
     N, K2 = weight.shape
     assert K2 == K and weight.stride(1) == 1
+    _forget_sidecars(out)
     if out is None:
         out = torch.empty(x.shape[:-1] + (N,), device=x.device, dtype=torch.float32 if out_f32 else _BF16)
     Mo, No, ldc = _rows(out)
@@ -133,6 +143,7 @@ def layernorm(x, gamma, beta, eps, act=ACT_NONE, out=None):
     _need_gpu(x, gamma, beta, out)
     assert x.dtype == _BF16 and gamma.dtype == _BF16 and beta.dtype == _BF16
     M, D, ldx = _rows(x)
+    _forget_sidecars(out)
     if out is None:
         out = torch.empty(x.shape, device=x.device, dtype=_BF16)
     _, _, ldy = _rows(out)
@@ -250,6 +261,7 @@ def mha(q, k, v, heads, scale, key_bias=None, out=None, small=None):
     assert kbs == vbs
     D = q.shape[2]
     hd = D // heads
+    _forget_sidecars(out)
     if out is None:
         out = torch.empty(B, Lq, D, device=q.device, dtype=_BF16)
     _, _, ldo, obs = _rows_per_batch(out)
@@ -278,6 +290,7 @@ def sam_attention(qkv, qkv_bias, rel_pos_h, rel_pos_w, B, grid, window, heads, o
     hd = D // heads
     assert qkv.is_contiguous() and qkv.shape[0] == B * grid * grid and qkv.dtype == _BF16
     assert rel_pos_h.shape == (2 * window - 1, hd) and rel_pos_h.is_contiguous() and rel_pos_w.is_contiguous()
+    _forget_sidecars(out)
     if out is None:
         out = torch.empty(B * grid * grid, D, device=qkv.device, dtype=_BF16)
     rc = _lib.lib().wg_sam_attn_relpos_bf16(qkv.data_ptr(), qkv_bias.data_ptr(), rel_pos_h.data_ptr(),
@@ -316,6 +329,7 @@ def add_rows(a, b, out=None):
     rows, cols, lda = _rows(a)
     rb, cb, ldb = _rows(b)
     assert cb == cols
+    _forget_sidecars(out)
     if out is None:
         out = torch.empty(a.shape, device=a.device, dtype=_BF16)
     _, _, ldo = _rows(out)
@@ -492,6 +506,7 @@ def linear_mxfp8(x, w, bias=None, act=ACT_NONE, residual=None, res_row_mod=0, ou
     assert wq.shape[1] == K and x_mx.shape[0] == K // 32 and w_mx.shape[0] == K // 32
     dev = xq.device
     assert bf16_out or mx_out
+    _forget_sidecars(out)
     if out is None and bf16_out:
         out = torch.empty(xq.shape[:-1] + (N,), device=dev, dtype=_BF16)
     ldc = _rows(out)[2] if out is not None else 0
@@ -537,6 +552,7 @@ def linear_fp8(xq, x_scale, wq, w_scale, bias=None, act=ACT_NONE, residual=None,
     M = xq.numel() // K
     N = wq.shape[0]
     assert wq.shape[1] == K and x_scale.numel() == M and w_scale.numel() == N
+    _forget_sidecars(out)
     if out is None:
         out = torch.empty(xq.shape[:-1] + (N,), device=xq.device, dtype=_BF16)
     _, _, ldc = _rows(out)
