@@ -167,3 +167,48 @@ def test_attention_large_uneven_scores(dev, mode):
     o = out.float().cpu()
     assert torch.isfinite(o).all()
     assert (o - ref).abs().max().item() < 0.06
+
+
+@pytest.mark.parametrize("B,Lq,Lk,heads", [(1, 4096, 4096, 2), (2, 1024, 1024, 2), (1, 300, 1025, 3), (1, 512, 256, 2)])
+def test_mha_pipelined_loop(dev, B, Lq, Lk, heads):
+    """head_dim 64 without a key bias on whole 64-key tiles: the software-pipelined kernel (attn_pipe.hip; eight-wave and four-wave
+    workgroups, with and without the lone 1025th key, the shortest loop it takes)."""
+    hd = 64
+    D = heads * hd
+    q, k, v = _rand((B, Lq, D), 31), _rand((B, Lk, D), 32), _rand((B, Lk, D), 33)
+    ref = _ref_mha(q, k, v, heads, hd ** -0.5)
+    out = ops.mha(q.to(dev), k.to(dev), v.to(dev), heads, hd ** -0.5, small=False)
+    err = (out.float().cpu() - ref).abs().max().item()
+    assert err < 0.03, err
+
+
+@pytest.mark.parametrize("mode", ["global", "plain"])
+def test_pipelined_attention_rescales_a_pending_tile(dev, mode):
+    """The pipelined loop decides tile t's rescale while the P.V product of tile t-1 is still pending: that tile's probabilities must be
+    rescaled with the accumulator (cdna_hip_programming.md T13: a rare, data-dependent branch needs an input that FORCES it).  Keys are
+    scaled so that the row maximum jumps by far more than the lazy-rescale threshold at chosen tiles late in the loop -- once, twice in
+    consecutive tiles, and in the very last tile -- against an fp32 reference over the full tensor."""
+    g = torch.Generator().manual_seed(5)
+    heads, hd = 2, 64
+    D = heads * hd
+    L = 4096 if mode == "global" else 2048
+    ramp = torch.ones(L)
+    for t, f in ((7, 3.0), (8, 5.0), (20, 8.0), (L // 64 - 1, 12.0)):
+        ramp[t * 64:(t + 1) * 64] = f
+    if mode == "global":
+        qkv = torch.randn(L, 3 * D, generator=g)
+        qkv[:, D:2 * D] *= ramp[:, None]
+        qkv = qkv.to(torch.bfloat16)
+        bias = _rand((3 * D,), 2, 0.5)
+        rel_h, rel_w = _rand((127, hd), 3, 0.2), _rand((127, hd), 4, 0.2)
+        ref = _ref_sam_attention(qkv, bias, rel_h, rel_w, 1, 64, 64, heads)
+        out = ops.sam_attention(qkv.to(dev), bias.to(dev), rel_h.to(dev), rel_w.to(dev), 1, 64, 64, heads)
+    else:
+        q, k, v = torch.randn(1, L, D, generator=g), torch.randn(1, L, D, generator=g), torch.randn(1, L, D, generator=g)
+        k *= ramp[None, :, None]
+        q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+        ref = _ref_mha(q, k, v, heads, hd ** -0.5)
+        out = ops.mha(q.to(dev), k.to(dev), v.to(dev), heads, hd ** -0.5, small=False)
+    o = out.float().cpu()
+    assert torch.isfinite(o).all()
+    assert (o - ref).abs().max().item() < 0.06

@@ -657,20 +657,8 @@ class PresetLM(nn.Module):
         self.states = None
         self.config = SimpleNamespace(eos_token_id=EOS)
 
-    @property
-    def embed(self):
-        return self.embed_tokens
-
-    @property
-    def head(self):
-        return self.lm_head
-
     def get_input_embeddings(self):
-        return self.embed_tokens
-
-    def resize_token_embeddings(self, new_num_tokens=None, **kw):
-        assert new_num_tokens in (None, V), "the toy LM keeps its vocabulary"
-        return self.embed_tokens
+        return self.embed
 
     def forward(self, inputs_embeds=None, attention_mask=None, labels=None, output_hidden_states=False, **kw):
         assert self.states.shape[:2] == inputs_embeds.shape[:2], (self.states.shape, inputs_embeds.shape)
