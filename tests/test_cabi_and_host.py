@@ -216,3 +216,14 @@ def test_mx_scale_plane_layout_host_side():
     mx[1, ops.mx_scale_index(M)[129]] = 130                                             # row 129, columns 32..63: x 8
     d = ops.mx_dequantize(q, mx)
     assert d.shape == (M, K) and float(d[129, 40]) == 8.0 and float(d[129, 3]) == 1.0 and float(d[0, 40]) == 1.0
+
+
+def test_hand_placed_streams_have_no_unpadded_mfma_operand():
+    """attn_pipe.hip places every instruction of its loop as an `asm volatile` statement; hipcc's hazard recogniser cannot see that a
+    statement is an MFMA, so a vector instruction the COMPILER emits directly in front of one that reads its result gets no wait states
+    (found the hard way: stale operands, wrong rows that came and went with the register allocation).  The lint compiles the file and scans
+    the ISA for that pattern."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lint_asm_hazards.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr

@@ -39,9 +39,31 @@ template <int I, int N, class F> __device__ __forceinline__ void wg_static_for(F
 }
 
 // ---- one instruction per statement ------------------------------------------------------------------------------------------
-#define PA_MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
-#define PA_MFMA_C(d, a, b, c) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : "v"(a), "v"(b), "v"(c))
-#define PA_MFMA_Z(d, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b))
+// Where the MFMA operands live (WG_PIPE_AGPR = 1; default 0: see notes/r04_experiments.md): the O^T accumulators and the K / Q / V^T fragments in the accumulation half of the
+// register file, the scores, P^T and everything the vector ALU touches in the arch half -- an MFMA's 40 register reads / writes per lane
+// then mostly stay off the ports the exponentials use (MI355X_MICROARCH.md: the files are one 512-entry space, split at accum_offset).
+#ifndef WG_PIPE_AGPR
+#define WG_PIPE_AGPR 0
+#endif
+#if WG_PIPE_AGPR
+#define PA_F "a"
+#define PA_FO "=a"
+#define PA_FIO "+a"
+#else
+#define PA_F "v"
+#define PA_FO "=v"
+#define PA_FIO "+v"
+#endif
+// S^T (scores, arch VGPRs): A = K fragment, B = Q fragment
+#define PA_MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : PA_F(a), PA_F(b))
+#define PA_MFMA_C(d, a, b, c) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : PA_F(a), PA_F(b), "v"(c))
+#define PA_MFMA_Z(d, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, 0" : "=&v"(d) : PA_F(a), PA_F(b))
+// rank-3 offset update of the scores: both operands come off the vector ALU -- possibly materialised by the COMPILER right in front of this
+// statement (its hazard recogniser does not know the statement is an MFMA: a v_mov of a zero dword one instruction ahead was read stale, and
+// a stale NaN pattern times the other operand's zero poisoned whole rows).  The two wait states of that hazard therefore live inside.
+#define PA_MFMA_VV(acc, a, b) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b))
+// O^T (accumulator file): A = V^T fragment, B = P^T (arch VGPRs)
+#define PA_MFMA_O(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : PA_FIO(acc) : PA_F(a), "v"(b))
 #define PA_LGKM(n) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory")
 #define PA_MAX3(d, a, b, c) asm volatile("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c))
 #define PA_FMA_S(d, a, s, c) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(s), "v"(c))
@@ -51,7 +73,12 @@ template <int I, int N, class F> __device__ __forceinline__ void wg_static_for(F
 
 template <int OFF> __device__ __forceinline__ u32x4 pa_ds_read_b128(unsigned lds_addr) {
     u32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : PA_FO(v) : "v"(lds_addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF> __device__ __forceinline__ u32x2 pa_ds_read_tr(unsigned lds_addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : PA_FO(v) : "v"(lds_addr), "n"(OFF));
     return v;
 }
 __device__ __forceinline__ float pa_ds_read_b32(unsigned lds_addr) {
@@ -59,6 +86,26 @@ __device__ __forceinline__ float pa_ds_read_b32(unsigned lds_addr) {
     asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(lds_addr) : "memory");
     return v;
 }
+
+// Diagnostic build only (-DWG_ATTN_STAMP, tools/attn_pipe_stamps.py): lane 0 of every wave of workgroup 0 stores s_memtime at five points of
+// its first 14 iterations.  The stamp drains the LDS queue (s_memtime shares lgkmcnt), so the build's timings are read as shares only.
+#ifdef WG_ATTN_STAMP
+__device__ unsigned* wg_attn_pipe_stamp_ptr = nullptr;
+extern "C" int wg_debug_attn_pipe_stamps(unsigned* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(wg_attn_pipe_stamp_ptr), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+// segment sums in scalar registers (no store, no vector-memory operation inside the loop): k = 0 iteration start, 1 head done, 2 main stream done,
+// 3 requested tiles landed, 4 barrier passed
+#define PA_STAMP(k)                                                                                                   \
+    do {                                                                                                              \
+        unsigned long long now;                                                                                       \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");                                   \
+        if ((k) > 0) st_sum[(k) - 1] += now - st_prev;                                                                \
+        st_prev = now;                                                                                                \
+    } while (0)
+#else
+#define PA_STAMP(k) do { } while (0)
+#endif
 
 // S: 0 = plain (CLIP: no bias, a lone key past a multiple of 64 is folded in after the loop), 64 = SAM global attention.
 // NW waves of 32 queries; needs an even number >= 4 of key tiles (the launcher checks).
@@ -70,8 +117,9 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
     constexpr int SS = S * S;
     constexpr int SP = GRID ? S + 1 : 1;          // relh table row (fp32 words, odd => conflict-free)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* kv = smem;                               // [2 buffers][K tile | V tile]
-    float* tab = (float*)(smem + 2 * TILE2);       // grid: per-wave rel table
+    constexpr int KV_BYTES = 5 * TILE;             // K tiles: ring of three | V tiles: ring of two
+    char* kv = smem;
+    float* tab = (float*)(smem + KV_BYTES);        // grid: per-wave rel table
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -100,7 +148,8 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
     const int ql_raw = (qc * NW + wave) * 32 + ql_lane;
     const int ql = ql_raw < Lq ? ql_raw : Lq - 1;
     const bool qvalid = ql_raw < Lq;
-    const int qh = GRID ? ql / S : 0, qw = GRID ? ql % S : 0;
+    constexpr int SD = GRID ? S : 1;
+    const int qh = GRID ? ql / SD : 0, qw = GRID ? ql % SD : 0;
     const long qrow = GRID ? (long)b * SS + ql : (long)b * a.q_bs + ql;
     bf16x8 qf[KSTEPS];
     {
@@ -125,10 +174,10 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
             runp[o][i] = (o ? a.V + r * a.ldv : a.K + r * a.ldk) + hcol + c * 8;
         }
     const unsigned strideK = (unsigned)(64L * a.ldk), strideV = (unsigned)(64L * a.ldv);
-    // tile j of K (o = 0) or V (o = 1) -> buffer j & 1; per operand the tiles are staged in order 0, 1, 2, ...  (every tile the loop
-    // stages is a whole tile: the launcher guarantees 64 | number of keys walked)
-    auto stage = [&](int j, int o) __attribute__((always_inline)) {
-        char* dst = kv + (j & 1) * TILE2 + (o ? TILE : 0);
+    // K tile -> ring slot `slot` (0..2) / V tile j -> slot j & 1; per operand the tiles are staged in order 0, 1, 2, ...  (every tile the
+    // loop stages is a whole tile: the launcher guarantees 64 | number of keys walked)
+    auto stage = [&](int slot, int o) __attribute__((always_inline)) {
+        char* dst = kv + (o ? 3 * TILE + (slot & 1) * TILE : slot * TILE);
 #pragma unroll
         for (int i = 0; i < NPW; ++i) {
             __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(runp[o][i]), WG_LDS_PTR(dst + (wave + i * NW) * 1024), 16, 0, 0);
@@ -139,6 +188,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
     const int nt = nkeys / 64;
     stage(0, 0);
     stage(1, 0);
+    stage(2, 0);
 
     // ---- rel-pos tables (grid), as wg_attn_kernel: width term -> 32 registers (C operand), height term -> LDS ---------------------------
     f32x16 relw_c[2];
@@ -169,20 +219,39 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
                 }
             }
         };
-        const float inv_sc2 = 1.0f / (a.scale * LOG2E);
         rel_pass(0);
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
             const int kw = (e & 3) + 8 * (e >> 2) + 4 * hi;
-            relw_c[e >> 4][e & 15] = mytab[ql_lane * SP + kw] * inv_sc2;
+            relw_c[e >> 4][e & 15] = mytab[ql_lane * SP + kw];      // (already times log2 e: the scores below are in the exp2 domain)
         }
         asm volatile("" ::: "memory");
         rel_pass(1);
     }
+    // The S^T MFMAs run on q * scale * log2(e), rounded to bf16 once (the rel-pos terms above used the unscaled q, as the reference does:
+    // image_encoder.py:244 against :247-249): the scores leave the matrix pipe in the exp2 domain and the vector ALU never multiplies them.
     const float sc2 = a.scale * LOG2E;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[s][e] = (bf16)((float)qf[s][e] * sc2);
+    // The exponent offset of a tile (row maximum and height term: one value per query and tile) is ADDED BY THE MATRIX PIPE as well: a
+    // rank-3 update S^T += 1 . n^T with n split into three bf16 pieces (24 significant bits), one MFMA per key block in front of the
+    // exponentials -- instead of 32 v_fma per tile on the vector ALU, which is the unit this loop is bound by.
+    const unsigned one3 = hi == 0 ? 0x3F803F80u : 0u;
+    const u32x4 ones_a = {one3, hi == 0 ? 0x00003F80u : 0u, 0u, 0u};      // A operand: k = 0, 1, 2 of every key row are 1.0
+    u32x4 ones_a_pinned;                                                   // (the copy the loop uses: see the pin in front of the pre-loop)
+    // softmax denominators from the matrix pipe: osum += 1 . P^T (an all-ones A operand) beside every k-step of P.V -- every element of osum
+    // ends up holding the row sum over BOTH lane halves' keys.  The loop is bound by instruction ISSUE (stamps + PMC): 4 MFMAs
+    // (8 issue cycles each) replace 32 v_add (4 each), on a pipe that is ~55 % busy
+    f32x16 osum;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) osum[r] = 0.f;
+    u32x4 ones_full = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // A operand of the row-sum MFMAs
+    u32x4 noff_b = {0u, 0u, 0u, 0u};                                      // B operand: k = 0, 1, 2 of this lane's query = the three pieces
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem);
-    unsigned relh_ad = lds0 + 2 * TILE2 + (unsigned)((wave * 32 + ql_lane) * SP * 4);    // this lane's relh row, entry t
+    unsigned relh_ad = lds0 + KV_BYTES + (unsigned)((wave * 32 + ql_lane) * SP * 4);    // this lane's relh row, entry t
 
     // ---- fragment addresses ---------------------------------------------------------------------------------------------------------
     // K fragment of S^T MFMA (kb, s): row kb*32 + ql_lane, 16-byte chunk (2s + hi) ^ swzK(row); the swizzle does not depend on kb
@@ -198,18 +267,30 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
         for (int d = 0; d < DB; ++d) {
             const int col = 32 * d + 16 * (g & 1) + 4 * cp;
             const int chunk = col >> 3;
-            vt_ad[d] = lds0 + TILE + (4 * hi + rq) * ROWB + ((chunk ^ swzV<HD>(4 * hi + rq)) << 4) + (col & 7) * 2;
+            vt_ad[d] = lds0 + 3 * TILE + (4 * hi + rq) * ROWB + ((chunk ^ swzV<HD>(4 * hi + rq)) << 4) + (col & 7) * 2;
         }
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    // Everything the compiler computed above and an asm MFMA below reads as an operand is pinned HERE, two wait states ahead of the first
+    // of them: hipcc placed the last v_cvt_pk of the query prescale directly in front of the first S^T MFMA (opaque to its hazard
+    // recogniser), which then read the old register -- wrong rows that came and went with the register allocation (tools/lint_asm_hazards.py
+    // scans the ISA for this pattern; tests/test_cabi_and_host.py runs it).
+    asm volatile("s_nop 1" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
+    {
+        u32x4 oa = ones_a;
+        asm volatile("s_nop 1" : "+v"(oa), "+v"(noff_b), "+v"(ones_full), "+v"(osum));
+        ones_a_pinned = oa;
+    }
+    if constexpr (GRID) asm volatile("s_nop 1" : "+v"(relw_c[0]), "+v"(relw_c[1]));
 
     if (!GRID && (qc * NW + wave) * 32 >= Lq) {
         // a wave without a single query (CLIP's 1025 = 32 blocks + 1): it stages its share of the tiles and keeps the barriers
         __builtin_amdgcn_s_barrier();
-        for (int t = 0; t < nt; ++t) {
-            if (t + 2 < nt) stage(t + 2, 0);
+        for (int t = 0, slot = 0; t < nt; ++t) {
+            if (t + 3 < nt) stage(slot, 0);
+            slot = slot == 2 ? 0 : slot + 1;
             stage(t, 1);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -229,15 +310,20 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int k = 0; k < 4; ++k) pf[i][k] = (u32x4){0u, 0u, 0u, 0u};
-    float m_run = NEG_BIG, la = 0.f, lb = 0.f;
+    float m_run = NEG_BIG;
     constexpr float RESCALE_THR = 6.0f;
+#ifdef WG_ATTN_STAMP
+    unsigned long long st_sum[4] = {0, 0, 0, 0}, st_prev = 0;
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
-    // S^T MFMA g = (kb = g >> 2, s = g & 3) of the tile in buffer BUF into score buffer SB
+    // S^T MFMA g = (kb = g >> 2, s = g & 3) into score buffer SB; its K fragment from the tile whose ring slot is baked into `ad`
     u32x4 kf[4];
-    auto k_read = [&kf, &kad](auto gc, auto bufc) __attribute__((always_inline)) {
-        constexpr int g = decltype(gc)::value, BUF = decltype(bufc)::value;
+    unsigned kx[KSTEPS], ky[KSTEPS];      // fragment addresses of the two K tiles an iteration reads (roles alternate, see iter)
+    auto k_read = [&kf](auto gc, const unsigned (&ad)[KSTEPS]) __attribute__((always_inline)) {
+        constexpr int g = decltype(gc)::value;
         constexpr int kb = g >> 2, s = g & 3;
-        kf[s] = pa_ds_read_b128<BUF * TILE2 + kb * 32 * ROWB>(kad[s]);
+        kf[s] = pa_ds_read_b128<kb * 32 * ROWB>(ad[s]);
     };
     auto qk_mfma = [&sa, &qf, &relw_c, &kf](auto gc, auto sbc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value, SB = decltype(sbc)::value;
@@ -255,155 +341,261 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
     auto v_read = [&vta, &vtb, &vt_ad](auto jc, auto bufc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value, BUF = decltype(bufc)::value;
         constexpr int ks = j >> 1, d = j & 1;
-        vta[j & 3] = wg_ds_read_tr<BUF * TILE2 + ks * 16 * ROWB>(vt_ad[d]);
-        vtb[j & 3] = wg_ds_read_tr<BUF * TILE2 + ks * 16 * ROWB + 8 * ROWB>(vt_ad[d]);
+        vta[j & 3] = pa_ds_read_tr<BUF * TILE + ks * 16 * ROWB>(vt_ad[d]);
+        vtb[j & 3] = pa_ds_read_tr<BUF * TILE + ks * 16 * ROWB + 8 * ROWB>(vt_ad[d]);
     };
     auto pv_mfma = [&ot, &pf, &vta, &vtb](auto jc, auto pbc) __attribute__((always_inline)) {
         constexpr int j = decltype(jc)::value, PB = decltype(pbc)::value;
         constexpr int ks = j >> 1, d = j & 1;
         const u32x4 vv = {vta[j & 3][0], vta[j & 3][1], vtb[j & 3][0], vtb[j & 3][1]};
-        PA_MFMA_ACC(ot[d], __builtin_bit_cast(bf16x8, vv), __builtin_bit_cast(bf16x8, pf[PB][ks]));
+        PA_MFMA_O(ot[d], vv, pf[PB][ks]);
     };
 
-    // ---- pre-loop: S^T of tile 0 ------------------------------------------------------------------------------------------------------
-    {
-        using B0 = std::integral_constant<int, 0>;
-        wg_static_for<0, 4>([&k_read](auto g) { k_read(g, B0{}); });
-        wg_static_for<0, 8>([&k_read, &qk_mfma](auto gc) {
-            constexpr int g = decltype(gc)::value;
-            PA_LGKM(g < 4 ? 3 : 7 - g);
-            qk_mfma(gc, B0{});
-            if constexpr (g < 4) k_read(std::integral_constant<int, g + 4>{}, B0{});
-        });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
-
-    // ---- one iteration: softmax of tile t (score buffer P) beside S^T of tile t+1 (into buffer P^1; K tile in LDS buffer P^1) and
-    //      P.V of tile t-1 (P^T buffer P^1; V tile in LDS buffer P^1).  P = t & 1.
-    auto iter = [&](int t, auto pc, auto do_qk_c, auto do_pv_c) __attribute__((always_inline)) {
-        constexpr int P = decltype(pc)::value, Q = P ^ 1;
-        constexpr bool DO_QK = decltype(do_qk_c)::value, DO_PV = decltype(do_pv_c)::value;
-        using BQ = std::integral_constant<int, Q>;
-        // tiles for the iterations to come
-        if (t + 2 < nt) stage(t + 2, 0);
-        stage(t, 1);
-        // LDS issue order (the counted waits below follow it): rh | K g0..g3 | K g4..g7 (one behind each of MFMA 0..3) | V pairs 0..3
-        // (behind MFMA 4..7) | V pairs 4..7 (behind P.V MFMA 0..3)
-        float rh = 0.f;
-        if constexpr (GRID) rh = pa_ds_read_b32(relh_ad);
-        if constexpr (DO_QK) wg_static_for<0, 4>([&](auto g) { k_read(g, BQ{}); });
-        else if constexpr (DO_PV) wg_static_for<0, 4>([&](auto j) { v_read(j, BQ{}); });
-        // running maximum of the tile: two chains over the 32 scores of this lane
-        float ma, mb;
-        PA_MAX3(ma, sa[P][0][0], sa[P][0][1], sa[P][0][2]);
-        PA_MAX3(mb, sa[P][0][3], sa[P][0][4], sa[P][0][5]);
-        wg_static_for<0, 13>([&ma, &mb, &sa](auto ic) {
-            constexpr int i = decltype(ic)::value, e = 6 + 2 * i;
-            if constexpr ((i & 1) == 0) PA_MAX3(ma, ma, sa[P][e >> 4][e & 15], sa[P][(e + 1) >> 4][(e + 1) & 15]);
-            else PA_MAX3(mb, mb, sa[P][e >> 4][e & 15], sa[P][(e + 1) >> 4][(e + 1) & 15]);
-        });
-        float mt;
-        PA_MAX3(mt, ma, mb, mb);
-        if constexpr (GRID) {
-            PA_LGKM(DO_QK || DO_PV ? (DO_QK ? 4 : 8) : 0);
-            relh_ad += 4;
-        }
-        PA_FMA_S(mt, mt, sc2, rh);
-        mt = wg_xor32_max(mt);      // the other half of the keys of this query lives in lane ^ 32
-        if (__any(mt > m_run + RESCALE_THR)) {
-            const float m_new = fmaxf(m_run, mt);
+    // running maximum of a score buffer: 16 v_max3 in four chains (an operand written by the statement two ahead makes hipcc pad an s_nop:
+    // its hazard recogniser assumes the worst of an asm statement); ops 0-3 start the chains (elements 0..11), ops 4-13 extend them by two
+    // elements each (12..31), ops 14, 15 join them into mt.  Ops 0-5 read key block 0 only.
+    float mch[4], mt;
+    auto max_op = [&mch, &mt, &sa](auto sbc, auto ic) __attribute__((always_inline)) {
+        constexpr int SB = decltype(sbc)::value, i = decltype(ic)::value;
+        if constexpr (i < 4) PA_MAX3(mch[i], sa[SB][0][3 * i], sa[SB][0][3 * i + 1], sa[SB][0][3 * i + 2]);
+        else if constexpr (i < 14) {
+            constexpr int e = 12 + 2 * (i - 4);
+            PA_MAX3(mch[i & 3], mch[i & 3], sa[SB][e >> 4][e & 15], sa[SB][(e + 1) >> 4][(e + 1) & 15]);
+        } else if constexpr (i == 14) PA_MAX3(mch[0], mch[0], mch[1], mch[2]);
+        else PA_MAX3(mt, mch[0], mch[3], mch[3]);
+    };
+    // exponent offset n = rh - m_run of a tile as three bf16 pieces in noff_b (truncations: every difference is exact in fp32); 7 instructions
+    float mx = 0.f;
+    auto offset_pieces = [&noff_b, &m_run](float rh) __attribute__((always_inline)) {
+        float n, r1, r2;
+        unsigned h1, h2;
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(n) : "v"(rh), "v"(m_run));
+        asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(h1) : "v"(n));
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(n), "v"(h1));
+        asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(h2) : "v"(r1));
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r2) : "v"(r1), "v"(h2));
+        asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(noff_b[0]) : "v"(h2), "v"(h1), "s"(0x07060302u));      // {mid[31:16], hi[31:16]}
+        asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(noff_b[1]) : "v"(r2));
+    };
+    // maximum of the tile over both lane halves (the other half of a query's keys lives in lane ^ 32), height term added: 4 instructions
+    auto exchange = [&mt, &mx](float rh) __attribute__((always_inline)) {
+        float a_, b_;
+        asm volatile("v_add_f32 %0, %1, %2" : "=v"(a_) : "v"(mt), "v"(rh));
+        asm volatile("v_mov_b32 %0, %1" : "=v"(b_) : "v"(a_));
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a_), "+v"(b_));
+        asm volatile("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(a_), "v"(b_));
+    };
+    // The rescale decision for the tile whose maximum sits in mx: lazy rescale of everything still at the old maximum -- O^T, the row sums and,
+    // PEND >= 0, the P^T fragments of the tile whose P.V product has not been issued yet (buffer PEND) -- and the offset pieces again.
+    auto decide = [&](float rh, auto pendc) __attribute__((always_inline)) {
+        constexpr int PEND = decltype(pendc)::value;
+        if (__any(mx > m_run + RESCALE_THR)) {
+            asm volatile("s_nop 15" ::: "memory");      // O^T comes out of MFMAs the hazard recogniser cannot see
+            const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
-            la *= alpha;
-            lb *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) osum[r] *= alpha;
 #pragma unroll
             for (int d = 0; d < DB; ++d)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) ot[d][r] *= alpha;
-            if constexpr (DO_PV) {      // the pending P^T of tile t-1 (none of its P.V MFMAs has been issued yet)
+            if constexpr (PEND >= 0) {
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                     for (int w = 0; w < 4; ++w) {
-                        const unsigned pr = pf[Q][ks][w];
+                        const unsigned pr = pf[PEND][ks][w];
                         const float lo = __builtin_bit_cast(float, pr << 16) * alpha, hi_ = __builtin_bit_cast(float, pr & 0xFFFF0000u) * alpha;
                         unsigned o;
                         PA_CVT(o, lo, hi_);
-                        pf[Q][ks][w] = o;
+                        pf[PEND][ks][w] = o;
                     }
             }
+            offset_pieces(rh);
+            asm volatile("s_nop 1" ::: "memory");
         }
-        const float noff = rh - m_run;      // p = exp2(s * sc2 + noff)
-        // exponential phase, skewed over the MFMA gaps: group k = fma of elements 2k, 2k+1 | exp of 2k-2, 2k-1 | sum + pack of 2k-4, 2k-3
-        float x[32], pe[32];
-        auto group = [&x, &pe, &sa, &pf, &la, &lb, &noff, sc2](auto kc) __attribute__((always_inline)) {
+    };
+    using IM1 = std::integral_constant<int, -1>;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // ---- pre-loop: S^T of tile 0, its maximum and offset; the first K fragments of tile 1 -------------------------------------------------
+#pragma unroll
+    for (int s = 0; s < KSTEPS; ++s) {
+        kx[s] = kad[s] + 1 * TILE;       // K tile 1 (ring slot 1)
+        ky[s] = kad[s] + 2 * TILE;       // K tile 2 (ring slot 2)
+    }
+    int kslot = 0;                       // ring slot of the K tile the next iteration requests (tile t + 3)
+    {
+        wg_static_for<0, 4>([&k_read, &kad](auto g) { k_read(g, kad); });
+        wg_static_for<0, 8>([&k_read, &qk_mfma, &kad](auto gc) {
+            constexpr int g = decltype(gc)::value;
+            PA_LGKM(g < 4 ? 3 : 7 - g);
+            qk_mfma(gc, I0{});
+            if constexpr (g < 4) k_read(std::integral_constant<int, g + 4>{}, kad);
+        });
+        wg_static_for<0, 4>([&k_read, &kx](auto g) { k_read(g, kx); });
+        float rh = 0.f;
+        if constexpr (GRID) {
+            rh = pa_ds_read_b32(relh_ad);
+            relh_ad += 4;
+        }
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // the S^T MFMAs' results before the first vector read
+        wg_static_for<0, 16>([&max_op](auto i) { max_op(I0{}, i); });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        exchange(rh);
+        offset_pieces(rh);
+        decide(rh, IM1{});
+        asm volatile("s_nop 1" ::: "memory");
+        PA_MFMA_VV(sa[0][0], ones_a_pinned, noff_b);
+        PA_MFMA_VV(sa[0][1], ones_a_pinned, noff_b);
+        __builtin_amdgcn_s_barrier();
+    }
+
+    // ---- one iteration (P = t & 1, Q = P ^ 1).
+    //   vector stream: the exponentials of tile t (score buffer P, offset already added) -> P^T buffer P; the maximum of tile t+1 (score
+    //                  buffer Q), its exchange and offset pieces; behind the last MFMA the rescale decision and the offset MFMAs of tile t+1
+    //   matrix stream: S^T of tile t+1 into score buffer Q (K fragments g0..g3 were read in the previous iteration, g4..g7 come from
+    //                  address set A), then P.V of tile t-1 (P^T buffer Q, V tile in slot Q)
+    //   LDS reads:     rh(t+1) | K g4..g7 of tile t+1 (behind MFMA 0..3) | V pairs 0..3 (behind MFMA 4..7) | behind P.V MFMA j = 0..3: V
+    //                  pair j+4, then K g = j of tile t+2 (address set B) for the next iteration
+    //   requests:      K tile t+3 -> ring slot kslot, V tile t -> slot P
+    // QK: t + 1 < nt.  PV: t > 0.  KP: t + 2 < nt.
+    auto iter = [&](int t, auto pc, auto do_qk_c, auto do_pv_c, auto do_kp_c, unsigned (&kA)[KSTEPS], unsigned (&kB)[KSTEPS]) __attribute__((always_inline)) {
+        constexpr int P = decltype(pc)::value, Q = P ^ 1;
+        constexpr bool DO_QK = decltype(do_qk_c)::value, DO_PV = decltype(do_pv_c)::value, DO_KP = decltype(do_kp_c)::value;
+        using BQ = std::integral_constant<int, Q>;
+        PA_STAMP(0);
+        if (t + 3 < nt) stage(kslot, 0);
+        stage(t, 1);
+        float rh = 0.f;
+        if constexpr (GRID && DO_QK) {
+            rh = pa_ds_read_b32(relh_ad);
+            relh_ad += 4;
+        }
+        if constexpr (!DO_QK) wg_static_for<0, 4>([&v_read](auto j) { v_read(j, BQ{}); });
+        PA_STAMP(1);
+        // exponential phase, skewed over the MFMA gaps: group k = exp of elements 2k, 2k+1 | pack of 2k-4, 2k-3 (two groups back: an operand
+        // written by the statement just ahead would make hipcc pad an s_nop)
+        float pe[32];
+        auto group = [&pe, &sa, &pf](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
             if constexpr (k < 16) {
                 constexpr int e = 2 * k;
-                PA_FMA_S(x[e], sa[P][e >> 4][e & 15], sc2, noff);
-                PA_FMA_S(x[e + 1], sa[P][(e + 1) >> 4][(e + 1) & 15], sc2, noff);
+                PA_EXP(pe[e], sa[P][e >> 4][e & 15]);
+                PA_EXP(pe[e + 1], sa[P][(e + 1) >> 4][(e + 1) & 15]);
             }
-            if constexpr (k >= 1 && k < 17) {
-                constexpr int e = 2 * k - 2;
-                PA_EXP(pe[e], x[e]);
-                PA_EXP(pe[e + 1], x[e + 1]);
-            }
-            if constexpr (k >= 2) {
+            if constexpr (k >= 2 && k < 18) {
                 constexpr int e = 2 * k - 4;       // element e = 16*kb + r -> fragment kb*2 + (r >> 3), dword (r & 7) >> 1
-                PA_ADD(la, pe[e]);
-                PA_ADD(lb, pe[e + 1]);
                 unsigned o;
                 PA_CVT(o, pe[e], pe[e + 1]);
                 pf[P][(e >> 4) * 2 + ((e & 15) >> 3)][(e & 7) >> 1] = o;
             }
         };
-        group(std::integral_constant<int, 0>{});
-        group(std::integral_constant<int, 1>{});
-        wg_static_for<0, 16>([&group, &k_read, &v_read, &qk_mfma, &pv_mfma](auto mc) {
+        asm volatile("s_nop 3" ::: "memory");      // (the offset MFMAs of the previous iteration's tail: barrier + requests + this: > 12 states)
+        group(I0{});
+        // MFMA slots: 0..7 S^T g = m | 8..19: per k-step ks = (m-8)/3 two P.V MFMAs (j = 2ks, 2ks+1) and the row-sum MFMA
+        wg_static_for<0, 20>([&group, &k_read, &v_read, &qk_mfma, &pv_mfma, &max_op, &exchange, &offset_pieces, &rh, &kA, &kB, &osum, &ones_full, &pf](auto mc) {
             constexpr int m = decltype(mc)::value;
+            constexpr bool RH = GRID && DO_QK;
             if constexpr (m < 8) {
                 if constexpr (DO_QK) {
-                    // K g landed?  issued behind it: K g+1..g+3 (m < 4: + nothing else yet), then the V pairs
-                    PA_LGKM(m < 5 ? 3 : (DO_PV ? 2 * (m - 4) + (7 - m) : 7 - m));
+                    // m >= 4: K g = m landed?  issued behind it: K m+1..7, then the V pairs
+                    if constexpr (m >= 4) PA_LGKM(DO_PV ? (m == 4 ? 3 : 2 * (m - 4) + (7 - m)) : 7 - m);
                     qk_mfma(mc, BQ{});
-                    if constexpr (m < 4) k_read(std::integral_constant<int, m + 4>{}, BQ{});
+                    if constexpr (m < 4) k_read(std::integral_constant<int, m + 4>{}, kA);
                     else if constexpr (DO_PV) v_read(std::integral_constant<int, m - 4>{}, BQ{});
                 }
             } else {
-                constexpr int j = m - 8;
-                if constexpr (DO_PV) {
-                    PA_LGKM(j < 5 ? 6 : 2 * (7 - j));
-                    pv_mfma(std::integral_constant<int, j>{}, BQ{});
-                    if constexpr (j < 4) v_read(std::integral_constant<int, j + 4>{}, BQ{});
+                constexpr int ks = (m - 8) / 3, r = (m - 8) % 3;
+                if constexpr (r < 2) {
+                    constexpr int j = 2 * ks + r;
+                    if constexpr (DO_PV) {
+                        // V pair j landed?  behind it, in issue order: [V j+1 .. V 3] [V 4, Kp 0, V 5, Kp 1, ...] as far as issued
+                        if constexpr (!DO_QK) PA_LGKM(j < 5 ? 6 : 2 * (7 - j));
+                        else if constexpr (DO_KP) PA_LGKM(j == 0 ? 6 : j == 1 ? 7 : j == 2 ? 8 : j == 3 ? 9 : j == 4 ? 10 : j == 5 ? 7 : j == 6 ? 4 : 1);
+                        else PA_LGKM(j < 5 ? 6 : 2 * (7 - j));
+                        pv_mfma(std::integral_constant<int, j>{}, BQ{});
+                        if constexpr (j < 4) v_read(std::integral_constant<int, j + 4>{}, BQ{});
+                    }
+                    if constexpr (j < 4 && DO_KP) k_read(std::integral_constant<int, j>{}, kB);
+                } else if constexpr (DO_PV) {
+                    PA_MFMA_VV(osum, ones_full, pf[Q][ks]);      // row sums of tile t-1, k-step ks
                 }
             }
-            group(std::integral_constant<int, m + 2>{});
+            if constexpr (m < 17) group(std::integral_constant<int, m + 1>{});
+            // maximum of tile t+1: key block 0 is complete behind slot 3, key block 1 behind slot 7 (+ the MFMA's own latency: the reads
+            // below start two MFMAs and their fillers later); then the exchange and the offset pieces on the assumption of no rescale
+            if constexpr (DO_QK) {
+                if constexpr (m >= 5 && m <= 7) {
+                    max_op(BQ{}, std::integral_constant<int, 2 * (m - 5)>{});
+                    max_op(BQ{}, std::integral_constant<int, 2 * (m - 5) + 1>{});
+                } else if constexpr (m >= 10 && m <= 13) {
+                    max_op(BQ{}, std::integral_constant<int, 6 + 2 * (m - 10)>{});
+                    max_op(BQ{}, std::integral_constant<int, 7 + 2 * (m - 10)>{});
+                } else if constexpr (m == 14) {
+                    max_op(BQ{}, std::integral_constant<int, 14>{});
+                } else if constexpr (m == 15) {
+                    max_op(BQ{}, std::integral_constant<int, 15>{});
+                } else if constexpr (m == 16) {
+                    if constexpr (RH) PA_LGKM(15);      // (rh is the oldest LDS operation of the iteration: long landed, and lgkmcnt is in order)
+                    exchange(rh);
+                } else if constexpr (m == 18) {
+                    offset_pieces(rh);
+                }
+            }
         });
+        PA_STAMP(2);
+        if constexpr (DO_QK) {
+            decide(rh, std::integral_constant<int, P>{});      // pending: P^T of tile t, just written
+            asm volatile("s_nop 1" ::: "memory");
+            PA_MFMA_VV(sa[Q][0], ones_a_pinned, noff_b);             // scores of tile t+1 += their exponent offset (rank-3 update, see noff_b)
+            PA_MFMA_VV(sa[Q][1], ones_a_pinned, noff_b);
+            // the fragment addresses of the K tile two iterations ahead take over set A (ring slot kslot, the one just requested)
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) kA[s] = kad[s] + (unsigned)(kslot * TILE);
+            kslot = kslot == 2 ? 0 : kslot + 1;
+        }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        PA_STAMP(3);
         __builtin_amdgcn_s_barrier();
+        PA_STAMP(4);
     };
     using T_ = std::true_type;
     using F_ = std::false_type;
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    iter(0, I0{}, T_{}, F_{});
-    for (int t = 1; t + 1 < nt; t += 2) {
-        iter(t, I1{}, T_{}, T_{});
-        iter(t + 1, I0{}, T_{}, T_{});
+    // t = 0 | 1 .. nt-3 | nt-2 | nt-1   (nt even, >= 4)
+    iter(0, I0{}, T_{}, F_{}, T_{}, kx, ky);
+    int t = 1;
+    for (; t + 1 < nt - 2; t += 2) {
+        iter(t, I1{}, T_{}, T_{}, T_{}, ky, kx);
+        iter(t + 1, I0{}, T_{}, T_{}, T_{}, kx, ky);
     }
-    iter(nt - 1, I1{}, F_{}, T_{});
-    // P.V of the last tile (odd: P^T buffer 1, V tile in LDS buffer 1)
+    iter(nt - 3, I1{}, T_{}, T_{}, T_{}, ky, kx);
+    iter(nt - 2, I0{}, T_{}, T_{}, F_{}, kx, ky);
+    iter(nt - 1, I1{}, F_{}, T_{}, F_{}, ky, kx);
+    // P.V and row sums of the last tile (odd: P^T buffer 1, V tile in slot 1)
     {
-        wg_static_for<0, 4>([&](auto j) { v_read(j, I1{}); });
-        wg_static_for<0, 8>([&](auto jc) {
+        wg_static_for<0, 4>([&v_read](auto j) { v_read(j, I1{}); });
+        wg_static_for<0, 8>([&v_read, &pv_mfma, &osum, &ones_full, &pf](auto jc) {
             constexpr int j = decltype(jc)::value;
             PA_LGKM(j < 5 ? 6 : 2 * (7 - j));
             pv_mfma(jc, I1{});
             if constexpr (j < 4) v_read(std::integral_constant<int, j + 4>{}, I1{});
+            if constexpr (j & 1) PA_MFMA_VV(osum, ones_full, pf[1][j >> 1]);
         });
     }
-    float l_run = la + lb;
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // the last MFMAs' results (opaque to the hazard recogniser) before the first vector read
+    float l_run = osum[0];      // (every element holds the row sum over both lane halves' keys)
+#ifdef WG_ATTN_STAMP
+    if (blockIdx.x < 8 && lane == 0 && wg_attn_pipe_stamp_ptr)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) wg_attn_pipe_stamp_ptr[(blockIdx.x * 8 + wave) * 4 + k] = (unsigned)st_sum[k];
+    if (blockIdx.x < 8 && lane == 0 && wave == 0 && wg_attn_pipe_stamp_ptr) {      // loop length in core cycles and in 100 MHz ticks: the clock the chip held
+        wg_attn_pipe_stamp_ptr[256 + blockIdx.x * 2] = (unsigned)(__builtin_amdgcn_s_memtime() - st_c0);
+        wg_attn_pipe_stamp_ptr[256 + blockIdx.x * 2 + 1] = (unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
+    }
+#endif
 
     if constexpr (!GRID) {
         if (lone_key) {      // the key past the last whole tile (CLIP's class token), on the vector ALU: as wg_attn_kernel
@@ -416,12 +608,12 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dot += (float)qf[s][e] * (float)kfv[e];
             }
-            const float sv = wg_xor32_sum(dot) * sc2;
+            const float sv = wg_xor32_sum(dot);      // (qf already carries scale * log2 e)
             const float m_new = fmaxf(m_run, sv);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             const float pl = __builtin_amdgcn_exp2f(sv - m_new);
             m_run = m_new;
-            l_run = l_run * alpha + (hi == 0 ? pl : 0.f);
+            l_run = l_run * alpha + pl;
             const bf16* vp = a.V + krow * a.ldv + hcol + 4 * hi;
 #pragma unroll
             for (int d = 0; d < DB; ++d)
@@ -434,8 +626,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
         }
     }
     // ---- epilogue: O = O^T / l, 8-byte stores ----------------------------------------------------------------------------------------
-    asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");      // the last P.V MFMAs' results (opaque to the hazard recogniser) before the first read
-    const float l_tot = wg_xor32_sum(l_run);
+    const float l_tot = l_run;
     if (qvalid) {
         const float inv = 1.0f / l_tot;
         const long orow = GRID ? qrow : (long)b * a.o_bs + ql;
@@ -454,7 +645,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
 
 template <int S, int NW>
 static int launch_pipe(const AttnArgs& a, hipStream_t st) {
-    size_t lds = 2 * 2 * 64 * 128;
+    size_t lds = 5 * 64 * 128;      // K ring of three, V ring of two
     if (S > 0) lds += (size_t)NW * 32 * (S + 1) * 4;
     static WgPerDevice once;
     int dev = 0;
@@ -469,12 +660,12 @@ bool wg_attn_pipe_takes(const AttnArgs& a, int head_dim, int S, int nw) {
     static const char* off = getenv("WG_ATTN_PIPE");
     if (off && off[0] == '0') return false;
     if (head_dim != 64 || (nw != 8 && nw != 4)) return false;
-    if (S == 64) return a.Hg == 64 && a.nW == 1 && nw == 8;
+    if (S == 64) return a.Hg == 64 && a.nW == 1;
     if (S != 0 || a.key_bias) return false;
     const int nt = a.Lk / 64;
     return (a.Lk % 64) <= 1 && nt >= 4 && (nt & 1) == 0;
 }
 int wg_attn_pipe_launch(const AttnArgs& a, int S, int nw, hipStream_t st) {
-    if (S == 64) return launch_pipe<64, 8>(a, st);
+    if (S == 64) return nw == 8 ? launch_pipe<64, 8>(a, st) : launch_pipe<64, 4>(a, st);
     return nw == 8 ? launch_pipe<0, 8>(a, st) : launch_pipe<0, 4>(a, st);
 }
