@@ -375,6 +375,10 @@ int wg_splice_multimodal_bwd_bf16(const long* ids, const int* img_pos, const voi
  *   up [P, HW, 32] bf16, hyper [P, K <= 4, 32] bf16 -> masks [P, K, HW] fp32;  backward: dup [P, HW, 32] bf16, dhyper [P, K, 32] fp32 (+=). */
 int wg_hyper_rows_f32(const void* up, const void* hyper, float* masks, int P, int HW, int C, int K, void* stream);
 int wg_hyper_rows_bwd_f32(const void* up, const void* hyper, const float* dmasks, void* dup, float* dhyper, int P, int HW, int C, int K, void* stream);
+/* The software-pipelined attention kernel (csrc/attn_pipe.hip; head_dim 64): which cases wg_sam_attn_relpos_bf16 / wg_mha_bf16 hand to it.
+ * 0 none, 1 (default) SAM global attention on a 64 x 64 grid (image_encoder.py:235-260 with window_size 0), 2 also plain attention without a key
+ * bias on whole 64-key tiles.  Returns the previous mode; a negative argument only queries.  Process-wide, not per stream. */
+int wg_attn_pipe_mode(int mode);
 /* Test support: writes `pattern` over the first 64 KiB of every compute unit's LDS (2048 workgroups; sink: one device word, or NULL).  LDS is not
  * cleared between launches, so a kernel that reads a word it never wrote sees whatever ran before it; tests poison with NaN bits first. */
 int wg_debug_fill_lds_u32(unsigned pattern, void* sink, void* stream);

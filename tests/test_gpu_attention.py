@@ -166,13 +166,20 @@ def test_attention_large_uneven_scores(dev, mode):
         out = ops.mha(q.to(dev), k.to(dev), v.to(dev), heads, hd ** -0.5, small=False)
     o = out.float().cpu()
     assert torch.isfinite(o).all()
-    err = (o - ref).abs().max().item()
-    print("pending-tile rescale (%s, key scales %s): max abs err %.4f" % (mode, ramp_f, err))
-    assert err < tol
+    assert (o - ref).abs().max().item() < 0.06
+
+
+@pytest.fixture
+def pipe_plain():
+    """Route plain attention through the pipelined kernel too (by default only SAM's global attention takes it: wg_attn_pipe_mode)."""
+    from walkgpt_amd import _lib
+    prev = _lib.lib().wg_attn_pipe_mode(2)
+    yield
+    _lib.lib().wg_attn_pipe_mode(prev)
 
 
 @pytest.mark.parametrize("B,Lq,Lk,heads", [(1, 4096, 4096, 2), (2, 1024, 1024, 2), (1, 300, 1025, 3), (1, 512, 256, 2)])
-def test_mha_pipelined_loop(dev, B, Lq, Lk, heads):
+def test_mha_pipelined_loop(dev, B, Lq, Lk, heads, pipe_plain):
     """head_dim 64 without a key bias on whole 64-key tiles: the software-pipelined kernel (attn_pipe.hip; eight-wave and four-wave
     workgroups, with and without the lone 1025th key, the shortest loop it takes)."""
     hd = 64
@@ -186,7 +193,7 @@ def test_mha_pipelined_loop(dev, B, Lq, Lk, heads):
 
 @pytest.mark.parametrize("mode,ramp_f,tol", [("global", (2.0, 3.0, 4.5, 6.0), 0.06), ("plain", (2.0, 3.0, 4.5, 6.0), 0.06),
                                            ("global", (3.0, 5.0, 8.0, 12.0), 0.15), ("plain", (3.0, 5.0, 8.0, 12.0), 0.15)])
-def test_pipelined_attention_rescales_a_pending_tile(dev, mode, ramp_f, tol):
+def test_pipelined_attention_rescales_a_pending_tile(dev, mode, ramp_f, tol, pipe_plain):
     """The pipelined loop decides tile t's rescale while the P.V product of tile t-1 is still pending: that tile's probabilities must be
     rescaled with the accumulator (cdna_hip_programming.md T13: a rare, data-dependent branch needs an input that FORCES it).  Keys are
     scaled so that the row maximum jumps by far more than the lazy-rescale threshold at chosen tiles late in the loop -- once, twice in

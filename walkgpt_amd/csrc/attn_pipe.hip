@@ -1,33 +1,40 @@
 // Software-pipelined fused attention for head_dim 64 on gfx950: SAM's global attention (64 x 64 grid, decomposed rel-pos;
-// image_encoder.py:235-260, 321-392) and CLIP's 1025-key self-attention without a key mask (HF CLIPAttention; custom_clip.py:50-104).
+// image_encoder.py:235-260, 321-392) and, on request (wg_attn_pipe_mode), plain attention without a key bias (CLIP; custom_clip.py:50-104).
 //
 // Same arithmetic, LDS images and fragment maps as wg_attn_kernel (attn.hip): S^T = K . Q^T on mfma 32x32x16 so that a lane owns
 // 32 scores of ONE query, P^T stays in registers as the B operand of O^T += V^T . P^T, V^T by ds_read_b64_tr_b16, K / V tiles of
 // 64 keys by LDS-DMA from running per-lane pointers, lazy rescale (2^6), rel-pos width term as the C operand of the first S^T
-// MFMA, height term folded into the exponent offset.  What differs is the ORDER of the work inside a wave:
+// MFMA, height term folded into the exponent offset, p = exp2(s * scale * log2 e + offset) in fp32.  What differs is the ORDER of the
+// work inside a wave:
 //
 //   wg_attn_kernel runs a tile as one dependent chain -- S^T MFMAs, maximum, exponentials, P.V MFMAs, barrier -- and with two
-//   waves per SIMD in lockstep a tile costs the SUM of its matrix segment (2 x 512 cycles) and its vector segment (2 x ~650)
-//   plus the LDS / barrier latencies between them: ~3300 cycles for 1024 cycles of MFMA work per SIMD (stamps).
-//   Here every wave runs a three-stage pipeline over the key tiles: in iteration t its matrix instructions are S^T of tile
-//   t+1 (into the second score buffer) and P.V of tile t-1, its vector instructions the softmax of tile t -- three tiles with no
-//   data dependence between them.  The instruction stream is hand-placed: every instruction of the loop body is its own `asm
-//   volatile` statement (hipcc keeps volatile asm statements in program order and allocates their registers; it scheduled the
-//   same pipeline written with builtins into clusters: rounds 1-3), one MFMA followed by ~7 vector instructions of the
-//   exponential phase and the LDS fragment reads of the MFMAs three to four slots ahead, behind counted lgkmcnt waits.
-//   MI355X_MICROARCH.md: an MFMA holds the SIMD's vector issue for 8 of its 32 cycles, a wave issues one vector instruction per 4
-//   cycles -- the two waves of a SIMD fill each other's gaps, and the matrix pipe sees MFMAs from both.
+//   waves per SIMD in lockstep a tile costs the SUM of its matrix segment and its vector segment plus the LDS / barrier latencies
+//   between them: ~3300 cycles for 1024 cycles of MFMA work per SIMD (stamps).
+//   Here every wave runs a three-stage pipeline over the key tiles: in iteration t its matrix instructions are S^T of tile t+1 (into
+//   the second score buffer), P.V of tile t-1 and that tile's row sums (an all-ones A operand: 4 MFMAs instead of 32 v_add), its
+//   vector instructions the exponentials of tile t and the maximum of tile t+1 -- no data dependence between the streams.  The
+//   instruction stream is hand-placed: every instruction of the loop body is its own `asm volatile` statement (hipcc keeps volatile asm
+//   statements in program order and allocates their registers; the same pipeline written with builtins was scheduled into clusters:
+//   rounds 1-3): one MFMA, then 2 v_fma + 2 v_exp + 1 v_cvt_pk of the exponential phase, the LDS fragment reads of the
+//   MFMAs three to four slots ahead and the counted lgkmcnt wait of the next one.  The first four K fragments of an iteration are read
+//   in the previous one (K tiles live in a ring of three), the row maximum, its cross-half exchange and the exponent offset are
+//   finished inside the stream: between the last MFMA of an iteration and the barrier only the rescale decision is left.
+//   Measured (B = 8, 12 heads, alone on the GPU): 580 us against 604 us; stamps: 2100 cycles per tile and SIMD at 2.0 GHz, issue-bound --
+//   the two waves of a SIMD present ~1800 cycles of instruction issue per tile (MFMA 8, v_exp 8, everything else ~4 each; they do not
+//   overlap), which is why variants that trade vector instructions for MFMAs one for one ran at the same speed (notes/r04_experiments.md).
 //
 // Hazards this file owns (the compiler sees opaque statements):
-//   * LDS reads are asm: every consumer sits behind an `s_waitcnt lgkmcnt(N)` counted from the issue order written below (LDS
-//     operations return in order; the loop body contains no scalar loads -- check the ISA after edits: an s_load inside the loop
-//     would share the counter).
-//   * MFMA results are read by vector instructions one iteration later (S^T) or after the loop (O^T); P^T fragments written by
-//     v_cvt_pk are read by MFMAs one iteration later.  The rare rescale path multiplies O^T (written by the previous iteration's
-//     last MFMAs, > 40 instructions and a barrier earlier) and the pending P^T of tile t-1, whose P.V MFMAs all come later in the
-//     iteration: the decision never splits a pending tile (cdna_hip_programming.md T13).
-//   * LDS-DMA: tile K(t+2) / V(t) are requested in iteration t into the buffers whose last reads ended before the barrier that
-//     opens the iteration; `s_waitcnt vmcnt(0)` + s_barrier close it.
+//   * LDS reads are asm: every consumer sits behind an `s_waitcnt lgkmcnt(N)` counted from the issue order written at the iteration
+//     (LDS operations return in order; the loop body contains no scalar loads -- an s_load inside the loop would share the counter).
+//   * MFMA results are read by vector instructions at least two MFMAs and their fillers later (maximum), one iteration later
+//     (exponentials) or after the loop (O^T, row sums); P^T fragments written by v_cvt_pk are read by MFMAs one iteration later.  The
+//     rescale decision for tile t+1 is taken behind the LAST MFMA of iteration t: everything still at the old maximum -- O^T, the row
+//     sums, and the P^T fragments of tile t, none of whose MFMAs has been issued -- is rescaled together, so the decision never splits a
+//     pending tile (cdna_hip_programming.md T13; tests/test_gpu_attention.py forces it late in the loop).
+//   * Operands the COMPILER computes for an asm MFMA (ones, zero-initialised accumulators, the rel-pos C operand) are pinned two wait
+//     states ahead of the first use: its hazard recogniser does not know the statement is an MFMA (tools/lint_asm_hazards.py).
+//   * LDS-DMA: tile K(t+3) / V(t) are requested in iteration t into the slots whose last reads ended before the barrier that opens the
+//     iteration; `s_waitcnt vmcnt(0)` + s_barrier close it.
 #include "attn_common.h"
 #include <type_traits>
 
@@ -219,29 +226,22 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
                 }
             }
         };
+        const float inv_sc2 = 1.0f / (a.scale * LOG2E);
         rel_pass(0);
         asm volatile("" ::: "memory");
 #pragma unroll
         for (int e = 0; e < 32; ++e) {
             const int kw = (e & 3) + 8 * (e >> 2) + 4 * hi;
-            relw_c[e >> 4][e & 15] = mytab[ql_lane * SP + kw];      // (already times log2 e: the scores below are in the exp2 domain)
+            relw_c[e >> 4][e & 15] = mytab[ql_lane * SP + kw] * inv_sc2;      // pre-divided by scale * log2 e: C operand of the first S^T MFMA
         }
         asm volatile("" ::: "memory");
         rel_pass(1);
     }
-    // The S^T MFMAs run on q * scale * log2(e), rounded to bf16 once (the rel-pos terms above used the unscaled q, as the reference does:
-    // image_encoder.py:244 against :247-249): the scores leave the matrix pipe in the exp2 domain and the vector ALU never multiplies them.
+    // p = exp2(s * sc2 + noff): scale and offset stay on the vector ALU (one v_fma per score).  Measured alternative (round 4,
+    // notes/r04_experiments.md): q pre-multiplied by scale * log2 e and the offset added by a rank-3 MFMA update of the scores -- 32 v_fma
+    // fewer per tile, the same run time, and the second bf16 rounding of q cost 0.07-0.11 of absolute error on scores of several hundred
+    // (tests/test_gpu_attention.py::test_attention_large_uneven_scores): not kept.
     const float sc2 = a.scale * LOG2E;
-#pragma unroll
-    for (int s = 0; s < KSTEPS; ++s)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qf[s][e] = (bf16)((float)qf[s][e] * sc2);
-    // The exponent offset of a tile (row maximum and height term: one value per query and tile) is ADDED BY THE MATRIX PIPE as well: a
-    // rank-3 update S^T += 1 . n^T with n split into three bf16 pieces (24 significant bits), one MFMA per key block in front of the
-    // exponentials -- instead of 32 v_fma per tile on the vector ALU, which is the unit this loop is bound by.
-    const unsigned one3 = hi == 0 ? 0x3F803F80u : 0u;
-    const u32x4 ones_a = {one3, hi == 0 ? 0x00003F80u : 0u, 0u, 0u};      // A operand: k = 0, 1, 2 of every key row are 1.0
-    u32x4 ones_a_pinned;                                                   // (the copy the loop uses: see the pin in front of the pre-loop)
     // softmax denominators from the matrix pipe: osum += 1 . P^T (an all-ones A operand) beside every k-step of P.V -- every element of osum
     // ends up holding the row sum over BOTH lane halves' keys.  The loop is bound by instruction ISSUE (stamps + PMC): 4 MFMAs
     // (8 issue cycles each) replace 32 v_add (4 each), on a pipe that is ~55 % busy
@@ -249,7 +249,6 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) osum[r] = 0.f;
     u32x4 ones_full = {0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u};   // A operand of the row-sum MFMAs
-    u32x4 noff_b = {0u, 0u, 0u, 0u};                                      // B operand: k = 0, 1, 2 of this lane's query = the three pieces
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem);
     unsigned relh_ad = lds0 + KV_BYTES + (unsigned)((wave * 32 + ql_lane) * SP * 4);    // this lane's relh row, entry t
 
@@ -274,15 +273,11 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // Everything the compiler computed above and an asm MFMA below reads as an operand is pinned HERE, two wait states ahead of the first
-    // of them: hipcc placed the last v_cvt_pk of the query prescale directly in front of the first S^T MFMA (opaque to its hazard
-    // recogniser), which then read the old register -- wrong rows that came and went with the register allocation (tools/lint_asm_hazards.py
-    // scans the ISA for this pattern; tests/test_cabi_and_host.py runs it).
+    // of them: in one variant of this kernel hipcc placed the last v_cvt_pk of a query prescale directly in front of the first S^T MFMA
+    // (opaque to its hazard recogniser), which then read the old register -- wrong rows that came and went with the register allocation
+    // (tools/lint_asm_hazards.py scans the ISA for this pattern; tests/test_cabi_and_host.py runs it).
     asm volatile("s_nop 1" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3]));
-    {
-        u32x4 oa = ones_a;
-        asm volatile("s_nop 1" : "+v"(oa), "+v"(noff_b), "+v"(ones_full), "+v"(osum));
-        ones_a_pinned = oa;
-    }
+    asm volatile("s_nop 1" : "+v"(ones_full), "+v"(osum));
     if constexpr (GRID) asm volatile("s_nop 1" : "+v"(relw_c[0]), "+v"(relw_c[1]));
 
     if (!GRID && (qc * NW + wave) * 32 >= Lq) {
@@ -364,23 +359,15 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
         } else if constexpr (i == 14) PA_MAX3(mch[0], mch[0], mch[1], mch[2]);
         else PA_MAX3(mt, mch[0], mch[3], mch[3]);
     };
-    // exponent offset n = rh - m_run of a tile as three bf16 pieces in noff_b (truncations: every difference is exact in fp32); 7 instructions
-    float mx = 0.f;
-    auto offset_pieces = [&noff_b, &m_run](float rh) __attribute__((always_inline)) {
-        float n, r1, r2;
-        unsigned h1, h2;
-        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(n) : "v"(rh), "v"(m_run));
-        asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(h1) : "v"(n));
-        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r1) : "v"(n), "v"(h1));
-        asm volatile("v_and_b32 %0, 0xffff0000, %1" : "=v"(h2) : "v"(r1));
-        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(r2) : "v"(r1), "v"(h2));
-        asm volatile("v_perm_b32 %0, %1, %2, %3" : "=v"(noff_b[0]) : "v"(h2), "v"(h1), "s"(0x07060302u));      // {mid[31:16], hi[31:16]}
-        asm volatile("v_lshrrev_b32 %0, 16, %1" : "=v"(noff_b[1]) : "v"(r2));
+    // exponent offset of a tile: p = exp2(s * sc2 + noff), noff = rh - m_run (one instruction, redone by the rare rescale path)
+    float mx = 0.f, noff = 0.f;
+    auto offset_of = [&noff, &m_run](float rh) __attribute__((always_inline)) {
+        asm volatile("v_sub_f32 %0, %1, %2" : "=v"(noff) : "v"(rh), "v"(m_run));
     };
     // maximum of the tile over both lane halves (the other half of a query's keys lives in lane ^ 32), height term added: 4 instructions
-    auto exchange = [&mt, &mx](float rh) __attribute__((always_inline)) {
+    auto exchange = [&mt, &mx, sc2](float rh) __attribute__((always_inline)) {
         float a_, b_;
-        asm volatile("v_add_f32 %0, %1, %2" : "=v"(a_) : "v"(mt), "v"(rh));
+        PA_FMA_S(a_, mt, sc2, rh);
         asm volatile("v_mov_b32 %0, %1" : "=v"(b_) : "v"(a_));
         asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a_), "+v"(b_));
         asm volatile("v_max_f32 %0, %1, %2" : "=v"(mx) : "v"(a_), "v"(b_));
@@ -412,8 +399,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
                         pf[PEND][ks][w] = o;
                     }
             }
-            offset_pieces(rh);
-            asm volatile("s_nop 1" ::: "memory");
+            offset_of(rh);
         }
     };
     using IM1 = std::integral_constant<int, -1>;
@@ -445,11 +431,8 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
         wg_static_for<0, 16>([&max_op](auto i) { max_op(I0{}, i); });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         exchange(rh);
-        offset_pieces(rh);
+        offset_of(rh);
         decide(rh, IM1{});
-        asm volatile("s_nop 1" ::: "memory");
-        PA_MFMA_VV(sa[0][0], ones_a_pinned, noff_b);
-        PA_MFMA_VV(sa[0][1], ones_a_pinned, noff_b);
         __builtin_amdgcn_s_barrier();
     }
 
@@ -476,27 +459,33 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
         }
         if constexpr (!DO_QK) wg_static_for<0, 4>([&v_read](auto j) { v_read(j, BQ{}); });
         PA_STAMP(1);
-        // exponential phase, skewed over the MFMA gaps: group k = exp of elements 2k, 2k+1 | pack of 2k-4, 2k-3 (two groups back: an operand
-        // written by the statement just ahead would make hipcc pad an s_nop)
-        float pe[32];
-        auto group = [&pe, &sa, &pf](auto kc) __attribute__((always_inline)) {
+        // exponential phase, skewed over the MFMA gaps: group k = fma of elements 2k, 2k+1 | exp of 2k-2, 2k-1 | pack of 2k-6, 2k-5 (an
+        // operand written by the statement just ahead would make hipcc pad an s_nop).  The offset of THIS tile is copied first: the tail
+        // of the iteration overwrites noff with the next tile's while the last groups still run
+        float x[32], pe[32];
+        const float noff_t = noff;
+        auto group = [&x, &pe, &sa, &pf, &noff_t, sc2](auto kc) __attribute__((always_inline)) {
             constexpr int k = decltype(kc)::value;
             if constexpr (k < 16) {
                 constexpr int e = 2 * k;
-                PA_EXP(pe[e], sa[P][e >> 4][e & 15]);
-                PA_EXP(pe[e + 1], sa[P][(e + 1) >> 4][(e + 1) & 15]);
+                PA_FMA_S(x[e], sa[P][e >> 4][e & 15], sc2, noff_t);
+                PA_FMA_S(x[e + 1], sa[P][(e + 1) >> 4][(e + 1) & 15], sc2, noff_t);
             }
-            if constexpr (k >= 2 && k < 18) {
-                constexpr int e = 2 * k - 4;       // element e = 16*kb + r -> fragment kb*2 + (r >> 3), dword (r & 7) >> 1
+            if constexpr (k >= 1 && k < 17) {
+                constexpr int e = 2 * k - 2;
+                PA_EXP(pe[e], x[e]);
+                PA_EXP(pe[e + 1], x[e + 1]);
+            }
+            if constexpr (k >= 3 && k < 19) {
+                constexpr int e = 2 * k - 6;       // element e = 16*kb + r -> fragment kb*2 + (r >> 3), dword (r & 7) >> 1
                 unsigned o;
                 PA_CVT(o, pe[e], pe[e + 1]);
                 pf[P][(e >> 4) * 2 + ((e & 15) >> 3)][(e & 7) >> 1] = o;
             }
         };
-        asm volatile("s_nop 3" ::: "memory");      // (the offset MFMAs of the previous iteration's tail: barrier + requests + this: > 12 states)
         group(I0{});
         // MFMA slots: 0..7 S^T g = m | 8..19: per k-step ks = (m-8)/3 two P.V MFMAs (j = 2ks, 2ks+1) and the row-sum MFMA
-        wg_static_for<0, 20>([&group, &k_read, &v_read, &qk_mfma, &pv_mfma, &max_op, &exchange, &offset_pieces, &rh, &kA, &kB, &osum, &ones_full, &pf](auto mc) {
+        wg_static_for<0, 20>([&group, &k_read, &v_read, &qk_mfma, &pv_mfma, &max_op, &exchange, &offset_of, &rh, &kA, &kB, &osum, &ones_full, &pf](auto mc) {
             constexpr int m = decltype(mc)::value;
             constexpr bool RH = GRID && DO_QK;
             if constexpr (m < 8) {
@@ -524,7 +513,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
                     PA_MFMA_VV(osum, ones_full, pf[Q][ks]);      // row sums of tile t-1, k-step ks
                 }
             }
-            if constexpr (m < 17) group(std::integral_constant<int, m + 1>{});
+            if constexpr (m < 18) group(std::integral_constant<int, m + 1>{});
             // maximum of tile t+1: key block 0 is complete behind slot 3, key block 1 behind slot 7 (+ the MFMA's own latency: the reads
             // below start two MFMAs and their fillers later); then the exchange and the offset pieces on the assumption of no rescale
             if constexpr (DO_QK) {
@@ -541,17 +530,13 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
                 } else if constexpr (m == 16) {
                     if constexpr (RH) PA_LGKM(15);      // (rh is the oldest LDS operation of the iteration: long landed, and lgkmcnt is in order)
                     exchange(rh);
-                } else if constexpr (m == 18) {
-                    offset_pieces(rh);
+                    offset_of(rh);
                 }
             }
         });
         PA_STAMP(2);
         if constexpr (DO_QK) {
             decide(rh, std::integral_constant<int, P>{});      // pending: P^T of tile t, just written
-            asm volatile("s_nop 1" ::: "memory");
-            PA_MFMA_VV(sa[Q][0], ones_a_pinned, noff_b);             // scores of tile t+1 += their exponent offset (rank-3 update, see noff_b)
-            PA_MFMA_VV(sa[Q][1], ones_a_pinned, noff_b);
             // the fragment addresses of the K tile two iterations ahead take over set A (ring slot kslot, the one just requested)
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) kA[s] = kad[s] + (unsigned)(kslot * TILE);
@@ -608,7 +593,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) dot += (float)qf[s][e] * (float)kfv[e];
             }
-            const float sv = wg_xor32_sum(dot);      // (qf already carries scale * log2 e)
+            const float sv = wg_xor32_sum(dot) * sc2;
             const float m_new = fmaxf(m_run, sv);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             const float pl = __builtin_amdgcn_exp2f(sv - m_new);
@@ -654,14 +639,25 @@ static int launch_pipe(const AttnArgs& a, hipStream_t st) {
     return wg_check_launch("wg_attn(pipelined)");
 }
 
-// Does the pipelined kernel take this case?  head_dim 64; plain: no key bias, whole 64-key tiles (+ at most the one lone key), an even
-// number >= 4 of them; grid: the 64 x 64 global attention over a 64 x 64 token grid (no padding, every tile one key row).
+// Which cases the pipelined kernel takes: 0 none, 1 (default) SAM global attention only -- the case it wins (580 vs 604 us at B = 8, 12 heads) --,
+// 2 also plain attention without a key bias on whole 64-key tiles (+ at most the one lone key), an even number >= 4 of them: measured equal to
+// wg_attn_kernel there (CLIP 55.2 vs 54.5 us, 4096 keys 663 vs 640), kept for the tests and for other chips.  WG_ATTN_PIPE in the environment
+// sets the initial mode; wg_attn_pipe_mode() changes it (returns the previous one; a negative argument only queries).
+static int g_pipe_mode = -1;
+extern "C" int wg_attn_pipe_mode(int mode) {
+    if (g_pipe_mode < 0) {
+        const char* e = getenv("WG_ATTN_PIPE");
+        g_pipe_mode = (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+    }
+    const int prev = g_pipe_mode;
+    if (mode >= 0 && mode <= 2) g_pipe_mode = mode;
+    return prev;
+}
 bool wg_attn_pipe_takes(const AttnArgs& a, int head_dim, int S, int nw) {
-    static const char* off = getenv("WG_ATTN_PIPE");
-    if (off && off[0] == '0') return false;
-    if (head_dim != 64 || (nw != 8 && nw != 4)) return false;
+    const int mode = wg_attn_pipe_mode(-1);
+    if (mode == 0 || head_dim != 64 || (nw != 8 && nw != 4)) return false;
     if (S == 64) return a.Hg == 64 && a.nW == 1;
-    if (S != 0 || a.key_bias) return false;
+    if (mode < 2 || S != 0 || a.key_bias) return false;
     const int nt = a.Lk / 64;
     return (a.Lk % 64) <= 1 && nt >= 4 && (nt & 1) == 0;
 }
