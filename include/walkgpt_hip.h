@@ -375,6 +375,17 @@ int wg_splice_multimodal_bwd_bf16(const long* ids, const int* img_pos, const voi
  *   up [P, HW, 32] bf16, hyper [P, K <= 4, 32] bf16 -> masks [P, K, HW] fp32;  backward: dup [P, HW, 32] bf16, dhyper [P, K, 32] fp32 (+=). */
 int wg_hyper_rows_f32(const void* up, const void* hyper, float* masks, int P, int HW, int C, int K, void* stream);
 int wg_hyper_rows_bwd_f32(const void* up, const void* hyper, const float* dmasks, void* dup, float* dhyper, int P, int HW, int C, int K, void* stream);
+/* fp32 verification route (csrc/fp32_ref.hip; not a product path, not benched): fp32 storage, exact fp32 matrix math on v_mfma_f32_16x16x4_f32,
+ * plain kernels.  Exists so that north_star's "text logits within 1e-4 abs of the reference CPU path" can be held on the GPU on SOME route
+ * (walkgpt_amd/fp32_route.py, tests/test_gpu_fp32_route.py); the bf16 path's distance to fp32 is set by its bf16 weights.
+ *   wg_f32_gemm_bias_act: C = act(A . W^T + bias) (+ R[m % res_row_mod or m]), K % 4 == 0   (HF CLIP linears, patch embedding rows, llava_arch.py:36-42)
+ *   wg_f32_layernorm:     biased-variance LayerNorm per row                                 (HF CLIP pre_layrnorm / layer_norm1 / layer_norm2)
+ *   wg_f32_mha:           softmax(scale q k^T + key_bias[b, j]) v per head, rows [B, L, ld]  (HF CLIPAttention, custom_clip.py:27-38 mask) */
+int wg_f32_gemm_bias_act(const float* A, long lda, const float* W, long ldw, const float* bias, const float* residual, long ldr, int res_row_mod,
+                         float* C, long ldc, int M, int N, int K, int act, void* stream);
+int wg_f32_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int C, float eps, void* stream);
+int wg_f32_mha(const float* q, const float* k, const float* v, float* o, const float* key_bias, long ld, long ldo, int B, int heads, int head_dim,
+               int Lq, int Lk, float scale, void* stream);
 /* The software-pipelined attention kernel (csrc/attn_pipe.hip; head_dim 64): which cases wg_sam_attn_relpos_bf16 / wg_mha_bf16 hand to it.
  * 0 none, 1 (default) SAM global attention on a 64 x 64 grid (image_encoder.py:235-260 with window_size 0), 2 also plain attention without a key
  * bias on whole 64-key tiles.  Returns the previous mode; a negative argument only queries.  Process-wide, not per stream. */
