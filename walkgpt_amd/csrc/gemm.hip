@@ -99,9 +99,29 @@ extern "C" int wg_debug_gemm_stamps(unsigned* buf) {
             if (lane == 0 && wg_gemm_stamp_ptr) wg_gemm_stamp_ptr[512 + (blockIdx.x ? 16 : 0) + (wave >> 2) * 8 + (k)] = now;    \
         }                                                                                                                         \
     } while (0)
+// persistent kernel (tools/gemm_phase_stamps.py): phase sums over all tiles of a workgroup in scalar registers (no store inside the loops);
+// k = 0 tile start (first slab requested earlier), 1 first slab landed and barrier passed, 2 main loop done, 3 epilogue issued (stores may
+// still drain under the next tile)
+#define WG_PSTAMP(k)                                                                                                              \
+    do {                                                                                                                          \
+        unsigned long long now;                                                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");                                               \
+        if ((k) > 0) pst_sum[(k) - 1] += now - pst_prev;                                                                          \
+        pst_prev = now;                                                                                                           \
+    } while (0)
+// ... and inside the epilogue (relative to pst_e)
+#define WG_ESTAMP(k)                                                                                                              \
+    do {                                                                                                                          \
+        unsigned long long now;                                                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now)::"memory");                                               \
+        pst_sum[(k)] += now - pst_e;                                                                                              \
+        pst_e = now;                                                                                                              \
+    } while (0)
 #else
 #define WG_GSTAMP(k) do { } while (0)
 #define WG_TSTAMP(k) do { } while (0)
+#define WG_PSTAMP(k) do { } while (0)
+#define WG_ESTAMP(k) do { } while (0)
 #endif
 
 template <int N_> __device__ __forceinline__ void wg_wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N_) : "memory"); }
@@ -1270,8 +1290,14 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
     first_slab(m0, n0, 0);
     bool stores_in_flight = false;
     int par = 0;
+#ifdef WG_GEMM_STAMP
+    unsigned long long pst_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pst_prev = 0, pst_e = 0;      // 0 first-slab wait, 1 main loop, 2 epilogue | 3.. its parts
+    unsigned pst_tiles = 0;
+    const unsigned long long pst_c0 = __builtin_amdgcn_s_memtime(), pst_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     while (true) {
+        WG_PSTAMP(0);
         const int nbase = n0 + wn * WTN;
         f32x4 acc[8][FJ];
 #pragma unroll
@@ -1323,6 +1349,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
             // the previous tile's row sums: the four column waves' shares meet here (their LDS writes are behind the barrier above)
             if (stores_in_flight) wg_stats_combine(spart, FP8 ? wave * 64 + lane_now() : tid, g.stats_part, g.tiles_n * g.stats_mpad, sp_off);
         }
+        WG_PSTAMP(1);
         if (grp == 1) __builtin_amdgcn_s_barrier();
         for (int kt = 0; kt < nk; ++kt) {
             const char* ldsA = smem + (kt & 1) * STAGE;
@@ -1386,6 +1413,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();
         // every wave is past its last LDS read of this tile (each M half-phase retired its reads before its barrier)
+        WG_PSTAMP(2);
 
         const int vn = v + gridDim.x;
         const bool has_next = vn < nwg;
@@ -1415,6 +1443,10 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
             set_sources(m0, n0);
             first_slab(m0, n0, par ^ 1);
         }
+#ifdef WG_GEMM_STAMP
+        pst_e = pst_prev;
+        WG_ESTAMP(3);
+#endif
         auto finish = [&](auto has_r) __attribute__((always_inline)) {
             constexpr bool HAS_R = decltype(has_r)::value;
             u32x4 rres[NIT];
@@ -1452,6 +1484,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                     })
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
+                WG_ESTAMP(4 + 2 * half);
                 // slab reads + residual sums, then (first slab) the second slab's residual loads into the same registers, then
                 // the stores: no load is ever issued behind a store that a later wait would have to cover
                 constexpr int RPSl = 64 / CH;
@@ -1556,10 +1589,15 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
+                WG_ESTAMP(5 + 2 * half);
             }
         };
         if (g.R) finish(std::true_type{}); else finish(std::false_type{});
         if constexpr (STATS) sp_off = (nbase / BN) * (int)g.stats_mpad + cm0;
+#ifdef WG_GEMM_STAMP
+        WG_PSTAMP(3);
+        ++pst_tiles;
+#endif
         if (!has_next) break;
         v = vn;
         par ^= 1;
@@ -1567,6 +1605,15 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
         // range check, not branched around) and every load of the epilogue is consumed before the last stores issue: exact count
         stores_in_flight = true;
     }
+#ifdef WG_GEMM_STAMP
+    if (wg_gemm_stamp_ptr && lane == 0 && (wave == 0 || wave == 4) && blockIdx.x < 32) {      // [workgroup][wave half]: 3 phase sums, tiles, cycles, 100 MHz ticks
+        unsigned* o = wg_gemm_stamp_ptr + (blockIdx.x * 2 + (wave >> 2)) * 8;
+        o[0] = (unsigned)pst_sum[0]; o[1] = (unsigned)pst_sum[1]; o[2] = (unsigned)pst_sum[2]; o[3] = pst_tiles;
+        o[4] = (unsigned)(__builtin_amdgcn_s_memtime() - pst_c0); o[5] = (unsigned)(__builtin_amdgcn_s_memrealtime() - pst_r0);
+        unsigned* e = wg_gemm_stamp_ptr + 512 + (blockIdx.x * 2 + (wave >> 2)) * 8;      // epilogue parts: next-tile setup | rows 0-63: compute + LDS, read + stores | rows 64-127
+        for (int q = 0; q < 5; ++q) e[q] = (unsigned)pst_sum[3 + q];
+    }
+#endif
     if constexpr (STATS) {   // the last tile's row sums
         __syncthreads();
         wg_stats_combine(spart, FP8 ? wave * 64 + lane_now() : tid, g.stats_part, g.tiles_n * g.stats_mpad, sp_off);
