@@ -72,24 +72,14 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     constexpr int NTG = GRID ? (S + RPT - 1) / RPT : 0;   // key tiles per window
     constexpr int SP = GRID ? NTG * RPT + 1 : 1;          // relh table row (fp32 words, odd => conflict-free)
     constexpr int NRW = GRID ? RP / 2 : 1;                // width-bias registers per lane
-    // STAG (experiment, -DWG_ATTN_STAGGER; MI355X_MICROARCH.md, Two waves per SIMD, item 9): the eight-wave kernels run waves w and w + 4 of a
-    // SIMD through the same program with one barrier per tile, i.e. in lockstep -- both on the matrix pipe, then both on the vector ALU.  Here
-    // waves 4-7 carry the P.V MFMAs of a tile over the barrier into the next block, so that their matrix work sits beside the other half's
-    // exponentials and vice versa.  V tiles then live for two blocks: a ring of three V buffers next to the two K buffers.
-#if defined(WG_ATTN_STAGGER) && WG_ATTN_STAGGER
-    constexpr bool STAG = (NW == 8);
-#else
-    constexpr bool STAG = false;
-#endif
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* kv = smem;                                  // [2 buffers][K tile | V tile]      (STAG: [2][K tile] | [3][V tile])
-    float* tab = (float*)(smem + 2 * TILE2 + (STAG ? TILEV : 0));   // grid: per-wave rel table; plain: key bias row
+    char* kv = smem;                                  // [2 buffers][K tile | V tile]
+    float* tab = (float*)(smem + 2 * TILE2);          // grid: per-wave rel table; plain: key bias row
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql_lane = lane & 31, hi = lane >> 5;
-    const bool late = STAG && wave >= NW / 2;
 
     // ---- decode the block id -> (batch, window, head, q chunk) ------------------------------------------------
     int bid = blockIdx.x;
@@ -209,8 +199,8 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     const unsigned strideK = (unsigned)((GRID ? (long)RPT * a.Hg : 64L) * a.ldk);
     const unsigned strideV = (unsigned)((GRID ? (long)RPT * a.Hg : 64L) * a.ldv);
     // tile t of K (or V) -> buffer `buf`; per operand the tiles must be staged in order 0, 1, 2, ... (running pointers)
-    auto stage = [&](int t, int buf, bool isV, int vslot = 0) __attribute__((always_inline)) {
-        char* dst = STAG ? (isV ? kv + 2 * TILE + vslot * TILEV : kv + buf * TILE) : kv + buf * TILE2 + (isV ? TILE : 0);
+    auto stage = [&](int t, int buf, bool isV) __attribute__((always_inline)) {
+        char* dst = kv + buf * TILE2 + (isV ? TILE : 0);
         const int lim = klim0 - t * (GRID ? RPT : 64);
         const int o = isV ? 1 : 0;
         const int cpr = (isV ? ROWBV : ROWB) / 16, ninst = isV ? NINSTV : NINSTK;
@@ -324,17 +314,6 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) ot[d][r] = 0.f;
     float m_run = NEG_BIG;
     float l_run = 0.f;   // running softmax denominator (this lane's half of the keys)
-#if defined(WG_ATTN_MFMA_SUM) && WG_ATTN_MFMA_SUM
-    // experiment (-DWG_ATTN_MFMA_SUM=1): the denominator from the matrix pipe -- one more P.V-shaped MFMA per k-step with an all-ones A operand
-    // leaves sum_k P[q][k] (both lane halves' keys) in every row of osum: 4 MFMAs per tile instead of 32 v_add_f32, and no cross-half sum at the end
-    constexpr bool MSUM = true;
-    f32x16 osum;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) osum[r] = 0.f;
-    const bf16x8 ones8 = {(bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f, (bf16)1.f};
-#else
-    constexpr bool MSUM = false;
-#endif
     const float sc2 = a.scale * LOG2E;
 
     // ---- main loop ---------------------------------------------------------------------------------------------------------------
@@ -362,22 +341,10 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         const int kb = g & 1, s = g >> 1;
         const int row = kb * 32 + ql_lane;
         const int c = (2 * s + hi) ^ swzK<HD>(row);
-#if defined(WG_ATTN_ABL) && WG_ATTN_ABL == 6
-        kfr[g] = qf[s];   // ablation build: no K fragment reads
-        return;
-#endif
         kfr[g] = *(const bf16x8*)(kbuf + row * ROWB + c * 16);
     };
     auto qk_one = [&](f32x16* st, int g) __attribute__((always_inline)) {
         const int kb = g & 1, s = g >> 1;
-#if defined(WG_ATTN_ABL) && WG_ATTN_ABL == 3
-        asm volatile("" ::"v"(kfr[g]));   // ablation build: no S^T MFMAs
-        if (s == 0) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st[kb][r] = 0.01f * r;
-        }
-        return;
-#endif
         if (s == 0) {
             if constexpr (GRID) {
                 st[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr[g], qf[s], relw_c[kb % NC], 0, 0, 0);
@@ -431,10 +398,6 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
             const float alpha = wg_exp2(m_run - m_new);
             m_run = m_new;
             l_run *= alpha;
-#if defined(WG_ATTN_MFMA_SUM) && WG_ATTN_MFMA_SUM
-#pragma unroll
-            for (int r = 0; r < 16; ++r) osum[r] *= alpha;
-#endif
 #pragma unroll
             for (int d = 0; d < DB; ++d)
 #pragma unroll
@@ -449,7 +412,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     {
         const int g = lane >> 4, i16 = lane & 15;
         const int rq = i16 >> 2, cp = i16 & 3;
-        const unsigned vbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem) + (unsigned)(STAG ? 2 * TILE : TILE);
+        const unsigned vbase = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem) + (unsigned)TILE;
 #pragma unroll
         for (int d = 0; d < DB; ++d) {
             const int col = 32 * d + 16 * (g & 1) + 4 * cp;
@@ -461,11 +424,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     // the two transposed reads that feed P.V MFMA g = ks*DB + d (the offset must be an immediate: switch on the unrolled ks)
     auto vt_pair = [&](int g, int buf) __attribute__((always_inline)) {
         const int ks = g / DB, d = g % DB;
-        const unsigned ad = vt_ad[d] + (unsigned)(buf * (STAG ? TILEV : TILE2));   // STAG: buf = slot of the V ring
-#if defined(WG_ATTN_ABL) && WG_ATTN_ABL == 7
-        vt[ks][d][0] = (u32x2){ad, ad}; vt[ks][d][1] = (u32x2){ad, ad};   // ablation build: no V^T reads
-        return;
-#endif
+        const unsigned ad = vt_ad[d] + (unsigned)(buf * TILE2);
         switch (ks) {
             case 0: vt[0][d][0] = wg_ds_read_tr<0 * 16 * ROWBV>(ad); vt[0][d][1] = wg_ds_read_tr<0 * 16 * ROWBV + 8 * ROWBV>(ad); break;
             case 1: vt[1][d][0] = wg_ds_read_tr<1 * 16 * ROWBV>(ad); vt[1][d][1] = wg_ds_read_tr<1 * 16 * ROWBV + 8 * ROWBV>(ad); break;
@@ -475,44 +434,19 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     };
     // exponentials, row sum and bf16 packing of score elements [e0, e1)
     auto probs = [&](const f32x16* st, float off, int e0, int e1) __attribute__((always_inline)) {
-#if defined(WG_ATTN_PACKED) && WG_ATTN_PACKED
-        // experiment (-DWG_ATTN_PACKED=1): scale-and-offset and the row sum on float pairs (v_pk_fma_f32 / v_pk_add_f32: half the issue slots of
-        // the 32 fma + 32 add per tile); the sum runs as two partial sums that meet once per tile
-        f32x2 l2 = {0.f, 0.f};
-        const f32x2 sc2v = {sc2, sc2}, offv = {off, off};
-#pragma unroll
-        for (int e = e0; e < e1; e += 2) {
-            const int kb = e >> 4, r = e & 15;
-            f32x2 x = {st[kb][r], st[kb][r + 1]};
-            x = RAW ? x * sc2v - offv : x - offv;
-            const f32x2 p = {wg_exp2(x.x), wg_exp2(x.y)};
-            l2 += p;
-            pf[kb * 2 + (r >> 3)][r & 7] = (bf16)p.x;
-            pf[kb * 2 + (r >> 3)][(r & 7) + 1] = (bf16)p.y;
-        }
-        l_run += l2.x + l2.y;
-#else
 #pragma unroll
         for (int e = e0; e < e1; ++e) {
             const int kb = e >> 4, r = e & 15;
             const float p = RAW ? wg_exp2(st[kb][r] * sc2 - off) : wg_exp2(st[kb][r] - off);
-            if (!MSUM) l_run += p;
+            l_run += p;
             pf[kb * 2 + (r >> 3)][r & 7] = (bf16)p;
         }
-#endif
     };
     auto pv_one = [&](int g) __attribute__((always_inline)) {
         const int ks = g / DB, d = g % DB;
         u32x4 vv = {vt[ks][d][0][0], vt[ks][d][0][1], vt[ks][d][1][0], vt[ks][d][1][1]};
         const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
-#if defined(WG_ATTN_ABL) && WG_ATTN_ABL == 2
-        asm volatile("" ::"v"(vf), "v"(pf[ks]));   // ablation build: no P.V MFMAs
-        return;
-#endif
         ot[d] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], ot[d], 0, 0, 0);
-#if defined(WG_ATTN_MFMA_SUM) && WG_ATTN_MFMA_SUM
-        if (d == 0) osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pf[ks], osum, 0, 0, 0);
-#endif
     };
 
     // Windows whose last tile holds keys in its first key block only (S = 14 at four padded rows per tile: rows 12, 13 | 14, 15): the dead
@@ -522,12 +456,11 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         // a wave without a single query (the last chunk of a ragged query count: CLIP's 1025 = 32 blocks + 1 leaves three such waves in
         // every ninth workgroup): it stages its share of the K / V tiles and keeps the barriers, nothing else -- its SIMD time goes to
         // the other workgroups of the CU
-        for (int t = 0, vn = 1; t < nt; ++t) {
+        for (int t = 0; t < nt; ++t) {
             if (t + 1 < nt) {
                 stage(t + 1, (t & 1) ^ 1, false);
-                stage(t + 1, (t & 1) ^ 1, true, vn);
+                stage(t + 1, (t & 1) ^ 1, true);
             }
-            vn = vn == 2 ? 0 : vn + 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
@@ -535,7 +468,6 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
     }
 #endif
     constexpr bool HALF_LAST = GRID && RPT > 1 && (S % RPT) != 0 && (S % RPT) * RP <= 32;
-    static_assert(!(STAG && HALF_LAST), "the staggered loop is written for the whole-tile form only");
     auto tile = [&](int t, auto half_c) __attribute__((always_inline)) {
         constexpr bool HALF = decltype(half_c)::value;
         constexpr int NE = HALF ? 16 : 32;           // score elements per lane that can hold a key
@@ -585,45 +517,26 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         for (int g = 0; g < NPV; ++g)
             if (!HALF || g / DB < 2) pv_one(g);
         WG_STAMP(3);
-#if !(defined(WG_ATTN_ABL) && WG_ATTN_ABL == 5)   // (ablation build 5: no per-tile wait / barrier -- wrong results, timing only)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-#endif
         WG_STAMP(4);
     };
-#if defined(WG_ATTN_PRIO) && WG_ATTN_PRIO
-    // experiment (MI355X_MICROARCH.md, Two waves per SIMD, item 4): one static s_setprio 1 for the second-dispatched half of the workgroup
-    if (NW >= 8 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
-#endif
     if constexpr (HALF_LAST) {
         for (int t = 0; t + 1 < nt; ++t) tile(t, std::false_type());
         tile(nt - 1, std::true_type());
     } else {
         // (the same loop written out: instantiating it through the generic lambda above shifts hipcc's register allocation and one
         // head_dim-128 variant starts to spill)
-        int vcur = 0, vprev = 2;                       // STAG: ring slots of V(t) and V(t - 1)
         for (int t = 0; t < nt; ++t) {
             const int buf = t & 1;
-            const int vnext = vcur == 2 ? 0 : vcur + 1;
             WG_STAMP(0);
             if (t + 1 < nt) {
                 stage(t + 1, buf ^ 1, false);
-                stage(t + 1, buf ^ 1, true, vnext);
-            }
-            if constexpr (STAG) {
-                if (late && t > 0) {   // P.V of the PREVIOUS tile, carried over the barrier: beside the other half's S^T / exponentials
-    #pragma unroll
-                    for (int g = 0; g < NPV; ++g) vt_pair(g, vprev);
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-                    for (int g = 0; g < NPV; ++g) pv_one(g);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                stage(t + 1, buf ^ 1, true);
             }
             bias_begin(t);
     #pragma unroll
-            for (int g = 0; g < NQK; ++g) qk_read(STAG ? kv + buf * TILE : kv + buf * TILE2, g);
+            for (int g = 0; g < NQK; ++g) qk_read(kv + buf * TILE2, g);
     #pragma unroll
             for (int g = 0; g < NQK; ++g) qk_one(sa, g);
             // V^T fragments: inline-asm reads (invisible to hipcc's wait insertion), issued as early as the registers allow so that
@@ -636,20 +549,16 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
                 for (int i = 0; i < RPT; ++i) asm volatile("" : "+v"(rh[i]));
             }
             if constexpr (EARLY_VT) {
-                if (!late) {
     #pragma unroll
-                    for (int g = 0; g < NPV; ++g) vt_pair(g, STAG ? vcur : buf);
-                }
+                for (int g = 0; g < NPV; ++g) vt_pair(g, buf);
             }
             float mt = NEG_BIG;
             if (ragged && t + 1 == nt) bias_max(sa, t, 0, 32, mt, true);
             else bias_max(sa, t, 0, 32, mt, false);
             const float off = bias_end(mt);
             if constexpr (!EARLY_VT) {
-                if (!late) {
     #pragma unroll
-                    for (int g = 0; g < NPV; ++g) vt_pair(g, STAG ? vcur : buf);
-                }
+                for (int g = 0; g < NPV; ++g) vt_pair(g, buf);
             }
             WG_STAMP(1);
             probs(sa, off, 0, 32);
@@ -657,28 +566,12 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
             // O^T += V^T . P^T  (operands of the asm reads above: wait for them here, fenced from the MFMAs)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if (!late) {
     #pragma unroll
-                for (int g = 0; g < NPV; ++g) pv_one(g);
-            }
-            vprev = vcur;
-            vcur = vnext;
+            for (int g = 0; g < NPV; ++g) pv_one(g);
             WG_STAMP(3);
-    #if !(defined(WG_ATTN_ABL) && WG_ATTN_ABL == 5)   // (ablation build 5: no per-tile wait / barrier -- wrong results, timing only)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-    #endif
             WG_STAMP(4);
-        }
-        if constexpr (STAG) {
-            if (late && nt > 0) {   // the last tile's P.V (its V tile still sits in its ring slot: nothing was staged after it)
-    #pragma unroll
-                for (int g = 0; g < NPV; ++g) vt_pair(g, vprev);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-    #pragma unroll
-                for (int g = 0; g < NPV; ++g) pv_one(g);
-            }
         }
     }
 
@@ -704,9 +597,6 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
             const float pl = wg_exp2(sv - m_new);
             m_run = m_new;
             l_run = l_run * alpha + (hi == 0 ? pl : 0.f);              // (the two lane halves' sums are added below)
-#if defined(WG_ATTN_MFMA_SUM) && WG_ATTN_MFMA_SUM
-            osum[0] = osum[0] * alpha + pl;                            // (osum already holds both halves)
-#endif
             const bf16* vp = a.V + krow * a.ldv + hcol + 4 * hi;
 #pragma unroll
             for (int d = 0; d < DB; ++d)
@@ -720,11 +610,7 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_kernel(AttnArgs a) {
         }
     }
     // ---- epilogue: O = O^T / l, 8-byte stores ---------------------------------------------------------------------------
-#if defined(WG_ATTN_MFMA_SUM) && WG_ATTN_MFMA_SUM
-    const float l_tot = osum[0];
-#else
     const float l_tot = wg_xor32_sum(l_run);
-#endif
     if (qvalid) {
         const float inv = 1.0f / l_tot;
         long orow;
@@ -1155,9 +1041,6 @@ static int launch_attn_impl(const AttnArgs& a, int groups, hipStream_t st) {
     constexpr int RPT = 64 / RP;
     constexpr int SP = S > 0 ? ((S + RPT - 1) / RPT) * RPT + 1 : 1;
     size_t lds = 2 * TILE;
-#if defined(WG_ATTN_STAGGER) && WG_ATTN_STAGGER
-    if (NW == 8) lds += 64 * ((HD == 80) ? 192 : 2 * (HD == 16 ? 32 : HD));   // the third V buffer of the staggered loop
-#endif
     if (S > 0) lds += (size_t)NW * 32 * SP * 4;
     else lds += (size_t)((a.Lk + 63) / 64) * 64 * 4;
     if (lds > 160 * 1024) {
