@@ -32,7 +32,7 @@ def t_us(fn, n=20):
 
 shapes = [("SAM qkv (LN fold)", 32768, 2304, 768, "ln"), ("SAM lin1 (LN fold + GELU)", 32768, 3072, 768, "ln_gelu"),
           ("SAM proj (+ residual, row sums)", 32768, 768, 768, "res"), ("SAM lin2 (+ residual, row sums)", 32768, 768, 3072, "res"),
-          ("CLIP q|k|v (LN fold)", 8200, 3072, 1024, "ln"), ("CLIP fc1 (LN fold + quick-GELU)", 8200, 4096, 1024, "ln_qgelu"),
+          ("CLIP q,k,v (LN fold)", 8200, 3072, 1024, "ln"), ("CLIP fc1 (LN fold + quick-GELU)", 8200, 4096, 1024, "ln_qgelu"),
           ("CLIP out_proj (+ residual, row sums)", 8200, 1024, 1024, "res"), ("CLIP fc2 (+ residual, row sums)", 8200, 1024, 4096, "res"),
           ("8192^3 (bias only)", 8192, 8192, 8192, "bias")]
 print("# Persistent 256 x 256 GEMM: phases of a tile's life and operand fetch per shape (round 4)\n")
