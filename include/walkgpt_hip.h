@@ -397,6 +397,12 @@ int wg_topk_pool_bf16(const void* u, const void* kt, void* v, int M, int Kt, int
 int wg_topk_pool_bwd_bf16(const void* u, const void* kt, const void* dv, void* du, int M, int Kt, int D, void* stream);
 int wg_nce_tail_f32(const void* z, const void* vp, const float* sim, const int* own_row, float* loss_m, float* lse_m, int M, int rows, int N, int D,
                     float temperature, int exclude_same_row, void* stream);
+/* the same two backward entry points with their upstream gradients in DEVICE memory ({g_bce, g_dice} already scaled by 1 / (num_masks + 1e-8); one
+ * float for the InfoNCE tail): no host read inside a backward pass, so it can be captured into a graph */
+int wg_mask_losses_bwd_dev_f32(const float* pred_logits, const float* targets, float* dpred, float* workspace, long workspace_floats, int N, long hw,
+                               const float* g2, float dice_scale, float dice_eps, void* stream);
+int wg_nce_tail_bwd_dev_f32(const void* z, const void* vp, const float* sim, const int* own_row, const float* lse_m, const float* g, void* dz, void* dvp,
+                            float* dsim, int M, int rows, int N, int D, float temperature, int exclude_same_row, void* stream);
 int wg_nce_tail_bwd_f32(const void* z, const void* vp, const float* sim, const int* own_row, const float* lse_m, float g, void* dz, void* dvp,
                         float* dsim, int M, int rows, int N, int D, float temperature, int exclude_same_row, void* stream);
 

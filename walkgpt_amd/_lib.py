@@ -67,6 +67,9 @@ SIGNATURES = {
     "wg_nce_tail_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                             c_int, c_void_p],
     "wg_attn_pipe_mode": [c_int],
+    "wg_mask_losses_bwd_dev_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_void_p, c_float, c_float, c_void_p],
+    "wg_nce_tail_bwd_dev_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
+                                c_int, c_void_p],
     "wg_f32_gemm_bias_act": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p],
     "wg_f32_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_void_p],
     "wg_f32_mha": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],

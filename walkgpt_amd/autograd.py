@@ -281,10 +281,11 @@ class _MaskLosses(torch.autograd.Function):
         ws = torch.empty(nws, device=pred.device, dtype=torch.float32)
         dpred = torch.empty_like(pred)
         k = 1.0 / (num_masks + 1e-8)
-        gb = float(g_bce) * k if g_bce is not None else 0.0          # (one host read of two scalars per step)
-        gd = float(g_dice) * k if g_dice is not None else 0.0
-        rc = L.wg_mask_losses_bwd_f32(pred.data_ptr(), tgt.data_ptr(), dpred.data_ptr(), ws.data_ptr(), nws, N, hw, gb, gd, scale, eps, ops._stream())
-        _lib.check(rc, "wg_mask_losses_bwd_f32")
+        # the two upstream gradients stay on the device (no host read inside the backward pass)
+        zero = pred.new_zeros(())
+        g2 = (torch.stack([zero if g_bce is None else g_bce.reshape(()).float(), zero if g_dice is None else g_dice.reshape(()).float()]) * k).contiguous()
+        rc = L.wg_mask_losses_bwd_dev_f32(pred.data_ptr(), tgt.data_ptr(), dpred.data_ptr(), ws.data_ptr(), nws, N, hw, g2.data_ptr(), scale, eps, ops._stream())
+        _lib.check(rc, "wg_mask_losses_bwd_dev_f32")
         return dpred, None, None, None, None
 
 
@@ -485,9 +486,10 @@ class _NceTail(torch.autograd.Function):
         rows, N, temperature, exclude = ctx.cfg
         M, D = z.shape
         dz, dvp, dsim = torch.empty_like(z), torch.empty_like(vp), torch.empty_like(sim)
-        rc = _lib.lib().wg_nce_tail_bwd_f32(z.data_ptr(), vp.data_ptr(), sim.data_ptr(), own_row.data_ptr(), lse.data_ptr(), float(g), dz.data_ptr(),
-                                            dvp.data_ptr(), dsim.data_ptr(), M, rows, N, D, temperature, exclude, ops._stream())
-        _lib.check(rc, "wg_nce_tail_bwd_f32")
+        gd = g.reshape(1).float().contiguous()      # stays on the device: no host read inside the backward pass
+        rc = _lib.lib().wg_nce_tail_bwd_dev_f32(z.data_ptr(), vp.data_ptr(), sim.data_ptr(), own_row.data_ptr(), lse.data_ptr(), gd.data_ptr(), dz.data_ptr(),
+                                                dvp.data_ptr(), dsim.data_ptr(), M, rows, N, D, temperature, exclude, ops._stream())
+        _lib.check(rc, "wg_nce_tail_bwd_dev_f32")
         return dz, dvp, dsim, None, None, None, None, None
 
 

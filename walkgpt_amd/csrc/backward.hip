@@ -620,8 +620,10 @@ __global__ __launch_bounds__(256) void wg_topk_pool_kernel(const bf16* u, const 
 //     dz_m (positive term only) = g (p_0 - 1) / (T M) vp_m,  dvp_m = g (p_0 - 1) / (T M) z_m.
 template <bool BWD>
 __global__ __launch_bounds__(256) void wg_nce_tail_kernel(const bf16* z, const bf16* vp, const float* sim, const int* own_row, float* loss_m, float* lse_m,
-                                                          float g, bf16* dz, bf16* dvp, float* dsim, int M, int rows, int N, int D, float inv_t, int exclude) {
+                                                          float g, bf16* dz, bf16* dvp, float* dsim, int M, int rows, int N, int D, float inv_t, int exclude,
+                                                          const float* g_dev = nullptr) {
     __shared__ float red[8];
+    if (BWD && g_dev) g = g_dev[0];      // upstream gradient read on the device (no host synchronisation in the caller's backward pass)
     const int m = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long R = (long)rows * N;
     float pd = 0.f;
@@ -797,8 +799,16 @@ extern "C" int wg_nce_tail_bwd_f32(const void* z, const void* vp, const float* s
                                    float* dsim, int M, int rows, int N, int D, float temperature, int exclude_same_row, void* stream) {
     WG_REQUIRE(z && vp && sim && own_row && lse_m && dz && dvp && dsim && M > 0 && rows > 0 && N > 0 && D > 0 && temperature > 0.f, "nce_tail_bwd: bad arguments");
     hipLaunchKernelGGL(wg_nce_tail_kernel<true>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, (const bf16*)vp, sim, own_row, nullptr,
-                       (float*)lse_m, g, (bf16*)dz, (bf16*)dvp, dsim, M, rows, N, D, 1.0f / temperature, exclude_same_row);
+                       (float*)lse_m, g, (bf16*)dz, (bf16*)dvp, dsim, M, rows, N, D, 1.0f / temperature, exclude_same_row, nullptr);
     return wg_check_launch("wg_nce_tail_bwd_f32");
+}
+// ... with the upstream gradient in device memory (one float)
+extern "C" int wg_nce_tail_bwd_dev_f32(const void* z, const void* vp, const float* sim, const int* own_row, const float* lse_m, const float* g, void* dz, void* dvp,
+                                       float* dsim, int M, int rows, int N, int D, float temperature, int exclude_same_row, void* stream) {
+    WG_REQUIRE(z && vp && sim && own_row && lse_m && g && dz && dvp && dsim && M > 0 && rows > 0 && N > 0 && D > 0 && temperature > 0.f, "nce_tail_bwd_dev: bad arguments");
+    hipLaunchKernelGGL(wg_nce_tail_kernel<true>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16*)z, (const bf16*)vp, sim, own_row, nullptr,
+                       (float*)lse_m, 0.f, (bf16*)dz, (bf16*)dvp, dsim, M, rows, N, D, 1.0f / temperature, exclude_same_row, g);
+    return wg_check_launch("wg_nce_tail_bwd_dev_f32");
 }
 
 extern "C" int wg_avgpool_tokens_bwd_bf16(const void* dy, void* dx, int B, int H, int W, int C, int s, void* stream) {

@@ -558,8 +558,12 @@ extern "C" int wg_mask_losses_f32(const float* pred_logits, const float* targets
 // mean and the upstream gradient).  Per mask: bce_mean' = (s - y) / hw;  dice = 1 - num / den, num = 2 sum(s y) / scale + eps,
 // den = (sum s + sum y) / scale + eps:  d dice / d s_i = (num - 2 y_i den) / (scale den^2),  ds / dx = s (1 - s).
 __global__ __launch_bounds__(256) void wg_mask_losses_bwd_kernel(const float* pred, const float* gt, const float* numden, float* dpred, long hw, float g_bce,
-                                                                 float g_dice, float scale) {
+                                                                 float g_dice, float scale, const float* g_dev) {
     const int n = blockIdx.y;
+    if (g_dev) {   // upstream gradients read on the device (no host synchronisation in the caller's backward pass)
+        g_bce = g_dev[0];
+        g_dice = g_dev[1];
+    }
     const float num = numden[(long)n * 2], den = numden[(long)n * 2 + 1];
     const float kb = g_bce / (float)hw, kd = g_dice / (scale * den * den);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < hw; i += (long)gridDim.x * 256) {
@@ -569,8 +573,20 @@ __global__ __launch_bounds__(256) void wg_mask_losses_bwd_kernel(const float* pr
     }
 }
 
+static int wg_mask_losses_bwd_impl(const float* pred_logits, const float* targets, float* dpred, float* workspace, long workspace_floats, int N, long hw,
+                                   float g_bce, float g_dice, const float* g_dev, float dice_scale, float dice_eps, void* stream);
 extern "C" int wg_mask_losses_bwd_f32(const float* pred_logits, const float* targets, float* dpred, float* workspace, long workspace_floats, int N, long hw,
                                       float g_bce, float g_dice, float dice_scale, float dice_eps, void* stream) {
+    return wg_mask_losses_bwd_impl(pred_logits, targets, dpred, workspace, workspace_floats, N, hw, g_bce, g_dice, nullptr, dice_scale, dice_eps, stream);
+}
+// ... with the two upstream gradients {g_bce, g_dice} in device memory (graph-capturable backward passes: no host read)
+extern "C" int wg_mask_losses_bwd_dev_f32(const float* pred_logits, const float* targets, float* dpred, float* workspace, long workspace_floats, int N, long hw,
+                                          const float* g2, float dice_scale, float dice_eps, void* stream) {
+    WG_REQUIRE(g2, "mask_losses_bwd_dev: null gradient pointer");
+    return wg_mask_losses_bwd_impl(pred_logits, targets, dpred, workspace, workspace_floats, N, hw, 0.f, 0.f, g2, dice_scale, dice_eps, stream);
+}
+static int wg_mask_losses_bwd_impl(const float* pred_logits, const float* targets, float* dpred, float* workspace, long workspace_floats, int N, long hw,
+                                   float g_bce, float g_dice, const float* g_dev, float dice_scale, float dice_eps, void* stream) {
     WG_REQUIRE(pred_logits && targets && dpred && workspace && N > 0 && hw > 0, "mask_losses_bwd: bad arguments");
     const long nblk = wg_mask_stats_blocks(hw);
     WG_REQUIRE(workspace_floats >= (long)N * nblk * 4 + 2L * N, "mask_losses_bwd: workspace too small (need %ld floats)", (long)N * nblk * 4 + 2L * N);
@@ -580,7 +596,7 @@ extern "C" int wg_mask_losses_bwd_f32(const float* pred_logits, const float* tar
     hipLaunchKernelGGL(wg_mask_stats_final_kernel<2>, dim3(N), dim3(64), 0, st, workspace, numden, (int)nblk, hw, dice_scale, dice_eps);
     long gx = (hw + 255) / 256;
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(wg_mask_losses_bwd_kernel, dim3((unsigned)gx, N), dim3(256), 0, st, pred_logits, targets, numden, dpred, hw, g_bce, g_dice, dice_scale);
+    hipLaunchKernelGGL(wg_mask_losses_bwd_kernel, dim3((unsigned)gx, N), dim3(256), 0, st, pred_logits, targets, numden, dpred, hw, g_bce, g_dice, dice_scale, g_dev);
     return wg_check_launch("wg_mask_losses_bwd_f32");
 }
 
