@@ -70,6 +70,7 @@ def parse(argv=None):
     ap.add_argument("--with-msqp", action="store_true", default=None, help="also run the Multi-Scale Query Projector on the SAM tokens")
     ap.add_argument("--tail-tiles", action="store_true", help="allow the tail-absorbing 128x128 GEMM tiles (wins with --single-stream)")
     ap.add_argument("--side-priority", type=int, default=0, help="HIP priority of the CLIP stream (-1 = high)")
+    ap.add_argument("--dec-priority", type=int, default=0, help="HIP priority of the decode stream (-1 = high)")
     ap.add_argument("--clip-skip-unused-layer", action="store_true",
                     help="NOT the headline: stop the CLIP tower after the last hidden state the path reads (hidden_states[-2]); the reference runs "
                          "layer 24 and discards it (clip_encoder.py:77-93).  Same outputs, 1/24 of the tower less; the FLOP count follows")
@@ -390,7 +391,7 @@ def main():
 
     decode_ev = []
     side = torch.cuda.Stream(priority=args.side_priority) if not args.single_stream else None
-    dec = torch.cuda.Stream() if not args.single_stream else None
+    dec = torch.cuda.Stream(priority=args.dec_priority) if not args.single_stream else None
     dec_fn = model.decode_from_hidden if args.no_decode_graph else model.decode_from_hidden_graphed
 
     def step(record_decode=False, serial=False):
