@@ -220,6 +220,12 @@ int wg_tile_weight_bf16(const void* W, long ld, int N, int K, void* tiled, void*
 int wg_dec_tokens_f32(int stages, int skip_pe, float* queries, float* query_pe, const float* init_tokens, const void* init_prompt,
                       const void* const* weights, int n_weights, float* q_t2i, const float* attn_partials, int n_splits, const float* mlp_partials, void* k_i2t, void* v_i2t, int P,
                       float eps, void* stream);
+/* The first launch of a decode (INIT set) with the text projector's tail (utils_walkgpt.py:324-327) folded in: init_prompt [P,256] bf16 = the rows
+ * BEFORE the tail (output of CalibratedTextProjector.net[3]); prompt_tail = {net[4] gamma, beta, text_type, log_temp} (bf16; 256 / 256 / 256 / 1
+ * elements), prompt_tail_eps = net[4].eps.  Same bits as wg_ctp_tail_bf16 followed by wg_dec_tokens_f32. */
+int wg_dec_tokens_ctp_f32(int stages, int skip_pe, float* queries, float* query_pe, const float* init_tokens, const void* init_prompt,
+                          const void* const* prompt_tail, float prompt_tail_eps, const void* const* weights, int n_weights, float* q_t2i,
+                          const float* attn_partials, int n_splits, const float* mlp_partials, void* k_i2t, void* v_i2t, int P, float eps, void* stream);
 int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const void* Vimg, long ld_img, int head_stride, long img_rows_per_prompt,
                             const int* prompt_image, int hw,
                             float* partials, int n_splits, int P, void* stream);
@@ -248,6 +254,10 @@ int wg_postprocess_masks_f32(const float* low_res, float* out, int N, int low_h,
 long wg_postprocess_score_workspace_floats(int N, int out_h, int out_w);
 int wg_postprocess_masks_score_f32(const float* low_res, float* out, float* score, float* workspace, long workspace_floats, int N, int low_h,
                                    int low_w, int img_size, int in_h, int in_w, int out_h, int out_w, void* stream);
+/* The same in ONE launch (the workgroup that completes a mask folds its partials; same pixels, scores up to the summation order): `tickets` = N words, zero before the first call and
+ * left zero by every call; calls that share them must be ordered (one stream). */
+int wg_postprocess_masks_score_fused_f32(const float* low_res, float* out, float* score, float* workspace, long workspace_floats, unsigned* tickets,
+                                         int N, int low_h, int low_w, int img_size, int in_h, int in_w, int out_h, int out_w, void* stream);
 long wg_mask_score_workspace_floats(int N, long hw);
 int wg_mask_score_f32(const float* masks, float* score, float* workspace, long workspace_floats, int N, long hw,
                       void* stream);

@@ -97,6 +97,25 @@ def test_postprocess_and_score(dev, lh, img, inp, orig):
     # the one-pass form (postprocess + score): the same pixels bit for bit, the same score up to the summation order
     out2, sc2 = ops.postprocess_masks_scored(m.to(dev), img, inp, orig)
     assert torch.equal(out2, out[:, 0]) and torch.allclose(sc2.cpu(), sc, atol=1e-6)
+    # ... which is ONE launch (the workgroup that completes a mask folds its partials): the same pixels as the two-launch entry, the same score
+    # up to the summation order (its workgroups cover eight rows), and the same bits call after call (no race in the hand-over; the
+    # tickets go back to zero)
+    from walkgpt_amd import _lib
+    L = _lib.lib()
+    md = m.to(dev)
+    N, H0, W0 = 3, orig[0], orig[1]
+    nws = L.wg_postprocess_score_workspace_floats(N, H0, W0)
+    ws, o3, s3 = torch.empty(nws, device=dev), torch.empty(N, H0, W0, device=dev), torch.empty(N, device=dev)
+    rc = L.wg_postprocess_masks_score_f32(md.data_ptr(), o3.data_ptr(), s3.data_ptr(), ws.data_ptr(), nws, N, lh, lh, img, inp[0], inp[1], H0, W0,
+                                          torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    first = None
+    for _ in range(3):
+        out4, sc4 = ops.postprocess_masks_scored(md, img, inp, orig)
+        assert torch.equal(out4, o3) and torch.allclose(sc4, s3, rtol=0, atol=3e-6) and torch.allclose(sc4.cpu(), osam.mask_score(ref[:, 0]), atol=1e-5)
+        first = sc4.clone() if first is None else first
+        assert torch.equal(sc4, first)
+    assert int(ops._score_tickets(torch.device(dev)).abs().sum()) == 0
 
 
 def test_mask_iou_and_losses_vs_reference_golden(dev):

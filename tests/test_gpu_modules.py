@@ -311,6 +311,10 @@ def test_grounding_pipeline_end_to_end_vs_oracle(dev):
         gm, gs = model.decode_from_hidden_graphed(emb_t, hid, resize, orig)
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(em, gm)) and all(torch.equal(a, b) for a, b in zip(es, gs))
+    # the projector's tail folded into the decoder's first token launch (decode_from_hidden) against the unfolded chain (CTP with its own
+    # tail launch, then decode): the same bits -- both call wg_ctp_tail_row
+    pm, ps = model.decode(emb_t, model._project_seg_hidden(hid), resize, orig)
+    assert all(torch.equal(a, b) for a, b in zip(em, pm)) and all(torch.equal(a, b) for a, b in zip(es, ps))
     # a caller that keeps its data in the graph's own input buffers replays without staging copies, same result
     s_emb, s_hid = model.decode_graph_inputs(emb_t, hid, resize, orig)
     s_emb.copy_(emb_t)

@@ -80,6 +80,8 @@ SIGNATURES = {
                              c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_dec_tokens_f32": [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                           c_int, c_float, c_void_p],
+    "wg_dec_tokens_ctp_f32": [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_int,
+                              c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p],
     "wg_dec_attn_partial_f32": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p],
     "wg_dec_mlp_partial_f32": [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "wg_gemm_skinny_ln_supported": [c_int, c_int, c_int, c_long, c_long, c_long],
@@ -92,6 +94,8 @@ SIGNATURES = {
     "wg_postprocess_masks_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_postprocess_masks_score_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                        c_void_p],
+    "wg_postprocess_masks_score_fused_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                             c_int, c_void_p],
     "wg_mask_score_f32": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_void_p],
     "wg_mask_iou_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_void_p],
     "wg_mask_losses_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_float, c_void_p],

@@ -417,6 +417,9 @@ struct TokArgs {
     float* pe;                 // [P, 6, 256] fp32: the prompt tokens as they entered the transformer (query_pe); written by INIT
     const float* init_tokens;  // INIT: [5, 256] fp32 = cat(iou_token.weight, mask_tokens.weight)   (mask_decoder.py:125-128)
     const bf16* init_prompt;   //       [P, 256] bf16 = the sparse prompt embedding of each query  (:129-132)
+    const bf16* tail_g; const bf16* tail_b; const bf16* tail_tt; const bf16* tail_lt; float tail_eps;   // INIT, optional: init_prompt holds the rows
+                               //       BEFORE the text projector's tail (utils_walkgpt.py:324-327), which this launch applies (LayerNorm gamma, beta,
+                               //       text_type, log_temp): the [SEG] embedding is rounded to bf16 exactly as wg_ctp_tail_bf16 leaves it
     AttnW self_attn; NormW norm1;
     LinW t2i_q, t2i_o; NormW norm2;          // (tail: final_attn_token_to_image q / out, norm_final_attn)
     const bf16* lin2_b; NormW norm3;         // SUM_MLP: bias of mlp.lin2, norm3
@@ -642,10 +645,22 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
     __shared__ __attribute__((aligned(16))) bf16 sh[2][8 * (TK_C + 8)], sl[2][8 * (TK_C + 8)];
     const int p = blockIdx.x;
     const int tid = threadIdx.x;
+    const bool tail = (a.stages & ST_INIT) && a.tail_g;
+    if (tail) {                           // the text projector's tail on this prompt's row: one launch (4.6 us of a decode) less
+        if (tid < 64) {
+            float v[8];
+            wg_ctp_tail_row(a.init_prompt + (long)p * TK_C, a.tail_g, a.tail_b, a.tail_tt, a.tail_lt, TK_C, a.tail_eps, tid, v);
+            if (tid * 8 < TK_C) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t0[tid * 8 + e] = (float)(bf16)v[e];
+            }
+        }
+        __syncthreads();
+    }
     for (int i = tid; i < TK_N * TK_C; i += TK_THREADS) {
         float v, pv;
         if (a.stages & ST_INIT) {         // tokens = cat(output tokens, prompt) (mask_decoder.py:125-132) = queries = query_pe of the first block
-            v = pv = i < 5 * TK_C ? a.init_tokens[i] : (float)a.init_prompt[(long)p * TK_C + i - 5 * TK_C];
+            v = pv = i < 5 * TK_C ? a.init_tokens[i] : tail ? t0[i - 5 * TK_C] : (float)a.init_prompt[(long)p * TK_C + i - 5 * TK_C];
             a.pe[(long)p * TK_N * TK_C + i] = pv;
         } else {
             v = a.queries[(long)p * TK_N * TK_C + i];
@@ -661,34 +676,57 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
         pes[i] = pv;
     }
     __syncthreads();
-    if (a.stages & ST_SUM_MLP) {
-        // ---- norm3, then k / v of the image -> token attention (:172-178), one pass ----------------------------------------------------------
+    // SUM_MLP closes a block and the SELF / Q_T2I that follow open the next one: every Linear of both reads the SAME rows (norm3's output, with
+    // and without the positional term), so they are ONE pass over the weights -- the chain is a sequence of L2 round trips through one CU and a
+    // pass costs ~3.5 us whatever its width (round 4: the second launch of a decode ran four passes, 21 us; the last one two).
+    const bool sum = a.stages & ST_SUM_MLP, self = a.stages & ST_SELF, q_t2i = a.stages & ST_Q_T2I;
+    const bool self_in_sum = sum && self, q_in_sum = sum && !self && q_t2i;
+    if (sum) {
+        // ---- norm3, then k / v of the image -> token attention (:172-178) ------------------------------------------------------------------
         tok_layernorm(qs, TK_N, a.norm3, a.eps);
         tok_stage<TK_C>(qs, TK_C, pes, TK_N, sh[0], sl[0]);
         tok_stage<TK_C>(qs, TK_C, nullptr, TK_N, sh[1], sl[1]);
         __syncthreads();
-        const TokJob kv[2] = {{sh[0], sl[0], a.i2t_k, 128, t0, 128, 0, nullptr, 0}, {sh[1], sl[1], a.i2t_v, 128, t1, 128, 0, nullptr, 0}};
-        tok_mm<TK_C, 2>(kv, TK_N);
+        float* ki = t3;                    // [6][128] each
+        float* vi = t3 + TK_N * 128;
+        if (self_in_sum) {                 // + q, k, v of the next block's self attention (:153-160)
+            const int qk = a.skip_pe ? 1 : 0;
+            const TokJob jobs[5] = {{sh[0], sl[0], a.i2t_k, 128, ki, 128, 0, nullptr, 0}, {sh[1], sl[1], a.i2t_v, 128, vi, 128, 0, nullptr, 0},
+                                    {sh[qk], sl[qk], a.self_attn.q, TK_C, t0, TK_C, 0, nullptr, 0},
+                                    {sh[qk], sl[qk], a.self_attn.k, TK_C, t1, TK_C, 0, nullptr, 0},
+                                    {sh[1], sl[1], a.self_attn.v, TK_C, t2, TK_C, 0, nullptr, 0}};
+            tok_mm<TK_C, 5>(jobs, TK_N);
+        } else if (q_in_sum) {             // + q of the token -> image attention that follows (the tail: :96-99)
+            const TokJob jobs[3] = {{sh[0], sl[0], a.i2t_k, 128, ki, 128, 0, nullptr, 0}, {sh[1], sl[1], a.i2t_v, 128, vi, 128, 0, nullptr, 0},
+                                    {sh[0], sl[0], a.t2i_q, 128, t0, 128, 0, nullptr, 0}};
+            tok_mm<TK_C, 3>(jobs, TK_N);
+        } else {
+            const TokJob jobs[2] = {{sh[0], sl[0], a.i2t_k, 128, ki, 128, 0, nullptr, 0}, {sh[1], sl[1], a.i2t_v, 128, vi, 128, 0, nullptr, 0}};
+            tok_mm<TK_C, 2>(jobs, TK_N);
+        }
         for (int i = tid; i < TK_N * 128; i += TK_THREADS) {
-            a.k_i2t[(long)p * TK_N * 128 + i] = (bf16)t0[i];
-            a.v_i2t[(long)p * TK_N * 128 + i] = (bf16)t1[i];
+            a.k_i2t[(long)p * TK_N * 128 + i] = (bf16)ki[i];
+            a.v_i2t[(long)p * TK_N * 128 + i] = (bf16)vi[i];
+            if (q_in_sum) a.q_t2i[(long)p * TK_N * 128 + i] = t0[i];
         }
         __syncthreads();
     }
-    if (a.stages & ST_SELF) {
+    if (self) {
         // ---- self attention (:153-160): layer 0 replaces the queries and skips the positional term; q, k, v in one pass -----------------------
-        tok_stage<TK_C>(qs, TK_C, a.skip_pe ? nullptr : pes, TK_N, sh[0], sl[0]);
-        tok_stage<TK_C>(qs, TK_C, nullptr, TK_N, sh[1], sl[1]);
-        __syncthreads();
-        const TokJob qkv[3] = {{sh[0], sl[0], a.self_attn.q, TK_C, t0, TK_C, 0, nullptr, 0},
-                               {sh[0], sl[0], a.self_attn.k, TK_C, t1, TK_C, 0, nullptr, 0},
-                               {sh[1], sl[1], a.self_attn.v, TK_C, t2, TK_C, 0, nullptr, 0}};
-        tok_mm<TK_C, 3>(qkv, TK_N);
+        if (!self_in_sum) {
+            tok_stage<TK_C>(qs, TK_C, a.skip_pe ? nullptr : pes, TK_N, sh[0], sl[0]);
+            tok_stage<TK_C>(qs, TK_C, nullptr, TK_N, sh[1], sl[1]);
+            __syncthreads();
+            const TokJob qkv[3] = {{sh[0], sl[0], a.self_attn.q, TK_C, t0, TK_C, 0, nullptr, 0},
+                                   {sh[0], sl[0], a.self_attn.k, TK_C, t1, TK_C, 0, nullptr, 0},
+                                   {sh[1], sl[1], a.self_attn.v, TK_C, t2, TK_C, 0, nullptr, 0}};
+            tok_mm<TK_C, 3>(qkv, TK_N);
+        }
         tok_self_attention(t0, t1, t2, t3);
         tok_linear<TK_C>(t3, TK_C, TK_N, a.self_attn.o, TK_C, qs, TK_C, 0, a.skip_pe ? nullptr : qs, TK_C, sh[0], sl[0]);
         tok_layernorm(qs, TK_N, a.norm1, a.eps);
     }
-    if (a.stages & ST_Q_T2I) {
+    if (q_t2i && !q_in_sum) {
         // ---- q of the token -> image attention (:162-165; tail: :96-101), internal width 128 ------------------------------------------------
         tok_stage<TK_C>(qs, TK_C, pes, TK_N, sh[0], sl[0]);
         __syncthreads();
@@ -913,15 +951,44 @@ extern "C" int wg_tile_weight_bf16(const void* W, long ld, int N, int K, void* t
 // requested may be null), 24 entries:
 //   self_attn q,k,v,out (8) | norm1 (2) | token->image attention q,out (4) | norm2 or norm_final_attn (2) | mlp.lin2 bias (1) + unused (1) |
 //   norm3 (2) | image->token attention k,v (4)
+static int wg_dec_tokens_impl(int stages, int skip_pe, float* queries, float* query_pe, const float* init_tokens, const void* init_prompt,
+                              const void* const* prompt_tail, float prompt_tail_eps, const void* const* weights, int n_weights, float* q_t2i,
+                              const float* attn_partials, int n_splits, const float* mlp_partials, void* k_i2t, void* v_i2t, int P, float eps, void* stream);
+
 extern "C" int wg_dec_tokens_f32(int stages, int skip_pe, float* queries, float* query_pe, const float* init_tokens, const void* init_prompt,
                                  const void* const* weights, int n_weights, float* q_t2i, const float* attn_partials, int n_splits, const float* mlp_partials, void* k_i2t, void* v_i2t,
                                  int P, float eps, void* stream) {
+    return wg_dec_tokens_impl(stages, skip_pe, queries, query_pe, init_tokens, init_prompt, nullptr, 0.f, weights, n_weights, q_t2i, attn_partials, n_splits,
+                              mlp_partials, k_i2t, v_i2t, P, eps, stream);
+}
+
+// The first launch of a decode (stages must carry INIT) with the text projector's tail folded in: init_prompt [P, 256] bf16 holds the rows BEFORE
+// the tail (the output of CalibratedTextProjector.net[3]); prompt_tail = {LayerNorm gamma, beta, text_type, log_temp} (bf16, 256 / 256 / 256 / 1).
+extern "C" int wg_dec_tokens_ctp_f32(int stages, int skip_pe, float* queries, float* query_pe, const float* init_tokens, const void* init_prompt,
+                                     const void* const* prompt_tail, float prompt_tail_eps, const void* const* weights, int n_weights, float* q_t2i,
+                                     const float* attn_partials, int n_splits, const float* mlp_partials, void* k_i2t, void* v_i2t, int P, float eps,
+                                     void* stream) {
+    WG_REQUIRE((stages & ST_INIT) && prompt_tail && prompt_tail[0] && prompt_tail[1] && prompt_tail[2] && prompt_tail[3],
+               "dec_tokens_ctp: the tail is part of INIT and needs gamma, beta, text_type and log_temp");
+    WG_REQUIRE((((uintptr_t)prompt_tail[0] | (uintptr_t)prompt_tail[1] | (uintptr_t)prompt_tail[2] | (uintptr_t)init_prompt) & 15) == 0,
+               "dec_tokens_ctp: misaligned tail operands");
+    return wg_dec_tokens_impl(stages, skip_pe, queries, query_pe, init_tokens, init_prompt, prompt_tail, prompt_tail_eps, weights, n_weights, q_t2i,
+                              attn_partials, n_splits, mlp_partials, k_i2t, v_i2t, P, eps, stream);
+}
+
+static int wg_dec_tokens_impl(int stages, int skip_pe, float* queries, float* query_pe, const float* init_tokens, const void* init_prompt,
+                              const void* const* prompt_tail, float prompt_tail_eps, const void* const* weights, int n_weights, float* q_t2i,
+                              const float* attn_partials, int n_splits, const float* mlp_partials, void* k_i2t, void* v_i2t, int P, float eps, void* stream) {
     WG_REQUIRE(queries && query_pe && weights && n_weights == 24 && P > 0, "dec_tokens: bad arguments");
     WG_REQUIRE(stages > 0 && stages < 32, "dec_tokens: bad stage mask %d", stages);
     WG_REQUIRE(!(stages & ST_INIT) || (init_tokens && init_prompt && !(stages & ST_SUM_MLP)), "dec_tokens: INIT needs the output tokens and the prompt rows (and cannot follow an MLP)");
     TokArgs a{};
     a.stages = stages; a.skip_pe = skip_pe; a.P = P; a.n_splits = n_splits; a.queries = queries; a.pe = query_pe; a.eps = eps;
     a.init_tokens = init_tokens; a.init_prompt = (const bf16*)init_prompt;
+    if (prompt_tail) {
+        a.tail_g = (const bf16*)prompt_tail[0]; a.tail_b = (const bf16*)prompt_tail[1]; a.tail_tt = (const bf16*)prompt_tail[2];
+        a.tail_lt = (const bf16*)prompt_tail[3]; a.tail_eps = prompt_tail_eps;
+    }
     a.q_t2i = q_t2i; a.attn_part = attn_partials; a.mlp_part = mlp_partials; a.k_i2t = (bf16*)k_i2t; a.v_i2t = (bf16*)v_i2t;
     const bf16* const* w = (const bf16* const*)weights;
     auto need = [&](int lo, int hi) { for (int i = lo; i < hi; ++i) if (!w[i] || ((uintptr_t)w[i] & 15)) return false; return true; };

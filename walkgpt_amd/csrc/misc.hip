@@ -261,65 +261,141 @@ extern "C" int wg_hyper_mask_dot(const void* up, const void* hyper, float* masks
 // source-index rule is reproduced exactly: src = max(scale*(dst+0.5)-0.5, 0), i0 = floor, i1 = i0 + (i0 < in-1).
 // Algorithmic bytes: read N*lh*lw*4, write N*out_h*out_w*4.
 // ------------------------------------------------------------------------------------------------------------
+// The four source-index scales of the two resamples (torch: input size / output size in fp32), divided on the host: a device-side `/` under
+// -ffast-math is a reciprocal approximation times the numerator.  (Through double: a ratio of two small integers is never a rounding tie.)
+struct PostScales { float s1y, s1x, s2y, s2x; };
+static PostScales wg_post_scales(int lh, int lw, int img, int in_h, int in_w, int out_h, int out_w) {
+    return PostScales{(float)((double)lh / (double)img), (float)((double)lw / (double)img), (float)((double)in_h / (double)out_h),
+                      (float)((double)in_w / (double)out_w)};
+}
+
+// One IEEE operation, one rounding, whatever the translation unit's floating-point mode: HIP's __fmul_rn / __fadd_rn are plain `*` / `+` unless
+// OCML_BASIC_ROUNDED_OPERATIONS is defined, and under -ffast-math the back end fuses and re-associates them (differently from one
+// instantiation of a kernel to the next: the fused-score form of the postprocess kernel differed from the plain one by an ulp in column 0).
+__device__ __forceinline__ float wg_mul_rn(float a, float b) { float r; asm("v_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float wg_add_rn(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float wg_sub_rn(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ void wg_src_index(int dst, float scale, int in_size, int& i0, int& i1, float& l1) {
     // separate roundings (no FMA contraction) so the source index and weight match PyTorch's CPU kernel bit for bit
-    float s = __fsub_rn(__fmul_rn(scale, (float)dst + 0.5f), 0.5f);
+    float s = wg_sub_rn(wg_mul_rn(scale, (float)dst + 0.5f), 0.5f);
     s = s < 0.f ? 0.f : s;
     i0 = (int)s;
     i0 = i0 < in_size - 1 ? i0 : in_size - 1;
     i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
-    l1 = s - (float)i0;
+    l1 = wg_sub_rn(s, (float)i0);
 }
 
 // grid (output column blocks, output rows, masks): no 64-bit index division per pixel (the first version spent more on `i % out_w` than on
 // the sixteen taps); the four first-resample index sets a pixel needs (two rows, two columns) are formed once and shared by its four taps.
 // SCORE: the workgroup also leaves {sum of sigmoid(x) over x > 0, count of x > 0} of its 256 pixels in score_ws -- the first pass of the mask
 // score (model/walkgpt.py:540-542) without reading the masks back.
-template <bool SCORE>
-__global__ __launch_bounds__(256) void wg_postprocess_kernel(const float* low, float* out, float* score_ws, int N, int lh, int lw, int img,
-                                                             int in_h, int in_w, int out_h, int out_w) {
+// SCORE 2: the second pass too -- the workgroup whose arrival completes a mask (an agent-scope ticket per mask: `tickets`, zero before the first
+// launch and left zero) folds that mask's partials in the order wg_mask_score_final_kernel uses and writes score[n]: one dependent launch
+// (4.2 us of a 211-us decode) less.  Hand-over as MI355X_MICROARCH.md prescribes for "the workgroup whose add came last": the partial is ONE
+// 8-byte sc1 store by the lane that then drains it (s_waitcnt vmcnt(0)) and adds; the last arriver's wave reads every partial with sc1 loads
+// after its add has returned (and one acquire, in that workgroup only) -- no release fence, no L2 write-back.
+template <int SCORE, int ROWS>
+__global__ __launch_bounds__(256) void wg_postprocess_kernel(const float* __restrict__ low, float* __restrict__ out, float* score_ws, int N, int lh, int lw, PostScales sc,
+                                                             int in_h, int in_w, int out_h, int out_w, float* score, unsigned* tickets) {
     __shared__ float ssum[4], scnt[4];
-    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y, n = blockIdx.z;
-    float res = 0.f;       // (a pixel outside the row contributes nothing to the score)
+    __shared__ unsigned last;
+    const int ox = blockIdx.x * 256 + threadIdx.x, n = blockIdx.z;
+    float s_ = 0.f, c_ = 0.f;     // (a pixel outside the row contributes nothing to the score)
     if (ox < out_w) {
-    const float s1y = (float)lh / (float)img, s1x = (float)lw / (float)img;
-    const float s2y = (float)in_h / (float)out_h, s2x = (float)in_w / (float)out_w;
-    const float* m = low + (long)n * lh * lw;
-    int y0, y1, x0, x1;
-    float ly, lx;
-    wg_src_index(oy, s2y, in_h, y0, y1, ly);
-    wg_src_index(ox, s2x, in_w, x0, x1, lx);
-    int ya[2][2], xa[2][2];          // [second-resample tap][first-resample tap]
-    float lya[2], lxa[2];
-    wg_src_index(y0, s1y, lh, ya[0][0], ya[0][1], lya[0]);
-    wg_src_index(y1, s1y, lh, ya[1][0], ya[1][1], lya[1]);
-    wg_src_index(x0, s1x, lw, xa[0][0], xa[0][1], lxa[0]);
-    wg_src_index(x1, s1x, lw, xa[1][0], xa[1][1], lxa[1]);
-    float up[2][2];                  // the img^2 intermediate at (y0|y1, x0|x1), operation by operation as torch's first resample
+        const float s1y = sc.s1y, s1x = sc.s1x, s2y = sc.s2y, s2x = sc.s2x;
+        const float* m = low + (long)n * lh * lw;
+        // the column taps of this thread's output column are the same for every row the workgroup covers (ROWS of them: the fused score wants
+        // few, fat workgroups -- its tickets are adds to ONE word per mask and serialise at ~13 ns each)
+        int x0, x1, xa[2][2];            // [second-resample tap][first-resample tap]
+        float lx, lxa[2];
+        wg_src_index(ox, s2x, in_w, x0, x1, lx);
+        wg_src_index(x0, s1x, lw, xa[0][0], xa[0][1], lxa[0]);
+        wg_src_index(x1, s1x, lw, xa[1][0], xa[1][1], lxa[1]);
+        // rows in chunks of up to four: all 64 taps of a chunk are requested before the first is used (row by row, a store between two rows' loads
+        // made every row its own memory round trip); rows past the image repeat the last one and are not stored
+        constexpr int CH = ROWS < 4 ? ROWS : 4;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+        for (int r0 = 0; r0 < ROWS; r0 += CH) {
+            float tap[CH][2][2][4], ly[CH], lya[CH][2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float a = m[ya[j][0] * lw + xa[i][0]], b = m[ya[j][0] * lw + xa[i][1]];
-            const float c = m[ya[j][1] * lw + xa[i][0]], d = m[ya[j][1] * lw + xa[i][1]];
-            up[j][i] = __fadd_rn(__fmul_rn(1.f - lya[j], __fadd_rn(__fmul_rn(1.f - lxa[i], a), __fmul_rn(lxa[i], b))),
-                                 __fmul_rn(lya[j], __fadd_rn(__fmul_rn(1.f - lxa[i], c), __fmul_rn(lxa[i], d))));
+            for (int r = 0; r < CH; ++r) {
+                const int oy = blockIdx.y * ROWS + r0 + r;
+                int y0, y1, ya[2][2];
+                wg_src_index(oy < out_h ? oy : out_h - 1, s2y, in_h, y0, y1, ly[r]);
+                wg_src_index(y0, s1y, lh, ya[0][0], ya[0][1], lya[r][0]);
+                wg_src_index(y1, s1y, lh, ya[1][0], ya[1][1], lya[r][1]);
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        tap[r][j][i][0] = m[ya[j][0] * lw + xa[i][0]]; tap[r][j][i][1] = m[ya[j][0] * lw + xa[i][1]];
+                        tap[r][j][i][2] = m[ya[j][1] * lw + xa[i][0]]; tap[r][j][i][3] = m[ya[j][1] * lw + xa[i][1]];
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < CH; ++r) {
+                const int oy = blockIdx.y * ROWS + r0 + r;
+                float up[2][2];              // the img^2 intermediate at (y0|y1, x0|x1), operation by operation as torch's first resample
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const float wy = wg_sub_rn(1.f, lya[r][j]), wx = wg_sub_rn(1.f, lxa[i]);
+                        up[j][i] = wg_add_rn(wg_mul_rn(wy, wg_add_rn(wg_mul_rn(wx, tap[r][j][i][0]), wg_mul_rn(lxa[i], tap[r][j][i][1]))),
+                                             wg_mul_rn(lya[r][j], wg_add_rn(wg_mul_rn(wx, tap[r][j][i][2]), wg_mul_rn(lxa[i], tap[r][j][i][3]))));
+                    }
+                const float vy = wg_sub_rn(1.f, ly[r]), vx = wg_sub_rn(1.f, lx);
+                const float res = wg_add_rn(wg_mul_rn(vy, wg_add_rn(wg_mul_rn(vx, up[0][0]), wg_mul_rn(lx, up[0][1]))),
+                                            wg_mul_rn(ly[r], wg_add_rn(wg_mul_rn(vx, up[1][0]), wg_mul_rn(lx, up[1][1]))));
+                if (oy < out_h) {
+                    out[((long)n * out_h + oy) * out_w + ox] = res;
+                    if (SCORE != 0 && res > 0.f) { s_ += 1.0f / (1.0f + __expf(-res)); c_ += 1.f; }
+                }
+            }
         }
-    res = __fadd_rn(__fmul_rn(1.f - ly, __fadd_rn(__fmul_rn(1.f - lx, up[0][0]), __fmul_rn(lx, up[0][1]))),
-                    __fmul_rn(ly, __fadd_rn(__fmul_rn(1.f - lx, up[1][0]), __fmul_rn(lx, up[1][1]))));
-    out[((long)n * out_h + oy) * out_w + ox] = res;
     }
-    if constexpr (SCORE) {
-        float s_ = 0.f, c_ = 0.f;
-        if (res > 0.f) { s_ = 1.0f / (1.0f + __expf(-res)); c_ = 1.f; }
+    if constexpr (SCORE != 0) {
         s_ = wg_wave_sum(s_);
         c_ = wg_wave_sum(c_);
         if ((threadIdx.x & 63) == 0) { ssum[threadIdx.x >> 6] = s_; scnt[threadIdx.x >> 6] = c_; }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            const long blk = ((long)n * out_h + oy) * gridDim.x + blockIdx.x;
-            score_ws[blk * 2 + 0] = ssum[0] + ssum[1] + ssum[2] + ssum[3];
-            score_ws[blk * 2 + 1] = scnt[0] + scnt[1] + scnt[2] + scnt[3];
+        const int nblk = (int)(gridDim.y * gridDim.x);
+        const long blk = (long)n * nblk + blockIdx.y * gridDim.x + blockIdx.x;
+        if constexpr (SCORE == 1) {
+            if (threadIdx.x == 0) {
+                score_ws[blk * 2 + 0] = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+                score_ws[blk * 2 + 1] = scnt[0] + scnt[1] + scnt[2] + scnt[3];
+            }
+        } else {
+            if (threadIdx.x == 0) {
+                const f32x2 pr = {ssum[0] + ssum[1] + ssum[2] + ssum[3], scnt[0] + scnt[1] + scnt[2] + scnt[3]};
+                __hip_atomic_store((unsigned long long*)(score_ws + blk * 2), __builtin_bit_cast(unsigned long long, pr), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned t = __hip_atomic_fetch_add(tickets + n, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = t == (unsigned)nblk - 1u ? 1u : 0u;
+                if (t == (unsigned)nblk - 1u) {   // (several workgroups share a CU here, outside what the guide measured sc1 loads alone for: + the acquire)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                }
+            }
+            __syncthreads();                      // (the ticket's return is behind this barrier for every wave of the workgroup)
+            if (last && threadIdx.x < 64) {
+                float s = 0.f, c = 0.f;
+                for (int i = threadIdx.x; i < nblk; i += 64) {
+                    const unsigned long long raw = __hip_atomic_load((const unsigned long long*)(score_ws + ((long)n * nblk + i) * 2), __ATOMIC_RELAXED,
+                                                                     __HIP_MEMORY_SCOPE_AGENT);
+                    const f32x2 pr = __builtin_bit_cast(f32x2, raw);
+                    s += pr.x;
+                    c += pr.y;
+                }
+                s = wg_wave_sum(s);
+                c = wg_wave_sum(c);
+                if (threadIdx.x == 0) {
+                    score[n] = s / (c + 1e-6f);
+                    __hip_atomic_store(tickets + n, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+                }
+            }
         }
     }
 }
@@ -372,8 +448,9 @@ extern "C" int wg_postprocess_masks_f32(const float* low_res, float* out, int N,
     WG_REQUIRE(in_h > 0 && in_w > 0 && in_h <= img_size && in_w <= img_size && out_h > 0 && out_w > 0,
                "postprocess: crop (%d,%d) must lie inside the %d^2 padded image", in_h, in_w, img_size);
     WG_REQUIRE(out_h <= 65535 && N <= 65535, "postprocess: more than 65535 output rows or masks per call");
-    hipLaunchKernelGGL(wg_postprocess_kernel<false>, dim3((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)N), dim3(256), 0,
-                       (hipStream_t)stream, low_res, out, nullptr, N, low_h, low_w, img_size, in_h, in_w, out_h, out_w);
+    hipLaunchKernelGGL((wg_postprocess_kernel<0, 1>), dim3((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)N), dim3(256), 0,
+                       (hipStream_t)stream, low_res, out, nullptr, N, low_h, low_w, wg_post_scales(low_h, low_w, img_size, in_h, in_w, out_h, out_w), in_h, in_w,
+                       out_h, out_w, nullptr, nullptr);
     return wg_check_launch("wg_postprocess_masks_f32");
 }
 
@@ -451,10 +528,27 @@ extern "C" int wg_postprocess_masks_score_f32(const float* low_res, float* out, 
     WG_REQUIRE(out_h <= 65535 && N <= 65535, "postprocess_score: more than 65535 output rows or masks per call");
     const int gx = (out_w + 255) / 256;
     WG_REQUIRE(workspace_floats >= (long)N * out_h * gx * 2, "postprocess_score: workspace too small (need %ld floats)", (long)N * out_h * gx * 2);
-    hipLaunchKernelGGL(wg_postprocess_kernel<true>, dim3((unsigned)gx, (unsigned)out_h, (unsigned)N), dim3(256), 0, (hipStream_t)stream, low_res, out,
-                       workspace, N, low_h, low_w, img_size, in_h, in_w, out_h, out_w);
+    hipLaunchKernelGGL((wg_postprocess_kernel<1, 1>), dim3((unsigned)gx, (unsigned)out_h, (unsigned)N), dim3(256), 0, (hipStream_t)stream, low_res, out,
+                       workspace, N, low_h, low_w, wg_post_scales(low_h, low_w, img_size, in_h, in_w, out_h, out_w), in_h, in_w, out_h, out_w, nullptr, nullptr);
     hipLaunchKernelGGL(wg_mask_score_final_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, workspace, score, out_h * gx);
     return wg_check_launch("wg_postprocess_masks_score_f32");
+}
+
+// The same in ONE launch: `tickets` holds N words that are zero before the first call and that every call leaves zero (calls sharing them
+// must be ordered, e.g. on one stream); same pixels; scores equal to the two-launch form's up to the summation order (a workgroup
+// covers eight output rows here, one there).
+extern "C" int wg_postprocess_masks_score_fused_f32(const float* low_res, float* out, float* score, float* workspace, long workspace_floats, unsigned* tickets,
+                                                    int N, int low_h, int low_w, int img_size, int in_h, int in_w, int out_h, int out_w, void* stream) {
+    WG_REQUIRE(low_res && out && score && workspace && tickets && N > 0 && low_h > 0 && low_w > 0 && img_size > 0, "postprocess_score_fused: bad arguments");
+    WG_REQUIRE(in_h > 0 && in_w > 0 && in_h <= img_size && in_w <= img_size && out_h > 0 && out_w > 0,
+               "postprocess_score_fused: bad sizes (input %dx%d inside %d, output %dx%d)", in_h, in_w, img_size, out_h, out_w);
+    WG_REQUIRE(((uintptr_t)workspace & 7) == 0, "postprocess_score_fused: the workspace must be 8-byte aligned");
+    const int gx = (out_w + 255) / 256;
+    WG_REQUIRE(workspace_floats >= (long)N * out_h * gx * 2, "postprocess_score_fused: workspace too small (need %ld floats)", (long)N * out_h * gx * 2);
+    constexpr int ROWS = 8;
+    hipLaunchKernelGGL((wg_postprocess_kernel<2, ROWS>), dim3((unsigned)gx, (unsigned)((out_h + ROWS - 1) / ROWS), (unsigned)N), dim3(256), 0, (hipStream_t)stream, low_res, out,
+                       workspace, N, low_h, low_w, wg_post_scales(low_h, low_w, img_size, in_h, in_w, out_h, out_w), in_h, in_w, out_h, out_w, score, tickets);
+    return wg_check_launch("wg_postprocess_masks_score_fused_f32");
 }
 
 // ------------------------------------------------------------------------------------------------------------

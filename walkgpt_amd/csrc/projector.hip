@@ -100,39 +100,12 @@ __global__ __launch_bounds__(256) void wg_ctp_tail_kernel(const bf16* x, long ld
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= M) return;
     const int d = lane * 8;
-    const bool on = d < C;
     float v[8];
-    float s = 0.f;
-    if (on) {
-        const bf16x8 t = *(const bf16x8*)(x + (long)m * ldx + d);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { v[e] = (float)t[e]; s += v[e]; }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = 0.f;
-    }
-    const float mean = wg_wave_sum(s) / (float)C;
-    float q = 0.f;
-    if (on) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float t = v[e] - mean; q += t * t; }
-    }
-    const float rstd = 1.0f / sqrtf(wg_wave_sum(q) / (float)C + eps);
-    float n2 = 0.f;
-    if (on) {
-        const bf16x8 gm = *(const bf16x8*)(gamma + d), bt = *(const bf16x8*)(beta + d), tt = *(const bf16x8*)(text_type + d);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            v[e] = (v[e] - mean) * rstd * (float)gm[e] + (float)bt[e] + (float)tt[e];
-            n2 += v[e] * v[e];
-        }
-    }
-    const float nrm = fmaxf(sqrtf(wg_wave_sum(n2)), 1e-12f);
-    const float sc = __expf((float)log_temp[0]) / nrm;
-    if (on) {
+    wg_ctp_tail_row(x + (long)m * ldx, gamma, beta, text_type, log_temp, C, eps, lane, v);
+    if (d < C) {
         bf16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (bf16)(v[e] * sc);
+        for (int e = 0; e < 8; ++e) o[e] = (bf16)v[e];
         *(bf16x8*)(y + (long)m * ldy + d) = o;
     }
 }

@@ -78,6 +78,38 @@ __device__ __forceinline__ float wg_wave_sum(float v) {
     wg_permlane_swap<0>(v, a, b); v = a + b;
     wg_permlane_swap<1>(v, a, b); return a + b;
 }
+
+// CTP tail of ONE row by one wave (utils_walkgpt.py:321-327): LayerNorm(C) -> + text_type -> L2 normalise (eps 1e-12) -> * exp(log_temp); lane l holds
+// elements 8 l .. 8 l + 7 (C <= 512, C % 8 == 0).  v[e] returns the fp32 results (the caller rounds to bf16).  Shared by wg_ctp_tail_kernel and the
+// INIT stage of wg_dec_tokens_kernel, so the folded form is the same arithmetic bit for bit.
+__device__ __forceinline__ void wg_ctp_tail_row(const bf16* xrow, const bf16* gamma, const bf16* beta, const bf16* text_type, const bf16* log_temp, int C,
+                                                float eps, int lane, float (&v)[8]) {
+    const int d = lane * 8 < C ? lane * 8 : 0;      // (lanes past the row read its first piece and contribute nothing)
+    const bool on = lane * 8 < C;
+    // every operand is requested before the first reduction: the row's statistics are three dependent wave reductions, and loads issued
+    // between them would each add a memory round trip to a chain that is latency from end to end
+    const bf16x8 t = *(const bf16x8*)(xrow + d);
+    const bf16x8 gm = *(const bf16x8*)(gamma + d), bt = *(const bf16x8*)(beta + d), tt = *(const bf16x8*)(text_type + d);
+    const float lt = (float)log_temp[0];
+    float s = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { v[e] = on ? (float)t[e] : 0.f; s += v[e]; }
+    const float mean = wg_wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float u = v[e] - mean; q += on ? u * u : 0.f; }
+    const float rstd = 1.0f / sqrtf(wg_wave_sum(q) / (float)C + eps);
+    float n2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        v[e] = on ? (v[e] - mean) * rstd * (float)gm[e] + (float)bt[e] + (float)tt[e] : 0.f;
+        n2 += v[e] * v[e];
+    }
+    const float nrm = fmaxf(sqrtf(wg_wave_sum(n2)), 1e-12f);
+    const float sc = __expf(lt) / nrm;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] *= sc;
+}
 __device__ __forceinline__ float wg_wave_max(float v) {
     v = fmaxf(v, WG_DPP(v, 0xB1));
     v = fmaxf(v, WG_DPP(v, 0x4E));

@@ -600,11 +600,13 @@ def _f32_tokens(t, P, last):
 
 
 def dec_tokens(stages, skip_pe, queries, query_pe, weights, q_t2i=None, attn_partials=None, mlp_partials=None, k_i2t=None, v_i2t=None,
-               eps=1e-5, init_tokens=None, init_prompt=None):
+               eps=1e-5, init_tokens=None, init_prompt=None, prompt_tail=None):
     """Per-prompt stages of the token side of SAM's two-way transformer (csrc/decoder.hip: wg_dec_tokens_f32; stage bits TOK_*).
     queries / query_pe [P, 6, 256] fp32 (queries updated in place); weights: the 24-slot table the C-ABI documents (bf16 tensors or
     None for the slots of stages that do not run; the weight matrices in fragment order, ops.tile_weight).  TOK_INIT: queries and query_pe are OUTPUTS, both set to
-    cat(init_tokens [5, 256] fp32, init_prompt [P, 256] bf16) before the other stages run."""
+    cat(init_tokens [5, 256] fp32, init_prompt [P, 256] bf16) before the other stages run; with prompt_tail = (gamma, beta, text_type, log_temp
+    bf16 tensors, eps) init_prompt holds the text projector's rows BEFORE its tail and the launch applies the tail (wg_dec_tokens_ctp_f32: same
+    bits as ops.ctp_tail followed by the plain launch)."""
     import ctypes
     _need_gpu(queries, query_pe, q_t2i, attn_partials, mlp_partials, k_i2t, v_i2t, init_tokens, init_prompt, *weights)
     P = queries.shape[0]
@@ -626,6 +628,17 @@ def dec_tokens(stages, skip_pe, queries, query_pe, weights, q_t2i=None, attn_par
         for t in (k_i2t, v_i2t):
             assert t.dtype == _BF16 and t.is_contiguous() and t.shape == (P, 6, 128)
     table = (ctypes.c_void_p * 24)(*[None if w is None else w.data_ptr() for w in weights])
+    if prompt_tail is not None:
+        assert stages & TOK_INIT
+        g_, b_, tt_, lt_, teps = prompt_tail
+        _need_gpu(g_, b_, tt_, lt_)
+        assert all(t.dtype == _BF16 and t.is_contiguous() for t in (g_, b_, tt_, lt_)) and g_.numel() == b_.numel() == tt_.numel() == 256
+        ttab = (ctypes.c_void_p * 4)(g_.data_ptr(), b_.data_ptr(), tt_.data_ptr(), lt_.data_ptr())
+        rc = _lib.lib().wg_dec_tokens_ctp_f32(stages, 1 if skip_pe else 0, queries.data_ptr(), query_pe.data_ptr(), _ptr(init_tokens), _ptr(init_prompt),
+                                              ttab, float(teps), table, 24, _ptr(q_t2i), _ptr(attn_partials), n_splits, _ptr(mlp_partials),
+                                              _ptr(k_i2t), _ptr(v_i2t), P, float(eps), _stream())
+        _lib.check(rc, "wg_dec_tokens_ctp_f32")
+        return queries
     rc = _lib.lib().wg_dec_tokens_f32(stages, 1 if skip_pe else 0, queries.data_ptr(), query_pe.data_ptr(), _ptr(init_tokens), _ptr(init_prompt),
                                       table, 24, _ptr(q_t2i),
                                       _ptr(attn_partials), n_splits, _ptr(mlp_partials), _ptr(k_i2t), _ptr(v_i2t), P, float(eps), _stream())
@@ -778,10 +791,33 @@ def postprocess_masks_scored(low_res, img_size, input_size, original_size):
     L = _lib.lib()
     nws = L.wg_postprocess_score_workspace_floats(N, H0, W0)
     ws = torch.empty(nws, device=low_res.device, dtype=torch.float32)
+    if N <= _SCORE_FUSED_MASKS:
+        # one launch: the workgroup that completes a mask folds its partials (tickets: zero words the kernel leaves zero, one set per stream).
+        # For the few masks of one image's decode, where the chain is latency (-1.3 us of 200); with a batch's masks the fat workgroups of
+        # the fused form cost more than the second launch (8 masks: 19 against 15 us), so those keep the two-launch form
+        rc = L.wg_postprocess_masks_score_fused_f32(low_res.data_ptr(), out.data_ptr(), score.data_ptr(), ws.data_ptr(), nws,
+                                                    _score_tickets(low_res.device).data_ptr(), N, lh, lw, img_size, int(input_size[0]),
+                                                    int(input_size[1]), H0, W0, _stream())
+        _lib.check(rc, "wg_postprocess_masks_score_fused_f32")
+        return out, score
     rc = L.wg_postprocess_masks_score_f32(low_res.data_ptr(), out.data_ptr(), score.data_ptr(), ws.data_ptr(), nws, N, lh, lw, img_size,
                                           int(input_size[0]), int(input_size[1]), H0, W0, _stream())
     _lib.check(rc, "wg_postprocess_masks_score_f32")
     return out, score
+
+
+_SCORE_TICKETS = 64
+_SCORE_FUSED_MASKS = 4
+_score_ticket_cache = {}
+
+
+def _score_tickets(device):
+    """N <= 4096 zero words per (device, stream): launches on one stream are ordered, which is what sharing the tickets needs."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    t = _score_ticket_cache.get(key)
+    if t is None:
+        t = _score_ticket_cache[key] = torch.zeros(_SCORE_TICKETS, device=device, dtype=torch.int32)
+    return t
 
 
 def mask_score(masks):

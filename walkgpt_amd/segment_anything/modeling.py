@@ -560,14 +560,15 @@ class TwoWayTransformer(nn.Module):
         self.final_attn_token_to_image = DecoderAttention(embedding_dim, num_heads, downsample_rate=attention_downsample_rate)
         self.norm_final_attn = nn.LayerNorm(embedding_dim)
 
-    def run_tokens(self, src_tokens, pe_tokens, out_tokens, prompts, src_bias=None, prompt_image=None):
+    def run_tokens(self, src_tokens, pe_tokens, out_tokens, prompts, src_bias=None, prompt_image=None, prompt_tail=None):
         """transformer.py:62-106: the depth TwoWayAttentionBlocks and the final token->image attention + norm_final_attn.
         src_tokens [1|P, hw, C] bf16, pe_tokens [1, hw, C] bf16; out_tokens [5, C] fp32 (iou + mask tokens), prompts [P, 1, C] bf16: the
         point embedding of prompt p is cat(out_tokens, prompts[p]) (mask_decoder.py:125-132), built by the first launch; src_bias [1, C]:
         the image tokens are src_tokens + src_bias (the dense no-mask embedding, mask_decoder.py:136), folded into the first block;
         prompt_image (int32 [P]): src_tokens holds one block per IMAGE and prompt p belongs to image prompt_image[p] -- the reference
         repeats the image embedding per prompt (mask_decoder.py:135); the first block's image-side projection is the same for all prompts of
-        an image, so it runs once per image and the first block's kernels read it through the map
+        an image, so it runs once per image and the first block's kernels read it through the map; prompt_tail (gamma, beta, text_type,
+        log_temp, eps): `prompts` are the text projector's rows BEFORE its tail, applied by the first launch (ops.dec_tokens)
         -> (queries fp32 [P, 6, C] BEFORE the final attention's out_proj + norm_final_attn; the `combine` operands of that step, which
         ops.dec_heads applies in its own launch; keys [P, hw, C] bf16).
         Launch chain per block: tokens[close previous block | self attention | q] -> (previous block's image->token attention, norm4)
@@ -604,7 +605,7 @@ class TwoWayTransformer(nn.Module):
                 bits |= ops.TOK_INIT
             ops.dec_tokens(bits, layer is not None and layer.skip_first_layer_pe, queries, query_pe, table, q_t2i=q, mlp_partials=mlp_part,
                            k_i2t=kq, v_i2t=vq, eps=eps, init_tokens=out_tokens if first else None,
-                           init_prompt=prompts.to(BF16).contiguous() if first else None)
+                           init_prompt=prompts.to(BF16).contiguous() if first else None, prompt_tail=prompt_tail if first else None)
             first = False
             if prev is not None:
                 keys = prev.image_to_token(prev_proj, keys, kq, vq, P, src_bias, prompt_image)
@@ -728,25 +729,29 @@ class MaskDecoder(nn.Module, _Prepared):
                 w += _lin_pair(layer)
         return w
 
-    def predict_masks_tokens(self, src_tokens, pe_tokens, sparse, h, w, mask_slice, src_bias=None, prompt_image=None):
+    def predict_masks_tokens(self, src_tokens, pe_tokens, sparse, h, w, mask_slice, src_bias=None, prompt_image=None, prompt_tail=None):
         """src_tokens [1|P, hw, C] (image embedding + dense prompt, channels-last rows; or the image embedding alone with the dense
         no-mask embedding as src_bias [1, C]; with prompt_image (int32 [P]) one block per image instead of per prompt), pe_tokens [1, hw, C],
         sparse [P, n, C] -> (masks fp32 [P, k, 4h, 4w], iou fp32 [P, k]).
         Launches: TwoWayTransformer.run_tokens, then one kernel for the hypernetwork / IoU heads and one for upscaling + the
-        hypernetwork product."""
+        hypernetwork product.  prompt_tail (gamma, beta, text_type, log_temp, eps): `sparse` [P, 1, C] holds the text projector's rows
+        before its tail (CalibratedTextProjector.pre_tail), which the first token launch applies."""
         p = self._prep_get(self._build_prepared, (self.output_upscaling[0].weight, self.output_upscaling[3].weight, self.iou_token.weight,
                                                   self.mask_tokens.weight))
         P = sparse.shape[0]
         tr = self.transformer
         if self.num_mask_tokens != 4 or self.transformer_dim != 256 or not tr.fused_ok(1 + self.num_mask_tokens, sparse.shape[1]) \
                 or any(m.num_layers != 3 or m.sigmoid_output for m in list(self.output_hypernetworks_mlps) + [self.iou_prediction_head]):
+            if prompt_tail is not None:
+                g_, b_, tt_, lt_, teps = prompt_tail
+                sparse = ops.ctp_tail(sparse.reshape(P, -1).contiguous(), g_, b_, tt_, lt_, teps).reshape(sparse.shape)
             return self._predict_masks_general(src_tokens, pe_tokens, sparse, h, w, mask_slice, src_bias, prompt_image)
         if len(tr.layers) == 0 or not tr.layers[0].fused_i2t_ok(src_tokens, 6):
             if prompt_image is not None:
                 src_tokens, prompt_image = src_tokens.index_select(0, prompt_image.long()), None
             if src_bias is not None:
                 src_tokens, src_bias = ops.add_rows(src_tokens, src_bias), None
-        queries, final, keys = tr.run_tokens(src_tokens, pe_tokens, p["out_tokens_f32"], sparse, src_bias, prompt_image)
+        queries, final, keys = tr.run_tokens(src_tokens, pe_tokens, p["out_tokens_f32"], sparse, src_bias, prompt_image, prompt_tail)
         hyper, iou = ops.dec_heads(queries, self.head_weights(), combine=final, eps=tr.norm_final_attn.eps)
         ln1 = self.output_upscaling[1]
         k0, nk = mask_slice

@@ -162,7 +162,8 @@ class CalibratedTextProjector(nn.Module):
                 ent = cache[id(weight)] = (key, ops.tile_weight(weight.detach().contiguous()))
         return ent[1]
 
-    def forward(self, x):
+    def pre_tail(self, x):
+        """net[0..3] of :321-323: LayerNorm -> Linear -> GELU -> Linear, [.., in_dim] -> [.., out_dim] (before net[4], text_type, normalise)."""
         _check_bf16_gpu(x, "hidden states")
         if self.use_residual:
             raise NotImplementedError("use_residual=True is never configured by WalkGPT (walkgpt.py:115-123)")
@@ -171,8 +172,15 @@ class CalibratedTextProjector(nn.Module):
         few = x.numel() // x.shape[-1] <= 128         # up to 128 [SEG] rows: one-launch skinny GEMMs on weights kept in fragment order
         t1, t3 = (self._tiled(self.net[1].weight), self._tiled(self.net[3].weight)) if few else (None, None)
         y = ops.layernorm_linear(x, ln.weight, ln.bias, ln.eps, self.net[1].weight, self.net[1].bias, act=ops.ACT_GELU, weight_tiled=t1)
-        y = ops.layernorm_linear(y, None, None, 0.0, self.net[3].weight, self.net[3].bias, weight_tiled=t3)
-        return ops.ctp_tail(y, self.net[4].weight, self.net[4].bias, self.text_type.reshape(-1), self.log_temp, self.net[4].eps)
+        return ops.layernorm_linear(y, None, None, 0.0, self.net[3].weight, self.net[3].bias, weight_tiled=t3)
+
+    def tail_operands(self):
+        """(gamma, beta, text_type, log_temp, eps) of the tail (:324-327): ops.ctp_tail's operands, also taken by the mask decoder's first
+        token launch, which applies the tail itself on the inference path (WalkGPTGrounding.decode_from_hidden)."""
+        return (self.net[4].weight, self.net[4].bias, self.text_type.reshape(-1), self.log_temp, self.net[4].eps)
+
+    def forward(self, x):
+        return ops.ctp_tail(self.pre_tail(x), *self.tail_operands())
 
 
 class TinyCrossAttn(nn.Module, _Prepared):

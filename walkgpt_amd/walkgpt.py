@@ -161,12 +161,14 @@ class WalkGPTGrounding(nn.Module):
 
     # -- walkgpt.py:713-737 --------------------------------------------------------------------------------------------------------
     def decode(self, emb_tokens, pred_embeddings: Sequence[torch.Tensor], resize_list, original_size_list,
-               multimask_output=False) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
+               multimask_output=False, prompt_tail=None) -> Tuple[List[torch.Tensor], List[torch.Tensor]]:
         """emb_tokens [B, hw, 256]; pred_embeddings[i] [T_i, 256] -> (pred_masks[i] fp32 [T_i, H0, W0], mask_scores[i] [T_i]).
 
         The reference decodes image by image (walkgpt.py:716-737); here every prompt of every image goes through the
         prompt encoder / two-way decoder as ONE batch of P = sum(T_i) prompts (prompt p attends to the embedding of
-        its own image), and only the size-dependent postprocess runs per image.  Same arithmetic per prompt."""
+        its own image), and only the size-dependent postprocess runs per image.  Same arithmetic per prompt.
+        prompt_tail (CalibratedTextProjector.tail_operands()): pred_embeddings are the projector's rows BEFORE its tail
+        (CalibratedTextProjector.pre_tail), which the decoder's first token launch applies -- one launch less, same bits."""
         vm = self.visual_model
         h, w = vm.prompt_encoder.image_embedding_size
         dev = emb_tokens.device
@@ -190,7 +192,8 @@ class WalkGPTGrounding(nn.Module):
                 src = emb_tokens       # one block per image; the decoder's first block reads it through the prompt -> image map
                 pimg = self._prompt_image_index(tuple(counts), dev)
             # (+ the dense no-mask embedding, mask_decoder.py:136: folded into the decoder's first block instead of a pass over src)
-            low_res, _iou = vm.mask_decoder.predict_masks_tokens(src, pe, sparse, h, w, sl, src_bias=no_mask, prompt_image=pimg)
+            low_res, _iou = vm.mask_decoder.predict_masks_tokens(src, pe, sparse, h, w, sl, src_bias=no_mask, prompt_image=pimg,
+                                                                 prompt_tail=prompt_tail)
             off = 0
             same = len(set(zip(map(tuple, resize_list), map(tuple, original_size_list)))) == 1
             if same and sl[1] == 1:
@@ -261,17 +264,20 @@ class WalkGPTGrounding(nn.Module):
             s_all = torch.cat(list(seg_hidden), 0)        # one buffer for every image's [SEG] rows: one copy per replay, no cat inside
             s_hid = list(torch.split(s_all, [int(h.shape[0]) for h in seg_hidden], 0))
             s_emb.copy_(emb_tokens)
-            warm = torch.cuda.Stream()
-            warm.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(warm), torch.no_grad():
-                for _ in range(2):   # first-use work (attribute settings, caches) must not fall inside the capture
+            # warm-up and capture on ONE stream of the graph's own (kept with it): first-use work (attribute settings, caches, the
+            # per-stream ticket words of ops.postprocess_masks_scored) must not fall inside the capture, where an allocation + fill
+            # would become a node of every replay
+            cap = torch.cuda.Stream()
+            cap.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cap), torch.no_grad():
+                for _ in range(2):
                     self.decode_from_hidden(s_emb, s_hid, resize_list, original_size_list)
-            torch.cuda.current_stream().wait_stream(warm)
+            torch.cuda.current_stream().wait_stream(cap)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g), torch.no_grad():
+            with torch.cuda.graph(g, stream=cap), torch.no_grad():
                 out = self.decode_from_hidden(s_emb, s_hid, resize_list, original_size_list)
-            ent = graphs[key] = (g, s_emb, s_all, out, wkey)
-        g, s_emb, s_all, out, _ = ent
+            ent = graphs[key] = (g, s_emb, s_all, out, wkey, cap)
+        g, s_emb, s_all, out = ent[:4]
         # staging copies into the graph's static inputs -- skipped for an input that IS the static buffer (callers that keep their
         # data in the buffers `decode_graph_inputs` hands out: the two copies are 9 of a one-image decode's ~220 microseconds)
         if emb_tokens.data_ptr() != s_emb.data_ptr():
@@ -292,20 +298,24 @@ class WalkGPTGrounding(nn.Module):
         self.decode_from_hidden_graphed(emb_tokens, seg_hidden, resize_list, original_size_list)
         key = (tuple(emb_tokens.shape), tuple(tuple(h.shape) for h in seg_hidden), tuple(map(tuple, resize_list)),
                tuple(map(tuple, original_size_list)), str(emb_tokens.device), seg_hidden[0].dtype if seg_hidden else None)
-        _, s_emb, s_all, _, _ = self._decode_graphs[key]
+        s_emb, s_all = self._decode_graphs[key][1:3]
         return s_emb, list(torch.split(s_all, [int(h.shape[0]) for h in seg_hidden], 0))
 
     def decode_from_hidden(self, emb_tokens, seg_hidden: Sequence[torch.Tensor], resize_list, original_size_list):
         """seg_hidden[i] [T_i, H_llm]: last-layer LLM states at the positions preceding each [SEG] (walkgpt.py:406-447;
         CTP is per token, so projecting only the gathered rows equals projecting the sequence and gathering)."""
-        return self.decode(emb_tokens, self._project_seg_hidden(seg_hidden), resize_list, original_size_list)
+        ctp = self.text_hidden_fcs[0]
+        return self.decode(emb_tokens, self._project_seg_hidden(seg_hidden, tail=False), resize_list, original_size_list,
+                           prompt_tail=ctp.tail_operands())
 
-    def _project_seg_hidden(self, seg_hidden):
-        """CTP over all images' [SEG] rows in one call, split back per image."""
+    def _project_seg_hidden(self, seg_hidden, tail=True):
+        """CTP over all images' [SEG] rows in one call, split back per image (tail=False: without the projector's tail, for decode(prompt_tail=))."""
         counts = [int(h.shape[0]) for h in seg_hidden]
         if sum(counts) == 0:
             return [h.new_zeros(0, 256) for h in seg_hidden]
-        pred = self.text_hidden_fcs[0](self._cat_rows(seg_hidden))
+        ctp = self.text_hidden_fcs[0]
+        rows = self._cat_rows(seg_hidden)
+        pred = ctp(rows) if tail else ctp.pre_tail(rows)
         return list(torch.split(pred, counts, 0))
 
     @torch.no_grad()
@@ -332,10 +342,10 @@ class WalkGPTGrounding(nn.Module):
         emb_tokens = self.get_visual_emb_tokens(images)
         if hasattr(self, "out_mm_projector"):
             out["visual_tokens"] = self.project_visual_tokens(emb_tokens)
-            pred = self._project_seg_hidden(seg_hidden)
+            pred, tail = self._project_seg_hidden(seg_hidden, tail=False), self.text_hidden_fcs[0].tail_operands()
         else:
-            pred = list(seg_hidden)  # already 256-d prompt embeddings
-        out["pred_masks"], out["mask_scores"] = self.decode(emb_tokens, pred, resize_list, original_size_list)
+            pred, tail = list(seg_hidden), None  # already 256-d prompt embeddings
+        out["pred_masks"], out["mask_scores"] = self.decode(emb_tokens, pred, resize_list, original_size_list, prompt_tail=tail)
         if side is not None:
             cur = torch.cuda.current_stream()
             cur.wait_stream(side)
