@@ -405,6 +405,10 @@ int wg_attn_pipe_mode(int mode);
 int wg_debug_fill_lds_u32(unsigned pattern, void* sink, void* stream);
 int wg_topk_pool_bf16(const void* u, const void* kt, void* v, int M, int Kt, int D, void* stream);
 int wg_topk_pool_bwd_bf16(const void* u, const void* kt, const void* dv, void* du, int M, int Kt, int D, void* stream);
+/* The same pooling over any number of tokens (top_k > 16; or no top_k at all, utils_walkgpt.py:338-356: TinyCrossAttn's softmax over the whole row,
+ * W_v / out applied to the pooled token by the caller): tokens [rows, Kt, D] bf16 constants, query m pools row row_of[m] (null: row m). */
+int wg_pool_rows_bf16(const void* u, const void* tokens, const int* row_of, void* v, int M, int Kt, int D, void* stream);
+int wg_pool_rows_bwd_bf16(const void* u, const void* tokens, const int* row_of, const void* dv, void* du, int M, int Kt, int D, void* stream);
 int wg_nce_tail_f32(const void* z, const void* vp, const float* sim, const int* own_row, float* loss_m, float* lse_m, int M, int rows, int N, int D,
                     float temperature, int exclude_same_row, void* stream);
 /* the same two backward entry points with their upstream gradients in DEVICE memory ({g_bce, g_dice} already scaled by 1 / (num_masks + 1e-8); one

@@ -287,10 +287,12 @@ def test_msqp_splice_path_vs_oracle_autograd(dev):
           % (rel(embeds, emb_r), worst[1], worst[0], worst16[1], worst16[0]))
 
 
-@pytest.mark.parametrize("rows,exclude", [(3, True), (1, False)])
-def test_infonce_training_path_vs_oracle_autograd(dev, rows, exclude):
-    """Region-alignment InfoNCE (top_k = 8) through walkgpt_amd.train_head.infonce_loss: the loss and its gradients on the [SEG] embeddings and on
-    TinyCrossAttn's wq / wk against torch autograd over the oracle's restatement."""
+@pytest.mark.parametrize("rows,exclude,top_k", [(3, True, 8), (1, False, 8), (3, True, 40), (2, True, None), (1, False, 5000)])
+def test_infonce_training_path_vs_oracle_autograd(dev, rows, exclude, top_k):
+    """Region-alignment InfoNCE through walkgpt_amd.train_head.infonce_loss: the loss and its gradients on the [SEG] embeddings and on
+    TinyCrossAttn's projections against torch autograd over the oracle's restatement -- top_k = 8 (what model/walkgpt.py:469 passes), a top_k
+    beyond the wave-per-query kernel's 16, and the function's own default (top_k None, or >= N: no refinement, utils_walkgpt.py:36), where the
+    positive is TinyCrossAttn's output and wv / out train too."""
     from oracle import metrics as om
     from walkgpt_amd import train_head
     from walkgpt_amd.utils_walkgpt import TinyCrossAttn
@@ -305,27 +307,62 @@ def test_infonce_training_path_vs_oracle_autograd(dev, rows, exclude):
     sam = torch.randn(rows, N, D, generator=g).to(torch.bfloat16)
     ids = torch.randint(0, rows, (M,), generator=g)
     ph = _leaf(pred, dev)
-    loss = train_head.infonce_loss(ph, sam.to(dev), ids.to(dev), tx, temperature=0.07, top_k=8, exclude_same_row=exclude)
+    loss = train_head.infonce_loss(ph, sam.to(dev), ids.to(dev), tx, temperature=0.07, top_k=top_k, exclude_same_row=exclude)
     loss.backward()
 
     def oracle_run(dt):
         w = {k: v.detach().cpu().to(dt).clone().requires_grad_(True) for k, v in tx.state_dict().items()}
         pr = pred.detach().to(dt).clone().requires_grad_(True)
-        lr, _ = om.infonce_loss(w, pr, sam.to(dt), ids, temperature=0.07, top_k=8, exclude_same_row=exclude)
+        lr, _ = om.infonce_loss(w, pr, sam.to(dt), ids, temperature=0.07, top_k=top_k, exclude_same_row=exclude)
         lr.backward()
         return lr, pr.grad, w
     l32, g32, w32 = oracle_run(torch.float32)
     l16, g16, w16 = oracle_run(torch.bfloat16)
     e, e16 = rel(ph.grad, g32), rel(g16, g32)
-    print("InfoNCE rows=%d: loss %.5f (oracle %.5f); d loss / d [SEG] embedding rel err HIP %.4f, oracle in bf16 %.4f" % (rows, float(loss.detach()), float(l32.detach()), e, e16))
+    print("InfoNCE rows=%d top_k=%s: loss %.5f (oracle %.5f); d loss / d [SEG] embedding rel err HIP %.4f, oracle in bf16 %.4f" % (rows, top_k, float(loss.detach()), float(l32.detach()), e, e16))
+    # A wide selection on random tokens has near-ties at its edge (weights around rank 40 of 1024 differ in the fourth digit): the HIP forward
+    # ranks bf16-operand scores, the oracle fp32 ones, and one swapped token moves the pooled positive by ~1 / top_k.  The pooling operator itself
+    # is held to 1e-2 on fixed operands (test_pool_rows_forward_backward_vs_autograd); here the wide case gets the room a swap needs.
+    wide = top_k is not None and 16 < top_k < N
     assert abs(float(loss.detach()) - float(l32.detach())) < 2e-2 * abs(float(l32.detach()))
-    assert e < max(1.5 * e16, 0.03), (e, e16)
+    assert e < max(1.5 * e16, 0.08 if wide else 0.03), (e, e16)
     for k in ("wq.weight", "wk.weight"):
         p = dict(tx.named_parameters())[k]
         ek, ek16 = rel(p.grad, w32[k].grad), rel(w16[k].grad, w32[k].grad)
-        assert ek < max(1.5 * ek16, 0.05), (k, ek, ek16)
-    for k in ("wv.weight", "out.weight"):      # not on the loss's path in the top_k form
-        assert dict(tx.named_parameters())[k].grad is None and (w32[k].grad is None or float(w32[k].grad.abs().max()) == 0.0)
+        assert ek < max(1.5 * ek16, 0.12 if wide else 0.05), (k, ek, ek16)
+    refine = top_k is not None and 0 < top_k < N
+    for k in ("wv.weight", "out.weight"):
+        p = dict(tx.named_parameters())[k]
+        if refine:                                # not on the loss's path in the top_k form
+            assert p.grad is None and (w32[k].grad is None or float(w32[k].grad.abs().max()) == 0.0)
+        else:
+            ek, ek16 = rel(p.grad, w32[k].grad), rel(w16[k].grad, w32[k].grad)
+            assert ek < max(1.5 * ek16, 0.05), (k, ek, ek16)
+
+
+@pytest.mark.parametrize("Kt,shared", [(8, False), (40, False), (1000, True), (4096, True)])
+def test_pool_rows_forward_backward_vs_autograd(dev, Kt, shared):
+    """softmax-pooling of token rows (ag.topk_pool / ag.pool_rows: the positive of the region-alignment loss) against torch autograd in fp32 on the
+    same operands: the wave-per-query kernel (Kt <= 16) and the streaming one, tokens per query or whole rows addressed through row_of."""
+    g = torch.Generator().manual_seed(Kt)
+    M, D, rows = 7, 256, 3
+    u = (torch.randn(M, D, generator=g) * 0.5).to(torch.bfloat16)
+    dv = torch.randn(M, D, generator=g).to(torch.bfloat16)
+    if shared:
+        tok = torch.randn(rows, Kt, D, generator=g).to(torch.bfloat16)
+        row_of = torch.randint(0, rows, (M,), generator=g)
+        kt = tok[row_of]
+    else:
+        kt = torch.randn(M, Kt, D, generator=g).to(torch.bfloat16)
+    uh = _leaf(u, dev)
+    v = ag.pool_rows(uh, tok.to(dev), row_of.to(dev)) if shared else ag.topk_pool(uh, kt.to(dev))
+    v.backward(dv.to(dev))
+    u32 = u.float().requires_grad_(True)
+    p = torch.softmax(torch.einsum("md,mkd->mk", u32, kt.float()) / D ** 0.5, dim=1)
+    ref = torch.einsum("mk,mkd->md", p, kt.float())
+    ref.backward(dv.float())
+    assert rel(v.detach(), ref.detach()) < 6e-3
+    assert rel(uh.grad, u32.grad) < 1e-2, rel(uh.grad, u32.grad)
 
 
 @pytest.mark.parametrize("K", [1, 3])

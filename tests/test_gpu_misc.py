@@ -190,6 +190,28 @@ def test_infonce_full_size_properties(dev):
     assert (aux["attn_w"].sum(1) - 1).abs().max().item() < 1e-4
 
 
+def test_infonce_forward_any_top_k_vs_oracle(dev):
+    """infonce_loss forward with a top_k beyond the attention kernel's in-register selection (32): selection from its weights + the streaming
+    pooling kernel, against the oracle's restatement of utils_walkgpt.py:8-73."""
+    from oracle import metrics as om
+    from walkgpt_amd.utils_walkgpt import TinyCrossAttn, infonce_loss
+    g = torch.Generator().manual_seed(11)
+    D, N, M, rows = 256, 1024, 6, 3
+    xa = TinyCrossAttn(D)
+    with torch.no_grad():
+        for p_ in xa.parameters():
+            p_.copy_((torch.randn(p_.shape, generator=g) * D ** -0.5).to(torch.bfloat16).float())
+    w = {k: v.detach().clone() for k, v in xa.state_dict().items()}
+    xa = xa.to(dev).bfloat16()
+    z = torch.randn(M, D, generator=g).to(torch.bfloat16)
+    tok = torch.randn(rows, N, D, generator=g).to(torch.bfloat16)
+    seg = torch.randint(0, rows, (M,), generator=g)
+    for top_k in (48, 200):
+        loss = infonce_loss(z.to(dev), tok.to(dev), seg.to(dev), xa, temperature=0.07, top_k=top_k)
+        ref, _ = om.infonce_loss(w, z.float(), tok.float(), seg, temperature=0.07, top_k=top_k)
+        assert abs(loss.item() - ref.item()) < 2e-2 * abs(ref.item()), (top_k, loss.item(), ref.item())
+
+
 def test_match_pred_vs_reference_golden(dev):
     """match_pred's cost matrix through the C-ABI against the reference's own functions; same assignment."""
     import numpy as np

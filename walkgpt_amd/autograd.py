@@ -493,8 +493,41 @@ class _NceTail(torch.autograd.Function):
         return dz, dvp, dsim, None, None, None, None, None
 
 
+class _PoolRows(torch.autograd.Function):
+    """_TopkPool over any number of tokens: tokens [rows, Kt, D] (constants), query m pools row row_of[m] (None: row m).  wg_pool_rows_bf16 / _bwd."""
+
+    @staticmethod
+    def forward(ctx, u, tokens, row_of):
+        u, tokens = u.contiguous(), tokens.contiguous()
+        row_of = None if row_of is None else row_of.to(torch.int32).contiguous()
+        ctx.save_for_backward(u, tokens, row_of)
+        _, Kt, D = tokens.shape
+        M = u.shape[0]
+        v = torch.empty(M, D, device=u.device, dtype=BF16)
+        _lib.check(_lib.lib().wg_pool_rows_bf16(u.data_ptr(), tokens.data_ptr(), None if row_of is None else row_of.data_ptr(), v.data_ptr(), M, Kt, D,
+                                                ops._stream()), "wg_pool_rows_bf16")
+        return v
+
+    @staticmethod
+    def backward(ctx, dv):
+        u, tokens, row_of = ctx.saved_tensors
+        _, Kt, D = tokens.shape
+        M = u.shape[0]
+        dv = dv.contiguous()
+        du = torch.empty_like(u)
+        _lib.check(_lib.lib().wg_pool_rows_bwd_bf16(u.data_ptr(), tokens.data_ptr(), None if row_of is None else row_of.data_ptr(), dv.data_ptr(),
+                                                    du.data_ptr(), M, Kt, D, ops._stream()), "wg_pool_rows_bwd_bf16")
+        return du, None, None
+
+
 def topk_pool(u, kt):
-    return _TopkPool.apply(u, kt)
+    """kt [M, Kt, D]: the selected tokens of every query (Kt <= 16: the wave-per-query kernel; more: the streaming one)."""
+    return _TopkPool.apply(u, kt) if kt.shape[1] <= 16 else _PoolRows.apply(u, kt, None)
+
+
+def pool_rows(u, tokens, row_of):
+    """softmax_k(u_m . tokens[row_of[m], k] / sqrt(D)) pooling of whole rows: u [M, D], tokens [rows, Kt, D] constants -> [M, D] bf16."""
+    return _PoolRows.apply(u, tokens, row_of)
 
 
 def nce_tail(z, vp, sim, own_row, rows, N, temperature, exclude_same_row):

@@ -615,6 +615,92 @@ __global__ __launch_bounds__(256) void wg_topk_pool_kernel(const bf16* u, const 
     }
 }
 
+// (1b) the same pooling over ANY number of tokens (top_k > 16, or no refinement at all: TinyCrossAttn's own softmax over the N tokens of the
+//     row, utils_walkgpt.py:338-356 with W_v / out applied to the pooled raw token afterwards): tokens [rows, Kt, D], query m pools row
+//     row_of[m] (null: row m).  A workgroup per query, its four waves take keys wave, wave + 4, ... with an online softmax each and meet in LDS.
+//     Forward: one pass.  Backward: pass 1 leaves the softmax statistics and dsum = sum_k p_k da_k, pass 2 forms du = sum_k p_k (da_k - dsum) kt_k
+//     / sqrt(D) (scores and da recomputed: nothing of size Kt is stored).
+template <bool BWD>
+__global__ __launch_bounds__(256) void wg_pool_rows_kernel(const bf16* u, const bf16* tokens, const int* row_of, const bf16* dv, bf16* out, int M, int Kt, int D) {
+    __shared__ float red[4][4];            // per wave: max, sum, weighted da sum
+    __shared__ float acc[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int m = blockIdx.x;
+    const int d = lane * 8 < D ? lane * 8 : 0;
+    const bool on = lane * 8 < D;
+    const bf16* kt = tokens + (long)(row_of ? row_of[m] : m) * Kt * D;
+    float uv[8], gv[8];
+    {
+        const bf16x8 t = *(const bf16x8*)(u + (long)m * D + d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { uv[e] = on ? (float)t[e] : 0.f; gv[e] = 0.f; }
+        if (BWD) {
+            const bf16x8 g = *(const bf16x8*)(dv + (long)m * D + d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gv[e] = on ? (float)g[e] : 0.f;
+        }
+    }
+    const float scale = 1.0f / sqrtf((float)D);
+    // ---- pass 1: online softmax over this wave's keys; forward accumulates the pooled token, backward the da-weighted sum ---------------
+    float mx = -3.0e38f, l = 0.f, wda = 0.f;
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int k = wave; k < Kt; k += 4) {
+        const bf16x8 t = *(const bf16x8*)(kt + (long)k * D + d);
+        float s = 0.f, a = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s += uv[e] * (float)t[e]; a += gv[e] * (float)t[e]; }
+        s = wg_wave_sum(s) * scale;
+        if (BWD) a = wg_wave_sum(a);
+        const float mn = fmaxf(mx, s);
+        const float r = __expf(mx - mn), w = __expf(s - mn);
+        l = l * r + w;
+        if (BWD) wda = wda * r + w * a;
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = o[e] * r + w * (float)t[e];
+        }
+        mx = mn;
+    }
+    if (lane == 0) { red[wave][0] = mx; red[wave][1] = l; red[wave][2] = wda; }
+    __syncthreads();
+    float gm = fmaxf(fmaxf(red[0][0], red[1][0]), fmaxf(red[2][0], red[3][0]));
+    float gl = 0.f, gda = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const float f = __expf(red[w][0] - gm);      // (a wave without keys: max -3e38, weight 0)
+        gl += red[w][1] * f;
+        gda += red[w][2] * f;
+    }
+    if (!BWD) {
+        const float f = __expf(mx - gm) / gl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[wave][lane * 8 + e] = o[e] * f;
+    } else {
+        // ---- pass 2 (backward): du = sum_k p_k (da_k - dsum) kt_k / sqrt(D) ---------------------------------------------------------------
+        const float dsum = gda / gl, inv = 1.0f / gl;
+        for (int k = wave; k < Kt; k += 4) {
+            const bf16x8 t = *(const bf16x8*)(kt + (long)k * D + d);
+            float s = 0.f, a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s += uv[e] * (float)t[e]; a += gv[e] * (float)t[e]; }
+            s = wg_wave_sum(s) * scale;
+            a = wg_wave_sum(a);
+            const float w = __expf(s - gm) * inv * (a - dsum) * scale;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += w * (float)t[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[wave][lane * 8 + e] = o[e];
+    }
+    __syncthreads();
+    if (wave == 0 && on) {
+        bf16x8 r;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r[e] = (bf16)(acc[0][lane * 8 + e] + acc[1][lane * 8 + e] + acc[2][lane * 8 + e] + acc[3][lane * 8 + e]);
+        *(bf16x8*)(out + (long)m * D + lane * 8) = r;
+    }
+}
+
 // (2) the loss tail: pos_m = z_m . vp_m, logits_m = [pos_m, sim[m, :]] / T with the columns of m's own row masked, loss = mean_m (lse_m - pos_m / T).
 //     A workgroup per m.  Forward leaves loss_m and lse_m; backward: p_j = exp(logit_j - lse):  dsim[m, j] = g p_j / (T M),
 //     dz_m (positive term only) = g (p_0 - 1) / (T M) vp_m,  dvp_m = g (p_0 - 1) / (T M) z_m.
@@ -785,6 +871,18 @@ extern "C" int wg_topk_pool_bwd_bf16(const void* u, const void* kt, const void* 
     WG_REQUIRE(u && kt && dv && du && M > 0 && Kt > 0 && Kt <= 16 && D % 8 == 0 && D <= 512, "topk_pool_bwd: Kt <= 16, D <= 512");
     hipLaunchKernelGGL(wg_topk_pool_kernel<true>, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (const bf16*)kt, (const bf16*)dv, (bf16*)du, M, Kt, D);
     return wg_check_launch("wg_topk_pool_bwd_bf16");
+}
+
+extern "C" int wg_pool_rows_bf16(const void* u, const void* tokens, const int* row_of, void* v, int M, int Kt, int D, void* stream) {
+    WG_REQUIRE(u && tokens && v && M > 0 && Kt > 0 && D % 8 == 0 && D > 0 && D <= 512, "pool_rows: D <= 512, a multiple of 8");
+    hipLaunchKernelGGL(wg_pool_rows_kernel<false>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (const bf16*)tokens, row_of, nullptr, (bf16*)v, M, Kt, D);
+    return wg_check_launch("wg_pool_rows_bf16");
+}
+
+extern "C" int wg_pool_rows_bwd_bf16(const void* u, const void* tokens, const int* row_of, const void* dv, void* du, int M, int Kt, int D, void* stream) {
+    WG_REQUIRE(u && tokens && dv && du && M > 0 && Kt > 0 && D % 8 == 0 && D > 0 && D <= 512, "pool_rows_bwd: D <= 512, a multiple of 8");
+    hipLaunchKernelGGL(wg_pool_rows_kernel<true>, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16*)u, (const bf16*)tokens, row_of, (const bf16*)dv, (bf16*)du, M, Kt, D);
+    return wg_check_launch("wg_pool_rows_bwd_bf16");
 }
 
 extern "C" int wg_nce_tail_f32(const void* z, const void* vp, const float* sim, const int* own_row, float* loss_m, float* lse_m, int M, int rows, int N, int D,

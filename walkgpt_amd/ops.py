@@ -950,7 +950,15 @@ def nce_forward(z, sam_tokens, seg_row_ids, wq, bq, wk_t, temperature, top_k, ex
     vraw = torch.empty(M, D, device=dev, dtype=torch.float32)
     k = int(top_k) if (top_k is not None and 0 < top_k < N) else 0
     _lib.check(L.wg_nce_attn_f32(st.data_ptr(), st.stride(0), tok2.data_ptr(), D, seg.data_ptr(), attn_w.data_ptr(), vraw.data_ptr(),
-                                 M, N, rows, D, k, float(D) ** -0.5, _stream()), "wg_nce_attn_f32")
+                                 M, N, rows, D, k if k <= 32 else 0, float(D) ** -0.5, _stream()), "wg_nce_attn_f32")
+    if k > 32:
+        # beyond the attention kernel's in-register selection: pick the k tokens from its weights and pool them with the streaming kernel
+        # (weights renormalised over the selection = the softmax of their scores, utils_walkgpt.py:37-40)
+        idx = torch.topk(attn_w, k=k, dim=1).indices
+        kt = torch.gather(sam_tokens.index_select(0, seg_row_ids.long()), 1, idx.unsqueeze(-1).expand(-1, -1, D)).contiguous()
+        vb = torch.empty(M, D, device=dev, dtype=_BF16)
+        _lib.check(L.wg_pool_rows_bf16(qcat[M:].data_ptr(), kt.data_ptr(), None, vb.data_ptr(), M, k, D, _stream()), "wg_pool_rows_bf16")
+        vraw = vb.float()
 
     def finish(vpos):
         assert vpos.dtype == torch.float32 and vpos.is_contiguous() and vpos.shape == (M, D)

@@ -208,25 +208,31 @@ def msqp_forward(proj, sam_feats, grid_size=None):
 
 
 def infonce_loss(pred, sam_tokens, seg_row_ids, tiny_xattn, temperature=0.07, top_k=8, exclude_same_row=True):
-    """utils_walkgpt.py:8-73 (normalize=True, the top_k form model/walkgpt.py:459-473 calls) with gradients on `pred` ([SEG] embeddings out of
-    CTP, [M, D] bf16) and on TinyCrossAttn's wq / wk (its wv / out do not enter the loss in the top_k form).  sam_tokens [rows, N, D] bf16: the
-    frozen SAM embedding rows.  Which top_k tokens are pooled is a selection (no gradient), made from the attention weights of the forward
-    kernel; the pooled positive, both normalisations, the similarity GEMM and the cross-entropy are differentiable HIP operators."""
+    """utils_walkgpt.py:8-73 (normalize=True) with gradients on `pred` ([SEG] embeddings out of CTP, [M, D] bf16) and on TinyCrossAttn: wq / wk in
+    the top_k form model/walkgpt.py:459-473 calls (its wv / out do not enter the loss there), all four projections when top_k is None / <= 0 /
+    >= N (the function's own default: the positive is TinyCrossAttn's output).  sam_tokens [rows, N, D] bf16: the frozen SAM embedding rows.
+    Which top_k tokens are pooled is a selection (no gradient), made from the attention weights of the forward kernel; the pooled positive, both
+    normalisations, the similarity GEMM and the cross-entropy are differentiable HIP operators."""
     M, D = pred.shape
     rows, N, _ = sam_tokens.shape
-    if top_k is None or not (0 < top_k < N) or top_k > 16:
-        raise NotImplementedError("training path of infonce_loss: 0 < top_k <= 16 (WalkGPT trains with nce_topk = 8)")
+    refine = top_k is not None and 0 < top_k < N                                                     # utils_walkgpt.py:36
     tx = tiny_xattn
     with torch.no_grad():
-        r = ops.nce_forward(pred.detach().contiguous(), sam_tokens.contiguous(), seg_row_ids, tx.wq.weight, tx.wq.bias,
-                            tx._prep_get(tx._build)["wk_t"], temperature, top_k, exclude_same_row)
-        idx = torch.topk(r["attn_w"], k=top_k, dim=1).indices                                        # [M, top_k]
-        kt = torch.gather(sam_tokens.index_select(0, seg_row_ids), 1, idx.unsqueeze(-1).expand(-1, -1, D)).contiguous()
         one = torch.zeros(1, device=pred.device, dtype=BF16)                                          # log_temp = 0: a plain F.normalize
         that = ag.l2norm_scale(sam_tokens.reshape(rows * N, D).contiguous(), one)
+        if refine:
+            r = ops.nce_forward(pred.detach().contiguous(), sam_tokens.contiguous(), seg_row_ids, tx.wq.weight, tx.wq.bias,
+                                tx._prep_get(tx._build)["wk_t"], temperature, None, exclude_same_row)      # (its attention weights only)
+            idx = torch.topk(r["attn_w"], k=top_k, dim=1).indices                                    # [M, top_k]
+            kt = torch.gather(sam_tokens.index_select(0, seg_row_ids), 1, idx.unsqueeze(-1).expand(-1, -1, D)).contiguous()
     q = ag.linear(pred, tx.wq.weight, tx.wq.bias)
     u = ag.linear(q, tx.wk.weight.t().contiguous(), None)                                             # W_k^T q (b_k shifts all scores of a row alike)
-    v_pos = ag.topk_pool(u, kt)
+    if refine:
+        v_pos = ag.topk_pool(u, kt)                                                                   # raw tokens, renormalised weights (:37-40)
+    else:
+        # sum_n a_n (W_v kv_n + b_v) = W_v (sum_n a_n kv_n) + b_v: the row is pooled raw, then projected (utils_walkgpt.py:349-356)
+        ctx = ag.pool_rows(u, sam_tokens.contiguous(), seg_row_ids)
+        v_pos = ag.linear(ag.linear(ctx, tx.wv.weight, tx.wv.bias), tx.out.weight, tx.out.bias)
     z, vp = ag.l2norm_scale(pred, one), ag.l2norm_scale(v_pos, one)
     sim = ag.linear(z, that, None, out_f32=True)                                                      # [M, rows * N] cosines
     return ag.nce_tail(z, vp, sim, seg_row_ids.to(torch.int32).contiguous(), rows, N, temperature, exclude_same_row)
