@@ -403,6 +403,17 @@ int wg_attn_pipe_mode(int mode);
 /* Test support: writes `pattern` over the first 64 KiB of every compute unit's LDS (2048 workgroups; sink: one device word, or NULL).  LDS is not
  * cleared between launches, so a kernel that reads a word it never wrote sees whatever ran before it; tests poison with NaN bits first. */
 int wg_debug_fill_lds_u32(unsigned pattern, void* sink, void* stream);
+/* The two GEMMs of a Linear's backward pass on the operands as they lie (no transposed copies; csrc/gemm_bwd.hip):
+ *   wg_gemm_nn_bf16: dX[M,K] = dY[M,N] . W[N,K];   wg_gemm_tn_bf16: dW[N,K] = dY[M,N]^T . X[M,K] and, if db != null, db[N] = column sums of dY.
+ * bf16 operands, fp32 accumulation, results bf16 (out_f32 = 0) or fp32.  A long reduction over few output tiles is split; the fp32 partials go
+ * through `workspace` (wg_gemm_bwd_workspace_floats(rows of the result, columns of the result, reduction length, db != null) floats; 0 = none) and
+ * are summed in a fixed order (no atomics: the same bits every run).  Every leading dimension, N and K must be multiples of 8. */
+int wg_gemm_bwd_splits(int Mo, int Ko, int R);
+long wg_gemm_bwd_workspace_floats(int Mo, int Ko, int R, int with_colsum);
+int wg_gemm_tn_bf16(const void* dY, long lddy, const void* X, long ldx, void* dW, void* db, int out_f32, float* workspace, long workspace_floats, int M,
+                    int N, int K, void* stream);
+int wg_gemm_nn_bf16(const void* dY, long lddy, const void* W, long ldw, void* dX, int out_f32, float* workspace, long workspace_floats, int M, int N, int K,
+                    void* stream);
 int wg_topk_pool_bf16(const void* u, const void* kt, void* v, int M, int Kt, int D, void* stream);
 int wg_topk_pool_bwd_bf16(const void* u, const void* kt, const void* dv, void* du, int M, int Kt, int D, void* stream);
 /* The same pooling over any number of tokens (top_k > 16; or no top_k at all, utils_walkgpt.py:338-356: TinyCrossAttn's softmax over the whole row,

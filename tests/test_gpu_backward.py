@@ -20,8 +20,12 @@ def _leaf(t, dev):
     return t.to(dev).detach().requires_grad_(True)
 
 
-@pytest.mark.parametrize("M,K,N", [(300, 256, 512), (7, 256, 4), (4099, 768, 256), (64, 4096, 512)])
+@pytest.mark.parametrize("M,K,N", [(300, 256, 512), (7, 256, 4), (4099, 768, 256), (64, 4096, 512), (32768, 256, 256), (48, 2048, 256), (1, 256, 136),
+                                   (8 * 4096, 64, 32), (130, 72, 264)])
 def test_linear_backward(dev, M, K, N):
+    """dX, dW, db of a Linear against torch autograd in fp32: the operands-as-they-lie GEMMs of csrc/gemm_bwd.hip (ragged row counts, output
+    tiles cut by the matrix edge, reductions split over workgroups: 32 768 image-token rows into a 256 x 256 weight, a single row) and the
+    transposed-copy path for widths without 16-byte rows (N = 4).  Two backward passes give the same bits (no atomics on this path)."""
     g = torch.Generator().manual_seed(M + N)
     x = torch.randn(M, K, generator=g).to(torch.bfloat16)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16)
@@ -35,6 +39,12 @@ def test_linear_backward(dev, M, K, N):
     yr.backward(dy.float())
     assert rel(y, yr) < 4e-3
     assert rel(xh.grad, xr.grad) < 6e-3 and rel(wh.grad, wr.grad) < 6e-3 and rel(bh.grad, br.grad) < 6e-3
+    if N % 8 == 0:
+        first = [t.grad.clone() for t in (xh, wh, bh)]
+        for t in (xh, wh, bh):
+            t.grad = None
+        ag.linear(xh, wh, bh).backward(dy.to(dev))
+        assert all(torch.equal(a, t.grad) for a, t in zip(first, (xh, wh, bh)))
 
 
 @pytest.mark.parametrize("act", [1, 2, 3])

@@ -61,6 +61,10 @@ SIGNATURES = {
     "wg_sigmoid_gate_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     "wg_resample_tokens_bwd_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "wg_splice_multimodal_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
+    "wg_gemm_bwd_splits": [c_int, c_int, c_int],
+    "wg_gemm_bwd_workspace_floats": [c_int, c_int, c_int, c_int],
+    "wg_gemm_tn_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_int, c_void_p],
+    "wg_gemm_nn_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_int, c_void_p],
     "wg_topk_pool_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "wg_topk_pool_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
     "wg_pool_rows_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],

@@ -56,9 +56,47 @@ def colsum(t):
     return out
 
 
+def _bwd_gemm_ok(*ts):
+    """csrc/gemm_bwd.hip takes bf16 operands with 16-byte rows (every width a multiple of 8 elements); the few Linears that are not (the IoU
+    head's 4 outputs) keep the transposed-copy path."""
+    return all(t.dtype == BF16 and t.shape[-1] % 8 == 0 and t.shape[-1] >= 8 and t.data_ptr() % 16 == 0 for t in ts)
+
+
+def gemm_nn(dy2, w):
+    """dX[M, K] = dY[M, N] . W[N, K] on the operands as they lie (wg_gemm_nn_bf16) -> bf16 [M, K]."""
+    M, N = dy2.shape
+    K = w.shape[1]
+    L = _lib.lib()
+    dx = torch.empty(M, K, device=dy2.device, dtype=BF16)
+    nws = L.wg_gemm_bwd_workspace_floats(M, K, N, 0)
+    ws = torch.empty(nws, device=dy2.device, dtype=torch.float32) if nws else None
+    _lib.check(L.wg_gemm_nn_bf16(dy2.data_ptr(), N, w.data_ptr(), K, dx.data_ptr(), 0, ops._ptr(ws) or None, nws, M, N, K, ops._stream()), "wg_gemm_nn_bf16")
+    return dx
+
+
+def gemm_tn(dy2, x2, want_colsum, out_dtype):
+    """dW[N, K] = dY[M, N]^T . X[M, K] and (want_colsum) db[N] = column sums of dY, one pass over dY (wg_gemm_tn_bf16); partial sums of a split
+    reduction are combined in a fixed order: the same bits every run."""
+    M, N = dy2.shape
+    K = x2.shape[1]
+    L = _lib.lib()
+    f32 = out_dtype == torch.float32
+    dt = torch.float32 if f32 else BF16
+    dw = torch.empty(N, K, device=dy2.device, dtype=dt)
+    db = torch.empty(N, device=dy2.device, dtype=dt) if want_colsum else None
+    nws = L.wg_gemm_bwd_workspace_floats(N, K, M, 1 if want_colsum else 0)
+    ws = torch.empty(nws, device=dy2.device, dtype=torch.float32) if nws else None
+    _lib.check(L.wg_gemm_tn_bf16(dy2.data_ptr(), N, x2.data_ptr(), K, dw.data_ptr(), ops._ptr(db) or None, 1 if f32 else 0, ops._ptr(ws) or None, nws, M, N, K,
+                                 ops._stream()), "wg_gemm_tn_bf16")
+    if dt != out_dtype:
+        dw, db = dw.to(out_dtype), (None if db is None else db.to(out_dtype))
+    return dw, db
+
+
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b.  Backward: dX = dY W, dW = dY^T X (both on the bf16 MFMA GEMM, operands transposed by wg_tokens_to_nchw_bf16, the
-    reduction dimension padded to whole slabs; dW accumulated and returned in fp32 -> parameter dtype), db = column sums of dY."""
+    """y = x W^T + b.  Backward: dX = dY W and dW = dY^T X on the operands as they lie (csrc/gemm_bwd.hip: reduction-major tiles through the
+    hardware transpose read; db = column sums of dY from the same pass; a long reduction split and summed in a fixed order).  Operands without
+    16-byte rows take the older path: transposed copies (wg_tokens_to_nchw_bf16) through the forward GEMM, db by wg_colsum_f32."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, out_f32=False):
@@ -75,12 +113,22 @@ class _Linear(torch.autograd.Function):
         dy2 = _dense2d(dy.to(BF16), N)
         x2 = _dense2d(x, K)
         dx = dw = db = None
+        w2 = _dense2d(weight.detach(), K)
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[0]:
-            dx = ops.linear(dy2, transpose2d(weight.detach())).view(x.shape)                     # [M, N] @ [N, K]
+            if _bwd_gemm_ok(dy2, w2):
+                dx = gemm_nn(dy2, w2).view(x.shape)
+            else:
+                dx = ops.linear(dy2, transpose2d(w2)).view(x.shape)                              # [M, N] @ [N, K]
         if ctx.needs_input_grad[1]:
-            dyt, xt = transpose2d(_pad_rows(dy2)), transpose2d(_pad_rows(x2))                    # [N, Mp], [K, Mp]
-            dw = ops.linear(dyt, xt, out_f32=True).to(weight.dtype)                              # [N, K]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+            if _bwd_gemm_ok(dy2, x2):
+                dw, db_ = gemm_tn(dy2, x2, want_db, weight.dtype)
+                if want_db:
+                    db, want_db = db_, False
+            else:
+                dyt, xt = transpose2d(_pad_rows(dy2)), transpose2d(_pad_rows(x2))                # [N, Mp], [K, Mp]
+                dw = ops.linear(dyt, xt, out_f32=True).to(weight.dtype)                          # [N, K]
+        if want_db:
             db = colsum(dy2).to(weight.dtype)
         return dx, dw, db, None
 
