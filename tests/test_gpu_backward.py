@@ -62,7 +62,8 @@ def test_activation_backward(dev, act):
     assert rel(y, yr) < 4e-3 and rel(xh.grad, xr.grad) < 5e-3
 
 
-@pytest.mark.parametrize("M,C,eps", [(300, 256, 1e-5), (4099, 1280, 1e-6), (33, 4096, 1e-5), (77, 5120, 1e-5)])
+@pytest.mark.parametrize("M,C,eps", [(300, 256, 1e-5), (4099, 1280, 1e-6), (33, 4096, 1e-5), (77, 5120, 1e-5), (32768, 256, 1e-5), (5, 64, 1e-6), (1000, 512, 1e-5),
+                                     (70001, 128, 1e-6)])
 def test_layernorm_backward(dev, M, C, eps):
     g = torch.Generator().manual_seed(C)
     x = (torch.randn(M, C, generator=g) * 2 + 0.5).to(torch.bfloat16)
@@ -77,6 +78,12 @@ def test_layernorm_backward(dev, M, C, eps):
     yr.backward(dy.float())
     assert rel(y, yr) < 4e-3
     assert rel(xh.grad, xr.grad) < 6e-3 and rel(gh.grad, gr.grad) < 6e-3 and rel(bh.grad, br.grad) < 6e-3
+    if C in (64, 128, 256, 512):          # the deterministic kernel (fixed-order partial sums): the same bits on a second pass
+        first = [t.grad.clone() for t in (xh, gh, bh)]
+        for t in (xh, gh, bh):
+            t.grad = None
+        ag.layernorm(xh, gh, bh, eps).backward(dy.to(dev))
+        assert all(torch.equal(a, t.grad) for a, t in zip(first, (xh, gh, bh)))
 
 
 @pytest.mark.parametrize("B,H,hd,Lq,Lk", [(3, 8, 16, 6, 4096), (3, 8, 32, 6, 6), (2, 8, 16, 4096, 6), (2, 8, 128, 12, 1024), (4, 1, 64, 1, 300),

@@ -50,6 +50,8 @@ SIGNATURES = {
     "wg_act_bf16": [c_void_p, c_void_p, c_long, c_int, c_void_p],
     "wg_act_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     "wg_layernorm_bwd_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
+    "wg_layernorm_bwd_det_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p, c_long, c_int, c_int,
+                                  c_float, c_void_p],
     "wg_l2norm_scale_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "wg_l2norm_scale_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "wg_attn_bwd_short_side": [c_int, c_int],
@@ -61,8 +63,6 @@ SIGNATURES = {
     "wg_sigmoid_gate_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_void_p],
     "wg_resample_tokens_bwd_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "wg_splice_multimodal_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
-    "wg_gemm_bwd_splits": [c_int, c_int, c_int],
-    "wg_gemm_bwd_workspace_floats": [c_int, c_int, c_int, c_int],
     "wg_gemm_tn_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_int, c_void_p],
     "wg_gemm_nn_bf16": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_int, c_void_p],
     "wg_topk_pool_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p],
@@ -128,6 +128,9 @@ _SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, []),
             "wg_postprocess_score_workspace_floats": (c_long, [c_int, c_int, c_int]),
             "wg_mask_stats_workspace_floats": (c_long, [c_int, c_long]),
             "wg_match_cost_workspace_floats": (c_long, [c_int, c_int, c_int]),
+            "wg_gemm_bwd_splits": (c_int, [c_int, c_int, c_int]),
+            "wg_gemm_bwd_workspace_floats": (c_long, [c_int, c_int, c_int, c_int]),
+            "wg_layernorm_bwd_det_workspace_floats": (c_long, [c_int, c_int]),
             "wg_gemm_pick_tile": (c_int, [c_int, c_int]),
             "wg_gemm_ln_supported": (c_int, [c_int, c_int, c_int, c_long, c_long, c_long]),
             "wg_gemm_row_partials_supported": (c_int, [c_int, c_int, c_int, c_long, c_long, c_long]),

@@ -172,6 +172,18 @@ class _LayerNorm(torch.autograd.Function):
         M = x.numel() // C
         dy = dy.contiguous()
         dx = torch.empty_like(x)
+        L = _lib.lib()
+        if C in (64, 128, 256, 512) and gamma.dtype in (BF16, torch.float32) and dy.dtype == BF16:
+            # the head's widths: every lane busy, no atomics (fixed-order sums: the same bits every run), parameter gradients written in their dtype
+            f32 = gamma.dtype == torch.float32
+            dg, db = torch.empty_like(gamma), torch.empty_like(gamma)
+            nws = L.wg_layernorm_bwd_det_workspace_floats(M, C)
+            wsd = torch.empty(nws, device=x.device, dtype=torch.float32)
+            g16 = gamma if gamma.dtype == BF16 else gamma.to(BF16)
+            rc = L.wg_layernorm_bwd_det_bf16(x.data_ptr(), C, g16.data_ptr(), dy.data_ptr(), C, dx.data_ptr(), C, dg.data_ptr(), db.data_ptr(), 1 if f32 else 0,
+                                             wsd.data_ptr(), nws, M, C, float(ctx.eps), ops._stream())
+            _lib.check(rc, "wg_layernorm_bwd_det_bf16")
+            return dx, dg, db, None
         dg = torch.zeros(C, device=x.device, dtype=torch.float32)
         db = torch.zeros(C, device=x.device, dtype=torch.float32)
         ws = torch.empty(2 * M, device=x.device, dtype=torch.float32) if C > 4096 else None      # (wide rows: {mean, rstd} between the two kernels)

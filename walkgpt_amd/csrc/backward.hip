@@ -71,6 +71,87 @@ __global__ __launch_bounds__(256) void wg_act_kernel(const bf16* x, const bf16* 
     }
 }
 
+// ---- LayerNorm backward, rows of 64 VEC <= 512 channels (the head's widths: 64, 256, 512), deterministic ------------------------------------------
+// The general kernel below spreads a row over lane * 8 columns (half the wave idle at C = 256), carries registers for 4096 columns and ends in
+// 2 C atomics per wave: 90 us for the decoder's 32 768 x 256 image-token rows, 16 % of a head step.  Here lane l holds columns VEC l .. VEC l + VEC - 1
+// (every lane busy), a wave walks a contiguous run of rows with its dgamma / dbeta partials in 2 VEC registers, the four waves of a workgroup add
+// theirs in LDS, and the workgroup leaves ONE partial row pair in the workspace [blocks][2][C]; wg_ln_partials_kernel sums them in block order.
+template <int VEC>
+__global__ __launch_bounds__(256) void wg_layernorm_bwd_small_kernel(const bf16* x, long ldx, const bf16* gamma, const bf16* dy, long lddy, bf16* dx, long lddx,
+                                                                     float* part, int M, int rows_per_block, float eps) {
+    typedef __attribute__((ext_vector_type(VEC))) __bf16 vec_t;
+    constexpr int C = 64 * VEC;
+    __shared__ float red[4][2][C];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d = lane * VEC;
+    float gm[VEC], ag[VEC], ab[VEC];
+    {
+        const vec_t t = *(const vec_t*)(gamma + d);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { gm[e] = VEC == 1 ? (float)((const bf16*)&t)[0] : (float)t[e]; ag[e] = ab[e] = 0.f; }
+    }
+    const float invc = 1.0f / (float)C;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    for (int m = r0 + wave; m < r1; m += 4) {
+        const vec_t tx = *(const vec_t*)(x + (long)m * ldx + d), tg = *(const vec_t*)(dy + (long)m * lddy + d);
+        float v[VEC], g[VEC], s = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            v[e] = VEC == 1 ? (float)((const bf16*)&tx)[0] : (float)tx[e];
+            g[e] = VEC == 1 ? (float)((const bf16*)&tg)[0] : (float)tg[e];
+            s += v[e];
+        }
+        const float mean = wg_wave_sum(s) * invc;
+        float q = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { v[e] -= mean; q += v[e] * v[e]; }
+        const float rstd = 1.0f / sqrtf(wg_wave_sum(q) * invc + eps);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            v[e] *= rstd;                                              // xhat
+            const float gg = g[e] * gm[e];
+            sg += gg;
+            sgx += gg * v[e];
+            ag[e] += g[e] * v[e];
+            ab[e] += g[e];
+        }
+        const float mg = wg_wave_sum(sg) * invc, mgx = wg_wave_sum(sgx) * invc;
+        vec_t o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const bf16 r = (bf16)(rstd * (g[e] * gm[e] - mg - v[e] * mgx));
+            if (VEC == 1) ((bf16*)&o)[0] = r; else o[e] = r;
+        }
+        *(vec_t*)(dx + (long)m * lddx + d) = o;
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { red[wave][0][d + e] = ag[e]; red[wave][1][d + e] = ab[e]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        const int which = i / C, c = i % C;
+        part[((long)blockIdx.x * 2 + which) * C + c] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    }
+}
+
+// dgamma | dbeta [2][C] = sum over the `blocks` partial row pairs, in block order; out bf16 or fp32
+__global__ __launch_bounds__(256) void wg_ln_partials_kernel(const float* part, int blocks, int C, void* dgamma, void* dbeta, int out_f32) {
+    __shared__ float red[4];
+    const int col = blockIdx.x;          // 0 .. 2 C - 1: (which, c)
+    float s = 0.f;
+    for (int b = threadIdx.x; b < blocks; b += 256) s += part[(long)b * 2 * C + col];
+    s = wg_wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float t = red[0] + red[1] + red[2] + red[3];
+        void* dst = col < C ? dgamma : dbeta;
+        const int c = col < C ? col : col - C;
+        if (out_f32) ((float*)dst)[c] = t; else ((bf16*)dst)[c] = (bf16)t;
+    }
+}
+
 // ---- LayerNorm backward -----------------------------------------------------------------------------------------------------------------
 // xhat = (x - mean) rstd,  g = dy gamma:   dx = rstd (g - mean(g) - xhat mean(g xhat)),  dgamma += dy xhat,  dbeta += dy.
 // One wave per row at a time (rows strided over the grid's waves), the row read twice; a wave keeps its columns' dgamma / dbeta partials in
@@ -1012,6 +1093,31 @@ extern "C" int wg_act_bwd_bf16(const void* x, const void* dy, void* dx, long n, 
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(wg_act_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, (const bf16*)dy, (bf16*)dx, n / 8, act);
     return wg_check_launch("wg_act_bwd_bf16");
+}
+
+// Rows of 64, 128, 256 or 512 channels, deterministic (no atomics): dgamma / dbeta are written (bf16, or fp32 with out_f32), not accumulated;
+// workspace = wg_layernorm_bwd_det_workspace_floats(M, C) floats.  Returns -2 (nothing launched) for other widths: the caller falls back on
+// wg_layernorm_bwd_bf16.
+static int wg_lnb_blocks(int M) {
+    int b = (M + 63) / 64;               // >= 64 rows (16 per wave) per workgroup ...
+    return b > 1024 ? 1024 : b;          // ... and at most 1024 partial row pairs to fold
+}
+extern "C" long wg_layernorm_bwd_det_workspace_floats(int M, int C) { return (long)wg_lnb_blocks(M) * 2 * C; }
+extern "C" int wg_layernorm_bwd_det_bf16(const void* x, long ldx, const void* gamma, const void* dy, long lddy, void* dx, long lddx, void* dgamma, void* dbeta,
+                                         int out_f32, float* workspace, long workspace_floats, int M, int C, float eps, void* stream) {
+    WG_REQUIRE(x && gamma && dy && dx && dgamma && dbeta && workspace && M > 0, "layernorm_bwd_det: null operand");
+    if (!(C == 64 || C == 128 || C == 256 || C == 512)) return -2;
+    WG_REQUIRE(ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dy | (uintptr_t)dx) & 15) == 0,
+               "layernorm_bwd_det: misaligned operand");
+    const int blocks = wg_lnb_blocks(M);
+    WG_REQUIRE(workspace_floats >= (long)blocks * 2 * C, "layernorm_bwd_det: workspace too small (need %ld floats)", (long)blocks * 2 * C);
+    const int rpb = (M + blocks - 1) / blocks;
+#define WG_LNB(V) hipLaunchKernelGGL(wg_layernorm_bwd_small_kernel<V>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, (const bf16*)gamma, \
+                                     (const bf16*)dy, lddy, (bf16*)dx, lddx, workspace, M, rpb, eps)
+    if (C == 64) WG_LNB(1); else if (C == 128) WG_LNB(2); else if (C == 256) WG_LNB(4); else WG_LNB(8);
+#undef WG_LNB
+    hipLaunchKernelGGL(wg_ln_partials_kernel, dim3(2 * C), dim3(256), 0, (hipStream_t)stream, workspace, blocks, C, dgamma, dbeta, out_f32);
+    return wg_check_launch("wg_layernorm_bwd_det_bf16");
 }
 
 extern "C" int wg_layernorm_bwd_bf16(const void* x, long ldx, const void* gamma, const void* dy, long lddy, void* dx, long lddx, float* dgamma,
