@@ -30,13 +30,17 @@ def main():
     gt = [(torch.rand(T, 448, 448, device=dev) > 0.5).float() for _ in range(B)]
     ctp = g.text_hidden_fcs[0]
 
+    params = [p for p in g.parameters() if p.requires_grad]
+    gt_all = torch.cat(gt, 0)
+
     def step():
+        for p in params + hidden:          # optimizer.zero_grad(set_to_none=True), torch's default: gradients are stored, not added to old ones
+            p.grad = None
         pred = train_head.ctp_forward(ctp, torch.cat(hidden, 0))
         masks = train_head.decode(g, emb, list(torch.split(pred, T, 0)), resize, orig)
-        loss = 0.0
-        for m, t in zip(masks, gt):
-            bce, dice = ag.mask_losses(m.contiguous(), t, T)
-            loss = loss + 2.0 * bce + 0.5 * dice
+        # equal mask counts and sizes: one reduction over all masks (what causal_lm.model_forward does for such a batch)
+        bce, dice = ag.mask_losses(torch.cat(masks, 0).contiguous(), gt_all, T)
+        loss = (2.0 * bce + 0.5 * dice) * T / (B * T + 1e-8)
         loss.backward()
         return loss
 

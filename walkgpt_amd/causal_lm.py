@@ -465,13 +465,20 @@ class walkgptForCausalLM(nn.Module):  # noqa: N801  (the reference's class name)
         num_masks = 0
         for gt_mask, pred_mask in zip(masks_list, pred_masks):
             assert gt_mask.shape[0] == pred_mask.shape[0], "gt_mask.shape: {}, pred_mask.shape: {}".format(gt_mask.shape, pred_mask.shape)
-            if gt_mask.shape[0] == 0:
-                continue
-            bce, dice = (ag.mask_losses if train else ops.mask_losses)(pred_mask.float().contiguous(), gt_mask.float().contiguous(),
-                                                                      num_masks=gt_mask.shape[0])
-            mask_bce_loss = mask_bce_loss + bce * gt_mask.shape[0]
-            mask_dice_loss = mask_dice_loss + dice * gt_mask.shape[0]
-            num_masks += gt_mask.shape[0]
+        losses = ag.mask_losses if train else ops.mask_losses
+        live = [(g, p) for g, p in zip(masks_list, pred_masks) if g.shape[0] > 0]
+        if len(live) > 1 and len({tuple(g.shape) for g, _ in live}) == 1:
+            # every image has the same number of masks T at the same size (the usual batch): sum_i [S_i / (T + 1e-8)] * T is ONE reduction over
+            # all masks -- the per-image loop of walkgpt.py:565-583 costs ~12 launches per image forward and backward
+            T = live[0][0].shape[0]
+            bce, dice = losses(torch.cat([p for _, p in live], 0).float().contiguous(), torch.cat([g for g, _ in live], 0).float().contiguous(), num_masks=T)
+            mask_bce_loss, mask_dice_loss, num_masks = bce * T, dice * T, T * len(live)
+        else:
+            for gt_mask, pred_mask in live:
+                bce, dice = losses(pred_mask.float().contiguous(), gt_mask.float().contiguous(), num_masks=gt_mask.shape[0])
+                mask_bce_loss = mask_bce_loss + bce * gt_mask.shape[0]
+                mask_dice_loss = mask_dice_loss + dice * gt_mask.shape[0]
+                num_masks += gt_mask.shape[0]
         mask_bce_loss = self.bce_loss_weight * mask_bce_loss / (num_masks + 1e-8)
         mask_dice_loss = self.dice_loss_weight * mask_dice_loss / (num_masks + 1e-8)
         mask_loss = mask_bce_loss + mask_dice_loss
