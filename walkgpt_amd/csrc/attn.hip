@@ -1111,6 +1111,12 @@ extern "C" int wg_mha_bf16(const void* Q, long ldq, long q_rows_per_batch, const
 // SAM ViT attention over a packed qkv buffer [B*Hg*Hg, 3*D] (q | k | v, heads contiguous inside each third).
 // window == Hg: global attention; window < Hg: non-overlapping windows with zero padding to a multiple of
 // `window`, pad positions acting as keys/values equal to qkv_bias (their outputs are dropped).
+// WG_ATTN_WIN_UNIT=0: head_dim-64 windows on the tile-ahead kernel (A/B runs)
+static bool wg_window_unit_on() {
+    static const char* e = getenv("WG_ATTN_WIN_UNIT");
+    return !(e && e[0] == '0');
+}
+
 extern "C" int wg_sam_attn_relpos_bf16(const void* qkv, const void* qkv_bias, const void* rel_pos_h, const void* rel_pos_w,
                                        void* out, int B, int grid, int window, int heads, int head_dim, float scale,
                                        void* stream) {
@@ -1139,6 +1145,7 @@ extern "C" int wg_sam_attn_relpos_bf16(const void* qkv, const void* qkv_bias, co
             a.qchunks = (qblocks + pnw - 1) / pnw;                                                               \
             return wg_attn_pipe_launch(a, S_, pnw, st);                                                          \
         }                                                                                                        \
+        if (HD_ == 64 && S_ == 14 && wg_window_unit_on() && wg_attn_window_unit_takes(a)) return wg_attn_window_unit_launch(a, groups, st);      \
         if constexpr (S_ <= 32) return launch_attn_window<HD_, S_, NW_>(a, groups, st);   \
         else return launch_attn<HD_, S_, NW_>(a, groups, st);      \
     }

@@ -55,3 +55,7 @@ template <int OFF> __device__ __forceinline__ u32x2 wg_ds_read_tr(unsigned lds_a
 // attn_pipe.hip: the software-pipelined kernel for head_dim 64 (SAM global attention, CLIP without a key mask)
 bool wg_attn_pipe_takes(const AttnArgs& a, int head_dim, int S, int nw);
 int wg_attn_pipe_launch(const AttnArgs& a, int S, int nw, hipStream_t st);
+
+// attn_window_unit.hip: SAM's 14 x 14 windows at head_dim 64 with a whole (window, head) of K / V staged ahead
+bool wg_attn_window_unit_takes(const AttnArgs& a);
+int wg_attn_window_unit_launch(AttnArgs a, int groups, hipStream_t st);
