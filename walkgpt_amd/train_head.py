@@ -136,7 +136,10 @@ def decode(grounding, emb_tokens, pred_embeddings, resize_list, original_size_li
     out = [None] * len(counts)
     if P > 0:
         # every prompt of every image in ONE decoder pass (prompt p attends to the embedding of its own image), as WalkGPTGrounding.decode does
-        pimg = grounding._prompt_image_index(tuple(counts), dev)        # (cached per count tuple: no host-to-device copy per step)
+        if hasattr(grounding, "_prompt_image_index"):                   # (cached per count tuple: no host-to-device copy per step)
+            pimg = grounding._prompt_image_index(tuple(counts), dev)
+        else:
+            pimg = torch.tensor([i for i, c in enumerate(counts) for _ in range(c)], device=dev)
         src = emb_tokens.index_select(0, pimg)
         sparse = torch.cat([p for p in pred_embeddings if p.shape[0]], 0).unsqueeze(1)
         low_res, _ = decoder_forward(dec, src, pe, sparse, no_mask, h, w, sl)
