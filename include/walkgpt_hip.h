@@ -356,7 +356,8 @@ int wg_layernorm_bwd_det_bf16(const void* x, long ldx, const void* gamma, const 
  *   contiguous bf16, min(Lq, Lk) <= 16, head_dim % 8 == 0, <= 128.  The long side's gradients are written as bf16, the short side's
  *   accumulated into zeroed fp32 buffers; wg_attn_bwd_short_side: 1 = keys short (dq bf16, dk / dv fp32), 0 = queries short (dk / dv
  *   bf16, dq fp32), -1 = unsupported.  stats: B * heads * Lq * 2 floats of workspace.
- * wg_postprocess_masks_bwd_f32: adjoint of wg_postprocess_masks_f32 (d loss / d low-res logits +=, zeroed by the caller).
+ * wg_postprocess_masks_bwd_f32: adjoint of wg_postprocess_masks_f32 (d loss / d low-res logits; written, not accumulated -- a gather in a fixed
+ *   order since round 4: no atomics, the same bits every run).
  * wg_mask_losses_bwd_f32: d(g_bce sigmoid_ce_loss + g_dice dice_loss) / d logits (utils_walkgpt.py:76-120); workspace
  *   wg_mask_stats_workspace_floats(N, hw) + 2 N floats. */
 int wg_l2norm_scale_bf16(const void* x, const void* log_temp, void* y, int M, int C, float eps, void* stream);

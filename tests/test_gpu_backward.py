@@ -122,7 +122,8 @@ def test_ctp_tail_operators_backward(dev):
     assert rel(y, yr) < 6e-3 and rel(xh.grad, xr.grad) < 1.2e-2 and rel(th.grad, tr.grad) < 1.5e-2 and rel(lh.grad, lr.grad) < 1.5e-2
 
 
-@pytest.mark.parametrize("N,inp,orig", [(3, (1024, 1024), (448, 448)), (2, (683, 1024), (300, 450))])
+@pytest.mark.parametrize("N,inp,orig", [(3, (1024, 1024), (448, 448)), (2, (683, 1024), (300, 450)), (2, (768, 1024), (1080, 1440)), (1, (512, 384), (75, 96)),
+                                        (1, (1024, 1000), (2048, 2000))])
 def test_postprocess_and_mask_losses_backward(dev, N, inp, orig):
     """loss(postprocess(low_res)) differentiated through both HIP adjoints against torch autograd over F.interpolate and the reference's loss formulas."""
     g = torch.Generator().manual_seed(N)
@@ -145,6 +146,13 @@ def test_postprocess_and_mask_losses_backward(dev, N, inp, orig):
     (2.0 * bce_r + 0.5 * dice_r).backward()
     assert abs(float(bce.detach()) - float(bce_r.detach())) < 1e-5 and abs(float(dice.detach()) - float(dice_r.detach())) < 1e-5
     assert rel(lh.grad, lr.grad) < 1e-4, rel(lh.grad, lr.grad)
+    # the adjoint of the resamples is a gather in a fixed order (no atomics): a second pass gives the same bits
+    first = lh.grad.clone()
+    lh.grad = None
+    masks = ag.postprocess_masks(lh, 1024, inp, orig)
+    bce, dice = ag.mask_losses(masks[:, 0].contiguous(), tgt.to(dev), N)
+    (2.0 * bce + 0.5 * dice).backward()
+    assert torch.equal(first, lh.grad)
 
 
 def test_ctp_training_path_vs_oracle_autograd(dev):

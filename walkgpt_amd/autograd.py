@@ -313,7 +313,7 @@ class _Postprocess(torch.autograd.Function):
         shape, img, (ih, iw), (oh, ow) = ctx.geom
         N, C, lh, lw = shape
         dout = dout.contiguous().float()
-        dlow = torch.zeros(shape, device=dout.device, dtype=torch.float32)
+        dlow = torch.empty(shape, device=dout.device, dtype=torch.float32)      # (written, not accumulated: the gather form)
         rc = _lib.lib().wg_postprocess_masks_bwd_f32(dout.data_ptr(), dlow.data_ptr(), N * C, lh, lw, img, ih, iw, oh, ow, ops._stream())
         _lib.check(rc, "wg_postprocess_masks_bwd_f32")
         return dlow, None, None, None

@@ -400,45 +400,61 @@ __global__ __launch_bounds__(256) void wg_postprocess_kernel(const float* __rest
     }
 }
 
-// Adjoint of the two resamples (training: d loss / d low-res logits from d loss / d masks): every output pixel scatters its gradient to the 16
-// low-res taps it was blended from, with the weights the forward pass used (same index rule).  fp32 atomics; dlow zeroed by the caller.
-__global__ __launch_bounds__(256) void wg_postprocess_bwd_kernel(const float* dout, float* dlow, int N, int lh, int lw, int img, int in_h, int in_w,
-                                                                 int out_h, int out_w) {
-    const int ox = blockIdx.x * 256 + threadIdx.x, oy = blockIdx.y, n = blockIdx.z;
-    if (ox >= out_w) return;
-    const float g = dout[((long)n * out_h + oy) * out_w + ox];
-    if (g == 0.f) return;
-    const float s1y = (float)lh / (float)img, s1x = (float)lw / (float)img;
-    const float s2y = (float)in_h / (float)out_h, s2x = (float)in_w / (float)out_w;
-    float* m = dlow + (long)n * lh * lw;
-    int y0, y1, x0, x1;
-    float ly, lx;
-    wg_src_index(oy, s2y, in_h, y0, y1, ly);
-    wg_src_index(ox, s2x, in_w, x0, x1, lx);
-    int ya[2][2], xa[2][2];
-    float lya[2], lxa[2];
-    wg_src_index(y0, s1y, lh, ya[0][0], ya[0][1], lya[0]);
-    wg_src_index(y1, s1y, lh, ya[1][0], ya[1][1], lya[1]);
-    wg_src_index(x0, s1x, lw, xa[0][0], xa[0][1], lxa[0]);
-    wg_src_index(x1, s1x, lw, xa[1][0], xa[1][1], lxa[1]);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const float w2 = g * (j ? ly : 1.f - ly) * (i ? lx : 1.f - lx);
-            atomicAdd(m + ya[j][0] * lw + xa[i][0], w2 * (1.f - lya[j]) * (1.f - lxa[i]));
-            atomicAdd(m + ya[j][0] * lw + xa[i][1], w2 * (1.f - lya[j]) * lxa[i]);
-            atomicAdd(m + ya[j][1] * lw + xa[i][0], w2 * lya[j] * (1.f - lxa[i]));
-            atomicAdd(m + ya[j][1] * lw + xa[i][1], w2 * lya[j] * lxa[i]);
+// Adjoint of the two resamples (training: d loss / d low-res logits from d loss / d masks).  Rounds 2-3 scattered: every output pixel added its gradient
+// to the 16 low-res taps it was blended from with fp32 atomics.
+// Round 4, a GATHER: a thread per low-res pixel sums, in a fixed order, the output pixels whose taps reach it -- no atomics (the
+// scatter form issued 16 fp32 atomics per output pixel: 604 us for eight 448 x 448 masks, the largest kernel of a head step), dlow is written,
+// not accumulated, and two runs give the same bits.  Both resamples are separable, so the weight of output pixel (oy, ox) on low-res pixel (r, c) is
+// Wy(oy, r) Wx(ox, c); each factor is found by running the FORWARD index rule on the candidate and keeping what lands on r (c): border clamps and
+// the crop need no case analysis.  Candidates: a superset of the output rows (columns) whose second-resample taps fall on intermediate rows whose
+// first-resample taps fall on r -- (2 / s1 + 3) / s2 + 3 of them (7 at 1024 -> 448, 17 at 768 -> 1080).
+__device__ __forceinline__ float wg_post_w(int o, float s2, int in_sz, float s1, int low_sz, int r) {
+    int t0, t1, a0, a1;
+    float l, la, w;
+    wg_src_index(o, s2, in_sz, t0, t1, l);
+    wg_src_index(t0, s1, low_sz, a0, a1, la);
+    w = (1.f - l) * ((a0 == r ? 1.f - la : 0.f) + (a1 == r ? la : 0.f));
+    wg_src_index(t1, s1, low_sz, a0, a1, la);
+    return w + l * ((a0 == r ? 1.f - la : 0.f) + (a1 == r ? la : 0.f));
+}
+__device__ __forceinline__ void wg_post_range(int r, float s1, float s2, int in_sz, int out_sz, int& lo, int& hi) {
+    float ylo = ((float)r - 0.5f) / s1 - 1.5f, yhi = ((float)r + 1.5f) / s1 + 0.5f;      // intermediate rows that can touch r (+-1)
+    ylo = ylo < 0.f ? 0.f : ylo;
+    yhi = yhi > (float)(in_sz - 1) ? (float)(in_sz - 1) : yhi;
+    const float olo = (ylo - 0.5f) / s2 - 1.5f, ohi = (yhi + 1.5f) / s2 + 0.5f;          // output rows whose taps can touch those (+-1)
+    lo = olo < 0.f ? 0 : (int)olo;
+    hi = ohi > (float)(out_sz - 1) ? out_sz - 1 : (int)ohi;
+}
+__global__ __launch_bounds__(256) void wg_postprocess_bwd_gather_kernel(const float* __restrict__ dout, float* __restrict__ dlow, int lh, int lw, PostScales sc, int in_h,
+                                                                        int in_w, int out_h, int out_w) {
+    const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y, n = blockIdx.z;
+    if (c >= lw) return;
+    int ylo, yhi, xlo, xhi;
+    wg_post_range(r, sc.s1y, sc.s2y, in_h, out_h, ylo, yhi);
+    wg_post_range(c, sc.s1x, sc.s2x, in_w, out_w, xlo, xhi);
+    const float* g = dout + (long)n * out_h * out_w;
+    float acc = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+        const float wy = wg_post_w(oy, sc.s2y, in_h, sc.s1y, lh, r);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+            const float wx = wg_post_w(ox, sc.s2x, in_w, sc.s1x, lw, c);
+            row += wx * g[(long)oy * out_w + ox];
         }
+        acc += wy * row;
+    }
+    dlow[((long)n * lh + r) * lw + c] = acc;
 }
 
 extern "C" int wg_postprocess_masks_bwd_f32(const float* dout, float* dlow, int N, int low_h, int low_w, int img_size, int in_h, int in_w, int out_h,
                                             int out_w, void* stream) {
     WG_REQUIRE(dout && dlow && N > 0 && low_h > 0 && low_w > 0 && img_size > 0 && in_h > 0 && in_w > 0 && in_h <= img_size && in_w <= img_size &&
                    out_h > 0 && out_w > 0, "postprocess_bwd: bad arguments");
-    hipLaunchKernelGGL(wg_postprocess_bwd_kernel, dim3((unsigned)((out_w + 255) / 256), (unsigned)out_h, (unsigned)N), dim3(256), 0, (hipStream_t)stream,
-                       dout, dlow, N, low_h, low_w, img_size, in_h, in_w, out_h, out_w);
+    WG_REQUIRE(low_h <= 65535 && N <= 65535, "postprocess_bwd: more than 65535 low-res rows or masks per call");
+    // (dlow is overwritten: callers written against the scatter form zero it first, which is harmless)
+    hipLaunchKernelGGL(wg_postprocess_bwd_gather_kernel, dim3((unsigned)((low_w + 255) / 256), (unsigned)low_h, (unsigned)N), dim3(256), 0, (hipStream_t)stream,
+                       dout, dlow, low_h, low_w, wg_post_scales(low_h, low_w, img_size, in_h, in_w, out_h, out_w), in_h, in_w, out_h, out_w);
     return wg_check_launch("wg_postprocess_masks_bwd_f32");
 }
 
