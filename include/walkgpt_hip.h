@@ -339,6 +339,9 @@ int wg_resample_tokens_bf16(const void* x, void* y, int n, int p, int t, int C, 
  * wg_act_bf16 / _bwd:     y = act(x); dx = dy * act'(x)  (act codes of the GEMM epilogue: 1 erf-GELU, 2 quick-GELU, 3 ReLU)
  * wg_layernorm_bwd_bf16:  dx [M,C] bf16, dgamma / dbeta [C] fp32 (+=) of y = LayerNorm(x) gamma + beta */
 int wg_colsum_f32(const void* x, long ldx, float* out, int R, int C, void* stream);
+/* The same without atomics (per-workgroup partial rows folded in a fixed order): out [C] is written, fp32 or bf16; workspace: wg_colsum_det_workspace_floats. */
+long wg_colsum_det_workspace_floats(int R, int C);
+int wg_colsum_det_f32(const void* x, long ldx, void* out, int out_f32, float* workspace, long workspace_floats, int R, int C, void* stream);
 int wg_act_bf16(const void* x, void* y, long n, int act, void* stream);
 int wg_act_bwd_bf16(const void* x, const void* dy, void* dx, long n, int act, void* stream);
 int wg_layernorm_bwd_bf16(const void* x, long ldx, const void* gamma, const void* dy, long lddy, void* dx, long lddx, float* dgamma,
@@ -354,8 +357,8 @@ int wg_layernorm_bwd_det_bf16(const void* x, long ldx, const void* gamma, const 
  * wg_attn_bwd_bf16: gradients of o = softmax(scale q k^T) v per (batch, head) for the head's small attentions (two-way transformer,
  *   transformer.py:185-240; CrossAttnBlock / TinyCrossAttn, utils_walkgpt.py:163-185,330-357): q [B,Lq,D], k / v [B,Lk,D], o / dout [B,Lq,D]
  *   contiguous bf16, min(Lq, Lk) <= 16, head_dim % 8 == 0, <= 128.  The long side's gradients are written as bf16, the short side's
- *   accumulated into zeroed fp32 buffers; wg_attn_bwd_short_side: 1 = keys short (dq bf16, dk / dv fp32), 0 = queries short (dk / dv
- *   bf16, dq fp32), -1 = unsupported.  stats: B * heads * Lq * 2 floats of workspace.
+ *   WRITTEN as fp32 (round 4: per-wave LDS rows and per-workgroup partial planes summed in a fixed order, no atomics); wg_attn_bwd_short_side: 1 = keys short (dq bf16, dk / dv fp32), 0 = queries short (dk / dv
+ *   bf16, dq fp32), -1 = unsupported.  workspace: wg_attn_bwd_workspace_floats floats.
  * wg_postprocess_masks_bwd_f32: adjoint of wg_postprocess_masks_f32 (d loss / d low-res logits; written, not accumulated -- a gather in a fixed
  *   order since round 4: no atomics, the same bits every run).
  * wg_mask_losses_bwd_f32: d(g_bce sigmoid_ce_loss + g_dice dice_loss) / d logits (utils_walkgpt.py:76-120); workspace
@@ -363,9 +366,10 @@ int wg_layernorm_bwd_det_bf16(const void* x, long ldx, const void* gamma, const 
 int wg_l2norm_scale_bf16(const void* x, const void* log_temp, void* y, int M, int C, float eps, void* stream);
 int wg_l2norm_scale_bwd_bf16(const void* x, const void* dy, const void* log_temp, void* dx, float* dlog_temp, int M, int C, float eps, void* stream);
 int wg_attn_bwd_short_side(int Lq, int Lk);
+long wg_attn_bwd_workspace_floats(int B, int heads, int head_dim, int Lq, int Lk);
 int wg_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* dout, void* dq_bf16, void* dk_bf16, void* dv_bf16,
-                     float* dq_f32, float* dk_f32, float* dv_f32, float* stats, int B, int heads, int head_dim, int Lq, int Lk, float scale,
-                     void* stream);
+                     float* dq_f32, float* dk_f32, float* dv_f32, float* workspace, long workspace_floats, int B, int heads, int head_dim, int Lq, int Lk,
+                     float scale, void* stream);
 int wg_postprocess_masks_bwd_f32(const float* dout, float* dlow, int N, int low_h, int low_w, int img_size, int in_h, int in_w, int out_h,
                                  int out_w, void* stream);
 int wg_mask_losses_bwd_f32(const float* pred_logits, const float* targets, float* dpred, float* workspace, long workspace_floats, int N, long hw,
@@ -391,7 +395,9 @@ int wg_splice_multimodal_bwd_bf16(const long* ids, const int* img_pos, const voi
 /* masks = hyper_in @ upscaled (mask_decoder.py:150-160) on channels-last rows for all prompts at once, and its gradients (training path):
  *   up [P, HW, 32] bf16, hyper [P, K <= 4, 32] bf16 -> masks [P, K, HW] fp32;  backward: dup [P, HW, 32] bf16, dhyper [P, K, 32] fp32 (+=). */
 int wg_hyper_rows_f32(const void* up, const void* hyper, float* masks, int P, int HW, int C, int K, void* stream);
-int wg_hyper_rows_bwd_f32(const void* up, const void* hyper, const float* dmasks, void* dup, float* dhyper, int P, int HW, int C, int K, void* stream);
+long wg_hyper_rows_bwd_workspace_floats(int P, int HW, int K);
+int wg_hyper_rows_bwd_f32(const void* up, const void* hyper, const float* dmasks, void* dup, float* dhyper, float* workspace, long workspace_floats, int P, int HW,
+                          int C, int K, void* stream);   /* dhyper written (fixed-order sums of per-workgroup partials in `workspace`: no atomics) */
 /* fp32 verification route (csrc/fp32_ref.hip; not a product path, not benched): fp32 storage, exact fp32 matrix math on v_mfma_f32_16x16x4_f32,
  * plain kernels.  Exists so that north_star's "text logits within 1e-4 abs of the reference CPU path" can be held on the GPU on SOME route
  * (walkgpt_amd/fp32_route.py, tests/test_gpu_fp32_route.py); the bf16 path's distance to fp32 is set by its bf16 weights.

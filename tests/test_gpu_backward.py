@@ -105,6 +105,12 @@ def test_attention_backward(dev, B, H, hd, Lq, Lk):
     assert rel(o, orf) < 6e-3
     assert rel(qh.grad, qr.grad) < 1.5e-2 and rel(kh.grad, kr.grad) < 1.5e-2 and rel(vh.grad, vr.grad) < 1.5e-2, \
         (rel(qh.grad, qr.grad), rel(kh.grad, kr.grad), rel(vh.grad, vr.grad))
+    # the short side's gradient: per-wave LDS rows and per-workgroup partial planes summed in a fixed order (no atomics): a second pass, same bits
+    first = [t.grad.clone() for t in (qh, kh, vh)]
+    for t in (qh, kh, vh):
+        t.grad = None
+    ag.attention(qh, kh, vh, H, scale).backward(do.to(dev))
+    assert all(torch.equal(a, t.grad) for a, t in zip(first, (qh, kh, vh)))
 
 
 def test_ctp_tail_operators_backward(dev):
@@ -413,3 +419,37 @@ def test_hyper_rows_backward_reads_no_stale_lds(dev, K):
     assert float((masks.detach() - ref.detach()).abs().max()) < 1e-3 * float(ref.abs().max())
     assert float((up.grad.float() - u32.grad).norm() / u32.grad.norm()) < 6e-3
     assert float((hy.grad.float() - h32.grad).norm() / h32.grad.norm()) < 6e-3
+    first = (up.grad.clone(), hy.grad.clone())            # per-workgroup partials folded in a fixed order: the same bits on a second pass
+    up.grad = hy.grad = None
+    ag.hyper_rows(up, hy).backward(dm)
+    assert torch.equal(first[0], up.grad) and torch.equal(first[1], hy.grad)
+
+
+def test_head_training_step_is_deterministic(dev):
+    """Two identical forward + backward passes of the trainable grounding head (CTP -> mask decoder -> postprocess -> mask losses, SAM's decoder
+    geometry): every gradient tensor has the same bits -- Linear / LayerNorm / attention / hypernetwork-row / broadcast-add / postprocess gradients
+    all sum in a fixed order since round 4 (rounds 2-3: fp32 atomics)."""
+    from walkgpt_amd import train_head
+    from walkgpt_amd.walkgpt import WalkGPTGrounding
+    torch.manual_seed(0)
+    g = WalkGPTGrounding(sam="vit_b", llm_hidden=1024, with_clip=False).to(dev).bfloat16()
+    B, T = 3, 2
+    emb = torch.randn(B, 64 * 64, 256, device=dev).bfloat16()
+    hidden = [torch.randn(T, 1024, device=dev).bfloat16().requires_grad_(True) for _ in range(B)]
+    resize, orig = [(1024, 1024)] * B, [(448, 448)] * B
+    gt = torch.cat([(torch.rand(T, 448, 448, device=dev) > 0.5).float() for _ in range(B)], 0)
+    named = [(n, p) for n, p in g.named_parameters() if p.requires_grad] + [("hidden%d" % i, h) for i, h in enumerate(hidden)]
+
+    def step():
+        for _, p in named:
+            p.grad = None
+        pred = train_head.ctp_forward(g.text_hidden_fcs[0], torch.cat(hidden, 0))
+        masks = train_head.decode(g, emb, list(torch.split(pred, T, 0)), resize, orig)
+        bce, dice = ag.mask_losses(torch.cat(masks, 0).contiguous(), gt, T)
+        (2.0 * bce + 0.5 * dice).backward()
+        return {n: p.grad.clone() for n, p in named if p.grad is not None}
+
+    a, b = step(), step()
+    assert len(a) > 100
+    bad = [n for n in a if not torch.equal(a[n], b[n])]
+    assert not bad, bad[:5]

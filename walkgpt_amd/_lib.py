@@ -55,7 +55,7 @@ SIGNATURES = {
     "wg_l2norm_scale_bf16": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "wg_l2norm_scale_bwd_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p],
     "wg_attn_bwd_short_side": [c_int, c_int],
-    "wg_attn_bwd_bf16": [c_void_p] * 12 + [c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "wg_attn_bwd_bf16": [c_void_p] * 12 + [c_long, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "wg_postprocess_masks_bwd_f32": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_mask_losses_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_float, c_float, c_float, c_float, c_void_p],
     "wg_avgpool_tokens_bwd_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p],
@@ -81,7 +81,8 @@ SIGNATURES = {
     "wg_f32_mha": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "wg_debug_fill_lds_u32": [ctypes.c_uint, c_void_p, c_void_p],
     "wg_hyper_rows_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
-    "wg_hyper_rows_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
+    "wg_hyper_rows_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p],
+    "wg_colsum_det_f32": [c_void_p, c_long, c_void_p, c_int, c_void_p, c_long, c_int, c_int, c_void_p],
     "wg_upscale_mask_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_dec_tokens_f32": [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
@@ -131,6 +132,9 @@ _SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, []),
             "wg_gemm_bwd_splits": (c_int, [c_int, c_int, c_int]),
             "wg_gemm_bwd_workspace_floats": (c_long, [c_int, c_int, c_int, c_int]),
             "wg_layernorm_bwd_det_workspace_floats": (c_long, [c_int, c_int]),
+            "wg_hyper_rows_bwd_workspace_floats": (c_long, [c_int, c_int, c_int]),
+            "wg_colsum_det_workspace_floats": (c_long, [c_int, c_int]),
+            "wg_attn_bwd_workspace_floats": (c_long, [c_int, c_int, c_int, c_int, c_int]),
             "wg_gemm_pick_tile": (c_int, [c_int, c_int]),
             "wg_gemm_ln_supported": (c_int, [c_int, c_int, c_int, c_long, c_long, c_long]),
             "wg_gemm_row_partials_supported": (c_int, [c_int, c_int, c_int, c_long, c_long, c_long]),

@@ -44,15 +44,18 @@ def transpose2d(t):
 
 
 def colsum(t):
-    """[R, C] bf16 -> fp32 [C] column sums (wg_colsum_f32)."""
+    """[R, C] bf16 -> fp32 [C] column sums (wg_colsum_det_f32: per-workgroup partial rows folded in a fixed order, no atomics)."""
     R, C = t.shape
     if C % 8 or t.stride(0) % 8 or t.data_ptr() % 16:      # the kernel reads 16-byte pieces: a handful of columns (IoU head: 4) go padded
         Cp = (C + 7) // 8 * 8
         tp = torch.zeros(R, Cp, device=t.device, dtype=t.dtype)
         tp[:, :C] = t
         return colsum(tp)[:C]
-    out = torch.zeros(C, device=t.device, dtype=torch.float32)
-    _lib.check(_lib.lib().wg_colsum_f32(t.data_ptr(), t.stride(0), out.data_ptr(), R, C, ops._stream()), "wg_colsum_f32")
+    L = _lib.lib()
+    out = torch.empty(C, device=t.device, dtype=torch.float32)
+    nws = L.wg_colsum_det_workspace_floats(R, C)
+    ws = torch.empty(nws, device=t.device, dtype=torch.float32)
+    _lib.check(L.wg_colsum_det_f32(t.data_ptr(), t.stride(0), out.data_ptr(), 1, ws.data_ptr(), nws, R, C, ops._stream()), "wg_colsum_det_f32")
     return out
 
 
@@ -282,16 +285,17 @@ class _Attention(torch.autograd.Function):
             raise NotImplementedError("attention backward: one side must have at most 16 rows (Lq = %d, Lk = %d)" % (Lq, Lk))
         dev = q.device
         do = do.contiguous()
-        stats = torch.empty(B * H * Lq * 2, device=dev, dtype=torch.float32)
+        nws = L.wg_attn_bwd_workspace_floats(B, H, D // H, Lq, Lk)
+        ws = torch.empty(nws, device=dev, dtype=torch.float32)       # softmax statistics + the short side's partial planes (summed in a fixed order)
         if side == 1:      # few keys
             dq = torch.empty_like(q)
-            dk32, dv32 = torch.zeros(B, Lk, D, device=dev), torch.zeros(B, Lk, D, device=dev)
+            dk32, dv32 = torch.empty(B, Lk, D, device=dev), torch.empty(B, Lk, D, device=dev)
             args = (dq.data_ptr(), None, None, None, dk32.data_ptr(), dv32.data_ptr())
         else:              # few queries
             dk, dv = torch.empty_like(k), torch.empty_like(v)
-            dq32 = torch.zeros(B, Lq, D, device=dev)
+            dq32 = torch.empty(B, Lq, D, device=dev)
             args = (None, dk.data_ptr(), dv.data_ptr(), dq32.data_ptr(), None, None)
-        rc = L.wg_attn_bwd_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), *args, stats.data_ptr(), B, H, D // H, Lq, Lk,
+        rc = L.wg_attn_bwd_bf16(q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), do.data_ptr(), *args, ws.data_ptr(), nws, B, H, D // H, Lq, Lk,
                                 float(ctx.scale), ops._stream())
         _lib.check(rc, "wg_attn_bwd_bf16")
         if side == 1:
@@ -614,8 +618,11 @@ class _HyperRows(torch.autograd.Function):
         K = hyper.shape[1]
         dm = dm.contiguous().float()
         dup = torch.empty_like(up)
-        dh = torch.zeros(P, K, C, device=up.device, dtype=torch.float32)
-        rc = _lib.lib().wg_hyper_rows_bwd_f32(up.data_ptr(), hyper.data_ptr(), dm.data_ptr(), dup.data_ptr(), dh.data_ptr(), P, HW, C, K, ops._stream())
+        dh = torch.empty(P, K, C, device=up.device, dtype=torch.float32)
+        L = _lib.lib()
+        nws = L.wg_hyper_rows_bwd_workspace_floats(P, HW, K)
+        ws = torch.empty(nws, device=up.device, dtype=torch.float32)
+        rc = L.wg_hyper_rows_bwd_f32(up.data_ptr(), hyper.data_ptr(), dm.data_ptr(), dup.data_ptr(), dh.data_ptr(), ws.data_ptr(), nws, P, HW, C, K, ops._stream())
         _lib.check(rc, "wg_hyper_rows_bwd_f32")
         return dup, dh.to(hyper.dtype)
 

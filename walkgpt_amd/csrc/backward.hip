@@ -38,6 +38,39 @@ __global__ __launch_bounds__(256) void wg_colsum_kernel(const bf16* x, long ldx,
     for (int e = 0; e < 8; ++e) atomicAdd(out + c + e, s[e]);
 }
 
+// The same without atomics: every workgroup (256 rows x 512 columns) leaves its partial row in part[blockIdx.y][C]; wg_fold_rows_kernel sums the
+// partial rows in order.  (Fixed order: the same bits every run.)
+__global__ __launch_bounds__(256) void wg_colsum_part_kernel(const bf16* x, long ldx, float* part, int R, int C) {
+    __shared__ float red[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = blockIdx.x * 512 + lane * 8;
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int r0 = blockIdx.y * 256;
+    const int r1 = r0 + 256 < R ? r0 + 256 : R;
+    if (c < C) {
+        for (int r = r0 + wave; r < r1; r += 4) {
+            const bf16x8 t = *(const bf16x8*)(x + (long)r * ldx + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += (float)t[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[wave][lane * 8 + e] = s[e];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 512; i += 256) {
+        const int cc = blockIdx.x * 512 + i;
+        if (cc < C) part[(long)blockIdx.y * C + cc] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+    }
+}
+// out[c] = sum_b part[b][c] (b ascending), n = number of columns; fp32 or bf16 out
+__global__ __launch_bounds__(256) void wg_fold_rows_kernel(const float* part, int blocks, long n, void* out, int out_f32) {
+    const long c = (long)blockIdx.x * 256 + threadIdx.x;
+    if (c >= n) return;
+    float s = 0.f;
+    for (int b = 0; b < blocks; ++b) s += part[(long)b * n + c];
+    if (out_f32) ((float*)out)[c] = s; else ((bf16*)out)[c] = (bf16)s;
+}
+
 // ---- activations as separate operators ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float wg_act_grad(float x, int act) {
     switch (act) {
@@ -411,14 +444,19 @@ __global__ __launch_bounds__(256) void wg_attn_rowstats_kernel(const bf16* q, co
 // a: the long side's rows this workgroup's lanes own (queries for BYQ, keys for BYKEY); s_*: the short side
 template <bool BYKEY>
 __global__ __launch_bounds__(256) void wg_attn_bwd_kernel(const bf16* q, const bf16* k, const bf16* v, const bf16* dout, const float* stats, bf16* dlong_a,
-                                                          bf16* dlong_b, float* dshort_a, float* dshort_b, int H, int hd, int Lq, int Lk, float scale) {
-    // BYQ:   dlong_a = dq (bf16, direct);           dshort_a = dk, dshort_b = dv (fp32, atomics)
-    // BYKEY: dlong_a = dk, dlong_b = dv (direct);    dshort_a = dq (fp32, atomics)
-    __shared__ float s_a[ATT_S][ATT_HD];      // BYQ: K rows          BYKEY: Q rows
-    __shared__ float s_b[ATT_S][ATT_HD];      // BYQ: V rows          BYKEY: dO rows
-    __shared__ float acc_a[ATT_S][ATT_HD];    // BYQ: dK              BYKEY: dQ
-    __shared__ float acc_b[BYKEY ? 1 : ATT_S][BYKEY ? 1 : ATT_HD];   // BYQ: dV
+                                                          bf16* dlong_b, float* part_a, float* part_b, long plane, int H, int hd, int Lq, int Lk, float scale) {
+    // BYQ:   dlong_a = dq (bf16, direct);           part_a = dk, part_b = dv partials
+    // BYKEY: dlong_a = dk, dlong_b = dv (direct);    part_a = dq partials
+    // The short side's gradient is a sum over every row of the long side.  Round 4, no atomics: each wave adds into LDS rows of its own, the four waves'
+    // rows are summed in wave order, and the workgroup leaves ONE partial [B, Ls, D] plane (part_*[blockIdx.x * plane + ...], output layout) for
+    // wg_fold_rows_kernel to sum in workgroup order -- the same bits every run.  (LDS sized by the head dim: dynamic.)
+    extern __shared__ float att_smem[];
+    float* s_a = att_smem;                        // [ATT_S][hd]  BYQ: K rows          BYKEY: Q rows
+    float* s_b = s_a + ATT_S * hd;                // [ATT_S][hd]  BYQ: V rows          BYKEY: dO rows
+    float* acc_a = s_b + ATT_S * hd;              // [4 waves][ATT_S][hd]  BYQ: dK     BYKEY: dQ
+    float* acc_b = acc_a + 4 * ATT_S * hd;        // [4 waves][ATT_S][hd]  BYQ: dV     (BYKEY: unused, not allocated)
     __shared__ float s_st[ATT_S][2];
+    const int wave = threadIdx.x >> 6;
     const int bh = blockIdx.y, b = bh / H, h = bh % H, D = H * hd;
     const int Ll = BYKEY ? Lk : Lq, Ls = BYKEY ? Lq : Lk;
     const int lane = threadIdx.x & 63;
@@ -427,10 +465,13 @@ __global__ __launch_bounds__(256) void wg_attn_bwd_kernel(const bf16* q, const b
     for (int t = threadIdx.x; t < Ls * hd; t += 256) {
         const int r = t / hd, d = t % hd;
         const long off = ((long)b * Ls + r) * D + h * hd + d;
-        s_a[r][d] = (float)sa_src[off];
-        s_b[r][d] = (float)sb_src[off];
-        acc_a[r][d] = 0.f;
-        if (!BYKEY) acc_b[r][d] = 0.f;
+        s_a[r * hd + d] = (float)sa_src[off];
+        s_b[r * hd + d] = (float)sb_src[off];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            acc_a[(w * ATT_S + r) * hd + d] = 0.f;
+            if (!BYKEY) acc_b[(w * ATT_S + r) * hd + d] = 0.f;
+        }
     }
     if (BYKEY && threadIdx.x < Ls * 2) s_st[threadIdx.x >> 1][threadIdx.x & 1] = stats[((long)bh * Lq + (threadIdx.x >> 1)) * 2 + (threadIdx.x & 1)];
     __syncthreads();
@@ -452,11 +493,11 @@ __global__ __launch_bounds__(256) void wg_attn_bwd_kernel(const bf16* q, const b
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (BYKEY) {               // s_ij = q_i . k_j ;  dp_ij = dO_i . v_j
-                        sc[r] += s_a[r][d + e] * (float)ta[e];
-                        dp[r] += s_b[r][d + e] * (float)tb[e];
+                        sc[r] += s_a[r * hd + d + e] * (float)ta[e];
+                        dp[r] += s_b[r * hd + d + e] * (float)tb[e];
                     } else {                   // s_ij = q_i . k_j ;  dp_ij = dO_i . v_j
-                        sc[r] += (float)ta[e] * s_a[r][d + e];
-                        dp[r] += (float)tb[e] * s_b[r][d + e];
+                        sc[r] += (float)ta[e] * s_a[r * hd + d + e];
+                        dp[r] += (float)tb[e] * s_b[r * hd + d + e];
                     }
                 }
             }
@@ -497,15 +538,15 @@ __global__ __launch_bounds__(256) void wg_attn_bwd_kernel(const bf16* q, const b
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     if (BYKEY) {
-                        o1[e] += ds[r] * s_a[r][d + e];          // dk_j = sum_i ds_ij q_i
-                        o2[e] += pr[r] * s_b[r][d + e];          // dv_j = sum_i p_ij dO_i
+                        o1[e] += ds[r] * s_a[r * hd + d + e];          // dk_j = sum_i ds_ij q_i
+                        o2[e] += pr[r] * s_b[r * hd + d + e];          // dv_j = sum_i p_ij dO_i
                         const float c = wg_wave_sum(ds[r] * (float)ta[e]);      // dq_i += sum_j ds_ij k_j
-                        if (lane == 0) atomicAdd(&acc_a[r][d + e], c);
+                        if (lane == 0) acc_a[(wave * ATT_S + r) * hd + d + e] += c;
                     } else {
-                        o1[e] += ds[r] * s_a[r][d + e];          // dq_i = sum_j ds_ij k_j
+                        o1[e] += ds[r] * s_a[r * hd + d + e];          // dq_i = sum_j ds_ij k_j
                         const float c1 = wg_wave_sum(ds[r] * (float)ta[e]);     // dk_j += sum_i ds_ij q_i
                         const float c2 = wg_wave_sum(pr[r] * (float)tb[e]);     // dv_j += sum_i p_ij dO_i
-                        if (lane == 0) { atomicAdd(&acc_a[r][d + e], c1); atomicAdd(&acc_b[r][d + e], c2); }
+                        if (lane == 0) { acc_a[(wave * ATT_S + r) * hd + d + e] += c1; acc_b[(wave * ATT_S + r) * hd + d + e] += c2; }
                     }
                 }
             }
@@ -522,8 +563,9 @@ __global__ __launch_bounds__(256) void wg_attn_bwd_kernel(const bf16* q, const b
     for (int t = threadIdx.x; t < Ls * hd; t += 256) {
         const int r = t / hd, d = t % hd;
         const long off = ((long)b * Ls + r) * D + h * hd + d;
-        atomicAdd(dshort_a + off, acc_a[r][d]);
-        if (!BYKEY) atomicAdd(dshort_b + off, acc_b[r][d]);
+        const int f = r * hd + d, ws = ATT_S * hd;
+        part_a[(long)blockIdx.x * plane + off] = acc_a[f] + acc_a[ws + f] + acc_a[2 * ws + f] + acc_a[3 * ws + f];
+        if (!BYKEY) part_b[(long)blockIdx.x * plane + off] = acc_b[f] + acc_b[ws + f] + acc_b[2 * ws + f] + acc_b[3 * ws + f];
     }
 }
 
@@ -836,7 +878,7 @@ __global__ __launch_bounds__(256) void wg_nce_tail_kernel(const bf16* z, const b
 // ---- masks = hyper_in @ upscaled (mask_decoder.py:150-160) on channels-last rows, all prompts in one launch, and its gradients ------------------
 // up [P, HW, C] bf16 (C = 32: the upscaled embedding, one row per output pixel), hyper [P, K, C] bf16 (K <= 4 mask tokens' hypernetwork outputs)
 // -> masks [P, K, HW] fp32.  A thread per pixel, the prompt's K hyper rows in LDS.
-// Backward: dup[p, x, :] = sum_k dm[p, k, x] hyper[p, k, :];  dhyper[p, k, :] += sum_x dm[p, k, x] up[p, x, :] (workgroup partials -> fp32 atomics).
+// Backward: dup[p, x, :] = sum_k dm[p, k, x] hyper[p, k, :];  dhyper[p, k, :] = sum_x dm[p, k, x] up[p, x, :] (one partial per workgroup, folded in a fixed order: no atomics).
 constexpr int HM_C = 32, HM_K = 4;
 template <int MODE>   // 0 forward, 1 backward
 __global__ __launch_bounds__(256) void wg_hyper_rows_kernel(const bf16* up, const bf16* hyper, const float* dm, float* masks, bf16* dup, float* dhyper, int HW,
@@ -904,9 +946,9 @@ __global__ __launch_bounds__(256) void wg_hyper_rows_kernel(const bf16* up, cons
                 if (lane == 0) red[wave][k][c] = v;
             }
         __syncthreads();
-        if (threadIdx.x < K * HM_C) {
+        if (threadIdx.x < K * HM_C) {       // this workgroup's partial of dhyper[p]: plane blockIdx.x of [gridDim.x][P * K * C] (summed in order by wg_fold_rows_kernel)
             const int k = threadIdx.x / HM_C, c = threadIdx.x % HM_C;
-            atomicAdd(dhyper + ((long)p * K + k) * HM_C + c, red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c]);
+            dhyper[((long)blockIdx.x * gridDim.y + p) * K * HM_C + k * HM_C + c] = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
         }
     }
 }
@@ -934,11 +976,17 @@ extern "C" int wg_hyper_rows_f32(const void* up, const void* hyper, float* masks
     return wg_check_launch("wg_hyper_rows_f32");
 }
 
-extern "C" int wg_hyper_rows_bwd_f32(const void* up, const void* hyper, const float* dmasks, void* dup, float* dhyper, int P, int HW, int C, int K, void* stream) {
-    WG_REQUIRE(up && hyper && dmasks && dup && dhyper && P > 0 && HW > 0 && C == HM_C && K > 0 && K <= HM_K, "hyper_rows_bwd: C must be %d, K <= %d", HM_C, HM_K);
-    int gx = (HW + 255) / 256;
-    if (gx > 64) gx = 64;
-    hipLaunchKernelGGL(wg_hyper_rows_kernel<1>, dim3(gx, P), dim3(256), 0, (hipStream_t)stream, (const bf16*)up, (const bf16*)hyper, dmasks, nullptr, (bf16*)dup, dhyper, HW, K);
+// dhyper [P, K, C] fp32 is WRITTEN (round 4: fixed-order sums, no atomics); workspace: wg_hyper_rows_bwd_workspace_floats(P, HW, K) floats.
+static int wg_hyper_gx(int HW) { const int gx = (HW + 255) / 256; return gx > 64 ? 64 : gx; }
+extern "C" long wg_hyper_rows_bwd_workspace_floats(int P, int HW, int K) { return (long)wg_hyper_gx(HW) * P * K * HM_C; }
+extern "C" int wg_hyper_rows_bwd_f32(const void* up, const void* hyper, const float* dmasks, void* dup, float* dhyper, float* workspace, long workspace_floats, int P, int HW,
+                                     int C, int K, void* stream) {
+    WG_REQUIRE(up && hyper && dmasks && dup && dhyper && workspace && P > 0 && HW > 0 && C == HM_C && K > 0 && K <= HM_K, "hyper_rows_bwd: C must be %d, K <= %d", HM_C, HM_K);
+    const int gx = wg_hyper_gx(HW);
+    WG_REQUIRE(workspace_floats >= (long)gx * P * K * HM_C, "hyper_rows_bwd: workspace too small (need %ld floats)", (long)gx * P * K * HM_C);
+    hipLaunchKernelGGL(wg_hyper_rows_kernel<1>, dim3(gx, P), dim3(256), 0, (hipStream_t)stream, (const bf16*)up, (const bf16*)hyper, dmasks, nullptr, (bf16*)dup, workspace, HW, K);
+    const long n = (long)P * K * HM_C;
+    hipLaunchKernelGGL(wg_fold_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, workspace, gx, n, dhyper, 1);
     return wg_check_launch("wg_hyper_rows_bwd_f32");
 }
 
@@ -1045,29 +1093,55 @@ extern "C" int wg_l2norm_scale_bwd_bf16(const void* x, const void* dy, const voi
 }
 
 // q [B,Lq,D], k / v [B,Lk,D], o / dout [B,Lq,D] contiguous bf16 (D = heads * head_dim); min(Lq, Lk) <= 16, head_dim % 8 == 0, <= 128.
-// dq / dk / dv: bf16 for the long side(s) written directly, fp32 (+=, zeroed by the caller) for the short side: the caller passes BOTH forms
+// dq / dk / dv: bf16 for the long side(s) written directly, fp32 (WRITTEN, round 4: fixed-order sums) for the short side: the caller passes BOTH forms
 // for every gradient and reads the one that applies (wg_attn_bwd_short_side tells which side is short).
-// stats: workspace of B * heads * Lq * 2 floats (used when the queries are the short side).
+// workspace: wg_attn_bwd_workspace_floats(B, heads, head_dim, Lq, Lk) floats (softmax statistics + one partial plane per workgroup of long-side rows).
 extern "C" int wg_attn_bwd_short_side(int Lq, int Lk) { return Lk <= ATT_S ? 1 : (Lq <= ATT_S ? 0 : -1); }   // 1: keys short, 0: queries short
 
+extern "C" long wg_attn_bwd_workspace_floats(int B, int heads, int head_dim, int Lq, int Lk) {
+    const int side = wg_attn_bwd_short_side(Lq, Lk);
+    if (side < 0) return 0;
+    const long D = (long)heads * head_dim, nblk = ((side == 1 ? Lq : Lk) + 255) / 256;
+    const long plane = (long)B * (side == 1 ? Lk : Lq) * D;
+    return (long)B * heads * Lq * 2 + nblk * plane * (side == 1 ? 2 : 1);
+}
+
 extern "C" int wg_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* dout, void* dq_bf16, void* dk_bf16, void* dv_bf16,
-                                float* dq_f32, float* dk_f32, float* dv_f32, float* stats, int B, int heads, int head_dim, int Lq, int Lk, float scale,
-                                void* stream) {
-    WG_REQUIRE(q && k && v && o && dout && stats, "attn_bwd: null operand");
+                                float* dq_f32, float* dk_f32, float* dv_f32, float* workspace, long workspace_floats, int B, int heads, int head_dim, int Lq, int Lk,
+                                float scale, void* stream) {
+    WG_REQUIRE(q && k && v && o && dout && workspace, "attn_bwd: null operand");
     WG_REQUIRE(B > 0 && heads > 0 && Lq > 0 && Lk > 0 && head_dim % 8 == 0 && head_dim <= ATT_HD, "attn_bwd: head_dim = %d must be a multiple of 8, at most %d", head_dim, ATT_HD);
     const int side = wg_attn_bwd_short_side(Lq, Lk);
     WG_REQUIRE(side >= 0, "attn_bwd: one side must have at most %d rows (Lq = %d, Lk = %d)", ATT_S, Lq, Lk);
+    WG_REQUIRE(workspace_floats >= wg_attn_bwd_workspace_floats(B, heads, head_dim, Lq, Lk), "attn_bwd: workspace too small (need %ld floats)",
+               wg_attn_bwd_workspace_floats(B, heads, head_dim, Lq, Lk));
     hipStream_t st = (hipStream_t)stream;
+    float* stats = workspace;
+    float* part = workspace + (long)B * heads * Lq * 2;
+    const long D = (long)heads * head_dim;
+    static WgPerDevice once;
+    int dev = 0;
+    if (once.first(&dev)) {
+        (void)hipFuncSetAttribute((const void*)wg_attn_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 + 8) * ATT_S * ATT_HD * 4);
+        (void)hipFuncSetAttribute((const void*)wg_attn_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (2 + 4) * ATT_S * ATT_HD * 4);
+    }
     if (side == 1) {   // few keys: a lane per query
         WG_REQUIRE(dq_bf16 && dk_f32 && dv_f32, "attn_bwd: dq (bf16), dk / dv (fp32) outputs");
-        hipLaunchKernelGGL(wg_attn_bwd_kernel<false>, dim3((Lq + 255) / 256, B * heads), dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v,
-                           (const bf16*)dout, stats, (bf16*)dq_bf16, nullptr, dk_f32, dv_f32, heads, head_dim, Lq, Lk, scale);
+        const int nblk = (Lq + 255) / 256;
+        const long plane = (long)B * Lk * D;
+        hipLaunchKernelGGL(wg_attn_bwd_kernel<false>, dim3(nblk, B * heads), dim3(256), (size_t)(2 + 8) * ATT_S * head_dim * 4, st, (const bf16*)q, (const bf16*)k,
+                           (const bf16*)v, (const bf16*)dout, stats, (bf16*)dq_bf16, nullptr, part, part + nblk * plane, plane, heads, head_dim, Lq, Lk, scale);
+        hipLaunchKernelGGL(wg_fold_rows_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, part, nblk, plane, dk_f32, 1);
+        hipLaunchKernelGGL(wg_fold_rows_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, part + nblk * plane, nblk, plane, dv_f32, 1);
     } else {           // few queries: a lane per key, softmax statistics first
         WG_REQUIRE(dk_bf16 && dv_bf16 && dq_f32, "attn_bwd: dk / dv (bf16), dq (fp32) outputs");
+        const int nblk = (Lk + 255) / 256;
+        const long plane = (long)B * Lq * D;
         hipLaunchKernelGGL(wg_attn_rowstats_kernel, dim3(Lq, B * heads), dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)o, (const bf16*)dout,
                            stats, heads, head_dim, Lq, Lk, scale);
-        hipLaunchKernelGGL(wg_attn_bwd_kernel<true>, dim3((Lk + 255) / 256, B * heads), dim3(256), 0, st, (const bf16*)q, (const bf16*)k, (const bf16*)v,
-                           (const bf16*)dout, stats, (bf16*)dk_bf16, (bf16*)dv_bf16, dq_f32, nullptr, heads, head_dim, Lq, Lk, scale);
+        hipLaunchKernelGGL(wg_attn_bwd_kernel<true>, dim3(nblk, B * heads), dim3(256), (size_t)(2 + 4) * ATT_S * head_dim * 4, st, (const bf16*)q, (const bf16*)k,
+                           (const bf16*)v, (const bf16*)dout, stats, (bf16*)dk_bf16, (bf16*)dv_bf16, part, nullptr, plane, heads, head_dim, Lq, Lk, scale);
+        hipLaunchKernelGGL(wg_fold_rows_kernel, dim3((unsigned)((plane + 255) / 256)), dim3(256), 0, st, part, nblk, plane, dq_f32, 1);
     }
     return wg_check_launch("wg_attn_bwd_bf16");
 }
@@ -1076,6 +1150,17 @@ extern "C" int wg_colsum_f32(const void* x, long ldx, float* out, int R, int C, 
     WG_REQUIRE(x && out && R > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, "colsum: x [R, C] bf16 with C %% 8 == 0, 16-byte rows");
     hipLaunchKernelGGL(wg_colsum_kernel, dim3((C + 511) / 512, (R + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, out, R, C);
     return wg_check_launch("wg_colsum_f32");
+}
+
+// Column sums without atomics: out [C] is WRITTEN (fp32, or bf16 with out_f32 = 0); workspace: ceil(R / 256) * C floats.
+extern "C" long wg_colsum_det_workspace_floats(int R, int C) { return (long)((R + 255) / 256) * C; }
+extern "C" int wg_colsum_det_f32(const void* x, long ldx, void* out, int out_f32, float* workspace, long workspace_floats, int R, int C, void* stream) {
+    WG_REQUIRE(x && out && workspace && R > 0 && C > 0 && C % 8 == 0 && ldx % 8 == 0 && ((uintptr_t)x & 15) == 0, "colsum_det: x [R, C] bf16 with C %% 8 == 0, 16-byte rows");
+    const int rb = (R + 255) / 256;
+    WG_REQUIRE(workspace_floats >= (long)rb * C && rb <= 65535, "colsum_det: workspace too small (need %ld floats)", (long)rb * C);
+    hipLaunchKernelGGL(wg_colsum_part_kernel, dim3((C + 511) / 512, rb), dim3(256), 0, (hipStream_t)stream, (const bf16*)x, ldx, workspace, R, C);
+    hipLaunchKernelGGL(wg_fold_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, workspace, rb, (long)C, out, out_f32);
+    return wg_check_launch("wg_colsum_det_f32");
 }
 
 extern "C" int wg_act_bf16(const void* x, void* y, long n, int act, void* stream) {
