@@ -39,7 +39,7 @@ def main():
         pred = train_head.ctp_forward(ctp, torch.cat(hidden, 0))
         masks = train_head.decode(g, emb, list(torch.split(pred, T, 0)), resize, orig)
         # equal mask counts and sizes: one reduction over all masks (what causal_lm.model_forward does for such a batch)
-        bce, dice = ag.mask_losses(torch.cat(masks, 0).contiguous(), gt_all, T)
+        bce, dice = ag.mask_losses(masks.stacked.contiguous(), gt_all, T)
         loss = (2.0 * bce + 0.5 * dice) * T / (B * T + 1e-8)
         loss.backward()
         return loss

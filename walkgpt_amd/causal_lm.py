@@ -471,7 +471,10 @@ class walkgptForCausalLM(nn.Module):  # noqa: N801  (the reference's class name)
             # every image has the same number of masks T at the same size (the usual batch): sum_i [S_i / (T + 1e-8)] * T is ONE reduction over
             # all masks -- the per-image loop of walkgpt.py:565-583 costs ~12 launches per image forward and backward
             T = live[0][0].shape[0]
-            bce, dice = losses(torch.cat([p for _, p in live], 0).float().contiguous(), torch.cat([g for g, _ in live], 0).float().contiguous(), num_masks=T)
+            stacked = getattr(pred_masks, "stacked", None)          # the training decode's own [sum T, H0, W0] tensor, if every image has masks
+            if stacked is None or stacked.shape[0] != T * len(live):
+                stacked = torch.cat([p for _, p in live], 0)
+            bce, dice = losses(stacked.float().contiguous(), torch.cat([g for g, _ in live], 0).float().contiguous(), num_masks=T)
             mask_bce_loss, mask_dice_loss, num_masks = bce * T, dice * T, T * len(live)
         else:
             for gt_mask, pred_mask in live:

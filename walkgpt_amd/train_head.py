@@ -121,9 +121,16 @@ def decoder_forward(dec, src_tokens, pos_tokens, sparse, dense_vec, h, w, mask_s
     return masks, iou[:, k0:k1]
 
 
+class _MaskList(list):
+    """pred_masks[i] as the reference returns them, plus `.stacked`: every image's masks as ONE tensor [sum T_i, H0, W0] when all images share
+    a size (the list entries are then slices of it).  A caller that reduces over all masks at once (causal_lm.model_forward's batched mask
+    losses) takes `.stacked`: concatenating the slices back costs a zero-fill, a copy and an add per image in the backward pass."""
+    stacked = None
+
+
 def decode(grounding, emb_tokens, pred_embeddings, resize_list, original_size_list, multimask_output=False):
     """WalkGPTGrounding.decode with gradients: emb_tokens [B, hw, 256] (frozen SAM embedding), pred_embeddings[i] [T_i, 256] (CTP output).
-    -> pred_masks[i] fp32 [T_i, H0, W0] (logits), differentiable in pred_embeddings and the decoder's parameters."""
+    -> pred_masks[i] fp32 [T_i, H0, W0] (logits), differentiable in pred_embeddings and the decoder's parameters (a _MaskList)."""
     vm = grounding.visual_model
     h, w = vm.prompt_encoder.image_embedding_size
     pe = vm.prompt_encoder.dense_pe_tokens().unsqueeze(0).to(BF16)
@@ -133,7 +140,7 @@ def decode(grounding, emb_tokens, pred_embeddings, resize_list, original_size_li
     counts = [int(p.shape[0]) for p in pred_embeddings]
     P = sum(counts)
     dev = emb_tokens.device
-    out = [None] * len(counts)
+    out = _MaskList([None] * len(counts))
     if P > 0:
         # every prompt of every image in ONE decoder pass (prompt p attends to the embedding of its own image), as WalkGPTGrounding.decode does
         if hasattr(grounding, "_prompt_image_index"):                   # (cached per count tuple: no host-to-device copy per step)
@@ -146,6 +153,7 @@ def decode(grounding, emb_tokens, pred_embeddings, resize_list, original_size_li
         same = len(set(zip(map(tuple, resize_list), map(tuple, original_size_list)))) == 1
         if same:
             full = ag.postprocess_masks(low_res.contiguous(), vm.image_encoder.img_size, resize_list[0], original_size_list[0])[:, 0]
+            out.stacked = full
         off = 0
         for i, c in enumerate(counts):
             if c:
