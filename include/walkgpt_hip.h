@@ -122,6 +122,12 @@ int wg_mha_small_bf16(const void* Q, long ldq, long q_rows_per_batch, const void
  * Compiled (head_dim, window): (64,14) (64,64) (64,32) (32,14) (32,28) (80,14) (80,64) -- 80 = SAM ViT-H. */
 int wg_sam_attn_relpos_bf16(const void* qkv, const void* qkv_bias, const void* rel_pos_h, const void* rel_pos_w,
                             void* out, int B, int grid, int window, int heads, int head_dim, float scale, void* stream);
+/* The same for the fp8 chain (head_dim 64; window 14 or the 64 x 64 global grid): the output leaves as e4m3 bytes out_q [B * grid^2, heads * 64] + E8M0 block
+ * scales out_mx [heads * 2][mx_pitch] in wg_quantize_mx_fp8's group-128 layout -- bit for bit that pass's result on the bf16 output, which is never written
+ * (the proj Linear behind the attention, image_encoder.py:235-260, takes it as its MX operand). */
+int wg_sam_attn_mx_supported(int B, int grid, int window, int heads, int head_dim);
+int wg_sam_attn_relpos_mx_bf16(const void* qkv, const void* qkv_bias, const void* rel_pos_h, const void* rel_pos_w, void* out_q, void* out_mx, long mx_pitch,
+                               int B, int grid, int window, int heads, int head_dim, float scale, void* stream);
 
 /* NCHW bf16 images -> rows [B*(H/P)*(W/P), Kpad], columns (c, ky, kx) zero padded to Kpad: the im2row of
  * Conv2d(kernel=stride=P)  (image_encoder.py:422-426; CLIP patch_embedding). */

@@ -124,6 +124,41 @@ def test_quantize_mx_matches_the_stated_rule(dev, M, K, group):
         assert torch.allclose(part[..., 1].t(), (tiles * tiles).sum(-1), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("B,window,heads", [(2, 14, 12), (1, 64, 12), (3, 14, 16), (2, 64, 16)])
+def test_attention_writes_its_output_as_the_mx_operand(dev, B, window, heads):
+    """fp8 chain, head_dim 64 (ViT-B / ViT-L): the SAM attention kernels write e4m3 bytes + block scales themselves -- bit for bit what
+    wg_quantize_mx_fp8 makes of their bf16 output (the stated rule: test_quantize_mx_matches_the_stated_rule), scale bytes included, for the
+    windowed kernel (padded windows at the image edge: 64 = 4 x 14 + 8) and the global one."""
+    g = torch.Generator().manual_seed(B * 100 + window)
+    grid, hd = 64, 64
+    D = heads * hd
+    M = B * grid * grid
+    qkv = (torch.randn(M, 3 * D, generator=g) * 0.7).to(torch.bfloat16).to(dev)
+    qb = (torch.randn(3 * D, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    rh = (torch.randn(2 * window - 1, hd, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    rw = (torch.randn(2 * window - 1, hd, generator=g) * 0.1).to(torch.bfloat16).to(dev)
+    o = ops.sam_attention(qkv, qb, rh, rw, B, grid, window, heads)
+    q_ref, mx_ref = ops.quantize_mx_fp8(o)
+    got = ops.sam_attention(qkv, qb, rh, rw, B, grid, window, heads, mx_out=True)
+    assert isinstance(got, tuple), "head_dim 64 with window 14 / global 64 x 64 carries the MX epilogue"
+    q, mx = got
+    idx = ops.mx_scale_index(M, dev, 128)
+    assert torch.equal(mx[:, idx], mx_ref[:, idx])
+    assert torch.equal(q, q_ref)
+
+
+def test_attention_mx_epilogue_is_not_offered_at_head_dim_80(dev):
+    """ViT-H: a 32-column block would straddle two heads; the caller gets bf16 and quantises in a pass of its own."""
+    g = torch.Generator().manual_seed(1)
+    B, grid, window, heads, hd = 1, 64, 14, 16, 80
+    D = heads * hd
+    qkv = torch.randn(B * grid * grid, 3 * D, generator=g).to(torch.bfloat16).to(dev)
+    qb = torch.zeros(3 * D, dtype=torch.bfloat16, device=dev)
+    rh = torch.zeros(2 * window - 1, hd, dtype=torch.bfloat16, device=dev)
+    out = ops.sam_attention(qkv, qb, rh, rh.clone(), B, grid, window, heads, mx_out=True)
+    assert not isinstance(out, tuple) and out.dtype == torch.bfloat16
+
+
 @pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 264, 384), (1000, 520, 1280), (2100, 1032, 256)])
 def test_mxfp8_persistent_gemm_exact_on_small_integers(dev, M, N, K):
     """Both operands with per-(row, block) power-of-two scales on exact integer data, on the persistent kernel (several tiles per

@@ -30,6 +30,7 @@ SIGNATURES = {
                           c_long, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "wg_sam_attn_relpos_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                 c_float, c_void_p],
+    "wg_sam_attn_relpos_mx_bf16": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
     "wg_patchify_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p],
     "wg_im2row3x3_bf16": [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "wg_add_rows_bf16": [c_void_p, c_long, c_void_p, c_long, c_int, c_void_p, c_long, c_long, c_int, c_void_p],
@@ -135,6 +136,7 @@ _SPECIAL = {"wg_last_error": (ctypes.c_char_p, []), "wg_version": (c_int, []),
             "wg_hyper_rows_bwd_workspace_floats": (c_long, [c_int, c_int, c_int]),
             "wg_colsum_det_workspace_floats": (c_long, [c_int, c_int]),
             "wg_attn_bwd_workspace_floats": (c_long, [c_int, c_int, c_int, c_int, c_int]),
+            "wg_sam_attn_mx_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
             "wg_gemm_pick_tile": (c_int, [c_int, c_int]),
             "wg_gemm_ln_supported": (c_int, [c_int, c_int, c_int, c_long, c_long, c_long]),
             "wg_gemm_row_partials_supported": (c_int, [c_int, c_int, c_int, c_long, c_long, c_long]),

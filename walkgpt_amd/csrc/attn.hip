@@ -1117,10 +1117,38 @@ static bool wg_window_unit_on() {
     return !(e && e[0] == '0');
 }
 
+static int wg_sam_attn_impl(const void* qkv, const void* qkv_bias, const void* rel_pos_h, const void* rel_pos_w, void* out, void* out_q, void* out_mx, long mx_pitch,
+                            int B, int grid, int window, int heads, int head_dim, float scale, void* stream);
+
 extern "C" int wg_sam_attn_relpos_bf16(const void* qkv, const void* qkv_bias, const void* rel_pos_h, const void* rel_pos_w,
                                        void* out, int B, int grid, int window, int heads, int head_dim, float scale,
                                        void* stream) {
-    WG_REQUIRE(qkv && qkv_bias && rel_pos_h && rel_pos_w && out, "sam_attn: null operand");
+    WG_REQUIRE(out, "sam_attn: null operand");
+    return wg_sam_attn_impl(qkv, qkv_bias, rel_pos_h, rel_pos_w, out, nullptr, nullptr, 0, B, grid, window, heads, head_dim, scale, stream);
+}
+
+// The fp8 chain's form (config C5's nn.Linear chain, ViT-B / ViT-L geometry): the attention output leaves as the proj GEMM's MX operand -- e4m3 bytes
+// out_q [B * grid^2, D] and E8M0 block scales out_mx [D / 32][mx_pitch] in wg_quantize_mx_fp8's group-128 layout, bit for bit what that pass makes of
+// the bf16 output -- and the bf16 tensor is never written.  head_dim 64 only (a 32-column block must not straddle two heads: not ViT-H's 80), on the
+// kernels that carry the epilogue (wg_sam_attn_mx_supported).
+extern "C" int wg_sam_attn_mx_supported(int B, int grid, int window, int heads, int head_dim) {
+    if (head_dim != 64 || B <= 0 || heads <= 0) return 0;
+    AttnArgs a{};
+    a.B = B; a.heads = heads; a.Hg = grid; a.nW = (grid + window - 1) / window; a.ldo = (long)heads * head_dim;
+    if (window == 64) return wg_attn_pipe_takes(a, head_dim, 64, 8) ? 1 : 0;
+    if (window == 14) return (wg_window_unit_on() && wg_attn_window_unit_takes(a)) ? 1 : 0;
+    return 0;
+}
+extern "C" int wg_sam_attn_relpos_mx_bf16(const void* qkv, const void* qkv_bias, const void* rel_pos_h, const void* rel_pos_w, void* out_q, void* out_mx, long mx_pitch,
+                                          int B, int grid, int window, int heads, int head_dim, float scale, void* stream) {
+    WG_REQUIRE(out_q && out_mx && wg_sam_attn_mx_supported(B, grid, window, heads, head_dim), "sam_attn_mx: head_dim 64 with window 14 or a 64 x 64 global grid only");
+    WG_REQUIRE(mx_pitch >= ((long)B * grid * grid + 127) / 128 * 128 && ((uintptr_t)out_q & 3) == 0, "sam_attn_mx: scale pitch must cover the rows in groups of 128");
+    return wg_sam_attn_impl(qkv, qkv_bias, rel_pos_h, rel_pos_w, nullptr, out_q, out_mx, mx_pitch, B, grid, window, heads, head_dim, scale, stream);
+}
+
+static int wg_sam_attn_impl(const void* qkv, const void* qkv_bias, const void* rel_pos_h, const void* rel_pos_w, void* out, void* out_q, void* out_mx, long mx_pitch,
+                            int B, int grid, int window, int heads, int head_dim, float scale, void* stream) {
+    WG_REQUIRE(qkv && qkv_bias && rel_pos_h && rel_pos_w && (out || out_q), "sam_attn: null operand");
     WG_REQUIRE(B > 0 && grid > 0 && window > 0 && window <= grid && heads > 0, "sam_attn: bad shape");
     const long D = (long)heads * head_dim;
     WG_REQUIRE((((uintptr_t)qkv | (uintptr_t)qkv_bias | (uintptr_t)rel_pos_h | (uintptr_t)rel_pos_w) & 15) == 0 &&
@@ -1129,6 +1157,7 @@ extern "C" int wg_sam_attn_relpos_bf16(const void* qkv, const void* qkv_bias, co
     const bf16* base = (const bf16*)qkv;
     a.Q = base; a.K = base + D; a.V = base + 2 * D; a.O = (bf16*)out;
     a.ldq = a.ldk = a.ldv = 3 * D; a.ldo = D;
+    a.Oq = (unsigned char*)out_q; a.ldoq = D; a.Omx = (unsigned char*)out_mx; a.mx_pitch = mx_pitch;
     a.padK = (const bf16*)qkv_bias + D; a.padV = (const bf16*)qkv_bias + 2 * D;
     a.rel_h = (const bf16*)rel_pos_h; a.rel_w = (const bf16*)rel_pos_w;
     a.B = B; a.heads = heads; a.Hg = grid; a.nW = (grid + window - 1) / window; a.scale = scale;

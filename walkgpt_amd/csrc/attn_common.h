@@ -17,6 +17,9 @@ struct AttnArgs {
     int nW;                      // windows per side
     int qchunks;                 // workgroups per (batch, window, head)
     float scale;
+    // fp8 chain (grid mode, head_dim 64): the output leaves as e4m3 bytes + one E8M0 scale per (row, 32 columns) -- the A operand of the
+    // MX GEMM behind the attention (gemm.hip GemmArgs::mx_a layout: rows r, r + 16, .. of a 128-row group adjacent) -- instead of bf16
+    unsigned char* Oq; long ldoq; unsigned char* Omx; long mx_pitch;
 };
 
 template <int HD> __device__ __forceinline__ int swzK(int row) {
@@ -59,3 +62,37 @@ int wg_attn_pipe_launch(const AttnArgs& a, int S, int nw, hipStream_t st);
 // attn_window_unit.hip: SAM's 14 x 14 windows at head_dim 64 with a whole (window, head) of K / V staged ahead
 bool wg_attn_window_unit_takes(const AttnArgs& a);
 int wg_attn_window_unit_launch(AttnArgs a, int groups, hipStream_t st);
+
+// The epilogue of a head_dim-64 attention kernel in its fp8 form: lane (query, hi) holds rows 8 g4 + 4 hi + e of the two 32-row blocks of O^T,
+// i.e. 16 of the 32 columns of the MX block (query row, head, d); its partner lane ^ 32 holds the other 16.  The rule is wg_quantize_mx_fp8's on
+// the bf16-ROUNDED output (what the quantisation pass used to read back): scale = the power of two at or above max|block| / 448.
+template <int DB>
+__device__ __forceinline__ void wg_attn_store_mx(const f32x16 (&ot)[DB], float inv_l, bool valid, long row, int hcol, int hi, const AttnArgs& a) {
+    const long r = row % 128;
+    const long spos = (row - r) + (r % 16) * 8 + r / 16;
+#pragma unroll
+    for (int d = 0; d < DB; ++d) {
+        float v[16], am = 0x1p-100f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            v[i] = (float)(bf16)(ot[d][i] * inv_l);
+            am = fmaxf(am, fabsf(v[i]));
+        }
+        am = wg_xor32_max(am);
+        const unsigned bits = __builtin_bit_cast(unsigned, am * (1.0f / 448.0f));
+        unsigned e8 = (bits >> 23) + ((bits & 0x7FFFFFu) ? 1u : 0u);
+        e8 = e8 > 253u ? 253u : e8;
+        const float s = __builtin_bit_cast(float, (254u - e8) << 23);
+        if (valid) {
+            unsigned char* qp = a.Oq + row * a.ldoq + hcol + 32 * d + 4 * hi;
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                int w = 0;
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * g4] * s, v[4 * g4 + 1] * s, w, false);
+                w = __builtin_amdgcn_cvt_pk_fp8_f32(v[4 * g4 + 2] * s, v[4 * g4 + 3] * s, w, true);
+                *(unsigned*)(qp + 8 * g4) = (unsigned)w;
+            }
+            if (hi == 0) a.Omx[(long)((hcol + 32 * d) >> 5) * a.mx_pitch + spos] = (unsigned char)e8;
+        }
+    }
+}

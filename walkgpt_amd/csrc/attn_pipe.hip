@@ -612,6 +612,10 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
     }
     // ---- epilogue: O = O^T / l, 8-byte stores ----------------------------------------------------------------------------------------
     const float l_tot = l_run;
+    if (GRID && a.Oq) {            // fp8 chain: e4m3 + block scales instead of bf16 (uniform branch)
+        wg_attn_store_mx<DB>(ot, 1.0f / l_tot, qvalid, qrow, hcol, hi, a);
+        return;
+    }
     if (qvalid) {
         const float inv = 1.0f / l_tot;
         const long orow = GRID ? qrow : (long)b * a.o_bs + ql;

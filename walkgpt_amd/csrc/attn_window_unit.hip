@@ -361,7 +361,8 @@ __global__ __launch_bounds__(NW * 64) void wg_attn_window_unit_kernel(AttnArgs a
         // exec-mask branch around the stores.)  Tried and not kept: holding the packed output in registers and storing it behind the NEXT
         // unit's requests, so that the wait at the head of the loop finds no young stores to drain -- 97 us per launch against 88.
         const float l_tot = wg_xor32_sum(l_run);
-        {
+        if (a.Oq) wg_attn_store_mx<DB>(ot, 1.0f / l_tot, cur.qvalid != 0, cur.qrow, cur.hcol, hi, a);      // fp8 chain (uniform branch)
+        else {
             const float inv = 1.0f / l_tot;
             const unsigned ooff = cur.qvalid != 0 ? (unsigned)((cur.qrow * a.ldo + cur.hcol) * 2) : 0x80000000u;
 #pragma unroll

@@ -283,13 +283,24 @@ def mha(q, k, v, heads, scale, key_bias=None, out=None, small=None):
     return out
 
 
-def sam_attention(qkv, qkv_bias, rel_pos_h, rel_pos_w, B, grid, window, heads, out=None):
-    """SAM ViT attention over packed qkv rows [B*grid*grid, 3D]; window == grid means global attention."""
+def sam_attention(qkv, qkv_bias, rel_pos_h, rel_pos_w, B, grid, window, heads, out=None, mx_out=False):
+    """SAM ViT attention over packed qkv rows [B*grid*grid, 3D]; window == grid means global attention.
+    mx_out: the fp8 chain's form -- where the kernels carry it (head_dim 64; window 14 or the 64 x 64 global grid) the result is the tuple
+    (e4m3 bytes, E8M0 block scales) quantize_mx_fp8 would make of the bf16 output, written by the attention kernel itself; elsewhere the bf16
+    tensor as usual (the caller quantises)."""
     _need_gpu(qkv, qkv_bias, rel_pos_h, rel_pos_w, out)
     D = qkv.shape[-1] // 3
     hd = D // heads
     assert qkv.is_contiguous() and qkv.shape[0] == B * grid * grid and qkv.dtype == _BF16
     assert rel_pos_h.shape == (2 * window - 1, hd) and rel_pos_h.is_contiguous() and rel_pos_w.is_contiguous()
+    if mx_out and out is None and _lib.lib().wg_sam_attn_mx_supported(B, grid, window, heads, hd):
+        M = B * grid * grid
+        q = torch.empty(M, D, device=qkv.device, dtype=torch.uint8)
+        mx = torch.empty(D // 32, mx_pitch(M), device=qkv.device, dtype=torch.uint8)
+        rc = _lib.lib().wg_sam_attn_relpos_mx_bf16(qkv.data_ptr(), qkv_bias.data_ptr(), rel_pos_h.data_ptr(), rel_pos_w.data_ptr(), q.data_ptr(), mx.data_ptr(),
+                                                   mx.shape[1], B, grid, window, heads, hd, float(hd) ** -0.5, _stream())
+        _lib.check(rc, "wg_sam_attn_relpos_mx_bf16")
+        return q, mx
     _forget_sidecars(out)
     if out is None:
         out = torch.empty(B * grid * grid, D, device=qkv.device, dtype=_BF16)

@@ -128,15 +128,18 @@ class Block(nn.Module, _Prepared):
         """The block as one MX chain on the persistent fp8 GEMM (ops.linear_mxfp8): e4m3 operands with a power-of-two scale per 32
         values on both sides; both LayerNorms folded into the GEMM behind them from the partial sums the GEMM in front left; the
         residual GEMMs (proj, lin2) leave the stream as bf16 AND as the next GEMM's e4m3 operand; the MLP's hidden layer only ever
-        exists as e4m3.  The one quantisation pass left per block is the attention output's.  Attention, the residual stream and every
+        exists as e4m3.  At head_dim 64 the attention kernels write their output as the proj GEMM's MX operand themselves (round 4); at ViT-H's 80 a
+        32-column block would straddle two heads and the attention output keeps one quantisation pass per block.  Attention, the residual stream and every
         statistic stay bf16 / fp32."""
         a, m = self.attn, self.mlp
         w = self._prep_get(self._build_mx, (self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, self.norm2.weight,
                                             self.norm2.bias, m.lin1.weight, m.lin1.bias, m.lin2.weight), slot="_mx")
         qkv = ops.linear_mxfp8(x, w["qkv"], ln_eps=self.norm1.eps)
         window = self.window_size if self.window_size > 0 else grid
-        o = ops.sam_attention(qkv, a.qkv.bias, a.rel_pos_h, a.rel_pos_w, B, grid, window, a.num_heads)
-        x = ops.linear_mxfp8(ops.quantize_mx_fp8(o), w["proj"], bias=a.proj.bias, residual=x, mx_out=True, row_partials=True)
+        o = ops.sam_attention(qkv, a.qkv.bias, a.rel_pos_h, a.rel_pos_w, B, grid, window, a.num_heads, mx_out=True)
+        if not isinstance(o, tuple):       # (head_dim 80, other windows: the attention kernel writes bf16 and the quantisation is a pass of its own)
+            o = ops.quantize_mx_fp8(o)
+        x = ops.linear_mxfp8(o, w["proj"], bias=a.proj.bias, residual=x, mx_out=True, row_partials=True)
         h = ops.linear_mxfp8(x, w["lin1"], act=m._act_code, ln_eps=self.norm2.eps, mx_out=True, bf16_out=False)
         return ops.linear_mxfp8(h, w["lin2"], bias=m.lin2.bias, residual=x, mx_out=True, row_partials=True)
 
