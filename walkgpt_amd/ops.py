@@ -8,7 +8,14 @@ ACT_NONE, ACT_GELU, ACT_QUICK_GELU, ACT_RELU = 0, 1, 2, 3
 _BF16 = torch.bfloat16
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream():
+    """The current HIP stream's handle.  (torch.cuda.current_stream() builds a Stream object through three Python layers, ~4 us a call and one call per
+    launch: a third of a millisecond of a 590-launch training step; the raw accessor is the same handle in ~0.3 us.)"""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
