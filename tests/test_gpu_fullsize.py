@@ -257,3 +257,48 @@ def test_c4_per_gpu_share_at_its_own_batch(dev):
     assert e_m < 0.05 and e_f < 0.02
     assert rel_err(masks[9].float().cpu().numpy(), masks[0].float().cpu().numpy()) > 0.1
     assert ctp is model.text_hidden_fcs[0]
+
+
+def test_c2_step_on_three_streams_reproduces_itself_bit_for_bit(dev):
+    """The fused C2 step as bench.py runs it (CLIP tower / SAM encoder / graph-replayed decode on three HIP streams, bs = 8) 25 times on the same
+    inputs: CLIP features, SAM embedding, masks and scores of every pass equal the first pass's bit for bit.  The inference path has no atomics,
+    so a difference would be an intermittent fault -- a missing wait state in front of a hand-placed MFMA (attn_pipe.hip), a counted wait that
+    is one short (gemm.hip, attn_window_unit.hip), a buffer reused before its reader is done.  tools/soak_step.py is the long form (400 passes)."""
+    from walkgpt_amd.walkgpt import WalkGPTGrounding
+    B, T, Hl = 8, 1, 4096
+    torch.manual_seed(2)
+    model = WalkGPTGrounding(sam="vit_b", llm_hidden=Hl, with_clip=True).to(dev).bfloat16().eval()
+    del model.out_mm_projector
+    pe = model.visual_model.prompt_encoder.pe_layer
+    pe.positional_encoding_gaussian_matrix.data = pe.positional_encoding_gaussian_matrix.data.float()
+    _randomise_sam_tables(model.visual_model.image_encoder)
+    g = torch.Generator().manual_seed(13)
+    x = torch.randn(B, 3, 1024, 1024, generator=g).to(dev, torch.bfloat16)
+    xc = torch.randn(B, 3, 448, 448, generator=g).to(dev, torch.bfloat16)
+    hid = [torch.randn(T, Hl, generator=g).to(dev, torch.bfloat16) for _ in range(B)]
+    sizes, orig, csz = [(1024, 1024)] * B, [(448, 448)] * B, [(448, 448)] * B
+    side, dec = torch.cuda.Stream(), torch.cuda.Stream()
+
+    def step():
+        with torch.no_grad():
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                feats, _ = model.encode_images_clip(xc, csz)
+            emb = model.get_visual_emb_tokens(x)
+            dec.wait_stream(cur)
+            emb.record_stream(dec)
+            with torch.cuda.stream(dec):
+                masks, scores = model.decode_from_hidden_graphed(emb, hid, sizes, orig)
+                masks, scores = [m.clone() for m in masks], [s.clone() for s in scores]
+            cur.wait_stream(side)
+            cur.wait_stream(dec)
+        torch.cuda.synchronize()
+        return [feats.clone(), emb.clone()] + masks + scores
+
+    ref = step()
+    assert all(torch.isfinite(t.float()).all() for t in ref)
+    for it in range(25):
+        out = step()
+        bad = [i for i, (a, b) in enumerate(zip(ref, out)) if not torch.equal(a, b)]
+        assert not bad, "pass %d: tensors %s differ from the first pass" % (it, bad)
