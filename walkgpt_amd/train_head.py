@@ -53,11 +53,12 @@ def _two_way_block(blk, queries, keys, query_pe, key_pe):
         q = queries + query_pe
         queries = queries + _attention(blk.self_attn, q, q, queries)
     queries = _ln(queries, blk.norm1)
-    q, k = queries + query_pe, keys + key_pe
+    k = keys + key_pe                      # (the image tokens do not change until the end of the block: one sum for both cross attentions)
+    q = queries + query_pe
     queries = _ln(queries + _attention(blk.cross_attn_token_to_image, q, k, keys), blk.norm2)
     h = _lin(_lin(queries, blk.mlp.lin1, blk.mlp._act_code), blk.mlp.lin2)
     queries = _ln(queries + h, blk.norm3)
-    q, k = queries + query_pe, keys + key_pe
+    q = queries + query_pe
     keys = _ln(keys + _attention(blk.cross_attn_image_to_token, k, q, queries), blk.norm4)
     return queries, keys
 
