@@ -489,16 +489,21 @@ def main():
         for name, fn, arg in (("graph", model.decode_from_hidden_graphed, resident), ("graph_staged", model.decode_from_hidden_graphed, one),
                               ("eager", model.decode_from_hidden, one)):
             one_ = arg
-            for _ in range(3):
+            # 20 untimed calls, then the median of three timed runs of 50: ten calls right behind the step loop (round 3's form) sat 5-7 % above
+            # what tools/bench_decode.py measures for the same chain on the same box -- the part's clocks are still settling from the full load
+            for _ in range(20):
                 fn(*one_)
             torch.cuda.synchronize()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(10):
-                fn(*one_)
-            e1.record()
-            torch.cuda.synchronize()
-            lat[name] = e0.elapsed_time(e1) / 10
+            runs = []
+            for _rep in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50):
+                    fn(*one_)
+                e1.record()
+                torch.cuda.synchronize()
+                runs.append(e0.elapsed_time(e1) / 50)
+            lat[name] = sorted(runs)[1]
 
     # ---- instrumented step: per-launch HIP-event timing of every GEMM, grouped by the kernel that ran ---------------------------
     # serialised (one stream): the events then bracket each launch running alone on the chip, which is what a kernel roofline
@@ -560,7 +565,7 @@ def main():
                            "one_image_latency_eager_ms": round(lat["eager"], 3),
                            "amortised_ms_per_image": round(decode_batch_ms / B, 3), "batch_ms_overlapped": round(decode_batch_ms, 3),
                            "prompts_per_image": T,
-                           "note": "latency: prompt encoder + mask decoder + postprocess of one image's T prompts alone on the GPU (CTP included), graph "
+                           "note": "latency (median of 3 runs of 50 calls after 20 untimed ones): prompt encoder + mask decoder + postprocess of one image's T prompts alone on the GPU (CTP included), graph "
                                    "replay with the embedding and [SEG] states resident in the graph's input buffers (staged: + the two copies into them); "
                                    "amortised: the batch's decode chain as timed inside the step, overlapped with the next step's encoders, / images"},
            "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 3),
