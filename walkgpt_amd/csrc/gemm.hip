@@ -1514,15 +1514,18 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                         // (plain fp32 arithmetic on the unpacked pairs: v_dot2c_f32_bf16 would halve the count, but through the builtin
                         // this hipcc reads dword 0 of the vector for every k, and as inline asm the DPP steps below would follow it
                         // without the wait states the compiler only inserts behind instructions it can see)
-                        f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+                        // v_dot2c_f32_bf16: one instruction per pair and sum (was: unpack, add, multiply-add on fp32 pairs -- the residual + row-sum
+                        // epilogue is vector-bound).  Each dword goes through a scalar copy first: handed a vector ELEMENT, this hipcc's builtin read
+                        // dword 0 for every k.
+                        float sv = 0.f, qv = 0.f;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
-                            const unsigned pr = t[it][k];
-                            const f32x2 v2 = {__builtin_bit_cast(float, pr << 16), __builtin_bit_cast(float, pr & 0xFFFF0000u)};
-                            s2 += v2;
-                            q2 += v2 * v2;
+                            unsigned pr = t[it][k];
+                            asm volatile("" : "+v"(pr));
+                            const bf16x2 p2 = __builtin_bit_cast(bf16x2, pr);
+                            sv = __builtin_amdgcn_fdot2_f32_bf16(p2, (bf16x2){(bf16)1.0f, (bf16)1.0f}, sv, false);
+                            qv = __builtin_amdgcn_fdot2_f32_bf16(p2, p2, qv, false);
                         }
-                        float sv = s2.x + s2.y, qv = q2.x + q2.y;
                         sv += WG_DPP(sv, 0xB1); qv += WG_DPP(qv, 0xB1);      // quad_perm [1,0,3,2]
                         sv += WG_DPP(sv, 0x4E); qv += WG_DPP(qv, 0x4E);      // quad_perm [2,3,0,1]
                         sv += WG_DPP(sv, 0x141); qv += WG_DPP(qv, 0x141);    // row_half_mirror: the other quad of the 8 lanes
