@@ -1511,12 +1511,10 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                     // wave's 64 columns -> spart[row][wn] = {sum, sum of squares}.
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
-                        // (plain fp32 arithmetic on the unpacked pairs: v_dot2c_f32_bf16 would halve the count, but through the builtin
-                        // this hipcc reads dword 0 of the vector for every k, and as inline asm the DPP steps below would follow it
-                        // without the wait states the compiler only inserts behind instructions it can see)
                         // v_dot2c_f32_bf16: one instruction per pair and sum (was: unpack, add, multiply-add on fp32 pairs -- the residual + row-sum
                         // epilogue is vector-bound).  Each dword goes through a scalar copy first: handed a vector ELEMENT, this hipcc's builtin read
-                        // dword 0 for every k.
+                        // dword 0 for every k (and as inline asm the DPP steps below would follow it without the wait states the compiler only inserts behind
+                        // instructions it can see: hence the builtin on a scalar copy).
                         float sv = 0.f, qv = 0.f;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
