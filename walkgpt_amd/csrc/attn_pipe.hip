@@ -46,21 +46,11 @@ template <int I, int N, class F> __device__ __forceinline__ void wg_static_for(F
 }
 
 // ---- one instruction per statement ------------------------------------------------------------------------------------------
-// Where the MFMA operands live (WG_PIPE_AGPR = 1; default 0: see notes/r04_experiments.md): the O^T accumulators and the K / Q / V^T fragments in the accumulation half of the
-// register file, the scores, P^T and everything the vector ALU touches in the arch half -- an MFMA's 40 register reads / writes per lane
-// then mostly stay off the ports the exponentials use (MI355X_MICROARCH.md: the files are one 512-entry space, split at accum_offset).
-#ifndef WG_PIPE_AGPR
-#define WG_PIPE_AGPR 0
-#endif
-#if WG_PIPE_AGPR
-#define PA_F "a"
-#define PA_FO "=a"
-#define PA_FIO "+a"
-#else
+// Every MFMA operand lives in arch VGPRs.  (Round 4 tried the accumulation half of the register file through "a" constraints: hipcc shuttles such values through
+// v_accvgpr_write in front of the asm MFMAs without the wait states -- wrong rows; the diff is kept in notes/r04_attn_pipe_agpr.diff, not in the product sources.)
 #define PA_F "v"
 #define PA_FO "=v"
 #define PA_FIO "+v"
-#endif
 // S^T (scores, arch VGPRs): A = K fragment, B = Q fragment
 #define PA_MFMA_ACC(acc, a, b) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(acc) : PA_F(a), PA_F(b))
 #define PA_MFMA_C(d, a, b, c) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %3" : "=&v"(d) : PA_F(a), PA_F(b), "v"(c))
@@ -377,7 +367,11 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
     auto decide = [&](float rh, auto pendc) __attribute__((always_inline)) {
         constexpr int PEND = decltype(pendc)::value;
         if (__any(mx > m_run + RESCALE_THR)) {
-            asm volatile("s_nop 15" ::: "memory");      // O^T comes out of MFMAs the hazard recogniser cannot see
+            // O^T and the row sums come out of MFMAs the hazard recogniser cannot see: the wait states are TIED to the registers (an untied
+            // s_nop orders nothing: hipcc may schedule its own multiplies by alpha, ordered only behind the asm MFMA, ahead of the nop)
+            asm volatile("s_nop 15\n\ts_nop 1" : "+v"(osum));
+#pragma unroll
+            for (int d = 0; d < DB; ++d) asm volatile("" : "+v"(ot[d]));
             const float m_new = fmaxf(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
@@ -570,7 +564,10 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
             if constexpr (j & 1) PA_MFMA_VV(osum, ones_full, pf[1][j >> 1]);
         });
     }
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // the last MFMAs' results (opaque to the hazard recogniser) before the first vector read
+    // the last MFMAs' results (opaque to the hazard recogniser) before the first vector read: wait states tied to the registers they cover
+    asm volatile("s_nop 15\n\ts_nop 7" : "+v"(osum));
+#pragma unroll
+    for (int d = 0; d < DB; ++d) asm volatile("" : "+v"(ot[d]));
     float l_run = osum[0];      // (every element holds the row sum over both lane halves' keys)
 #ifdef WG_ATTN_STAMP
     if (blockIdx.x < 8 && lane == 0 && wg_attn_pipe_stamp_ptr)

@@ -17,65 +17,8 @@
 //   * workgroup -> tile map is XCD-aware: blocks that share an XCD (same id mod 8) walk one contiguous
 //     stripe of the tile grid, so the A row panel and the weight slab are re-read from that XCD's L2.
 #include "wg_common.h"
+#include "gemm_args.h"
 #include <type_traits>
-
-struct GemmArgs {
-    const bf16* A; long lda;
-    const bf16* W; long ldw;
-    const bf16* bias;
-    const bf16* R; long ldr; int res_mod;
-    void* C; long ldc;
-    int M, N, K;
-    int act;
-    int out_f32;
-    int tiles_m, tiles_n;
-    int col_block;               // tile order: column blocks of this many tile columns, row-major inside a block (0 = plain row-major)
-    const float* ln_stats;       // LayerNorm folded into this GEMM (persistent kernel only): [M][2] = {mean, rstd} of the rows of A,
-    const float* ln_s;           //   [N] column sums of the (gamma-scaled, bf16) weight rows,
-    const float* ln_b;           //   [N] folded bias  b + W beta:   C = rstd * (A W'^T - mean * s) + b'
-    const float* ln_part;        // ... or, instead of ln_stats, the rows' statistics as partial sums left by the GEMM that PRODUCED A
-    int ln_np; long ln_mpad;     //   (stats_part below): [ln_np][ln_mpad][2] = {sum x, sum x^2} per 256-column tile of A's row;
-    float ln_eps;                //   mean / rstd are formed in this kernel (K = the LayerNorm width)
-    float* stats_part;           // producer side (persistent kernel, bf16 output, N % 256 == 0): [tiles_n][stats_mpad][2] fp32 =
-    long stats_mpad;             //   {sum, sum of squares} of the STORED (bf16-rounded) values of each output row over the tile's 256 columns
-    unsigned c_bytes, r_bytes;   // extents of C and R for the staged epilogue's buffer descriptors (0: not addressable in 32 bits)
-    const float* scale_a;        // fp8 operands (wg_gemm_fp8_bias_act): per-row scale of A [M] and per-output-channel scale of W [N];
-    const float* scale_w;        //   A, W then point at e4m3 bytes and lda / ldw / K count PAIRS of bytes (see the entry point)
-    const unsigned char* mx_a = nullptr;   // persistent fp8 kernel, MX operand: E8M0 scale of every 32-value block of A's rows, [K/32][mx_a_pitch]
-    long mx_a_pitch = 0;                   //   bytes, the rows of a 128-row group permuted to (row % 16) * 8 + row / 16 (a lane's 8 fragments = 8 adjacent bytes)
-    unsigned char* mx_c = nullptr;         // ... and the block scales of its e4m3 output copy Cq (below), same layout [N/32][mx_c_pitch]: the next
-    long mx_c_pitch = 0;                   //   GEMM's mx_a
-    unsigned mx_c_bytes = 0;
-    const unsigned char* mx_w = nullptr;   // persistent fp8 kernel: the weights' block scales, [K/32][mx_w_pitch], rows of a 64-row group at
-    long mx_w_pitch = 0;                   //   (row % 16) * 4 + row / 16 (a lane's 4 column fragments = one dword)
-    void* Cq = nullptr;                    // persistent fp8 kernel: the stored values once more as e4m3 bytes [M][ldcq] with block scales mx_c
-    long ldcq = 0;                         //   (the next fp8 GEMM's A operand); C itself may then be null (c_bytes 0: its stores are dropped)
-    unsigned cq_bytes = 0;
-    const bf16* sk_gamma;        // skinny kernel only: LayerNorm(A) applied to the rows on their way into the MFMA (gamma, beta [K], eps)
-    const bf16* sk_beta;
-    float sk_eps;
-    int sk_tiled;                // skinny kernel only: W is in MFMA fragment order (wg_tile_weight_bf16) instead of row-major [N][K]
-};
-
-// Linear tile index -> (tile row, tile column).  With col_block = c > 0 the grid is walked in blocks of c tile columns, row-major
-// inside a block: the workgroups that share an XCD (a contiguous range of this order) then touch only c column panels of W,
-// which stay in that XCD's 4 MiB L2 while the A row panels stream past (plain row-major makes every XCD cycle through ALL
-// of W once per round of tiles: at N = 2304..4096 that is 3.5-8 MB per round, and the measured HBM-side reads were 2-4x
-// the operands, profiles/r01_gemm_traffic_by_shape.md).
-__device__ __forceinline__ void wg_tile_of(int wgid, int tiles_m, int tiles_n, int col_block, int& tile_m, int& tile_n) {
-    if (col_block <= 0 || col_block >= tiles_n) {
-        tile_m = wgid / tiles_n;
-        tile_n = wgid % tiles_n;
-        return;
-    }
-    const int per_block = tiles_m * col_block;
-    const int b = wgid / per_block;                    // column block
-    const int c0 = b * col_block;
-    const int w = (tiles_n - c0) < col_block ? (tiles_n - c0) : col_block;   // width of this (possibly last, narrower) block
-    const int idx = wgid - b * per_block;
-    tile_m = idx / w;
-    tile_n = c0 + idx % w;
-}
 
 // Diagnostic build only (-DWG_GEMM_STAMP, tools/gemm_stamps.py): lane 0 of waves 0 and 4 of workgroup 0 records s_memtime at the
 // half-phase boundaries of K slabs 2..9 of the ping-pong loop into the LDS bytes behind the two slabs.  No stamp in normal builds.
@@ -187,6 +130,10 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 
 // Experiment knobs of the persistent 256x256 kernel (diagnostic builds only, tools/build_variant.py): cache policy bits of its output
 // stores and of its operand loads (gfx950 aux: 1 = sc0, 2 = nt, 16 = sc1).  Default 0 = the plain policy.
+// WG_GEMM_TAIL (persistent bf16 kernel): MFMAs of a cluster issued BEHIND its hand-over barrier (0: the barrier closes the cluster)
+#ifndef WG_GEMM_TAIL
+#define WG_GEMM_TAIL 0
+#endif
 #ifndef WG_GEMM_C_AUX
 #define WG_GEMM_C_AUX 0
 #endif
@@ -196,20 +143,7 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 #ifndef WG_GEMM_W_AUX
 #define WG_GEMM_W_AUX 0
 #endif
-// WG_GEMM_AGPR (persistent kernel): 1 = accumulators in AGPRs, 2 = accumulators and both operand fragments in AGPRs (hipcc by itself
-// keeps every MFMA operand in arch VGPRs; tools/micro/coexec_probe.hip measures the same MFMA stream 10 / 15 % faster this way)
-#ifndef WG_GEMM_AGPR
-#define WG_GEMM_AGPR 0
-#endif
-__device__ __forceinline__ void wg_mfma16_acc(f32x4& acc, bf16x8 a, bf16x8 b) {
-#if WG_GEMM_AGPR == 1
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-#elif WG_GEMM_AGPR == 2
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc) : "a"(a), "a"(b));
-#else
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
-#endif
-}
+__device__ __forceinline__ void wg_mfma16_acc(f32x4& acc, bf16x8 a, bf16x8 b) { acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0); }
 
 // FP8 = true: the same kernel on e4m3 (OCP) operands.  A K slab is still 128 bytes per row -- 128 fp8 values instead of 64 bf16 -- so
 // staging, swizzle, barriers and the ping-pong schedule are unchanged; a fragment is the two 16-byte chunks k = 16*fq .. 16*fq+15
@@ -1403,12 +1337,23 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
+                        for (int j = 0; j < 4; ++j) {
+                            if (WG_GEMM_TAIL > 0 && ks * 16 + i * 4 + j == 32 - WG_GEMM_TAIL) {
+                                // The hand-over barrier WG_GEMM_TAIL MFMAs before the end of the cluster: the partner group (parked at this barrier
+                                // since its load half-phase ended) is released while this wave still has matrix work to issue, so the barrier's
+                                // release latency passes under the tail instead of under an idle matrix pipe.  The tail outranks the partner's
+                                // fresh cluster (priority 2 against 1: ties go to the older wave, which would starve a younger wave's tail).
+                                __builtin_amdgcn_sched_barrier(0);
+                                __builtin_amdgcn_s_setprio(2);
+                                __builtin_amdgcn_s_barrier();
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
                             wg_mfma16_acc(acc[4 * sc + i][j], wf2[j >> 1][j & 1][ks], af[i][ks]);
+                        }
                 }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
+                if (FP8 || WG_GEMM_TAIL == 0) __builtin_amdgcn_s_barrier();
             }
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();
@@ -1857,6 +1802,10 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
                            (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0 && g.r_bytes != 0));
     const bool small_ops = (long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31);
     if (tile == 11 && !(can_stage && small_ops)) tile = 1;
+    if (tile == 17) {   // free-running persistent 256x256 kernel (gemm_fr.hip) where it takes the operands, else the ping-pong persistent one
+        if (can_stage && small_ops && wg_gemm_fr_supports(g)) return wg_launch_gemm_fr(g, st);
+        tile = 16;
+    }
     if (tile == 16 && !(can_stage && small_ops && (!bias || ((uintptr_t)bias % 16 == 0 && N % 8 == 0)))) {
         WG_REQUIRE(!(g.ln_part || g.stats_part || g.ln_stats), "gemm: this operand layout cannot take the persistent kernel's staged epilogue");
         tile = 14;

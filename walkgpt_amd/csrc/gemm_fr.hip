@@ -1,0 +1,389 @@
+// Free-running persistent 256 x 256 bf16 GEMM for gfx950:  C[M,N] = act(A[M,K] . W[N,K]^T + bias[N])
+//
+// Same operands, tile geometry (8 waves = 2 x 4, wave tile 128 x 64, 64-deep K slabs of 128-byte LDS rows brought in by LDS-DMA, two slab
+// slots, source-side XOR swizzle) and arithmetic (v_mfma_f32_16x16x32_bf16, weights as the A operand, k in ascending order: the sums are
+// bit-identical) as wg_gemm_pp_persist_kernel (gemm.hip), which it replaces on the shapes wg_gemm_fr_supports() accepts
+// (image_encoder.py:238,257, common.py:25-26 and HF CLIP's q|k|v / out_proj / fc1 / fc2 behind custom_clip.py:50-104).
+//
+// What is different is the loop.  The ping-pong kernel makes the two waves of a SIMD alternate between a matrix half-phase and a load
+// half-phase across FOUR workgroup barriers per slab; in-kernel stamps (profiles/r04_gemm_phases.md) put its slab at 2430-2540 cycles against
+// 2048 of matrix work, and tools/micro/fetch_ceiling.hip + dma_issue_cost.hip (profiles/r05_gemm_micro.md) show that neither the operand fetch
+// (42-44 B/clk/CU available on these shapes against the 32 a 256 x 256 tile needs) nor the issue of the LDS-DMA pieces (7-13 cycles each beside
+// MFMAs) is what costs the difference: the barriers are.  Here every wave runs ONE instruction stream per slab in which fragment reads,
+// LDS-DMA pieces and MFMAs are interleaved by hand (every instruction its own `asm volatile` statement: hipcc keeps their order and
+// allocates the registers, as in attn_pipe.hip), and the workgroup meets at ONE barrier per slab:
+//   * a k-step (32 deep) is four passes j = 0..3 of eight MFMAs acc[i][j] += W_j . A_i; the A fragments a[0..7] stay in registers for the
+//     k-step, the W fragment of pass j + 1 is requested when pass j starts (two buffers), and in the last pass every a[i] is re-requested
+//     for the NEXT k-step right behind the MFMA that read it last -- the LDS latency of a fragment always has >= 8 MFMAs to hide under,
+//     and the SIMD's other wave fills the matrix pipe whenever this one waits;
+//   * the barrier sits in the last pass of a slab, after this wave's last fragment read of the slab has returned and its own pieces of
+//     the next slab have landed (counted vmcnt), in front of the requests for the next slab's first fragments: behind it the wave still has
+//     the eight MFMAs of that pass to issue, so the pipe is busy while the next slab's fragments are in flight;
+//   * the pieces of slab g + 2 go into the slot slab g has just freed, two per pass over the following four passes.
+// The slab stream runs across tile boundaries (the issue side is two slabs ahead of the consuming side and walks the tile list itself).
+#include "wg_common.h"
+#include "gemm_args.h"
+#include <type_traits>
+
+#define FR_RSRC_FLAGS 0x00020000   // raw buffer, 32-bit data format
+#define FR_OOB 0xC0000000u         // a byte offset beyond every operand the kernel accepts (wg_gemm_fr_supports): the range check drops the access
+
+template <int I, int N, class F> __device__ __forceinline__ void fr_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        fr_for<I + 1, N>(f);
+    }
+}
+
+// WG_GEMM_FR_ABL (timing-only builds, wrong results): bit 0 = no LDS-DMA pieces, bit 1 = no fragment reads, bit 2 = no barrier, bit 3 = no waits
+#ifndef WG_GEMM_FR_ABL
+#define WG_GEMM_FR_ABL 0
+#endif
+// ---- one instruction per statement --------------------------------------------------------------------------------------------
+#define FR_MFMA(acc, w, a) asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(w), "v"(a))
+#define FR_LGKM(n) do { if (!(WG_GEMM_FR_ABL & 8)) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(n) : "memory"); } while (0)
+#define FR_VMCNT(n) do { if (!(WG_GEMM_FR_ABL & 8)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory"); } while (0)
+template <int OFF> __device__ __forceinline__ void fr_read(u32x4& v, unsigned lds_addr) {
+    if constexpr (WG_GEMM_FR_ABL & 2) asm volatile("" : "+v"(v) : "v"(lds_addr));
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_addr), "n"(OFF) : "memory");
+}
+// One LDS-DMA piece: 64 lanes x 16 bytes from (descriptor base + per-lane byte offset) to LDS at lds_dst + lane * 16.  M0 is written in the
+// statement that reads it (hipcc does not preserve it around asm); offsets at or beyond the descriptor's extent are dropped by the range check
+// and still count in vmcnt, which keeps every wave's count of outstanding operations independent of the data.
+__device__ __forceinline__ void fr_dma(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned lds_dst) {
+    if constexpr (WG_GEMM_FR_ABL & 1) asm volatile("" ::"v"(voff), "s"(lds_dst));
+    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+}
+
+// Diagnostic build only (-DWG_GEMM_STAMP, tools/gemm_fr_stamps.py): s_memtime sums in scalar registers at points where the LDS queue is empty anyway
+// (behind the wave's last fragment read of a slab): wait for this wave's pieces of the next slab, wait at the barrier, the slab, the epilogue.
+#ifdef WG_GEMM_STAMP
+__device__ unsigned* wg_gemm_fr_stamp_ptr = nullptr;
+extern "C" int wg_debug_gemm_fr_stamps(unsigned* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(wg_gemm_fr_stamp_ptr), &buf, sizeof(buf)) == hipSuccess ? 0 : -3;
+}
+#define FR_STAMP(var) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory")
+#else
+#define FR_STAMP(var) do { } while (0)
+#endif
+
+// Experiment knob (tools/build_variant.py): WG_GEMM_FR_SLEEP = n > 0 makes the older half of the workgroup (waves 0-3, which win every
+// arbitration against their SIMD partners by age) sleep n x 64 cycles at the start of every pass.
+#ifndef WG_GEMM_FR_SLEEP
+#define WG_GEMM_FR_SLEEP 0
+#endif
+#define FR_YIELD() do { if (WG_GEMM_FR_SLEEP > 0 && polite) asm volatile("s_sleep %0" ::"n"(WG_GEMM_FR_SLEEP)); } while (0)
+
+// LDS map (bytes): slab slot s at s * 65536: A rows 0..255 (128 B each), then W rows 0..255; then the bias rows of two tiles.
+constexpr int FR_SLOT = 65536, FR_WOFF = 32768, FR_BIAS = 2 * FR_SLOT, FR_LDS = FR_BIAS + 2 * 512;
+constexpr int FR_NSTORE = 16;      // output stores per wave and tile
+
+__global__ __launch_bounds__(512, 2) void wg_gemm_fr_kernel(GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    [[maybe_unused]] const bool polite = wave < 4;
+    const int fr = lane & 15, fq = lane >> 4;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int nk = g.K >> 6;
+    auto tile_of = [&](int v, int& m0, int& n0) {
+        const int q = nwg >> 3, r = nwg & 7, xcd = v & 7;
+        const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+        int tm, tn;
+        wg_tile_of(wgid, g.tiles_m, g.tiles_n, g.col_block, tm, tn);
+        m0 = tm * 256;
+        n0 = tn * 256;
+    };
+
+    // ---- issue side: LDS-DMA of the slab stream, two slabs ahead of the consuming side ---------------------------------------------
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (unsigned)(((long)(g.M - 1) * g.lda + g.K) * 2), FR_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (unsigned)(((long)(g.N - 1) * g.ldw + g.K) * 2), FR_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)g.bias, 0, g.bias ? (unsigned)(g.N * 2) : 0u, FR_RSRC_FLAGS);
+    // piece q of an operand for this wave: rows q * 64 + wave * 8 + lane / 8 of the tile, 16-byte chunk (lane & 7) ^ swizzle(row);
+    // swizzle(row) = (row >> 1) & 7 = (wave * 4 + lane / 16) & 7 for every q
+    const unsigned rl = (unsigned)(wave * 8 + (lane >> 3));
+    const unsigned cs = (unsigned)((lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7));
+    const unsigned vbaseA = (rl * (unsigned)g.lda + cs * 8) * 2;
+    const unsigned vbaseW = (rl * (unsigned)g.ldw + cs * 8) * 2;
+    int iv = blockIdx.x, ikt = 0, im0, in0;       // tile and slab the issue side is at
+    bool ivalid = iv < nwg;
+    tile_of(iv, im0, in0);
+    unsigned islot = 0;                            // slot of the slab being issued
+    unsigned dA = 0, dW = 0, dslot = 0;            // the slab whose pieces are being issued: byte offsets of (tile row 0, slab column 0), slot
+    int dbias = -1;                                // >= 0: its tile's bias row (first slab of a tile), LDS parity
+    int ipar = 0;
+    auto next_slab = [&]() {
+        dA = ivalid ? (unsigned)((im0 * (int)g.lda + ikt * 64) * 2) : FR_OOB;
+        dW = ivalid ? (unsigned)((in0 * (int)g.ldw + ikt * 64) * 2) : FR_OOB;
+        dslot = islot;
+        dbias = (ivalid && ikt == 0) ? in0 : -1;
+        islot ^= 1;
+        if (++ikt == nk) {
+            ikt = 0;
+            iv += gridDim.x;
+            ivalid = iv < nwg;
+            if (ivalid) tile_of(iv, im0, in0);
+        }
+    };
+    auto piece = [&](int p) {   // p = 0..3: A rows p * 64 ..; 4..7: W rows (p - 4) * 64 ..
+        const int q = p & 3;
+        if (p < 4) fr_dma(vbaseA + dA + (unsigned)(q * 64 * (int)g.lda * 2), ars, lds0 + dslot * FR_SLOT + (unsigned)((q * 64 + wave * 8) * 128));
+        else fr_dma(vbaseW + dW + (unsigned)(q * 64 * (int)g.ldw * 2), wrs, lds0 + dslot * FR_SLOT + FR_WOFF + (unsigned)((q * 64 + wave * 8) * 128));
+    };
+    auto bias_piece = [&]() {   // the tile's 256 bias values (512 bytes) ride in front of its first slab: lanes 0..31 of wave 0 (exec-masked: 512 bytes written)
+        // (wave 0 then has one more operation in flight per tile than the others; it is older than the slab it travels with, and every counted wait
+        // of the loop is placed so that this operation is covered by it)
+        if (dbias >= 0 && g.bias && wave == 0 && lane < 32) fr_dma((unsigned)((dbias + lane * 8) * 2), brs, lds0 + FR_BIAS + (unsigned)ipar * 512);
+        if (dbias >= 0) ipar ^= 1;
+    };
+
+    // ---- consuming side ---------------------------------------------------------------------------------------------------------------
+    // fragment addresses: A(i, ks) = slot + vA[ks] + i * 2048, W(j, ks) = slot + vW[ks] + j * 2048 (the slot is toggled by xor 65536)
+    const unsigned swz = (unsigned)((fr >> 1) & 7);
+    unsigned vA[2], vW[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        vA[ks] = lds0 + (unsigned)((wm * 128 + fr) * 128) + ((((unsigned)(ks * 4 + fq)) ^ swz) << 4);
+        vW[ks] = lds0 + FR_WOFF + (unsigned)((wn * 64 + fr) * 128) + ((((unsigned)(ks * 4 + fq)) ^ swz) << 4);
+    }
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.c_bytes, FR_RSRC_FLAGS);
+
+    f32x4 acc[8][4];
+    u32x4 a[8], w[2];
+    if constexpr (WG_GEMM_FR_ABL & 2) {      // (ablation: the fragments are never loaded)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = (u32x4){0x3f803f80u + (unsigned)lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        w[0] = w[1] = a[0];
+    }
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                asm volatile("" : "+v"(acc[i][j]));      // materialised here, not sunk in front of the first MFMA
+            }
+    };
+    auto req_w = [&](auto bufc, auto ksc, auto jc) {
+        constexpr int BUF = decltype(bufc)::value, KS = decltype(ksc)::value, J = decltype(jc)::value;
+        fr_read<J * 2048>(w[BUF], vW[KS]);
+    };
+    auto req_a = [&](auto ic, auto ksc) {
+        constexpr int I = decltype(ic)::value, KS = decltype(ksc)::value;
+        fr_read<I * 2048>(a[I], vA[KS]);
+    };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    using C3 = std::integral_constant<int, 3>;
+
+    // prologue: slabs 0 and 1 of the first tile (or of the stream), then the first fragments
+    int v = blockIdx.x, m0, n0;
+    tile_of(v, m0, n0);
+    int par = 0;
+    next_slab();
+    bias_piece();
+#pragma unroll
+    for (int p = 0; p < 8; ++p) piece(p);
+    next_slab();
+    bias_piece();
+#pragma unroll
+    for (int p = 0; p < 8; ++p) piece(p);
+    zero_acc();
+    FR_VMCNT(8);      // slab 0 (and its bias row) landed; slab 1 may be in flight (K >= 128: it belongs to the same tile, no bias operation behind it)
+    asm volatile("s_barrier" ::: "memory");
+    req_w(C0{}, C0{}, C0{});
+    fr_for<0, 8>([&](auto ic) { req_a(ic, C0{}); });
+    bool stores_in_flight = false;
+#ifdef WG_GEMM_STAMP
+    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_prev = 0, st_e = 0;
+    unsigned long long st_vm = 0, st_bar = 0, st_slab = 0, st_epi = 0;
+    unsigned st_tiles = 0, st_slabs = 0;
+    const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+
+    while (true) {
+        for (int kt = 0; kt < nk; ++kt) {
+            const bool last = kt + 1 == nk;
+            // ================= k-step 0 =================
+            // pass 0 (w[0]): outstanding on entry: w0, a0..a7 (requested in the previous slab's last pass)
+            FR_YIELD();
+            req_w(C1{}, C0{}, C1{});
+            FR_LGKM(8); FR_MFMA(acc[0][0], w[0], a[0]);
+            FR_LGKM(6); FR_MFMA(acc[1][0], w[0], a[1]); FR_MFMA(acc[2][0], w[0], a[2]);
+            if (kt != 0) piece(2);
+            FR_LGKM(4); FR_MFMA(acc[3][0], w[0], a[3]); FR_MFMA(acc[4][0], w[0], a[4]);
+            FR_LGKM(2); FR_MFMA(acc[5][0], w[0], a[5]); FR_MFMA(acc[6][0], w[0], a[6]);
+            if (kt != 0) piece(3);
+            FR_LGKM(1); FR_MFMA(acc[7][0], w[0], a[7]);
+            // pass 1 (w[1])
+            FR_YIELD();
+            FR_LGKM(0);
+            req_w(C0{}, C0{}, C2{});
+            FR_MFMA(acc[0][1], w[1], a[0]); FR_MFMA(acc[1][1], w[1], a[1]); FR_MFMA(acc[2][1], w[1], a[2]);
+            if (kt != 0) piece(4);
+            FR_MFMA(acc[3][1], w[1], a[3]); FR_MFMA(acc[4][1], w[1], a[4]); FR_MFMA(acc[5][1], w[1], a[5]); FR_MFMA(acc[6][1], w[1], a[6]);
+            if (kt != 0) piece(5);
+            FR_MFMA(acc[7][1], w[1], a[7]);
+            // pass 2 (w[0])
+            FR_YIELD();
+            FR_LGKM(0);
+            req_w(C1{}, C0{}, C3{});
+            FR_MFMA(acc[0][2], w[0], a[0]); FR_MFMA(acc[1][2], w[0], a[1]); FR_MFMA(acc[2][2], w[0], a[2]);
+            if (kt != 0) piece(6);
+            FR_MFMA(acc[3][2], w[0], a[3]); FR_MFMA(acc[4][2], w[0], a[4]); FR_MFMA(acc[5][2], w[0], a[5]); FR_MFMA(acc[6][2], w[0], a[6]);
+            if (kt != 0) piece(7);
+            FR_MFMA(acc[7][2], w[0], a[7]);
+            // pass 3 (w[1]): every a[i] is re-requested for k-step 1 behind its last MFMA
+            FR_YIELD();
+            FR_LGKM(0);
+            req_w(C0{}, C1{}, C0{});
+            fr_for<0, 8>([&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                FR_MFMA(acc[I][3], w[1], a[I]);
+                req_a(ic, C1{});
+            });
+            // ================= k-step 1 =================
+            // pass 0 (w[0]): outstanding: w0, a0..a7
+            FR_YIELD();
+            req_w(C1{}, C1{}, C1{});
+            FR_LGKM(8); FR_MFMA(acc[0][0], w[0], a[0]);
+            FR_LGKM(6); FR_MFMA(acc[1][0], w[0], a[1]); FR_MFMA(acc[2][0], w[0], a[2]);
+            FR_LGKM(4); FR_MFMA(acc[3][0], w[0], a[3]); FR_MFMA(acc[4][0], w[0], a[4]);
+            FR_LGKM(2); FR_MFMA(acc[5][0], w[0], a[5]); FR_MFMA(acc[6][0], w[0], a[6]);
+            FR_LGKM(1); FR_MFMA(acc[7][0], w[0], a[7]);
+            // pass 1 (w[1])
+            FR_YIELD();
+            FR_LGKM(0);
+            req_w(C0{}, C1{}, C2{});
+            FR_MFMA(acc[0][1], w[1], a[0]); FR_MFMA(acc[1][1], w[1], a[1]); FR_MFMA(acc[2][1], w[1], a[2]); FR_MFMA(acc[3][1], w[1], a[3]);
+            FR_MFMA(acc[4][1], w[1], a[4]); FR_MFMA(acc[5][1], w[1], a[5]); FR_MFMA(acc[6][1], w[1], a[6]); FR_MFMA(acc[7][1], w[1], a[7]);
+            // pass 2 (w[0])
+            FR_YIELD();
+            FR_LGKM(0);
+            req_w(C1{}, C1{}, C3{});
+            FR_MFMA(acc[0][2], w[0], a[0]); FR_MFMA(acc[1][2], w[0], a[1]); FR_MFMA(acc[2][2], w[0], a[2]); FR_MFMA(acc[3][2], w[0], a[3]);
+            FR_MFMA(acc[4][2], w[0], a[4]); FR_MFMA(acc[5][2], w[0], a[5]); FR_MFMA(acc[6][2], w[0], a[6]); FR_MFMA(acc[7][2], w[0], a[7]);
+            // pass 3 (w[1]): this wave's last fragment of the slab is in; its pieces of the next slab have landed; everybody meets
+            FR_LGKM(0);
+            FR_STAMP(st_a);
+            if (kt == 0 && stores_in_flight) FR_VMCNT(FR_NSTORE); else FR_VMCNT(0);
+            FR_STAMP(st_b);
+            if (!(WG_GEMM_FR_ABL & 4)) asm volatile("s_barrier" ::: "memory");
+            FR_STAMP(st_c);
+#ifdef WG_GEMM_STAMP
+            st_vm += st_b - st_a; st_bar += st_c - st_b;
+            if (st_prev) { st_slab += st_c - st_prev; ++st_slabs; }
+            st_prev = st_c;
+#endif
+            // the other slot: the next slab's fragments, and (behind the barrier) the slab after that into the slot just freed
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) { vA[ks] ^= FR_SLOT; vW[ks] ^= FR_SLOT; }
+            next_slab();
+            req_w(C0{}, C0{}, C0{});
+            bias_piece();
+            fr_for<0, 8>([&](auto ic) {
+                constexpr int I = decltype(ic)::value;
+                FR_MFMA(acc[I][3], w[1], a[I]);
+                req_a(ic, C0{});
+                if constexpr (I == 2) piece(0);
+                if constexpr (I == 5) piece(1);
+            });
+            if (last) {      // the next tile's second slab is sent whole in front of the epilogue's stores (the next wait can then count them)
+#pragma unroll
+                for (int p = 2; p < 8; ++p) piece(p);
+            }
+        }
+        // ---- epilogue: bias, activation, bf16, 64-byte row segments straight from registers (v_permlane16_swap pairs two column blocks) ----
+#ifdef WG_GEMM_STAMP
+        FR_LGKM(0);      // (diagnostic build: the stamp's wait would drain the next tile's first fragments anyway)
+        FR_STAMP(st_e);
+#endif
+        {
+            asm volatile("s_nop 15" ::: "memory");      // the last MFMAs' results before the first vector read (opaque to the hazard recogniser)
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+            float bv[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bf16x4 b = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+                if (g.bias) b = *(const bf16x4*)(smem + FR_BIAS + par * 512 + (wn * 64 + j * 16 + fq * 4) * 2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[j][e] = (float)b[e];
+            }
+            // after the swaps lane (fr, fq) holds 16 bytes = columns jp * 32 + (fq & 1) * 16 + (fq >> 1) * 8 .. + 7 of row i * 16 + fr
+            const int ncol = n0 + wn * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
+            const int mrow = m0 + wm * 128 + fr;
+            WG_ACT_SWITCH(g.act,
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) {
+                    u32x2 pk[4];
+                    _Pragma("unroll") for (int j = 0; j < 4; ++j) pk[j] = __builtin_bit_cast(u32x2, wg_epi_pack<ACT>(acc[i][j], bv[j]));
+                    _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {
+                        unsigned x0 = pk[2 * jp][0], x1 = pk[2 * jp][1], y0 = pk[2 * jp + 1][0], y1 = pk[2 * jp + 1][1];
+                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
+                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
+                        const int n = ncol + jp * 32;
+                        const int off = n < g.N ? ((mrow + i * 16) * (int)g.ldc + n) * 2 : (int)0x80000000;
+                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){x0, x1, y0, y1}, crs, off, 0, 0);
+                    }
+                })
+        }
+#ifdef WG_GEMM_STAMP
+        {
+            unsigned long long now;
+            FR_STAMP(now);
+            st_epi += now - st_e;
+            st_slab -= now - st_e;      // (the epilogue sits between two slab stamps)
+            ++st_tiles;
+        }
+#endif
+        const int vn = v + gridDim.x;
+        if (vn >= nwg) break;
+        v = vn;
+        tile_of(v, m0, n0);
+        par ^= 1;
+        stores_in_flight = true;
+        zero_acc();
+    }
+    FR_VMCNT(0);
+    FR_LGKM(0);
+#ifdef WG_GEMM_STAMP
+    if (wg_gemm_fr_stamp_ptr && lane == 0 && blockIdx.x < 32) {      // [workgroup][wave][8]
+        unsigned* o = wg_gemm_fr_stamp_ptr + (blockIdx.x * 8 + wave) * 8;
+        o[0] = (unsigned)st_vm; o[1] = (unsigned)st_bar; o[2] = (unsigned)st_slab; o[3] = (unsigned)st_epi; o[4] = st_tiles; o[5] = st_slabs;
+        o[6] = (unsigned)(__builtin_amdgcn_s_memtime() - st_c0); o[7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
+    }
+#endif
+}
+
+int wg_gemm_fr_supports(const GemmArgs& g) {
+    const long abytes = ((long)(g.M - 1) * g.lda + g.K) * 2, wbytes = ((long)(g.N - 1) * g.ldw + g.K) * 2;
+    return (g.K % 64 == 0 && g.K >= 128 && g.N % 8 == 0 && g.lda % 8 == 0 && g.ldw % 8 == 0 && g.ldc % 8 == 0 && !g.out_f32 && g.c_bytes != 0 &&
+            abytes < (1L << 31) && wbytes < (1L << 31) && !g.R && !g.ln_stats && !g.ln_part && !g.stats_part && !g.mx_w &&
+            (!g.bias || ((uintptr_t)g.bias % 16 == 0))) ? 1 : 0;
+}
+
+int wg_launch_gemm_fr(GemmArgs& g, hipStream_t st) {
+    g.tiles_m = (g.M + 255) / 256;
+    g.tiles_n = (g.N + 255) / 256;
+    {
+        const long panel = 256L * g.K * 2, wbytes = (long)g.N * g.K * 2;
+        const int cb = (int)((3L << 19) / (panel > 0 ? panel : 1));
+        g.col_block = (wbytes > (3L << 20) && cb >= 2 && cb < g.tiles_n) ? cb : 0;
+    }
+    static WgPerDevice once;
+    int dev = 0;
+    if (once.first(&dev)) (void)hipFuncSetAttribute((const void*)wg_gemm_fr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FR_LDS);
+    const int nwg = g.tiles_m * g.tiles_n;
+    const int cus = wg_cu_count(dev);
+    const int grid = nwg < cus ? nwg : cus;
+    hipLaunchKernelGGL(wg_gemm_fr_kernel, dim3(grid), dim3(512), FR_LDS, st, g);
+    return wg_check_launch("wg_gemm_bias_act_bf16(free-running persistent)");
+}
