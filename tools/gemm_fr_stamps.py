@@ -13,7 +13,7 @@ buf = torch.zeros(32 * 8 * 8, device=dev, dtype=torch.int32)
 assert lib.wg_debug_gemm_fr_stamps(buf.data_ptr()) == 0
 shapes = [("sam qkv", 32768, 2304, 768, "bias"), ("sam lin1", 32768, 3072, 768, "gelu"), ("sam proj", 32768, 768, 768, "bias"), ("sam lin2", 32768, 768, 3072, "bias"),
           ("clip qkv", 8200, 3072, 1024, "bias"), ("clip fc2", 8200, 1024, 4096, "bias"), ("8k", 8192, 8192, 8192, "none")]
-print("| shape | us | TF/s | GHz | cycles / slab | of it: wait for own pieces | barrier | epilogue cycles / tile | per wave: slab cycles (waves 0-7) | barrier wait (waves 0-7) |")
+print("| shape | us | TF/s | GHz | cycles / slab | load half-phase (issue + reads) grp 0 / 1 | wait at its barrier grp 0 / 1 | matrix half-phase grp 0 / 1 | wait at its barrier grp 0 / 1 | two stamps back to back (per slab) grp 0 / 1 |")
 print("|---|---|---|---|---|---|---|---|---|---|")
 for name, M, N, K, epi in shapes:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
@@ -35,12 +35,13 @@ for name, M, N, K, epi in shapes:
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     r = (buf.cpu().numpy().astype("int64") & 0xffffffff).reshape(32, 8, 8).astype(float)
-    r = r[r[:, 0, 4] > 0]
+    r = r[r[:, 0, 5] > 0]
     slabs = r[:, :, 5]
-    per_slab = (r[:, :, 2] / slabs).mean(0)
-    vm = (r[:, :, 0] / slabs).mean(0)
-    bar = (r[:, :, 1] / slabs).mean(0)
-    epi_c = (r[:, :, 3] / r[:, :, 4]).mean()
+    tiles = slabs / (K // 64)
+    def g(col, per):      # mean per group of four waves
+        x = (r[:, :, col] / per).mean(0)
+        return "%.0f / %.0f" % (x[:4].mean(), x[4:].mean())
+    tot = ((r[:, :, 0] + r[:, :, 1] + r[:, :, 2] + r[:, :, 3]) / slabs).mean()
     clk = (r[:, :, 6] / r[:, :, 7]).mean() * 0.1
-    print("| %s %dx%dx%d | %.1f | %.0f | %.2f | %.0f | %.0f | %.0f | %.0f | %s | %s |" % (name, M, N, K, us, 2.0 * M * N * K / us / 1e6, clk, per_slab.mean(), vm.mean(), bar.mean(), epi_c,
-          " ".join("%.0f" % x for x in per_slab), " ".join("%.0f" % x for x in bar)), flush=True)
+    print("| %s %dx%dx%d | %.1f | %.0f | %.2f | %.0f | %s | %s | %s | %s | %s |" % (name, M, N, K, us, 2.0 * M * N * K / us / 1e6, clk, tot, g(0, slabs), g(1, slabs), g(2, slabs), g(3, slabs),
+          g(4, slabs)), flush=True)

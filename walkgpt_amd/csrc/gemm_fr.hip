@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_fr_kernel(GemmArgs g) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    [[maybe_unused]] const bool polite = wave < 4;
+    const int grp = wm;                            // 0: waves 0-3 (they also issue every LDS-DMA piece), 1: waves 4-7, one half-phase behind
     const int fr = lane & 15, fq = lane >> 4;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -99,28 +99,36 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_fr_kernel(GemmArgs g) {
         n0 = tn * 256;
     };
 
-    // ---- issue side: LDS-DMA of the slab stream, two slabs ahead of the consuming side ---------------------------------------------
+    // ---- issue side (group 0 only): the slab stream by LDS-DMA, one slab ahead of the group's own load half-phase --------------------
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (unsigned)(((long)(g.M - 1) * g.lda + g.K) * 2), FR_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (unsigned)(((long)(g.N - 1) * g.ldw + g.K) * 2), FR_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)g.bias, 0, g.bias ? (unsigned)(g.N * 2) : 0u, FR_RSRC_FLAGS);
-    // piece q of an operand for this wave: rows q * 64 + wave * 8 + lane / 8 of the tile, 16-byte chunk (lane & 7) ^ swizzle(row);
-    // swizzle(row) = (row >> 1) & 7 = (wave * 4 + lane / 16) & 7 for every q
-    const unsigned rl = (unsigned)(wave * 8 + (lane >> 3));
-    const unsigned cs = (unsigned)((lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7));
+    // piece (q, h) of an operand for wave w < 4: rows q * 64 + (w + 4 h) * 8 + lane / 8 of the tile, 16-byte chunk (lane & 7) ^ swizzle(row);
+    // swizzle(row) = (row >> 1) & 7 = (w * 4 + lane / 16) & 7 for every q and h
+    const unsigned rl = (unsigned)((wave & 3) * 8 + (lane >> 3));
+    const unsigned cs = (unsigned)((lane & 7) ^ (((wave & 3) * 4 + (lane >> 4)) & 7));
     const unsigned vbaseA = (rl * (unsigned)g.lda + cs * 8) * 2;
     const unsigned vbaseW = (rl * (unsigned)g.ldw + cs * 8) * 2;
     int iv = blockIdx.x, ikt = 0, im0, in0;       // tile and slab the issue side is at
     bool ivalid = iv < nwg;
     tile_of(iv, im0, in0);
-    unsigned islot = 0;                            // slot of the slab being issued
-    unsigned dA = 0, dW = 0, dslot = 0;            // the slab whose pieces are being issued: byte offsets of (tile row 0, slab column 0), slot
-    int dbias = -1;                                // >= 0: its tile's bias row (first slab of a tile), LDS parity
+    unsigned islot = 0;
     int ipar = 0;
-    auto next_slab = [&]() {
-        dA = ivalid ? (unsigned)((im0 * (int)g.lda + ikt * 64) * 2) : FR_OOB;
-        dW = ivalid ? (unsigned)((in0 * (int)g.ldw + ikt * 64) * 2) : FR_OOB;
-        dslot = islot;
-        dbias = (ivalid && ikt == 0) ? in0 : -1;
+    auto issue_slab = [&]() {   // all 64 pieces of the next slab of the stream: 16 per wave of group 0 (+ the tile's bias row in front of its first slab)
+        const unsigned dA = ivalid ? (unsigned)((im0 * (int)g.lda + ikt * 64) * 2) : FR_OOB;
+        const unsigned dW = ivalid ? (unsigned)((in0 * (int)g.ldw + ikt * 64) * 2) : FR_OOB;
+        const unsigned dst = lds0 + islot * FR_SLOT + (unsigned)((wave & 3) * 8 * 128);
+        if (ivalid && ikt == 0) {
+            if (g.bias && wave == 0 && lane < 32) fr_dma((unsigned)((in0 + lane * 8) * 2), brs, lds0 + FR_BIAS + (unsigned)ipar * 512);
+            ipar ^= 1;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                fr_dma(vbaseA + dA + (unsigned)((q * 64 + h * 32) * (int)g.lda * 2), ars, dst + (unsigned)((q * 64 + h * 32) * 128));
+                fr_dma(vbaseW + dW + (unsigned)((q * 64 + h * 32) * (int)g.ldw * 2), wrs, dst + FR_WOFF + (unsigned)((q * 64 + h * 32) * 128));
+            }
         islot ^= 1;
         if (++ikt == nk) {
             ikt = 0;
@@ -128,17 +136,6 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_fr_kernel(GemmArgs g) {
             ivalid = iv < nwg;
             if (ivalid) tile_of(iv, im0, in0);
         }
-    };
-    auto piece = [&](int p) {   // p = 0..3: A rows p * 64 ..; 4..7: W rows (p - 4) * 64 ..
-        const int q = p & 3;
-        if (p < 4) fr_dma(vbaseA + dA + (unsigned)(q * 64 * (int)g.lda * 2), ars, lds0 + dslot * FR_SLOT + (unsigned)((q * 64 + wave * 8) * 128));
-        else fr_dma(vbaseW + dW + (unsigned)(q * 64 * (int)g.ldw * 2), wrs, lds0 + dslot * FR_SLOT + FR_WOFF + (unsigned)((q * 64 + wave * 8) * 128));
-    };
-    auto bias_piece = [&]() {   // the tile's 256 bias values (512 bytes) ride in front of its first slab: lanes 0..31 of wave 0 (exec-masked: 512 bytes written)
-        // (wave 0 then has one more operation in flight per tile than the others; it is older than the slab it travels with, and every counted wait
-        // of the loop is placed so that this operation is covered by it)
-        if (dbias >= 0 && g.bias && wave == 0 && lane < 32) fr_dma((unsigned)((dbias + lane * 8) * 2), brs, lds0 + FR_BIAS + (unsigned)ipar * 512);
-        if (dbias >= 0) ipar ^= 1;
     };
 
     // ---- consuming side ---------------------------------------------------------------------------------------------------------------
@@ -153,12 +150,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_fr_kernel(GemmArgs g) {
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.c_bytes, FR_RSRC_FLAGS);
 
     f32x4 acc[8][4];
-    u32x4 a[8], w[2];
-    if constexpr (WG_GEMM_FR_ABL & 2) {      // (ablation: the fragments are never loaded)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = (u32x4){0x3f803f80u + (unsigned)lane, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-        w[0] = w[1] = a[0];
-    }
+    u32x4 a[2][8], w[2][4];
     auto zero_acc = [&]() {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -168,196 +160,136 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_fr_kernel(GemmArgs g) {
                 asm volatile("" : "+v"(acc[i][j]));      // materialised here, not sunk in front of the first MFMA
             }
     };
-    auto req_w = [&](auto bufc, auto ksc, auto jc) {
-        constexpr int BUF = decltype(bufc)::value, KS = decltype(ksc)::value, J = decltype(jc)::value;
-        fr_read<J * 2048>(w[BUF], vW[KS]);
+    // ---- epilogue of the tile at (m0, n0): bias, activation, bf16, 64-byte row segments straight from registers (v_permlane16_swap pairs
+    //      two column blocks: lane (fr, fq) ends with 16 bytes = columns jp * 32 + (fq & 1) * 16 + (fq >> 1) * 8 .. + 7 of row i * 16 + fr)
+    auto epilogue = [&](int m0, int n0, int par) {
+        // lane coordinates re-derived here (two VALU instructions) instead of living in registers across the main loop, which runs at the
+        // 256-register limit: a spilled value's reload is a vector-memory operation, and hipcc drains the whole queue (vmcnt(0)) behind it
+        int el;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));
+        const int fr = el & 15, fq = el >> 4;
+        asm volatile("s_nop 15" ::: "memory");      // the last MFMAs' results before the first vector read (opaque to the hazard recogniser)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
+        float bv[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            bf16x4 b = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+            if (g.bias) b = *(const bf16x4*)(smem + FR_BIAS + par * 512 + (wn * 64 + j * 16 + fq * 4) * 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bv[j][e] = (float)b[e];
+        }
+        const int ncol = n0 + wn * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
+        const int mrow = m0 + wm * 128 + fr;
+        WG_ACT_SWITCH(g.act,
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) {
+                u32x2 pk[4];
+                _Pragma("unroll") for (int j = 0; j < 4; ++j) pk[j] = __builtin_bit_cast(u32x2, wg_epi_pack<ACT>(acc[i][j], bv[j]));
+                _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {
+                    unsigned x0 = pk[2 * jp][0], x1 = pk[2 * jp][1], y0 = pk[2 * jp + 1][0], y1 = pk[2 * jp + 1][1];
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
+                    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
+                    const int n = ncol + jp * 32;
+                    const int off = n < g.N ? ((mrow + i * 16) * (int)g.ldc + n) * 2 : (int)0x80000000;
+                    __builtin_amdgcn_raw_buffer_store_b128((u32x4){x0, x1, y0, y1}, crs, off, 0, 0);
+                }
+            })
     };
-    auto req_a = [&](auto ic, auto ksc) {
-        constexpr int I = decltype(ic)::value, KS = decltype(ksc)::value;
-        fr_read<I * 2048>(a[I], vA[KS]);
-    };
-    using C0 = std::integral_constant<int, 0>;
-    using C1 = std::integral_constant<int, 1>;
-    using C2 = std::integral_constant<int, 2>;
-    using C3 = std::integral_constant<int, 3>;
 
-    // prologue: slabs 0 and 1 of the first tile (or of the stream), then the first fragments
-    int v = blockIdx.x, m0, n0;
-    tile_of(v, m0, n0);
-    int par = 0;
-    next_slab();
-    bias_piece();
-#pragma unroll
-    for (int p = 0; p < 8; ++p) piece(p);
-    next_slab();
-    bias_piece();
-#pragma unroll
-    for (int p = 0; p < 8; ++p) piece(p);
+    // prologue: the stream's first slab; group 1 starts one half-phase behind
+    if (grp == 0) {
+        issue_slab();
+        FR_VMCNT(0);
+    }
     zero_acc();
-    FR_VMCNT(8);      // slab 0 (and its bias row) landed; slab 1 may be in flight (K >= 128: it belongs to the same tile, no bias operation behind it)
     asm volatile("s_barrier" ::: "memory");
-    req_w(C0{}, C0{}, C0{});
-    fr_for<0, 8>([&](auto ic) { req_a(ic, C0{}); });
-    bool stores_in_flight = false;
+    if (grp == 1) asm volatile("s_barrier" ::: "memory");
 #ifdef WG_GEMM_STAMP
-    unsigned long long st_a = 0, st_b = 0, st_c = 0, st_prev = 0, st_e = 0;
-    unsigned long long st_vm = 0, st_bar = 0, st_slab = 0, st_epi = 0;
+    unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_prev = 0;
+    unsigned long long st_m = 0, st_mb = 0, st_c = 0, st_cb = 0, st_epi = 0, st_lat = 0;
     unsigned st_tiles = 0, st_slabs = 0;
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 
+    int v = blockIdx.x, m0, n0;
+    tile_of(v, m0, n0);
+    int par = 0;
+    int pm0 = 0, pn0 = 0;
+    bool pending = false;        // the previous tile's epilogue has not run yet (it runs in the load half-phase of this tile's first slab)
     while (true) {
         for (int kt = 0; kt < nk; ++kt) {
-            const bool last = kt + 1 == nk;
-            // ================= k-step 0 =================
-            // pass 0 (w[0]): outstanding on entry: w0, a0..a7 (requested in the previous slab's last pass)
-            FR_YIELD();
-            req_w(C1{}, C0{}, C1{});
-            FR_LGKM(8); FR_MFMA(acc[0][0], w[0], a[0]);
-            FR_LGKM(6); FR_MFMA(acc[1][0], w[0], a[1]); FR_MFMA(acc[2][0], w[0], a[2]);
-            if (kt != 0) piece(2);
-            FR_LGKM(4); FR_MFMA(acc[3][0], w[0], a[3]); FR_MFMA(acc[4][0], w[0], a[4]);
-            FR_LGKM(2); FR_MFMA(acc[5][0], w[0], a[5]); FR_MFMA(acc[6][0], w[0], a[6]);
-            if (kt != 0) piece(3);
-            FR_LGKM(1); FR_MFMA(acc[7][0], w[0], a[7]);
-            // pass 1 (w[1])
-            FR_YIELD();
-            FR_LGKM(0);
-            req_w(C0{}, C0{}, C2{});
-            FR_MFMA(acc[0][1], w[1], a[0]); FR_MFMA(acc[1][1], w[1], a[1]); FR_MFMA(acc[2][1], w[1], a[2]);
-            if (kt != 0) piece(4);
-            FR_MFMA(acc[3][1], w[1], a[3]); FR_MFMA(acc[4][1], w[1], a[4]); FR_MFMA(acc[5][1], w[1], a[5]); FR_MFMA(acc[6][1], w[1], a[6]);
-            if (kt != 0) piece(5);
-            FR_MFMA(acc[7][1], w[1], a[7]);
-            // pass 2 (w[0])
-            FR_YIELD();
-            FR_LGKM(0);
-            req_w(C1{}, C0{}, C3{});
-            FR_MFMA(acc[0][2], w[0], a[0]); FR_MFMA(acc[1][2], w[0], a[1]); FR_MFMA(acc[2][2], w[0], a[2]);
-            if (kt != 0) piece(6);
-            FR_MFMA(acc[3][2], w[0], a[3]); FR_MFMA(acc[4][2], w[0], a[4]); FR_MFMA(acc[5][2], w[0], a[5]); FR_MFMA(acc[6][2], w[0], a[6]);
-            if (kt != 0) piece(7);
-            FR_MFMA(acc[7][2], w[0], a[7]);
-            // pass 3 (w[1]): every a[i] is re-requested for k-step 1 behind its last MFMA
-            FR_YIELD();
-            FR_LGKM(0);
-            req_w(C0{}, C1{}, C0{});
-            fr_for<0, 8>([&](auto ic) {
-                constexpr int I = decltype(ic)::value;
-                FR_MFMA(acc[I][3], w[1], a[I]);
-                req_a(ic, C1{});
-            });
-            // ================= k-step 1 =================
-            // pass 0 (w[0]): outstanding: w0, a0..a7
-            FR_YIELD();
-            req_w(C1{}, C1{}, C1{});
-            FR_LGKM(8); FR_MFMA(acc[0][0], w[0], a[0]);
-            FR_LGKM(6); FR_MFMA(acc[1][0], w[0], a[1]); FR_MFMA(acc[2][0], w[0], a[2]);
-            FR_LGKM(4); FR_MFMA(acc[3][0], w[0], a[3]); FR_MFMA(acc[4][0], w[0], a[4]);
-            FR_LGKM(2); FR_MFMA(acc[5][0], w[0], a[5]); FR_MFMA(acc[6][0], w[0], a[6]);
-            FR_LGKM(1); FR_MFMA(acc[7][0], w[0], a[7]);
-            // pass 1 (w[1])
-            FR_YIELD();
-            FR_LGKM(0);
-            req_w(C0{}, C1{}, C2{});
-            FR_MFMA(acc[0][1], w[1], a[0]); FR_MFMA(acc[1][1], w[1], a[1]); FR_MFMA(acc[2][1], w[1], a[2]); FR_MFMA(acc[3][1], w[1], a[3]);
-            FR_MFMA(acc[4][1], w[1], a[4]); FR_MFMA(acc[5][1], w[1], a[5]); FR_MFMA(acc[6][1], w[1], a[6]); FR_MFMA(acc[7][1], w[1], a[7]);
-            // pass 2 (w[0])
-            FR_YIELD();
-            FR_LGKM(0);
-            req_w(C1{}, C1{}, C3{});
-            FR_MFMA(acc[0][2], w[0], a[0]); FR_MFMA(acc[1][2], w[0], a[1]); FR_MFMA(acc[2][2], w[0], a[2]); FR_MFMA(acc[3][2], w[0], a[3]);
-            FR_MFMA(acc[4][2], w[0], a[4]); FR_MFMA(acc[5][2], w[0], a[5]); FR_MFMA(acc[6][2], w[0], a[6]); FR_MFMA(acc[7][2], w[0], a[7]);
-            // pass 3 (w[1]): this wave's last fragment of the slab is in; its pieces of the next slab have landed; everybody meets
-            FR_LGKM(0);
-            FR_STAMP(st_a);
-            if (kt == 0 && stores_in_flight) FR_VMCNT(FR_NSTORE); else FR_VMCNT(0);
-            FR_STAMP(st_b);
-            if (!(WG_GEMM_FR_ABL & 4)) asm volatile("s_barrier" ::: "memory");
-            FR_STAMP(st_c);
+            // ================= load half-phase: the next slab's pieces (group 0), the previous tile's epilogue, this slab's 24 fragments ======
+            FR_STAMP(st_0);
+            if (grp == 0) issue_slab();
+            if (kt == 0 && pending) {
 #ifdef WG_GEMM_STAMP
-            st_vm += st_b - st_a; st_bar += st_c - st_b;
-            if (st_prev) { st_slab += st_c - st_prev; ++st_slabs; }
-            st_prev = st_c;
+                unsigned long long e0, e1;
+                FR_STAMP(e0);
 #endif
-            // the other slot: the next slab's fragments, and (behind the barrier) the slab after that into the slot just freed
+                epilogue(pm0, pn0, par ^ 1);
+                zero_acc();
+#ifdef WG_GEMM_STAMP
+                FR_STAMP(e1);
+                st_epi += e1 - e0; st_0 += e1 - e0; ++st_tiles;
+#endif
+            }
+            fr_for<0, 4>([&](auto jc) { constexpr int J = decltype(jc)::value; fr_read<J * 2048>(w[0][J], vW[0]); });
+            fr_for<0, 8>([&](auto ic) { constexpr int I = decltype(ic)::value; fr_read<I * 2048>(a[0][I], vA[0]); });
+            fr_for<0, 4>([&](auto jc) { constexpr int J = decltype(jc)::value; fr_read<J * 2048>(w[1][J], vW[1]); });
+            fr_for<0, 8>([&](auto ic) { constexpr int I = decltype(ic)::value; fr_read<I * 2048>(a[1][I], vA[1]); });
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) { vA[ks] ^= FR_SLOT; vW[ks] ^= FR_SLOT; }
-            next_slab();
-            req_w(C0{}, C0{}, C0{});
-            bias_piece();
-            fr_for<0, 8>([&](auto ic) {
-                constexpr int I = decltype(ic)::value;
-                FR_MFMA(acc[I][3], w[1], a[I]);
-                req_a(ic, C0{});
-                if constexpr (I == 2) piece(0);
-                if constexpr (I == 5) piece(1);
-            });
-            if (last) {      // the next tile's second slab is sent whole in front of the epilogue's stores (the next wait can then count them)
-#pragma unroll
-                for (int p = 2; p < 8; ++p) piece(p);
-            }
-        }
-        // ---- epilogue: bias, activation, bf16, 64-byte row segments straight from registers (v_permlane16_swap pairs two column blocks) ----
+            FR_LGKM(0);
+            FR_STAMP(st_1);
+            asm volatile("s_barrier" ::: "memory");
+            FR_STAMP(st_2);
 #ifdef WG_GEMM_STAMP
-        FR_LGKM(0);      // (diagnostic build: the stamp's wait would drain the next tile's first fragments anyway)
-        FR_STAMP(st_e);
-#endif
-        {
-            asm volatile("s_nop 15" ::: "memory");      // the last MFMAs' results before the first vector read (opaque to the hazard recogniser)
-#pragma unroll
-            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(acc[i][j]));
-            float bv[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                bf16x4 b = (bf16x4){(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-                if (g.bias) b = *(const bf16x4*)(smem + FR_BIAS + par * 512 + (wn * 64 + j * 16 + fq * 4) * 2);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bv[j][e] = (float)b[e];
+            {      // two stamps back to back: what a stamp itself costs here (the second one opens the matrix half-phase)
+                unsigned long long t2b;
+                FR_STAMP(t2b);
+                st_lat += t2b - st_2;
+                st_2 = t2b;
             }
-            // after the swaps lane (fr, fq) holds 16 bytes = columns jp * 32 + (fq & 1) * 16 + (fq >> 1) * 8 .. + 7 of row i * 16 + fr
-            const int ncol = n0 + wn * 64 + (fq & 1) * 16 + (fq >> 1) * 8;
-            const int mrow = m0 + wm * 128 + fr;
-            WG_ACT_SWITCH(g.act,
-                _Pragma("unroll") for (int i = 0; i < 8; ++i) {
-                    u32x2 pk[4];
-                    _Pragma("unroll") for (int j = 0; j < 4; ++j) pk[j] = __builtin_bit_cast(u32x2, wg_epi_pack<ACT>(acc[i][j], bv[j]));
-                    _Pragma("unroll") for (int jp = 0; jp < 2; ++jp) {
-                        unsigned x0 = pk[2 * jp][0], x1 = pk[2 * jp][1], y0 = pk[2 * jp + 1][0], y1 = pk[2 * jp + 1][1];
-                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x0), "+v"(y0));
-                        asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(x1), "+v"(y1));
-                        const int n = ncol + jp * 32;
-                        const int off = n < g.N ? ((mrow + i * 16) * (int)g.ldc + n) * 2 : (int)0x80000000;
-                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){x0, x1, y0, y1}, crs, off, 0, 0);
-                    }
-                })
-        }
-#ifdef WG_GEMM_STAMP
-        {
-            unsigned long long now;
-            FR_STAMP(now);
-            st_epi += now - st_e;
-            st_slab -= now - st_e;      // (the epilogue sits between two slab stamps)
-            ++st_tiles;
-        }
 #endif
+            // ================= matrix half-phase: 64 MFMAs, nothing else in the stream =================
+            asm volatile("s_setprio 1");
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) FR_MFMA(acc[i][j], w[ks][j], a[ks][i]);
+            asm volatile("s_setprio 0");
+            if (grp == 0) FR_VMCNT(0);      // the slab sent in this slab's load half-phase has landed (two half-phases later)
+            FR_STAMP(st_3);
+            asm volatile("s_barrier" ::: "memory");
+#ifdef WG_GEMM_STAMP
+            {
+                unsigned long long now;
+                FR_STAMP(now);
+                st_m += st_1 - st_0; st_mb += st_2 - st_1; st_c += st_3 - st_2; st_cb += now - st_3; ++st_slabs;
+            }
+#endif
+        }
+        pm0 = m0; pn0 = n0; pending = true;
+        par ^= 1;
         const int vn = v + gridDim.x;
         if (vn >= nwg) break;
         v = vn;
         tile_of(v, m0, n0);
-        par ^= 1;
-        stores_in_flight = true;
-        zero_acc();
     }
+    // the last tile's epilogue; group 0 matches group 1's last barrier behind it
+    epilogue(pm0, pn0, par ^ 1);
+    if (grp == 0) asm volatile("s_barrier" ::: "memory");
     FR_VMCNT(0);
     FR_LGKM(0);
 #ifdef WG_GEMM_STAMP
     if (wg_gemm_fr_stamp_ptr && lane == 0 && blockIdx.x < 32) {      // [workgroup][wave][8]
         unsigned* o = wg_gemm_fr_stamp_ptr + (blockIdx.x * 8 + wave) * 8;
-        o[0] = (unsigned)st_vm; o[1] = (unsigned)st_bar; o[2] = (unsigned)st_slab; o[3] = (unsigned)st_epi; o[4] = st_tiles; o[5] = st_slabs;
+        o[0] = (unsigned)st_m; o[1] = (unsigned)st_mb; o[2] = (unsigned)st_c; o[3] = (unsigned)st_cb; o[4] = (unsigned)st_lat; o[5] = st_slabs;
         o[6] = (unsigned)(__builtin_amdgcn_s_memtime() - st_c0); o[7] = (unsigned)(__builtin_amdgcn_s_memrealtime() - st_r0);
     }
 #endif
