@@ -46,6 +46,27 @@ struct GemmArgs {
 // of W once per round of tiles: at N = 2304..4096 that is 3.5-8 MB per round, and the measured HBM-side reads were 2-4x
 // the operands, profiles/r01_gemm_traffic_by_shape.md).
 __device__ __forceinline__ void wg_tile_of(int wgid, int tiles_m, int tiles_n, int col_block, int& tile_m, int& tile_n) {
+    if (col_block < 0) {
+        // Row bands (experiment, WG_GEMM_COLBLOCK = -(band height * 16 + column block)): the grid is walked band by band of `bh` tile rows; inside a
+        // band in blocks of `cb` tile columns, row-major inside a block.  The 32 tiles an XCD has in flight then share bh row panels of A, which
+        // stay in its L2 while the band's column blocks pass: A leaves L2 once instead of once per column block.
+        const int bh = (-col_block) >> 4, cb = (-col_block) & 15;
+        const int per_band = bh * tiles_n;
+        const int band = wgid / per_band;
+        const int r0 = band * bh;
+        const int h = (tiles_m - r0) < bh ? (tiles_m - r0) : bh;      // (the last band may be lower)
+        int idx = wgid - band * per_band;
+        // bands above a lower last band are full, so idx indexes a band of height h only if h == bh; otherwise recompute inside the last band
+        if (h != bh) idx = wgid - band * per_band;
+        const int per_block = h * cb;
+        const int b = idx / per_block;
+        const int c0 = b * cb;
+        const int wdt = (tiles_n - c0) < cb ? (tiles_n - c0) : cb;
+        const int i2 = idx - b * per_block;
+        tile_m = r0 + i2 / wdt;
+        tile_n = c0 + i2 % wdt;
+        return;
+    }
     if (col_block <= 0 || col_block >= tiles_n) {
         tile_m = wgid / tiles_n;
         tile_n = wgid % tiles_n;

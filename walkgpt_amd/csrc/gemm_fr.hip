@@ -51,6 +51,7 @@ template <int OFF> __device__ __forceinline__ void fr_read(u32x4& v, unsigned ld
 // statement that reads it (hipcc does not preserve it around asm); offsets at or beyond the descriptor's extent are dropped by the range check
 // and still count in vmcnt, which keeps every wave's count of outstanding operations independent of the data.
 __device__ __forceinline__ void fr_dma(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned lds_dst) {
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);      // wave-uniform by construction; this makes it provably so (an "s" operand)
     if constexpr (WG_GEMM_FR_ABL & 1) asm volatile("" ::"v"(voff), "s"(lds_dst));
     else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rs), "s"(lds_dst) : "memory");
 }
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_fr_kernel(GemmArgs g) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
-    const int grp = wm;                            // 0: waves 0-3 (they also issue every LDS-DMA piece), 1: waves 4-7, one half-phase behind
+    const int grp = wm;                            // 0: waves 0-3, the leading group (priority 1); 1: waves 4-7, one half-phase behind
     const int fr = lane & 15, fq = lane >> 4;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
 
@@ -99,36 +100,42 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_fr_kernel(GemmArgs g) {
         n0 = tn * 256;
     };
 
-    // ---- issue side (group 0 only): the slab stream by LDS-DMA, one slab ahead of the group's own load half-phase --------------------
+    // ---- issue side: the slab stream by LDS-DMA, one slab ahead.  A slab is 64 pieces of 8 rows (0-31: A rows 8 p .., 32-63: W rows 8 (p - 32) ..):
+    //      wave w of group 0 sends pieces w + 4 k, k = 0..11 (48 of them), wave w of group 1 pieces 48 + w + 4 k, k = 0..3.  The row block of
+    //      a wave's pieces has the parity of w, so the swizzle ((row >> 1) & 7 = (block * 4 + lane / 16) & 7) is one value per lane.
     const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (unsigned)(((long)(g.M - 1) * g.lda + g.K) * 2), FR_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, (unsigned)(((long)(g.N - 1) * g.ldw + g.K) * 2), FR_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t brs = __builtin_amdgcn_make_buffer_rsrc((void*)g.bias, 0, g.bias ? (unsigned)(g.N * 2) : 0u, FR_RSRC_FLAGS);
-    // piece (q, h) of an operand for wave w < 4: rows q * 64 + (w + 4 h) * 8 + lane / 8 of the tile, 16-byte chunk (lane & 7) ^ swizzle(row);
-    // swizzle(row) = (row >> 1) & 7 = (w * 4 + lane / 16) & 7 for every q and h
-    const unsigned rl = (unsigned)((wave & 3) * 8 + (lane >> 3));
-    const unsigned cs = (unsigned)((lane & 7) ^ (((wave & 3) * 4 + (lane >> 4)) & 7));
-    const unsigned vbaseA = (rl * (unsigned)g.lda + cs * 8) * 2;
-    const unsigned vbaseW = (rl * (unsigned)g.ldw + cs * 8) * 2;
-    int iv = blockIdx.x, ikt = 0, im0, in0;       // tile and slab the issue side is at
+    const int w4 = wave & 3;
+    const unsigned cs = (unsigned)((lane & 7) ^ (((w4 & 1) * 4 + (lane >> 4)) & 7));
+    const unsigned vbaseA = ((unsigned)(lane >> 3) * (unsigned)g.lda + cs * 8) * 2;
+    const unsigned vbaseW = ((unsigned)(lane >> 3) * (unsigned)g.ldw + cs * 8) * 2;
+    int iv = blockIdx.x, ikt = 0, im0, in0;       // tile and slab the issue side is at (both groups walk the same list)
     bool ivalid = iv < nwg;
     tile_of(iv, im0, in0);
     unsigned islot = 0;
     int ipar = 0;
-    auto issue_slab = [&]() {   // all 64 pieces of the next slab of the stream: 16 per wave of group 0 (+ the tile's bias row in front of its first slab)
+    // pieces [P0, P0 + 4 * NP) step 4 of the next slab of the stream; BIAS: wave 0 also sends the tile's bias row in front of its first slab
+    auto issue_slab = [&](auto p0c, auto npc, auto biasc) {
+        constexpr int P0 = decltype(p0c)::value, NP = decltype(npc)::value;
         const unsigned dA = ivalid ? (unsigned)((im0 * (int)g.lda + ikt * 64) * 2) : FR_OOB;
         const unsigned dW = ivalid ? (unsigned)((in0 * (int)g.ldw + ikt * 64) * 2) : FR_OOB;
-        const unsigned dst = lds0 + islot * FR_SLOT + (unsigned)((wave & 3) * 8 * 128);
-        if (ivalid && ikt == 0) {
-            if (g.bias && wave == 0 && lane < 32) fr_dma((unsigned)((in0 + lane * 8) * 2), brs, lds0 + FR_BIAS + (unsigned)ipar * 512);
-            ipar ^= 1;
+        const unsigned dst = lds0 + islot * FR_SLOT + (unsigned)(w4 * 1024);
+        if constexpr (decltype(biasc)::value) {
+            if (ivalid && ikt == 0 && g.bias && wave == 0 && lane < 32) fr_dma((unsigned)((in0 + lane * 8) * 2), brs, lds0 + FR_BIAS + (unsigned)ipar * 512);
         }
+        if (ivalid && ikt == 0) ipar ^= 1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                fr_dma(vbaseA + dA + (unsigned)((q * 64 + h * 32) * (int)g.lda * 2), ars, dst + (unsigned)((q * 64 + h * 32) * 128));
-                fr_dma(vbaseW + dW + (unsigned)((q * 64 + h * 32) * (int)g.ldw * 2), wrs, dst + FR_WOFF + (unsigned)((q * 64 + h * 32) * 128));
-            }
+        for (int k = 0; k < NP; ++k) {
+            const int p = P0 + 4 * k;                 // (+ w4: folded into vbase row and dst)
+            const int rb = p & 31;
+            // (the piece's scalar offset is formed on the scalar unit and pinned there: added to the lane part first it is loop-invariant, and
+            // hipcc would keep one VGPR per piece alive across the main loop)
+            unsigned so = p < 32 ? dA + (unsigned)((rb + w4) * 8 * (int)g.lda * 2) : dW + (unsigned)((rb + w4) * 8 * (int)g.ldw * 2);
+            asm volatile("" : "+s"(so));
+            if (p < 32) fr_dma(vbaseA + so, ars, dst + (unsigned)(rb * 1024));
+            else fr_dma(vbaseW + so, wrs, dst + FR_WOFF + (unsigned)(rb * 1024));
+        }
         islot ^= 1;
         if (++ikt == nk) {
             ikt = 0;
@@ -137,6 +144,8 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_fr_kernel(GemmArgs g) {
             if (ivalid) tile_of(iv, im0, in0);
         }
     };
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
 
     // ---- consuming side ---------------------------------------------------------------------------------------------------------------
     // fragment addresses: A(i, ks) = slot + vA[ks] + i * 2048, W(j, ks) = slot + vW[ks] + j * 2048 (the slot is toggled by xor 65536)
@@ -160,10 +169,26 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_fr_kernel(GemmArgs g) {
                 asm volatile("" : "+v"(acc[i][j]));      // materialised here, not sunk in front of the first MFMA
             }
     };
+    auto read_frags = [&]() {      // the slab's 24 fragments, then the other slot
+        fr_for<0, 4>([&](auto jc) { constexpr int J = decltype(jc)::value; fr_read<J * 2048>(w[0][J], vW[0]); });
+        fr_for<0, 8>([&](auto ic) { constexpr int I = decltype(ic)::value; fr_read<I * 2048>(a[0][I], vA[0]); });
+        fr_for<0, 4>([&](auto jc) { constexpr int J = decltype(jc)::value; fr_read<J * 2048>(w[1][J], vW[1]); });
+        fr_for<0, 8>([&](auto ic) { constexpr int I = decltype(ic)::value; fr_read<I * 2048>(a[1][I], vA[1]); });
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) { vA[ks] ^= FR_SLOT; vW[ks] ^= FR_SLOT; }
+    };
+    auto burst = [&]() {           // the matrix half-phase: 64 MFMAs, nothing else in the stream
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) FR_MFMA(acc[i][j], w[ks][j], a[ks][i]);
+    };
     // ---- epilogue of the tile at (m0, n0): bias, activation, bf16, 64-byte row segments straight from registers (v_permlane16_swap pairs
     //      two column blocks: lane (fr, fq) ends with 16 bytes = columns jp * 32 + (fq & 1) * 16 + (fq >> 1) * 8 .. + 7 of row i * 16 + fr)
     auto epilogue = [&](int m0, int n0, int par) {
-        // lane coordinates re-derived here (two VALU instructions) instead of living in registers across the main loop, which runs at the
+        // lane coordinates re-derived here (two VALU instructions) instead of living in registers across the main loop, which runs close to the
         // 256-register limit: a spilled value's reload is a vector-memory operation, and hipcc drains the whole queue (vmcnt(0)) behind it
         int el;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));
@@ -198,18 +223,17 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_fr_kernel(GemmArgs g) {
             })
     };
 
-    // prologue: the stream's first slab; group 1 starts one half-phase behind
-    if (grp == 0) {
-        issue_slab();
-        FR_VMCNT(0);
+    // prologue: the stream's first slab by everyone (group 0: 48 pieces, group 1: 16)
+    if (grp == 0) issue_slab(C0{}, std::integral_constant<int, 12>{}, C1{});
+    else {
+        issue_slab(std::integral_constant<int, 48>{}, std::integral_constant<int, 4>{}, C0{});
+        issue_slab(std::integral_constant<int, 48>{}, std::integral_constant<int, 4>{}, C0{});      // (the trailing group stays one slab further ahead: see its loop)
     }
-    zero_acc();
-    asm volatile("s_barrier" ::: "memory");
-    if (grp == 1) asm volatile("s_barrier" ::: "memory");
+    FR_VMCNT(0);
 #ifdef WG_GEMM_STAMP
-    unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0, st_prev = 0;
+    unsigned long long st_0 = 0, st_1 = 0, st_2 = 0, st_3 = 0;
     unsigned long long st_m = 0, st_mb = 0, st_c = 0, st_cb = 0, st_epi = 0, st_lat = 0;
-    unsigned st_tiles = 0, st_slabs = 0;
+    unsigned st_slabs = 0;
     const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
@@ -219,71 +243,81 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_fr_kernel(GemmArgs g) {
     int par = 0;
     int pm0 = 0, pn0 = 0;
     bool pending = false;        // the previous tile's epilogue has not run yet (it runs in the load half-phase of this tile's first slab)
-    while (true) {
-        for (int kt = 0; kt < nk; ++kt) {
-            // ================= load half-phase: the next slab's pieces (group 0), the previous tile's epilogue, this slab's 24 fragments ======
-            FR_STAMP(st_0);
-            if (grp == 0) issue_slab();
-            if (kt == 0 && pending) {
+    if (grp == 0) {
+        // ---- leading group: [barrier] load half-phase (12 pieces of the next slab, this slab's fragments) | matrix half-phase | own pieces landed ----
+        asm volatile("s_setprio 1");      // this group's instructions win every arbitration against the SIMD partner's
+        zero_acc();
+        asm volatile("s_barrier" ::: "memory");      // slab 0 has landed
+        while (true) {
+            for (int kt = 0; kt < nk; ++kt) {
+                FR_STAMP(st_1);
+                if (kt == 0 && pending) {
+                    epilogue(pm0, pn0, par ^ 1);
+                    zero_acc();
+                }
+                read_frags();
+                issue_slab(C0{}, std::integral_constant<int, 12>{}, C1{});
+                FR_LGKM(0);
+                FR_STAMP(st_2);
+                burst();
+                FR_VMCNT(0);      // this wave's pieces of the next slab (sent in this slab's load half-phase) have landed
+                FR_STAMP(st_3);
+                // the next slab has landed and nobody reads the other slot any more (straight behind the burst: no taken branch between the last
+                // MFMA and the barrier that hands the matrix pipe over)
+                asm volatile("s_barrier" ::: "memory");
 #ifdef WG_GEMM_STAMP
-                unsigned long long e0, e1;
-                FR_STAMP(e0);
-#endif
-                epilogue(pm0, pn0, par ^ 1);
-                zero_acc();
-#ifdef WG_GEMM_STAMP
-                FR_STAMP(e1);
-                st_epi += e1 - e0; st_0 += e1 - e0; ++st_tiles;
+                FR_STAMP(st_0);
+                st_mb += st_0 - st_3; st_m += st_2 - st_1; st_c += st_3 - st_2; ++st_slabs;
 #endif
             }
-            fr_for<0, 4>([&](auto jc) { constexpr int J = decltype(jc)::value; fr_read<J * 2048>(w[0][J], vW[0]); });
-            fr_for<0, 8>([&](auto ic) { constexpr int I = decltype(ic)::value; fr_read<I * 2048>(a[0][I], vA[0]); });
-            fr_for<0, 4>([&](auto jc) { constexpr int J = decltype(jc)::value; fr_read<J * 2048>(w[1][J], vW[1]); });
-            fr_for<0, 8>([&](auto ic) { constexpr int I = decltype(ic)::value; fr_read<I * 2048>(a[1][I], vA[1]); });
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) { vA[ks] ^= FR_SLOT; vW[ks] ^= FR_SLOT; }
-            FR_LGKM(0);
-            FR_STAMP(st_1);
-            asm volatile("s_barrier" ::: "memory");
-            FR_STAMP(st_2);
-#ifdef WG_GEMM_STAMP
-            {      // two stamps back to back: what a stamp itself costs here (the second one opens the matrix half-phase)
-                unsigned long long t2b;
-                FR_STAMP(t2b);
-                st_lat += t2b - st_2;
-                st_2 = t2b;
-            }
-#endif
-            // ================= matrix half-phase: 64 MFMAs, nothing else in the stream =================
-            asm volatile("s_setprio 1");
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) FR_MFMA(acc[i][j], w[ks][j], a[ks][i]);
-            asm volatile("s_setprio 0");
-            if (grp == 0) FR_VMCNT(0);      // the slab sent in this slab's load half-phase has landed (two half-phases later)
-            FR_STAMP(st_3);
-            asm volatile("s_barrier" ::: "memory");
-#ifdef WG_GEMM_STAMP
-            {
-                unsigned long long now;
-                FR_STAMP(now);
-                st_m += st_1 - st_0; st_mb += st_2 - st_1; st_c += st_3 - st_2; st_cb += now - st_3; ++st_slabs;
-            }
-#endif
+            pm0 = m0; pn0 = n0; pending = true;
+            par ^= 1;
+            const int vn = v + gridDim.x;
+            if (vn >= nwg) break;
+            v = vn;
+            tile_of(v, m0, n0);
         }
-        pm0 = m0; pn0 = n0; pending = true;
-        par ^= 1;
-        const int vn = v + gridDim.x;
-        if (vn >= nwg) break;
-        v = vn;
-        tile_of(v, m0, n0);
+        epilogue(pm0, pn0, par ^ 1);
+    } else {
+        // ---- trailing group: load half-phase (4 pieces first, then the fragments) | [barrier] | matrix half-phase, which gets the matrix pipe whenever
+        //      the leading group is in ITS load half-phase (and is simply held up by the leading group's MFMAs otherwise: no hand-over latency) ----
+        asm volatile("s_barrier" ::: "memory");      // slab 0 has landed
+        zero_acc();
+        while (true) {
+            for (int kt = 0; kt < nk; ++kt) {
+                FR_STAMP(st_0);
+                if (kt == 0 && pending) {
+                    epilogue(pm0, pn0, par ^ 1);
+                    zero_acc();
+                    read_frags();
+                    FR_LGKM(0);
+                    FR_VMCNT(FR_NSTORE);      // the four pieces are older than the epilogue's stores
+                } else {
+                    read_frags();
+                    FR_LGKM(0);
+                    FR_VMCNT(0);
+                }
+                FR_STAMP(st_1);
+                asm volatile("s_barrier" ::: "memory");      // the next slab has landed; the leading group starts its load half-phase
+                FR_STAMP(st_2);
+                // this group's four pieces of the slab after the next one go out in front of the burst: the slot they land in has just been freed,
+                // and they have a whole slab's time to land (sent from the load half-phase they would have half of that, behind the leading group's 48)
+                issue_slab(std::integral_constant<int, 48>{}, std::integral_constant<int, 4>{}, C0{});
+                burst();
+                FR_STAMP(st_3);
+#ifdef WG_GEMM_STAMP
+                st_m += st_1 - st_0; st_mb += st_2 - st_1; st_c += st_3 - st_2; ++st_slabs;
+#endif
+            }
+            pm0 = m0; pn0 = n0; pending = true;
+            par ^= 1;
+            const int vn = v + gridDim.x;
+            if (vn >= nwg) break;
+            v = vn;
+            tile_of(v, m0, n0);
+        }
+        epilogue(pm0, pn0, par ^ 1);
     }
-    // the last tile's epilogue; group 0 matches group 1's last barrier behind it
-    epilogue(pm0, pn0, par ^ 1);
-    if (grp == 0) asm volatile("s_barrier" ::: "memory");
     FR_VMCNT(0);
     FR_LGKM(0);
 #ifdef WG_GEMM_STAMP
