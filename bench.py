@@ -109,10 +109,10 @@ def gemm_label(args):
 
 
 def workload_label(args, world):
-    return ("%s: bs=%d/GPU x %d GPU, 448x448 source images (CLIP input 448^2, SAM input 1024^2), CLIP ViT-L/14 + SAM %s encoder%s + CTP + "
+    return ("%s: bs=%d/GPU x %d GPU, %dx%d source images (CLIP input 448^2, SAM input 1024^2), CLIP ViT-L/14 + SAM %s encoder%s + CTP + "
             "prompt encoder + mask decoder + postprocess to %dx%d, T=%d [SEG]/image, %s GEMMs, random-init weights"
-            % (config_name(args, world), args.batch, world, args.sam, " + MSQP" if args.with_msqp else "", args.original, args.original,
-               args.seg_tokens, gemm_label(args))
+            % (config_name(args, world), args.batch, world, args.original, args.original, args.sam, " + MSQP" if args.with_msqp else "", args.original,
+               args.original, args.seg_tokens, gemm_label(args))
             + (" [NOT the headline workload: CLIP layer 24, whose output the path discards, is not run]" if args.clip_skip_unused_layer else ""))
 
 

@@ -30,7 +30,7 @@ extern "C" {
 #define WG_ACT_QUICK_GELU 2 /* x*sigmoid(1.702x)    HF CLIP MLP (custom_clip.py:50, third-party transformers) */
 #define WG_ACT_RELU 3       /* nn.ReLU()            model/segment_anything/modeling/transformer.py:23, mask_decoder.py:186 */
 
-int wg_version(void);               /* major*10000 + minor*100 + patch */
+int wg_version(void);               /* major*10000 + minor*100 + patch; 200 = 0.2.0: argument lists changed against 0.1.0 */
 const char* wg_last_error(void);    /* thread-local, valid until the next failing call on this thread */
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ R[m % res_row_mod or m, :]).  bf16 in, bf16 or fp32 out.
@@ -351,13 +351,13 @@ int wg_colsum_det_f32(const void* x, long ldx, void* out, int out_f32, float* wo
 int wg_act_bf16(const void* x, void* y, long n, int act, void* stream);
 int wg_act_bwd_bf16(const void* x, const void* dy, void* dx, long n, int act, void* stream);
 int wg_layernorm_bwd_bf16(const void* x, long ldx, const void* gamma, const void* dy, long lddy, void* dx, long lddx, float* dgamma,
-                          float* dbeta, float* row_stats, int M, int C, float eps, void* stream);
+                          float* dbeta, float* row_stats, int M, int C, float eps, void* stream);   /* row_stats: 2 M floats, needed when C > 4096 */
 /* The same for rows of 64 / 128 / 256 / 512 channels without atomics: a workgroup per run of rows leaves one partial {dgamma, dbeta} row pair,
  * summed in a fixed order; dgamma / dbeta are WRITTEN (bf16, or fp32 with out_f32).  workspace: wg_layernorm_bwd_det_workspace_floats(M, C) floats.
  * Returns -2 without launching for any other width. */
 long wg_layernorm_bwd_det_workspace_floats(int M, int C);
 int wg_layernorm_bwd_det_bf16(const void* x, long ldx, const void* gamma, const void* dy, long lddy, void* dx, long lddx, void* dgamma, void* dbeta,
-                              int out_f32, float* workspace, long workspace_floats, int M, int C, float eps, void* stream);   /* row_stats: 2 M floats, needed when C > 4096 */
+                              int out_f32, float* workspace, long workspace_floats, int M, int C, float eps, void* stream);
 /* wg_l2norm_scale_bf16 / _bwd: y = x / max(|x|, eps) * exp(log_temp), the tail of CalibratedTextProjector behind its LayerNorm and type
  *   embedding (utils_walkgpt.py:325-327) as a separate operator, and its backward (dx bf16; dlog_temp fp32 +=).  C <= 512.
  * wg_attn_bwd_bf16: gradients of o = softmax(scale q k^T) v per (batch, head) for the head's small attentions (two-way transformer,

@@ -191,16 +191,17 @@ def test_mha_pipelined_loop(dev, B, Lq, Lk, heads, pipe_plain):
     assert err < 0.03, err
 
 
-@pytest.mark.parametrize("mode,ramp_f,tol", [("global", (2.0, 3.0, 4.5, 6.0), 0.06), ("plain", (2.0, 3.0, 4.5, 6.0), 0.06),
-                                           ("global", (3.0, 5.0, 8.0, 12.0), 0.15), ("plain", (3.0, 5.0, 8.0, 12.0), 0.15)])
+@pytest.mark.parametrize("mode,ramp_f,tol", [("global", (2.0, 3.0, 4.5, 6.0), 0.03), ("plain", (2.0, 3.0, 4.5, 6.0), 0.03),
+                                           ("global", (3.0, 5.0, 8.0, 12.0), 0.03), ("plain", (3.0, 5.0, 8.0, 12.0), 0.03)])
 def test_pipelined_attention_rescales_a_pending_tile(dev, mode, ramp_f, tol, pipe_plain):
     """The pipelined loop decides tile t's rescale while the P.V product of tile t-1 is still pending: that tile's probabilities must be
     rescaled with the accumulator (cdna_hip_programming.md T13: a rare, data-dependent branch needs an input that FORCES it).  Keys are
     scaled so that the row maximum jumps by far more than the lazy-rescale threshold at chosen tiles late in the loop -- once, twice in
     consecutive tiles, and in the very last tile -- against an fp32 reference over the full tensor.  Two strengths: maxima that jump by
-    5-20 nats (held to the tolerance of the other attention tests), and scores of several hundred, where the softmax is one-hot up to ties
-    and the bf16 rounding of the pre-scaled queries (q * scale * log2 e is rounded once more, attn_pipe.hip) moves near-ties: 0.07-0.11
-    measured, bound 0.15."""
+    5-20 nats, and scores of several hundred, where the softmax is one-hot up to ties.  The kernel keeps the fp32 scale-and-offset of the
+    scores on the vector ALU (attn_pipe.hip; the variant that pre-multiplied the queries and rounded them to bf16 a second time was removed
+    in round 4): measured 0.009 (global) and 0.015-0.016 (plain) at both strengths on the shipped kernel, bound 0.03 -- the tolerance of the
+    other attention tests."""
     g = torch.Generator().manual_seed(5)
     heads, hd = 2, 64
     D = heads * hd

@@ -1,2 +1,3 @@
-timeout -k 10 200 python tools/bench_gemm_fr.py 2>&1 | grep -v amdgpu.ids
-echo "=== stamps"; WG_LIB=walkgpt_amd/_abl/lib_gstamp.so timeout -k 10 200 python tools/gemm_fr_stamps.py 2>&1 | grep -v amdgpu.ids
+for cb in "" -1; do
+  echo "=== WG_GEMM_COLBLOCK=$cb"; QUICK=1 WG_GEMM_COLBLOCK=$cb timeout -k 10 200 python tools/bench_gemm_fr.py 2>&1 | grep "^sam\|^clip\|^8k\|^4k" | awk '{print $1,$2,$3,$4,$5,$6,"|",$8,$9,$10,$11,$12,"|",$20,$21,$22,$23,$24}'
+done

@@ -46,6 +46,11 @@ struct GemmArgs {
 // of W once per round of tiles: at N = 2304..4096 that is 3.5-8 MB per round, and the measured HBM-side reads were 2-4x
 // the operands, profiles/r01_gemm_traffic_by_shape.md).
 __device__ __forceinline__ void wg_tile_of(int wgid, int tiles_m, int tiles_n, int col_block, int& tile_m, int& tile_n) {
+    if (col_block == -1) {      // timing-only experiment: every tile reads (and writes) one of 4 x 4 tiles, so all operands stay in every XCD's L2
+        tile_m = (wgid / tiles_n) & 3;
+        tile_n = (wgid % tiles_n) & 3;
+        return;
+    }
     if (col_block < 0) {
         // Row bands (experiment, WG_GEMM_COLBLOCK = -(band height * 16 + column block)): the grid is walked band by band of `bh` tile rows; inside a
         // band in blocks of `cb` tile columns, row-major inside a block.  The 32 tiles an XCD has in flight then share bh row panels of A, which

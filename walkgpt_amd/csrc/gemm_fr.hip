@@ -132,6 +132,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_fr_kernel(GemmArgs g) {
             // (the piece's scalar offset is formed on the scalar unit and pinned there: added to the lane part first it is loop-invariant, and
             // hipcc would keep one VGPR per piece alive across the main loop)
             unsigned so = p < 32 ? dA + (unsigned)((rb + w4) * 8 * (int)g.lda * 2) : dW + (unsigned)((rb + w4) * 8 * (int)g.ldw * 2);
+            so = __builtin_amdgcn_readfirstlane(so);      // (uniform by construction; hipcc may have formed it through VALU integer divisions)
             asm volatile("" : "+s"(so));
             if (p < 32) fr_dma(vbaseA + so, ars, dst + (unsigned)(rb * 1024));
             else fr_dma(vbaseW + so, wrs, dst + FR_WOFF + (unsigned)(rb * 1024));

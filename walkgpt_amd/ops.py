@@ -827,10 +827,22 @@ def postprocess_masks_scored(low_res, img_size, input_size, original_size):
 _SCORE_TICKETS = 64
 _SCORE_FUSED_MASKS = 4
 _score_ticket_cache = {}
+_score_ticket_pool = {}
 
 
 def _score_tickets(device):
-    """N <= 4096 zero words per (device, stream): launches on one stream are ordered, which is what sharing the tickets needs."""
+    """Zero words for wg_postprocess_masks_score_fused_f32 (the kernel leaves them zero).  Eager calls share one set per (device, stream): launches on
+    one HIP stream are ordered, which is all that sharing needs.  A call made under stream CAPTURE gets a set of its own: the graph is replayed on
+    whatever stream is current then, possibly beside eager calls on a stream whose pooled handle equals the capture stream's, and two launches adding
+    to the same words misdetect the last arriver.  The sets for captures come from a small pool zeroed eagerly on the first eager call (no memset node
+    in the latency-bound decode graph); a capture that finds the pool empty allocates inside the capture (a memset node, replayed with the graph)."""
+    if torch.cuda.is_current_stream_capturing():
+        pool = _score_ticket_pool.get(device.index)
+        if pool:
+            return pool.pop()
+        return torch.zeros(_SCORE_TICKETS, device=device, dtype=torch.int32)
+    if device.index not in _score_ticket_pool:
+        _score_ticket_pool[device.index] = list(torch.zeros(16, _SCORE_TICKETS, device=device, dtype=torch.int32).unbind(0))
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)
     t = _score_ticket_cache.get(key)
     if t is None:
