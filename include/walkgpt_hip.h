@@ -415,6 +415,11 @@ int wg_f32_gemm_bias_act(const float* A, long lda, const float* W, long ldw, con
 int wg_f32_layernorm(const float* x, const float* gamma, const float* beta, float* y, long rows, int C, float eps, void* stream);
 int wg_f32_mha(const float* q, const float* k, const float* v, float* o, const float* key_bias, long ld, long ldo, int B, int heads, int head_dim,
                int Lq, int Lk, float scale, void* stream);
+/* wg_f32_mha_ex: the same with queries [B, Lq, ldq] and keys / values [B, Lk, ldkv] in different tensors (nn.MultiheadAttention of CrossAttnBlock,
+ * utils_walkgpt.py:163-185) and an optional additive bias attn_bias [B, heads, Lq, Lk] (SAM's decomposed relative position term, image_encoder.py:321-392,
+ * which the caller forms from the UNSCALED queries, :247-249); the fp32 verification route of the SAM encoder -> MSQP -> language model path. */
+int wg_f32_mha_ex(const float* q, long ldq, const float* k, const float* v, long ldkv, float* o, long ldo, const float* key_bias, const float* attn_bias,
+                  int B, int heads, int head_dim, int Lq, int Lk, float scale, void* stream);
 /* The software-pipelined attention kernel (csrc/attn_pipe.hip; head_dim 64): which cases wg_sam_attn_relpos_bf16 / wg_mha_bf16 hand to it.
  * 0 none, 1 (default) SAM global attention on a 64 x 64 grid (image_encoder.py:235-260 with window_size 0), 2 also plain attention without a key
  * bias on whole 64-key tiles.  Returns the previous mode; a negative argument only queries.  Process-wide, not per stream. */

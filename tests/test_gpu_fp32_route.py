@@ -110,3 +110,66 @@ def test_f32_layernorm_and_attention(dev):
     a = (q * hd ** -0.5) @ k.transpose(2, 3) + kb.double()[:, None, None, :]
     ref = (a.softmax(-1) @ v).transpose(1, 2).reshape(B, L, D)
     assert float((o.double() - ref).abs().max()) < 1e-5
+
+
+def _llama(hidden, heads, vocab, seed):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(vocab_size=vocab, hidden_size=hidden, intermediate_size=max(128, hidden // 4), num_hidden_layers=2, num_attention_heads=heads,
+                      num_key_value_heads=heads, max_position_embeddings=2048)
+    torch.manual_seed(seed)
+    lm = LlamaForCausalLM(cfg).float().eval()
+    return lm
+
+
+@pytest.mark.parametrize("name", ["tiny", "vit_b_h4096"])
+def test_path_a_text_logits_on_the_fp32_route(dev, name):
+    """The OTHER text-logit path (model/walkgpt.py:313-330, the one model_forward feeds the language model from): SAM image encoder -> MSQP ->
+    6x6 -> 16x16 resample (llava_arch.py:252-259) -> splice -> a LLaMA-config language model (HF LlamaForCausalLM, 2 layers, stock fp32 PyTorch as
+    the language model is in the build), through walkgpt_amd.fp32_route on the GPU against the fp32 CPU oracle feeding the SAME language model.
+    tiny: 4 blocks of width 128 on a 32 x 32 grid (window 14 -> padded to 42, two global blocks with rel-pos), two images, llama width 64:
+    vit_b_h4096: ONE image through SAM ViT-B at 1024 x 1024 (12 blocks, 64 x 64 grid) and MSQP -> width 4096, a LLaMA-config model of hidden size
+    4096.  north_star's 1e-4 is asserted at both sizes."""
+    from oracle import projectors as oproj
+    from oracle import sam as osam
+    from oracle import splice as osplice
+    if name == "tiny":
+        c = cases.SAM_ENCODERS["tiny"]
+        pc = dict(cases.PROJECTORS["h64"])
+        hidden, heads, vocab = 64, 4, 96
+    else:
+        c = cases.SAM_ENCODERS["vit_b"]
+        pc = dict(llama_dim=4096, grid=64, batch=1, seed=33, ctp_shape=(1, 1))
+        hidden, heads, vocab = 4096, 32, 320
+    cfg = dict(patch=c["patch"], depth=c["depth"], heads=c["heads"], global_idx=c["global_idx"], window=c["window"])
+    w_enc = cases.sam_encoder_weights(c)
+    wm, _ = cases.projector_weights(pc)
+    x = cases.sam_encoder_input(c)
+    B = x.shape[0]
+    lm = _llama(hidden, heads, vocab, 5)
+    g = torch.Generator().manual_seed(21)
+    L = 14
+    ids = torch.randint(3, vocab, (B, L), generator=g)
+    ids[:, 2] = -200
+    with torch.no_grad():
+        emb_ref = osam.image_encoder(w_enc, x, cfg)
+        vis_ref = oproj.msqp(wm, emb_ref.flatten(2).transpose(1, 2))
+        feats_ref = oproj.resample_tokens(vis_ref)
+        amask, embeds_ref, _ = osplice.prepare_inputs_labels_for_multimodal(ids, None, None, feats_ref, lm.get_input_embeddings().weight)
+        l_ref = lm(inputs_embeds=embeds_ref, attention_mask=amask).logits
+        # the route: the same weights as fp32 CUDA tensors
+        wg = {k: v.to(dev).float().contiguous() for k, v in w_enc.items()}
+        wmg = {k: v.to(dev).float().contiguous() for k, v in wm.items()}
+        emb = fp32_route.sam_image_encoder(wg, x.to(dev), cfg)
+        vis = fp32_route.msqp(wmg, emb.flatten(2).transpose(1, 2).contiguous())
+        feats = fp32_route.resample_tokens(vis)
+        am2, embeds = fp32_route.splice_rows(ids.to(dev), feats, lm.get_input_embeddings().weight.to(dev))
+        torch.cuda.synchronize()
+        l_hip = lm(inputs_embeds=embeds.cpu(), attention_mask=am2.cpu()).logits
+    e_emb = rel_err(emb.cpu().numpy(), emb_ref.numpy())
+    e_vis = rel_err(vis.cpu().numpy(), vis_ref.numpy())
+    d = float((l_hip - l_ref).abs().max())
+    print("fp32 route, path A (%s): SAM embedding rel L2 vs the fp32 oracle %.2e, MSQP tokens %.2e; text logits (std %.2f) max |fp32 route - oracle| %.2e"
+          % (name, e_emb, e_vis, float(l_ref.std()), d))
+    assert torch.equal(am2.cpu(), amask.bool()) and torch.isfinite(l_hip).all()
+    assert e_emb < 2e-5 and e_vis < 2e-5
+    assert d <= 1e-4          # north_star's bar on path A, held on the fp32 route at both sizes (measured: 8.3e-7 tiny, 6.9e-6 at ViT-B / width 4096)

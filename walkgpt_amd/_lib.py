@@ -80,6 +80,8 @@ SIGNATURES = {
     "wg_f32_gemm_bias_act": [c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_long, c_int, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p],
     "wg_f32_layernorm": [c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_float, c_void_p],
     "wg_f32_mha": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_long, c_int, c_int, c_int, c_int, c_int, c_float, c_void_p],
+    "wg_f32_mha_ex": [c_void_p, c_long, c_void_p, c_void_p, c_long, c_void_p, c_long, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_float,
+                      c_void_p],
     "wg_debug_fill_lds_u32": [ctypes.c_uint, c_void_p, c_void_p],
     "wg_hyper_rows_f32": [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p],
     "wg_hyper_rows_bwd_f32": [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_long, c_int, c_int, c_int, c_int, c_void_p],

@@ -10,6 +10,9 @@
 //                          patch rows, llava_arch.py:36-42 (mm_projector)
 //   wg_f32_layernorm       HF CLIP pre_layrnorm / layer_norm1 / layer_norm2 (eps 1e-5)
 //   wg_f32_mha             HF CLIPAttention (eager): softmax(q k^T * scale + key bias) v, custom_clip.py:27-38 mask
+//   wg_f32_mha_ex          the same with queries and keys / values in different tensors (nn.MultiheadAttention of MSQP's CrossAttnBlock,
+//                          utils_walkgpt.py:163-185) and an additive bias per (batch, head, query, key): SAM's decomposed relative position
+//                          term, image_encoder.py:321-392, formed by the caller from the unscaled queries
 #include "wg_common.h"
 
 // C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ R[m % res_mod or m, :]); all fp32, K % 4 == 0.
@@ -110,4 +113,46 @@ extern "C" int wg_f32_mha(const float* q, const float* k, const float* v, float*
     hipLaunchKernelGGL(wg_f32_mha_kernel, dim3(Lq, heads, B), dim3(64), (size_t)Lk * 4, (hipStream_t)stream, q, k, v, o, key_bias, ld, ldo, heads, head_dim,
                        Lq, Lk, scale);
     return wg_check_launch("wg_f32_mha");
+}
+
+// o[b, i, h*hd + d] = sum_j softmax_j(scale * q_i . k_j + key_bias[b, j] + attn_bias[b, h, i, j]) v[j, d]; q rows [B, Lq, ldq], k / v rows [B, Lk, ldkv].
+__global__ __launch_bounds__(64) void wg_f32_mha_ex_kernel(const float* q, long ldq, const float* k, const float* v, long ldkv, float* o, long ldo,
+                                                           const float* key_bias, const float* attn_bias, int heads, int hd, int Lq, int Lk, float scale) {
+    extern __shared__ float p[];      // [Lk] probabilities of this query
+    const int lane = threadIdx.x;
+    const int i = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    const float* qi = q + ((long)b * Lq + i) * ldq + h * hd;
+    const float* ab = attn_bias ? attn_bias + (((long)b * heads + h) * Lq + i) * Lk : nullptr;
+    float mx = -INFINITY;
+    for (int j = lane; j < Lk; j += 64) {
+        const float* kj = k + ((long)b * Lk + j) * ldkv + h * hd;
+        float s = 0.f;
+        for (int d = 0; d < hd; ++d) s = fmaf(qi[d] * scale, kj[d], s);
+        if (key_bias) s += key_bias[(long)b * Lk + j];
+        if (ab) s += ab[j];
+        p[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    mx = wg_wave_max(mx);
+    float l = 0.f;
+    for (int j = lane; j < Lk; j += 64) {
+        const float e = expf(p[j] - mx);
+        p[j] = e;
+        l += e;
+    }
+    l = wg_wave_sum(l);
+    __syncthreads();
+    for (int d = lane; d < hd; d += 64) {
+        float acc = 0.f;
+        for (int j = 0; j < Lk; ++j) acc = fmaf(p[j], v[((long)b * Lk + j) * ldkv + h * hd + d], acc);
+        o[((long)b * Lq + i) * ldo + h * hd + d] = acc / l;
+    }
+}
+
+extern "C" int wg_f32_mha_ex(const float* q, long ldq, const float* k, const float* v, long ldkv, float* o, long ldo, const float* key_bias,
+                             const float* attn_bias, int B, int heads, int head_dim, int Lq, int Lk, float scale, void* stream) {
+    WG_REQUIRE(q && k && v && o && B > 0 && heads > 0 && head_dim > 0 && Lq > 0 && Lk > 0 && Lk <= 16384, "f32_mha_ex: bad arguments");
+    hipLaunchKernelGGL(wg_f32_mha_ex_kernel, dim3(Lq, heads, B), dim3(64), (size_t)Lk * 4, (hipStream_t)stream, q, ldq, k, v, ldkv, o, ldo, key_bias,
+                       attn_bias, heads, head_dim, Lq, Lk, scale);
+    return wg_check_launch("wg_f32_mha_ex");
 }
