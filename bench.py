@@ -75,6 +75,7 @@ def parse(argv=None):
                     help="NOT the headline: stop the CLIP tower after the last hidden state the path reads (hidden_states[-2]); the reference runs "
                          "layer 24 and discards it (clip_encoder.py:77-93).  Same outputs, 1/24 of the tower less; the FLOP count follows")
     ap.add_argument("--single-stream", action="store_true", help="run the CLIP tower and the SAM branch back to back")
+    ap.add_argument("--main-stream-created", action="store_true", help="experiment: the SAM branch on a stream of its own instead of the default stream")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-decode-graph", action="store_true", help="launch the decode chain eagerly instead of replaying its captured HIP graph")
     ap.add_argument("--steps-only", action="store_true", help="profiling runs: warm-up + timed steps only (no latency / instrumented / CPU passes)")
@@ -443,6 +444,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if args.main_stream_created:
+        torch.cuda.set_stream(torch.cuda.Stream())
     note("model built; warm-up")
     for _ in range(args.warmup):
         step()

@@ -1,3 +1,8 @@
-for cb in "" -1; do
-  echo "=== WG_GEMM_COLBLOCK=$cb"; QUICK=1 WG_GEMM_COLBLOCK=$cb timeout -k 10 200 python tools/bench_gemm_fr.py 2>&1 | grep "^sam\|^clip\|^8k\|^4k" | awk '{print $1,$2,$3,$4,$5,$6,"|",$8,$9,$10,$11,$12,"|",$20,$21,$22,$23,$24}'
+run() { echo "=== $*"; env "$@" | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; }
+timeout -k 10 400 python -m pytest tests/test_gpu_modules.py tests/test_gpu_fullsize.py -m gpu -x -q -k "clip or c2" 2>&1 | tail -3
+for i in 1 2; do
+run WG_PEEL_TAIL=0 timeout -k 10 200 python bench.py --steps 20 --warmup 5 --steps-only
+run WG_PEEL_TAIL=1 timeout -k 10 200 python bench.py --steps 20 --warmup 5 --steps-only
 done
+run WG_PEEL_TAIL=0 timeout -k 10 200 python bench.py --steps 20 --warmup 5 --steps-only --single-stream
+run WG_PEEL_TAIL=1 timeout -k 10 200 python bench.py --steps 20 --warmup 5 --steps-only --single-stream
