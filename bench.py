@@ -76,6 +76,7 @@ def parse(argv=None):
                          "layer 24 and discards it (clip_encoder.py:77-93).  Same outputs, 1/24 of the tower less; the FLOP count follows")
     ap.add_argument("--single-stream", action="store_true", help="run the CLIP tower and the SAM branch back to back")
     ap.add_argument("--main-stream-created", action="store_true", help="experiment: the SAM branch on a stream of its own instead of the default stream")
+    ap.add_argument("--attn-pipe-mode", type=int, default=None, help="experiment: wg_attn_pipe_mode (0 never, 1 SAM global attention only = default, 2 also plain attention: CLIP)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-decode-graph", action="store_true", help="launch the decode chain eagerly instead of replaying its captured HIP graph")
     ap.add_argument("--steps-only", action="store_true", help="profiling runs: warm-up + timed steps only (no latency / instrumented / CPU passes)")
@@ -446,6 +447,9 @@ def main():
 
     if args.main_stream_created:
         torch.cuda.set_stream(torch.cuda.Stream())
+    if args.attn_pipe_mode is not None:
+        from walkgpt_amd import _lib
+        _lib.lib().wg_attn_pipe_mode(args.attn_pipe_mode)
     note("model built; warm-up")
     for _ in range(args.warmup):
         step()
