@@ -77,6 +77,8 @@ def parse(argv=None):
     ap.add_argument("--single-stream", action="store_true", help="run the CLIP tower and the SAM branch back to back")
     ap.add_argument("--main-stream-created", action="store_true", help="experiment: the SAM branch on a stream of its own instead of the default stream")
     ap.add_argument("--attn-pipe-mode", type=int, default=None, help="experiment: wg_attn_pipe_mode (0 never, 1 SAM global attention only = default, 2 also plain attention: CLIP)")
+    ap.add_argument("--clip-split", type=int, default=1, help="experiment: the CLIP tower as this many independent sub-batches, each on a stream of its own")
+    ap.add_argument("--sam-split", type=int, default=1, help="the SAM encoder as this many independent slices of the batch, each on a stream of its own (WalkGPT.get_visual_emb_tokens(sub_batches=))")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-decode-graph", action="store_true", help="launch the decode chain eagerly instead of replaying its captured HIP graph")
     ap.add_argument("--steps-only", action="store_true", help="profiling runs: warm-up + timed steps only (no latency / instrumented / CPU passes)")
@@ -395,6 +397,7 @@ def main():
     side = torch.cuda.Stream(priority=args.side_priority) if not args.single_stream else None
     dec = torch.cuda.Stream(priority=args.dec_priority) if not args.single_stream else None
     dec_fn = model.decode_from_hidden if args.no_decode_graph else model.decode_from_hidden_graphed
+    clip_streams = [side] + [torch.cuda.Stream(priority=args.side_priority) for _ in range(args.clip_split - 1)] if side is not None else []
 
     def step(record_decode=False, serial=False):
         """One pass over one batch.  Three HIP streams in steady state: the CLIP tower (side), the SAM encoder (main) and
@@ -405,13 +408,27 @@ def main():
             cur = torch.cuda.current_stream()
             use_side = side is not None and not serial
             tails = bool(args.tail_tiles)
-            if use_side:
+            if use_side and args.clip_split > 1:
+                # experiment: independent sub-batches of the tower on streams of their own (finer interleaving of the persistent kernels)
+                per = B // args.clip_split
+                parts = []
+                for k, sk in enumerate(clip_streams):
+                    sk.wait_stream(cur)
+                    with torch.cuda.stream(sk):
+                        f, _pre = model.encode_images_clip(inp["images_clip"][k * per:(k + 1) * per], inp["clip_resize_list"][k * per:(k + 1) * per],
+                                                           tail_tiles=tails)
+                        parts.append(f)
+                for sk in clip_streams[1:]:
+                    side.wait_stream(sk)
+                with torch.cuda.stream(side):
+                    feats = torch.cat(parts, 0)
+            elif use_side:
                 side.wait_stream(cur)
                 with torch.cuda.stream(side):
                     feats, _pre = model.encode_images_clip(inp["images_clip"], inp["clip_resize_list"], tail_tiles=tails)
             else:
                 feats, _pre = model.encode_images_clip(inp["images_clip"], inp["clip_resize_list"], tail_tiles=tails)
-            emb = model.get_visual_emb_tokens(inp["images"])
+            emb = model.get_visual_emb_tokens(inp["images"], sub_batches=1 if serial or side is None else args.sam_split)
             if args.with_msqp:
                 model.project_visual_tokens(emb)
 

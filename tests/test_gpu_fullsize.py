@@ -260,7 +260,7 @@ def test_c4_per_gpu_share_at_its_own_batch(dev):
 
 
 def test_c2_step_on_three_streams_reproduces_itself_bit_for_bit(dev):
-    """The fused C2 step as bench.py runs it (CLIP tower / SAM encoder / graph-replayed decode on three HIP streams, bs = 8) 25 times on the same
+    """The fused C2 step as bench.py runs it (CLIP tower / SAM encoder in two slices / graph-replayed decode on HIP streams of their own, bs = 8) 25 times on the same
     inputs: CLIP features, SAM embedding, masks and scores of every pass equal the first pass's bit for bit.  The inference path has no atomics,
     so a difference would be an intermittent fault -- a missing wait state in front of a hand-placed MFMA (attn_pipe.hip), a counted wait that
     is one short (gemm.hip, attn_window_unit.hip), a buffer reused before its reader is done.  tools/soak_step.py is the long form (400 passes)."""
@@ -285,7 +285,7 @@ def test_c2_step_on_three_streams_reproduces_itself_bit_for_bit(dev):
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 feats, _ = model.encode_images_clip(xc, csz)
-            emb = model.get_visual_emb_tokens(x)
+            emb = model.get_visual_emb_tokens(x, sub_batches=2)      # (bench.py's default: two slices of the batch on two streams)
             dec.wait_stream(cur)
             emb.record_stream(dec)
             with torch.cuda.stream(dec):
@@ -298,6 +298,10 @@ def test_c2_step_on_three_streams_reproduces_itself_bit_for_bit(dev):
 
     ref = step()
     assert all(torch.isfinite(t.float()).all() for t in ref)
+    with torch.no_grad():
+        whole = model.get_visual_emb_tokens(x, sub_batches=1)
+    torch.cuda.synchronize()
+    assert torch.equal(whole, ref[1]), "the encoder in two slices of the batch differs from the single pass"
     for it in range(25):
         out = step()
         bad = [i for i, (a, b) in enumerate(zip(ref, out)) if not torch.equal(a, b)]

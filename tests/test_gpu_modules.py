@@ -305,6 +305,10 @@ def test_grounding_pipeline_end_to_end_vs_oracle(dev):
     # on a second replay with fresh inputs copied into the graph's static buffers (ragged prompt counts 2 + 3, two image sizes)
     hid = [h.to(dev, torch.bfloat16) for h in hidden]
     emb_t = model.get_visual_emb_tokens(x.to(dev, torch.bfloat16))
+    # the encoder as two slices of the batch on two streams writing one output: images are independent, same rows bit for bit
+    emb_s = model.get_visual_emb_tokens(x.to(dev, torch.bfloat16), sub_batches=2)
+    torch.cuda.synchronize()
+    assert emb_s.shape == emb_t.shape and torch.equal(emb_s, emb_t)
     for rep in range(2):
         hid = [h * (1.0 + rep) for h in hid]
         em, es = model.decode_from_hidden(emb_t, hid, resize, orig)

@@ -228,8 +228,8 @@ class ImageEncoderViT(nn.Module, _Prepared):
             "pos": None if self.pos_embed is None else self.pos_embed.reshape(-1, D),
         }
 
-    def forward_tokens(self, x: torch.Tensor) -> torch.Tensor:
-        """[B,3,S,S] bf16 -> channels-last embedding rows [B*g*g, out_chans]."""
+    def forward_tokens(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """[B,3,S,S] bf16 -> channels-last embedding rows [B*g*g, out_chans] (written to `out` when given)."""
         _check_bf16_gpu(x, "images")
         _check_bf16_gpu(self.patch_embed.proj.weight, "image encoder weights")
         B = x.shape[0]
@@ -245,7 +245,7 @@ class ImageEncoderViT(nn.Module, _Prepared):
         t = ops.linear(t, p["neck0_w"])
         t = ops.layernorm(t, self.neck[1].weight, self.neck[1].bias, self.neck[1].eps)
         t = ops.linear(ops.im2row3x3(t, B, g, g), p["neck2_w"])
-        return ops.layernorm(t, self.neck[3].weight, self.neck[3].bias, self.neck[3].eps)
+        return ops.layernorm(t, self.neck[3].weight, self.neck[3].bias, self.neck[3].eps, out=out)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         t = self.forward_tokens(x)

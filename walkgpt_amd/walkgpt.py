@@ -140,10 +140,39 @@ class WalkGPTGrounding(nn.Module):
     def get_visual_embs(self, pixel_values):
         return self.visual_model.image_encoder(pixel_values)
 
-    def get_visual_emb_tokens(self, pixel_values):
-        """Channels-last form of get_visual_embs: [B, h*w, 256] rows (what MSQP and the mask decoder consume)."""
-        t = self.visual_model.image_encoder.forward_tokens(pixel_values)
-        return t.view(pixel_values.shape[0], -1, t.shape[-1])
+    def get_visual_emb_tokens(self, pixel_values, sub_batches=None):
+        """Channels-last form of get_visual_embs: [B, h*w, 256] rows (what MSQP and the mask decoder consume).
+
+        sub_batches (default: self.sam_sub_batches, 1): the encoder runs as that many independent slices of the batch, each on a HIP
+        stream of its own (slice 0 on the current stream), all writing their rows of ONE output; the current stream waits for
+        them.  Images are independent in the encoder, so the rows are those of the single pass, bit for bit.  Why: the encoder's
+        kernels are persistent 256-workgroup launches with a partly filled last round (proj / lin2: 384 tiles = 1.5 rounds);
+        two half-batch chains side by side fill each other's (and the CLIP stream's) idle CUs -- bench.py C2: +2.1 ... +3.6 %
+        images/s at 2 slices, a loss at 4 (notes/r05_experiments.md section 5)."""
+        enc = self.visual_model.image_encoder
+        B = pixel_values.shape[0]
+        n = int(sub_batches if sub_batches is not None else getattr(self, "sam_sub_batches", 1))
+        if n <= 1 or B % n != 0 or not pixel_values.is_cuda:
+            t = enc.forward_tokens(pixel_values)
+            return t.view(B, -1, t.shape[-1])
+        g = enc.img_size // enc.patch_size
+        per = B // n
+        out = torch.empty(B * g * g, enc.out_chans, device=pixel_values.device, dtype=torch.bfloat16)
+        cur = torch.cuda.current_stream()
+        streams = self.__dict__.setdefault("_sam_streams", [])
+        while len(streams) < n - 1:
+            streams.append(torch.cuda.Stream())
+        for k in range(1, n):
+            sk = streams[k - 1]
+            sk.wait_stream(cur)
+            with torch.cuda.stream(sk):
+                enc.forward_tokens(pixel_values[k * per:(k + 1) * per], out=out[k * per * g * g:(k + 1) * per * g * g])
+        enc.forward_tokens(pixel_values[:per], out=out[:per * g * g])
+        for sk in streams[:n - 1]:
+            cur.wait_stream(sk)
+            out.record_stream(sk)
+            pixel_values.record_stream(sk)
+        return out.view(B, g * g, enc.out_chans)
 
     # -- llava_arch.py:160-193 + clip_encoder.py:71-98 ---------------------------------------------------------------------
     def encode_images_clip(self, images_clip, clip_resize_list=None, tail_tiles=False):
