@@ -564,7 +564,7 @@ def main():
     # of THIS run) stays null here; what the committed rocprofv3 passes of the same command measured (tools/profile_r04.sh: --pmc
     # FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md) is reported beside it, labelled with the
     # commit the profile was taken at, and only when it profiled THIS configuration and this kernel.
-    for pmc_file in ("r04_pmc_traffic.json", "r04_c5_fp8_pmc_traffic.json", "r03_pmc_traffic.json", "r03_c5_fp8_pmc_traffic.json"):
+    for pmc_file in ("r05_pmc_traffic.json", "r05_c5_fp8_pmc_traffic.json", "r04_pmc_traffic.json", "r04_c5_fp8_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)
