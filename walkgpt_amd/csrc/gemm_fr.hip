@@ -1,26 +1,24 @@
-// Free-running persistent 256 x 256 bf16 GEMM for gfx950:  C[M,N] = act(A[M,K] . W[N,K]^T + bias[N])
+// One-barrier persistent 256 x 256 bf16 GEMM for gfx950 (experimental, tile_hint 17):  C[M,N] = act(A[M,K] . W[N,K]^T + bias[N])
 //
 // Same operands, tile geometry (8 waves = 2 x 4, wave tile 128 x 64, 64-deep K slabs of 128-byte LDS rows brought in by LDS-DMA, two slab
 // slots, source-side XOR swizzle) and arithmetic (v_mfma_f32_16x16x32_bf16, weights as the A operand, k in ascending order: the sums are
-// bit-identical) as wg_gemm_pp_persist_kernel (gemm.hip), which it replaces on the shapes wg_gemm_fr_supports() accepts
-// (image_encoder.py:238,257, common.py:25-26 and HF CLIP's q|k|v / out_proj / fc1 / fc2 behind custom_clip.py:50-104).
+// bit-identical, tests/test_gpu_gemm_norm.py) as wg_gemm_pp_persist_kernel (gemm.hip), on the shapes wg_gemm_fr_supports() accepts
+// (image_encoder.py:238,257, common.py:25-26 and HF CLIP's q|k|v / out_proj / fc1 / fc2 behind custom_clip.py:50-104; bias / activation
+// epilogues only).  NOT dispatched by default: it is the round-5 answer to "can a different loop structure beat the four-barrier ping-pong",
+// and the answer measured is no except for the GELU shape (profiles/r05_gemm_phases.md, notes/r05_experiments.md section 2).
 //
-// What is different is the loop.  The ping-pong kernel makes the two waves of a SIMD alternate between a matrix half-phase and a load
-// half-phase across FOUR workgroup barriers per slab; in-kernel stamps (profiles/r04_gemm_phases.md) put its slab at 2430-2540 cycles against
-// 2048 of matrix work, and tools/micro/fetch_ceiling.hip + dma_issue_cost.hip (profiles/r05_gemm_micro.md) show that neither the operand fetch
-// (42-44 B/clk/CU available on these shapes against the 32 a 256 x 256 tile needs) nor the issue of the LDS-DMA pieces (7-13 cycles each beside
-// MFMAs) is what costs the difference: the barriers are.  Here every wave runs ONE instruction stream per slab in which fragment reads,
-// LDS-DMA pieces and MFMAs are interleaved by hand (every instruction its own `asm volatile` statement: hipcc keeps their order and
-// allocates the registers, as in attn_pipe.hip), and the workgroup meets at ONE barrier per slab:
-//   * a k-step (32 deep) is four passes j = 0..3 of eight MFMAs acc[i][j] += W_j . A_i; the A fragments a[0..7] stay in registers for the
-//     k-step, the W fragment of pass j + 1 is requested when pass j starts (two buffers), and in the last pass every a[i] is re-requested
-//     for the NEXT k-step right behind the MFMA that read it last -- the LDS latency of a fragment always has >= 8 MFMAs to hide under,
-//     and the SIMD's other wave fills the matrix pipe whenever this one waits;
-//   * the barrier sits in the last pass of a slab, after this wave's last fragment read of the slab has returned and its own pieces of
-//     the next slab have landed (counted vmcnt), in front of the requests for the next slab's first fragments: behind it the wave still has
-//     the eight MFMAs of that pass to issue, so the pipe is busy while the next slab's fragments are in flight;
-//   * the pieces of slab g + 2 go into the slot slab g has just freed, two per pass over the following four passes.
-// The slab stream runs across tile boundaries (the issue side is two slabs ahead of the consuming side and walks the tile list itself).
+// Structure ("priority ping-pong"): the two wave groups (waves 0-3 / 4-7 = the two waves of every SIMD) are half a slab apart and meet at
+// ONE workgroup barrier per slab.
+//   leading group (s_setprio 1):  barrier | load half-phase: 24 fragment reads of slab s, 12 LDS-DMA pieces of slab s + 1 per wave | 64-MFMA burst
+//   trailing group:               load half-phase: 24 fragment reads, wait for its pieces | barrier | its 4 pieces of slab s + 2 | 64-MFMA burst
+// so each group's burst has the matrix pipe while the other group reads and issues, with no hand-over latency between them, and every
+// instruction of the loop is its own `asm volatile` statement (hipcc keeps their order and allocates the registers, as in attn_pipe.hip).
+// The readings it is built on (tools/micro/*.hip): two MFMA-dense waves on a SIMD do not interleave (the older wave gets every slot), a
+// 64-MFMA burst is 1024 cycles, a DMA piece costs 7-13 cycles spaced and ~70 back to back, the fetch ceiling (42-44 B/clk/CU) is far
+// above what the loop uses (26).  The epilogue is LDS-free: v_permlane16_swap pairs two column blocks into 64-byte row segments, so a group's
+// epilogue runs beside its partner's burst.  Earlier forms (free-running waves with one hand-placed stream each; slab-level ping-pong
+// with two barriers) are in the history of this file (commit 01dce1e and the one after) and in the notes.
+// The slab stream runs across tile boundaries (the issue side is ahead of the consuming side and walks the tile list itself).
 #include "wg_common.h"
 #include "gemm_args.h"
 #include <type_traits>
