@@ -1,5 +1,5 @@
 #!/bin/bash
-# The bench line of every configuration the build reports, on one box, back to back (gpurun_out/r4_matrix.log -> profiles/r04_bench_matrix.md).
+# The bench line of every configuration the build reports, on one box, back to back (gpurun_out/r5_matrix.log -> profiles/r05_bench_matrix.md).
 cd "$GRAFT_REPO_ROOT"
 run() { echo "== $*"; python bench.py "$@" --steps-only 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], 'images/s', d['ms_per_step'], 'ms/step |', d['config']['workload'][:90])"; }
 run --steps 20 --warmup 5
