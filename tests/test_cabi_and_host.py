@@ -218,14 +218,14 @@ def test_mx_scale_plane_layout_host_side():
     assert d.shape == (M, K) and float(d[129, 40]) == 8.0 and float(d[129, 3]) == 1.0 and float(d[0, 40]) == 1.0
 
 
-@pytest.mark.parametrize("source", ["attn_pipe.hip", "gemm_fr.hip"])
+@pytest.mark.parametrize("source", ["walkgpt_amd/csrc/attn_pipe.hip", "tools/micro/gemm_fr.hip"])
 def test_hand_placed_streams_have_no_unpadded_mfma_operand(source):
-    """attn_pipe.hip and gemm_fr.hip place the instructions of their loops as `asm volatile` statements; hipcc's hazard recogniser cannot see
+    """attn_pipe.hip (product) and the gemm_fr.hip probe place the instructions of their loops as `asm volatile` statements; hipcc's hazard recogniser cannot see
     that a statement is an MFMA, so neither a vector instruction the COMPILER emits directly in front of one that reads its result, nor
     compiler code reading an asm MFMA's result behind it, gets wait states (found the hard way: stale operands, wrong rows that came and went
     with the register allocation).  The lint compiles the file with the product build's flags and scans the ISA for both patterns."""
     import subprocess
     import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lint_asm_hazards.py"), os.path.join(ROOT, "walkgpt_amd", "csrc", source)],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lint_asm_hazards.py"), os.path.join(ROOT, *source.split("/"))],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -285,7 +285,7 @@ def test_c2_step_on_three_streams_reproduces_itself_bit_for_bit(dev):
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 feats, _ = model.encode_images_clip(xc, csz)
-            emb = model.get_visual_emb_tokens(x, sub_batches=2)      # (bench.py's default: two slices of the batch on two streams)
+            emb = model.get_visual_emb_tokens(x, sub_batches=2)      # (bench.py --sam-split 2, the harder schedule: two slices on two streams; the bench's default is one slice)
             dec.wait_stream(cur)
             emb.record_stream(dec)
             with torch.cuda.stream(dec):

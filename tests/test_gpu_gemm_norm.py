@@ -270,9 +270,13 @@ def test_row_partials_are_refused_for_shapes_the_kernel_cannot_take(dev):
 @pytest.mark.parametrize("M,N,K", [(1777, 520, 256), (256, 256, 128), (8200, 1024, 1024), (4096, 2304, 768), (3000, 776, 192), (70000, 256, 128)])
 @pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_GELU, ops.ACT_QUICK_GELU])
 def test_gemm_one_barrier_kernel_matches_the_ping_pong_kernel_bit_for_bit(dev, M, N, K, act):
-    """tile 17 (csrc/gemm_fr.hip, the experimental one-barrier-per-slab persistent kernel: the leading wave group's load half-phase runs beside the
+    """tile 17 (tools/micro/gemm_fr.hip, the experimental one-barrier-per-slab persistent kernel: the leading wave group's load half-phase runs beside the
     trailing group's 64-MFMA burst by wave priority) sums in the same order as tile 16: identical bits on ragged M / N, several tiles per workgroup
-    and every activation; and both stay within the bf16 bound of fp32 torch."""
+    and every activation; and both stay within the bf16 bound of fp32 torch.  The kernel is a probe: it is linked into diagnostic builds only
+    (tools/build_variant.py <tag> -DWG_GEMM_FR, run with WG_LIB=...); against the product library this test has nothing to compare and skips."""
+    from walkgpt_amd import _lib
+    if not hasattr(_lib.lib(), "wg_gemm_fr_present"):
+        pytest.skip("product library: the one-barrier probe kernel is not linked in")
     g = torch.Generator().manual_seed(M + N + K + act)
     a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
     w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)

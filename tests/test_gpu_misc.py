@@ -118,6 +118,34 @@ def test_postprocess_and_score(dev, lh, img, inp, orig):
     assert int(ops._score_tickets(torch.device(dev)).abs().sum()) == 0
 
 
+def test_score_tickets_outlive_their_captured_graphs(dev):
+    """More captured fused postprocess calls than the ticket pool holds (16), then eager allocations that would reuse any freed ticket words:
+    every replay must still fold its scores (the graphs bake in the raw ticket addresses, so the sets have to stay allocated)."""
+    lh, img, inp, orig = 256, 1024, (1024, 1024), (448, 448)
+    ms = [(_rand((2, 1, lh, lh), 100 + i, 4.0, torch.float32)).to(dev) for i in range(20)]
+    want = [ops.postprocess_masks_scored(m, img, inp, orig) for m in ms]
+    torch.cuda.synchronize()
+    graphs, outs = [], []
+    side = torch.cuda.Stream()
+    for m in ms:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                outs.append(ops.postprocess_masks_scored(m, img, inp, orig))
+        graphs.append(g)
+    torch.cuda.synchronize()
+    # eager tensors of the ticket sets' size class, filled with ones: a freed set would be handed out again here
+    junk = [torch.ones(ops._SCORE_TICKETS, device=dev, dtype=torch.int32) for _ in range(256)]
+    for _ in range(2):
+        for g in graphs:
+            g.replay()
+    torch.cuda.synchronize()
+    for (o, s), (o0, s0) in zip(outs, want):
+        assert torch.equal(o, o0) and torch.allclose(s, s0, rtol=0, atol=3e-6)
+    assert all(int(j.sum()) == ops._SCORE_TICKETS for j in junk)
+    assert len(ops._score_ticket_keep) >= 20
+
+
 def test_mask_iou_and_losses_vs_reference_golden(dev):
     """SURVEY.md 8f rows 1-2 through the C-ABI against values the reference's own functions produced."""
     from tests.golden import cases

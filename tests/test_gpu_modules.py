@@ -342,6 +342,38 @@ def test_grounding_pipeline_end_to_end_vs_oracle(dev):
     assert not any(torch.equal(a, b) for a, b in zip(em2, em))
 
 
+def test_sub_batched_encoder_as_first_call_and_after_weight_edit(dev):
+    """get_visual_emb_tokens(sub_batches=2) on a model whose derived operands (LayerNorm folds, re-laid weights) do not exist yet, and again right
+    after an in-place weight edit: the operands are built on the caller's stream before the slices fork, so both slices read finished tensors --
+    the same rows bit for bit as the one-stream call."""
+    c = cases.SAM_ENCODERS["tiny"]
+    x = cases.sam_encoder_input(c).to(dev, torch.bfloat16)
+    x = torch.cat([x, x.flip(0)], 0) if x.shape[0] % 2 else x
+
+    def fresh():
+        m = WalkGPTGrounding(sam=dict(embed_dim=c["embed_dim"], depth=c["depth"], heads=c["heads"], global_idx=c["global_idx"], img=c["img"]),
+                             llm_hidden=64, with_clip=False)
+        load_into(m.visual_model.image_encoder, cases.sam_encoder_weights(c), "image_encoder.", dev)
+        return m
+    a, b = fresh(), fresh()
+    torch.cuda.synchronize()
+    first = a.get_visual_emb_tokens(x, sub_batches=2)          # nothing prepared yet on `a`
+    torch.cuda.synchronize()
+    ref = b.get_visual_emb_tokens(x)
+    torch.cuda.synchronize()
+    assert torch.equal(first, ref)
+    for m in (a, b):
+        with torch.no_grad():
+            blk = m.visual_model.image_encoder.blocks[0]
+            blk.norm1.weight.mul_(1.25)
+            blk.mlp.lin1.bias.add_(0.5)
+            m.visual_model.image_encoder.neck[2].weight.mul_(0.5)
+    again = a.get_visual_emb_tokens(x, sub_batches=2)          # every keyed operand of block 0 and the neck is stale here
+    ref2 = b.get_visual_emb_tokens(x)
+    torch.cuda.synchronize()
+    assert torch.equal(again, ref2) and not torch.equal(again, first)
+
+
 def test_decoder_first_block_reads_images_through_the_prompt_map(dev):
     """Token->image attention partials and the image->token rows kernel with one block of image tokens per IMAGE and a prompt -> image map
     (what the first decoder block uses when images have several prompts) == the same kernels on per-prompt copies, bit for bit."""

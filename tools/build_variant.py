@@ -26,8 +26,11 @@ def cc(src):
 
 
 _build.build_library()
+srcs = _build.sources()
+if "-DWG_GEMM_FR" in extra:      # the experimental one-barrier GEMM lives beside the other probes, not in the product library
+    srcs = srcs + [os.path.join(ROOT, "tools", "micro", "gemm_fr.hip")]
 with ThreadPoolExecutor(4) as ex:
-    objs = list(ex.map(cc, _build.sources()))
+    objs = list(ex.map(cc, srcs))
 lib = os.path.join(out_dir, "lib_%s.so" % tag)
 subprocess.run([_build.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs, check=True)
 print(lib)

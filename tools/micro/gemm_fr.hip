@@ -51,7 +51,7 @@ template <int OFF> __device__ __forceinline__ void fr_read(u32x4& v, unsigned ld
 __device__ __forceinline__ void fr_dma(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned lds_dst) {
     lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);      // wave-uniform by construction; this makes it provably so (an "s" operand)
     if constexpr (WG_GEMM_FR_ABL & 1) asm volatile("" ::"v"(voff), "s"(lds_dst));
-    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rs), "s"(lds_dst) : "memory");
+    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(rs), "s"(lds_dst) : "memory", "m0");
 }
 
 // Diagnostic build only (-DWG_GEMM_STAMP, tools/gemm_fr_stamps.py): s_memtime sums in scalar registers at points where the LDS queue is empty anyway
@@ -192,7 +192,9 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_fr_kernel(GemmArgs g) {
         int el;
         asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(el));
         const int fr = el & 15, fq = el >> 4;
-        asm volatile("s_nop 15" ::: "memory");      // the last MFMAs' results before the first vector read (opaque to the hazard recogniser)
+        // the last MFMAs' results before the first vector read (opaque to the hazard recogniser): the wait states are TIED to the accumulators they
+        // cover (an untied s_nop orders nothing against a copy or spill of acc the compiler might place in between)
+        asm volatile("s_nop 15" : "+v"(acc[0][0]));
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -352,3 +354,6 @@ int wg_launch_gemm_fr(GemmArgs& g, hipStream_t st) {
     hipLaunchKernelGGL(wg_gemm_fr_kernel, dim3(grid), dim3(512), FR_LDS, st, g);
     return wg_check_launch("wg_gemm_bias_act_bf16(free-running persistent)");
 }
+
+// lets tools and tests tell a -DWG_GEMM_FR build (tile 17 = this kernel) from the product library (tile 17 falls back to tile 16)
+extern "C" int wg_gemm_fr_present() { return 1; }

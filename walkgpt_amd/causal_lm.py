@@ -385,6 +385,10 @@ class walkgptForCausalLM(nn.Module):  # noqa: N801  (the reference's class name)
     def _wants_head_training(self):
         if self.head_training is not None:
             return self.head_training
+        # The automatic choice: does any parameter the head path can reach ask for a gradient?  Lazy and ordered: the generator stops at the first
+        # trainable parameter, and the modules every training recipe of the reference leaves trainable (text_hidden_fcs, then MSQP: train_walkgpt.py's
+        # trainable_list) come first -- in a training step this reads ONE flag.  The full walk over the language model only happens when nothing at all
+        # is trainable and the caller still asked for gradients (model_forward does not get here under no_grad or with inference=True).
         m = self.model
         mods = [getattr(m, "text_hidden_fcs", None), getattr(m, "out_mm_projector", None), getattr(m, "tiny_xattn", None),
                 getattr(getattr(m, "visual_model", None), "mask_decoder", None), self.llm]

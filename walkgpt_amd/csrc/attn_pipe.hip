@@ -421,7 +421,9 @@ __global__ __launch_bounds__(NW * 64, 2) void wg_attn_pipe_kernel(AttnArgs a) {
             rh = pa_ds_read_b32(relh_ad);
             relh_ad += 4;
         }
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // the S^T MFMAs' results before the first vector read
+        // the S^T MFMAs' results before the first vector read: the wait states are tied to the score registers they cover (as at the rescale and behind
+        // the loop; an untied s_nop orders nothing against compiler code that reads the scores)
+        asm volatile("s_nop 15\n\ts_nop 7" : "+v"(sa[0][0]), "+v"(sa[0][1]));
         wg_static_for<0, 16>([&max_op](auto i) { max_op(I0{}, i); });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         exchange(rh);

@@ -152,6 +152,10 @@ __global__ __launch_bounds__(64) void wg_f32_mha_ex_kernel(const float* q, long 
 extern "C" int wg_f32_mha_ex(const float* q, long ldq, const float* k, const float* v, long ldkv, float* o, long ldo, const float* key_bias,
                              const float* attn_bias, int B, int heads, int head_dim, int Lq, int Lk, float scale, void* stream) {
     WG_REQUIRE(q && k && v && o && B > 0 && heads > 0 && head_dim > 0 && Lq > 0 && Lk > 0 && Lk <= 16384, "f32_mha_ex: bad arguments");
+    // every head's head_dim columns of a row must lie inside the row's pitch (q, the k | v packing behind ldkv, and o): a short pitch from
+    // the caller would read or write past the rows without any message
+    WG_REQUIRE(ldq >= (long)heads * head_dim && ldkv >= (long)heads * head_dim && ldo >= (long)heads * head_dim,
+               "f32_mha_ex: a row pitch (ldq %ld, ldkv %ld, ldo %ld) is smaller than heads * head_dim = %d", ldq, ldkv, ldo, heads * head_dim);
     hipLaunchKernelGGL(wg_f32_mha_ex_kernel, dim3(Lq, heads, B), dim3(64), (size_t)Lk * 4, (hipStream_t)stream, q, ldq, k, v, ldkv, o, ldo, key_bias,
                        attn_bias, heads, head_dim, Lq, Lk, scale);
     return wg_check_launch("wg_f32_mha_ex");

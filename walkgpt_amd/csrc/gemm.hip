@@ -1574,7 +1574,14 @@ static int launch_pp_persist(GemmArgs& g, hipStream_t st) {
         const int cb = (int)((3L << 19) / (panel > 0 ? panel : 1));
         g.col_block = (wbytes > (3L << 20) && cb >= 2 && cb < g.tiles_n) ? cb : 0;
         static const char* force = getenv("WG_GEMM_COLBLOCK");      // experiments: tile order override (0 = row-major)
-        if (force && *force) g.col_block = atoi(force);
+        if (force && *force) {
+            g.col_block = atoi(force);
+#ifndef WG_GEMM_EXPERIMENT
+            if (g.col_block < 0) g.col_block = 0;      // the timing-only orders (resident 4 x 4 tiles, row bands) exist in diagnostic builds only
+#else
+            if (g.col_block < -1 && (((-g.col_block) >> 4) == 0 || ((-g.col_block) & 15) == 0)) g.col_block = 0;      // band height / block width 0
+#endif
+        }
     }
     constexpr int stage = 512 * 128, slab = 64 * (64 * 2 + 16);
     constexpr int base = 2 * stage + (8 - stage / slab) * slab;
@@ -1802,8 +1809,10 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
                            (!residual || (ldr % 8 == 0 && ((uintptr_t)residual & 15) == 0 && g.r_bytes != 0));
     const bool small_ops = (long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31);
     if (tile == 11 && !(can_stage && small_ops)) tile = 1;
-    if (tile == 17) {   // free-running persistent 256x256 kernel (gemm_fr.hip) where it takes the operands, else the ping-pong persistent one
+    if (tile == 17) {   // the experimental one-barrier persistent kernel (tools/micro/gemm_fr.hip): diagnostic builds only (tools/build_variant.py <tag> -DWG_GEMM_FR)
+#ifdef WG_GEMM_FR
         if (can_stage && small_ops && wg_gemm_fr_supports(g)) return wg_launch_gemm_fr(g, st);
+#endif
         tile = 16;
     }
     if (tile == 16 && !(can_stage && small_ops && (!bias || ((uintptr_t)bias % 16 == 0 && N % 8 == 0)))) {

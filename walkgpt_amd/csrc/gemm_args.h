@@ -1,4 +1,4 @@
-// Argument block and tile order shared by the GEMM kernels (gemm.hip, gemm_fr.hip).
+// Argument block and tile order shared by the GEMM kernels (gemm.hip; tools/micro/gemm_fr.hip).
 #pragma once
 #include "wg_common.h"
 
@@ -46,6 +46,7 @@ struct GemmArgs {
 // of W once per round of tiles: at N = 2304..4096 that is 3.5-8 MB per round, and the measured HBM-side reads were 2-4x
 // the operands, profiles/r01_gemm_traffic_by_shape.md).
 __device__ __forceinline__ void wg_tile_of(int wgid, int tiles_m, int tiles_n, int col_block, int& tile_m, int& tile_n) {
+#ifdef WG_GEMM_EXPERIMENT      // timing-only tile orders (notes/r05_experiments.md section 2): diagnostic builds only, the product walks col_block >= 0
     if (col_block == -1) {      // timing-only experiment: every tile reads (and writes) one of 4 x 4 tiles, so all operands stay in every XCD's L2
         tile_m = (wgid / tiles_n) & 3;
         tile_n = (wgid % tiles_n) & 3;
@@ -60,9 +61,7 @@ __device__ __forceinline__ void wg_tile_of(int wgid, int tiles_m, int tiles_n, i
         const int band = wgid / per_band;
         const int r0 = band * bh;
         const int h = (tiles_m - r0) < bh ? (tiles_m - r0) : bh;      // (the last band may be lower)
-        int idx = wgid - band * per_band;
-        // bands above a lower last band are full, so idx indexes a band of height h only if h == bh; otherwise recompute inside the last band
-        if (h != bh) idx = wgid - band * per_band;
+        const int idx = wgid - band * per_band;      // (bands above a lower last band are full)
         const int per_block = h * cb;
         const int b = idx / per_block;
         const int c0 = b * cb;
@@ -72,6 +71,7 @@ __device__ __forceinline__ void wg_tile_of(int wgid, int tiles_m, int tiles_n, i
         tile_n = c0 + i2 % wdt;
         return;
     }
+#endif
     if (col_block <= 0 || col_block >= tiles_n) {
         tile_m = wgid / tiles_n;
         tile_n = wgid % tiles_n;
@@ -87,6 +87,9 @@ __device__ __forceinline__ void wg_tile_of(int wgid, int tiles_m, int tiles_n, i
 }
 
 
-// free-running persistent 256x256 kernel (gemm_fr.hip): same operands and epilogue semantics as wg_gemm_pp_persist_kernel
+// the experimental one-barrier persistent 256x256 kernel (tools/micro/gemm_fr.hip, -DWG_GEMM_FR builds): same operands and epilogue
+// semantics as wg_gemm_pp_persist_kernel
+#ifdef WG_GEMM_FR
 int wg_launch_gemm_fr(GemmArgs& g, hipStream_t st);
 int wg_gemm_fr_supports(const GemmArgs& g);
+#endif

@@ -828,6 +828,7 @@ _SCORE_TICKETS = 64
 _SCORE_FUSED_MASKS = 4
 _score_ticket_cache = {}
 _score_ticket_pool = {}
+_score_ticket_keep = []      # every set ever handed to a capture: a captured graph bakes in the raw address, so the storage lives as long as the process
 
 
 def _score_tickets(device):
@@ -835,12 +836,14 @@ def _score_tickets(device):
     one HIP stream are ordered, which is all that sharing needs.  A call made under stream CAPTURE gets a set of its own: the graph is replayed on
     whatever stream is current then, possibly beside eager calls on a stream whose pooled handle equals the capture stream's, and two launches adding
     to the same words misdetect the last arriver.  The sets for captures come from a small pool zeroed eagerly on the first eager call (no memset node
-    in the latency-bound decode graph); a capture that finds the pool empty allocates inside the capture (a memset node, replayed with the graph)."""
+    in the latency-bound decode graph); a capture that finds the pool empty allocates inside the capture (a memset node, replayed with the graph).
+    The caller only takes data_ptr(): every set handed to a capture is therefore parked in _score_ticket_keep (views keep their whole block alive), or the
+    caching allocator would hand the words to a later tensor while replayed graphs still count arrivals in them."""
     if torch.cuda.is_current_stream_capturing():
         pool = _score_ticket_pool.get(device.index)
-        if pool:
-            return pool.pop()
-        return torch.zeros(_SCORE_TICKETS, device=device, dtype=torch.int32)
+        t = pool.pop() if pool else torch.zeros(_SCORE_TICKETS, device=device, dtype=torch.int32)
+        _score_ticket_keep.append(t)
+        return t
     if device.index not in _score_ticket_pool:
         _score_ticket_pool[device.index] = list(torch.zeros(16, _SCORE_TICKETS, device=device, dtype=torch.int32).unbind(0))
     key = (device.index, torch.cuda.current_stream(device).cuda_stream)

@@ -124,6 +124,29 @@ class Block(nn.Module, _Prepared):
         return {"qkv": ops.fold_layernorm_mx(self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias), "proj": ops.mx_weight(a.proj.weight),
                 "lin1": ops.fold_layernorm_mx(self.norm2.weight, self.norm2.bias, m.lin1.weight, m.lin1.bias), "lin2": ops.mx_weight(m.lin2.weight)}
 
+    # the derived operands of the three GEMM paths, each keyed on the parameters it reads
+    def _prep_bf16(self):
+        a, m = self.attn, self.mlp
+        return self._prep_get(self._build, (self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, self.norm2.weight, self.norm2.bias,
+                                            m.lin1.weight, m.lin1.bias))
+
+    def _prep_mx(self):
+        a, m = self.attn, self.mlp
+        return self._prep_get(self._build_mx, (self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, self.norm2.weight,
+                                               self.norm2.bias, m.lin1.weight, m.lin1.bias, m.lin2.weight), slot="_mx")
+
+    def _prep_fp8(self):
+        a, m = self.attn, self.mlp
+        return self._prep_get(self._build_fp8, (a.qkv.weight, a.proj.weight, m.lin1.weight, m.lin2.weight), slot="_fp8")
+
+    def prepare(self):
+        """Build (or refresh) the derived operands rows() will read, on the CURRENT stream: a caller that runs slices of a batch on side streams
+        calls this before it forks, so that no slice builds them lazily on one stream while another reads them unordered."""
+        if self.gemm_dtype != "fp8":
+            return self._prep_bf16()
+        m = self.mlp
+        return self._prep_mx() if ops.mx_chain_ok(self.norm1.weight.shape[0], m.lin1.weight.shape[0]) else self._prep_fp8()
+
     def rows_mx(self, x, B, grid):
         """The block as one MX chain on the persistent fp8 GEMM (ops.linear_mxfp8): e4m3 operands with a power-of-two scale per 32
         values on both sides; both LayerNorms folded into the GEMM behind them from the partial sums the GEMM in front left; the
@@ -132,8 +155,7 @@ class Block(nn.Module, _Prepared):
         32-column block would straddle two heads and the attention output keeps one quantisation pass per block.  Attention, the residual stream and every
         statistic stay bf16 / fp32."""
         a, m = self.attn, self.mlp
-        w = self._prep_get(self._build_mx, (self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, a.proj.weight, self.norm2.weight,
-                                            self.norm2.bias, m.lin1.weight, m.lin1.bias, m.lin2.weight), slot="_mx")
+        w = self._prep_mx()
         qkv = ops.linear_mxfp8(x, w["qkv"], ln_eps=self.norm1.eps)
         window = self.window_size if self.window_size > 0 else grid
         o = ops.sam_attention(qkv, a.qkv.bias, a.rel_pos_h, a.rel_pos_w, B, grid, window, a.num_heads, mx_out=True)
@@ -149,11 +171,7 @@ class Block(nn.Module, _Prepared):
         a, m = self.attn, self.mlp
         if ops.mx_chain_ok(x.shape[-1], m.lin1.weight.shape[0]) and ops.mx_prepare_rows(x):
             return self.rows_mx(x, B, grid)
-        w = self.__dict__.get("_fp8_val")
-        key = tuple((p.data_ptr(), p._version) for p in (a.qkv.weight, a.proj.weight, m.lin1.weight, m.lin2.weight))
-        if w is None or self.__dict__.get("_fp8_key") != key:
-            w = self._build_fp8()
-            self.__dict__["_fp8_val"], self.__dict__["_fp8_key"] = w, key
+        w = self._prep_fp8()
         q, s = ops.quantize_rows_fp8(x, ln=(self.norm1.weight, self.norm1.bias), eps=self.norm1.eps)
         qkv = ops.linear_fp8(q, s, *w["qkv"], bias=a.qkv.bias)
         window = self.window_size if self.window_size > 0 else grid
@@ -171,8 +189,7 @@ class Block(nn.Module, _Prepared):
             raise NotImplementedError("the HIP SAM attention is built for use_rel_pos=True, qkv_bias=True (build_sam.py:56-108)")
         if self.gemm_dtype == "fp8":
             return self.rows_fp8(x, B, grid)
-        p = self._prep_get(self._build, (self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, self.norm2.weight,
-                                         self.norm2.bias, self.mlp.lin1.weight, self.mlp.lin1.bias))
+        p = self._prep_bf16()
         qkv = ops.ln_linear(x, p["qkv"], self.norm1.eps)
         window = self.window_size if self.window_size > 0 else grid
         o = ops.sam_attention(qkv, a.qkv.bias, a.rel_pos_h, a.rel_pos_w, B, grid, window, a.num_heads)
@@ -228,6 +245,15 @@ class ImageEncoderViT(nn.Module, _Prepared):
             "pos": None if self.pos_embed is None else self.pos_embed.reshape(-1, D),
         }
 
+    def _prep_own(self):
+        return self._prep_get(self._build_prepared, (self.patch_embed.proj.weight, self.neck[0].weight, self.neck[2].weight, self.pos_embed))
+
+    def prepare(self):
+        """Every derived operand of forward_tokens, built on the current stream (see Block.prepare)."""
+        self._prep_own()
+        for blk in self.blocks:
+            blk.prepare()
+
     def forward_tokens(self, x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """[B,3,S,S] bf16 -> channels-last embedding rows [B*g*g, out_chans] (written to `out` when given)."""
         _check_bf16_gpu(x, "images")
@@ -236,7 +262,7 @@ class ImageEncoderViT(nn.Module, _Prepared):
         g = x.shape[-1] // self.patch_size
         if x.shape[-2] != x.shape[-1] or g != self.img_size // self.patch_size:
             raise RuntimeError("image encoder expects %dx%d inputs" % (self.img_size, self.img_size))
-        p = self._prep_get(self._build_prepared, (self.patch_embed.proj.weight, self.neck[0].weight, self.neck[2].weight, self.pos_embed))
+        p = self._prep_own()
         rows = ops.patchify(x.contiguous(), self.patch_size)
         t = ops.linear(rows, p["patch_w"], self.patch_embed.proj.bias, residual=p["pos"], res_row_mod=g * g if p["pos"] is not None else 0,
                        row_partials=True)      # block 0's norm1 reads these rows: the GEMM leaves their statistics with them

@@ -162,6 +162,10 @@ class WalkGPTGrounding(nn.Module):
         streams = self.__dict__.setdefault("_sam_streams", [])
         while len(streams) < n - 1:
             streams.append(torch.cuda.Stream())
+        # the encoder's derived operands (LayerNorm folds, re-laid weights, fp8 copies) are built lazily on whatever stream is current: build them
+        # HERE, on the caller's stream, before the fork -- a slice that built them on its side stream would leave the other slices reading them
+        # unordered (and out of that stream's allocator pool)
+        enc.prepare()
         for k in range(1, n):
             sk = streams[k - 1]
             sk.wait_stream(cur)
