@@ -22,6 +22,8 @@ Prints ONE JSON line (rank 0).  Extra objects:
                 that runs right after the timed region (same process, same buffers).  e2e_* = whole step.
   cpu_baseline  the CPU oracle (oracle/, fp32 PyTorch restatement pinned to the reference) timed on the host cores on a bounded
                 sample (one image of the batch: 1 warm-up + 3 timed runs), rank 0 at N=1 only.
+  secondary     (default C2 run at N=1 only) the other single-GPU configurations -- C3, C2 at T=14, C5 with fp8 -- as short passes in fresh
+                processes after the headline is final: [{config, images_per_s, ms_per_step, e2e_frac, steps}].  --no-secondary skips them.
 """
 import argparse
 import json
@@ -82,6 +84,7 @@ def parse(argv=None):
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--no-decode-graph", action="store_true", help="launch the decode chain eagerly instead of replaying its captured HIP graph")
     ap.add_argument("--steps-only", action="store_true", help="profiling runs: warm-up + timed steps only (no latency / instrumented / CPU passes)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short secondary passes (C3, C2 at T=14, C5 fp8) the default N=1 run appends to its line")
     ap.add_argument("--probe-launch", action="store_true", help="self-test of the rank launch only: gloo rendezvous, no GPU work (tests/test_bench_launch.py)")
     args = ap.parse_args(argv)
     preset = CONFIGS[args.config]
@@ -118,6 +121,43 @@ def workload_label(args, world):
             % (config_name(args, world), args.batch, world, args.original, args.original, args.sam, " + MSQP" if args.with_msqp else "", args.original,
                args.original, args.seg_tokens, gemm_label(args))
             + (" [NOT the headline workload: CLIP layer 24, whose output the path discards, is not run]" if args.clip_skip_unused_layer else ""))
+
+
+def gflop_per_step(args):
+    """Algorithmic GFLOP of one step on one GPU (2 * MAC, matmul / conv only, counted on the reference's modules)."""
+    gf_clip = GF_CLIP_L_448 if not args.clip_skip_unused_layer else GF_CLIP_L_448 - (GF_CLIP_L_448 - 0.6) / 24.0   # (0.6 GF: patch embedding)
+    return args.batch * (gf_clip + GF_SAM[args.sam] + (GF_MSQP if args.with_msqp else 0.0)
+                         + args.seg_tokens * (GF_DECODE_PER_TOKEN + GF_CTP_PER_TOKEN))
+
+
+# Secondary passes of the default single-GPU run: the other single-GPU configurations of BASELINE.json under the same clock as the headline.
+# Each is a fresh process of this file in --steps-only form (its own model, its own warm-up, its own synchronise bracket around its timed
+# steps); the headline `value` is never computed from them.
+SECONDARY = [("C3", ["--config", "C3", "--steps", "3", "--warmup", "1"]),
+             ("C2 with T=14 [SEG] tokens per image", ["--config", "C2", "--seg-tokens", "14", "--steps", "10", "--warmup", "3"]),
+             ("C5 (fp8 MX GEMMs in the SAM encoder)", ["--config", "C5", "--dtype", "fp8", "--steps", "3", "--warmup", "1"])]
+
+
+def run_secondary():
+    out = []
+    for name, flags in SECONDARY:
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps-only", "--no-secondary"] + flags
+        t0 = time.perf_counter()
+        try:
+            proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=420)
+            line = [ln for ln in proc.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+            if proc.returncode != 0 or not line:
+                out.append({"config": name, "error": "rc %d: %s" % (proc.returncode, proc.stderr.strip()[-300:])})
+                continue
+            d = json.loads(line[-1])
+            out.append({"config": d["config"]["workload"], "images_per_s": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"],
+                        "warmup": d["warmup"], "dtype": d["dtype"], "e2e_frac": d["e2e_frac"],
+                        "e2e_algorithmic_gflop_per_step": d["e2e_algorithmic_gflop_per_step"], "e2e_peak": d["e2e_peak"],
+                        "process_s": round(time.perf_counter() - t0, 1)})
+        except subprocess.TimeoutExpired:
+            out.append({"config": name, "error": "timed out after 420 s"})
+        note("secondary %s: %s" % (name, json.dumps(out[-1])[:200]))
+    return out
 
 
 def free_port():
@@ -490,6 +530,8 @@ def main():
         if rank == 0:
             print(json.dumps({"metric": "images/sec", "value": round(images_per_s, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "dtype": args.dtype, "steps_only": True,
+                              "e2e_algorithmic_gflop_per_step": round(gflop_per_step(args), 1), "e2e_peak": PEAK_TF["bf16"],
+                              "e2e_frac": round(gflop_per_step(args) / ms_per_step / PEAK_TF["bf16"], 4),      # per GPU: GFLOP / ms == TFLOP/s
                               "config": {"workload": workload_label(args, world)}}), flush=True)
         if dist is not None:
             dist.destroy_process_group()
@@ -548,8 +590,7 @@ def main():
     n_l, fl, sec, byt = per_kernel[dom]
     achieved_tf = fl / sec / 1e12
     peak = PEAK_TF["fp8" if dom in FP8_KERNELS else "bf16"]
-    gf_clip = GF_CLIP_L_448 if not args.clip_skip_unused_layer else GF_CLIP_L_448 - (GF_CLIP_L_448 - 0.6) / 24.0   # (0.6 GF: patch embedding)
-    gf_step = B * (gf_clip + GF_SAM[args.sam] + (GF_MSQP if args.with_msqp else 0.0) + T * (GF_DECODE_PER_TOKEN + GF_CTP_PER_TOKEN))
+    gf_step = gflop_per_step(args)
     roofline = {"bound": "mfma", "kernel": KERNEL_NAMES.get(dom, str(dom)),
                 "achieved": round(achieved_tf, 1), "peak": peak, "unit": "TFLOP/s",
                 "frac": round(achieved_tf / peak, 4), "traffic": None,
@@ -600,6 +641,14 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         note("cpu baseline (oracle on %d host threads)" % (args.cpu_threads or usable_cpus()))
         out["cpu_baseline"] = cpu_baseline(args)
+    if rank == 0 and world == 1 and not args.no_secondary and config_name(args, world) == "C2":
+        # the headline is measured and final; its model and buffers go before the secondary processes build theirs
+        del model, inp, emb, one, resident, s_emb, s_hid
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        note("secondary passes (fresh processes, --steps-only)")
+        out["secondary"] = run_secondary()
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
