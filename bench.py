@@ -394,9 +394,10 @@ KERNEL_NAMES = {1: "wg_gemm_kernel<128,128,64,2,2,2>", 2: "wg_gemm_kernel<256,25
                 21: "wg_gemm_pp_persist_kernel<0, false, true> (256x256 tiles, ping-pong, persistent, fp8 with MX block scales on both operands)",
                 22: "wg_gemm_pp_persist_kernel<2, false, true> (persistent fp8 MX, LayerNorm folded in from the producing GEMM's partial sums)",
                 23: "wg_gemm_pp_persist_kernel<0, true, true> (persistent fp8 MX, leaves its output's row sums and e4m3 + block-scale copy)"}
-PMC_PREFIX = {16: "wg_gemm_pp_persist_kernel<0, false, false>", 17: "wg_gemm_pp_persist_kernel<2, false, false>", 18: "wg_gemm_pp_persist_kernel<0, true, false>",
-              20: "wg_gemm_kernel<256, 256, 64, 2, 2, 4, true, 2, true>", 21: "wg_gemm_pp_persist_kernel<0, false, true>",
-              22: "wg_gemm_pp_persist_kernel<2, false, true>", 23: "wg_gemm_pp_persist_kernel<0, true, true>"}
+# (prefixes: round 6 added a fourth template argument -- the tile-seam flow -- behind these three)
+PMC_PREFIX = {16: "wg_gemm_pp_persist_kernel<0, false, false", 17: "wg_gemm_pp_persist_kernel<2, false, false", 18: "wg_gemm_pp_persist_kernel<0, true, false",
+              20: "wg_gemm_kernel<256, 256, 64, 2, 2, 4, true, 2, true>", 21: "wg_gemm_pp_persist_kernel<0, false, true",
+              22: "wg_gemm_pp_persist_kernel<2, false, true", 23: "wg_gemm_pp_persist_kernel<0, true, true"}
 FP8_KERNELS = (20, 21, 22, 23)
 
 

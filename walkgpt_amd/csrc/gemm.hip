@@ -134,6 +134,19 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 #ifndef WG_GEMM_TAIL
 #define WG_GEMM_TAIL 0
 #endif
+// WG_GEMM_ALIGN (persistent bf16 kernel): placement of a cluster's 32 MFMAs (8-byte instructions) in the code.  hipcc puts ONE 4-byte s_waitcnt between
+// this statement and the first MFMA, so "pad to 8" leaves the MFMAs at addresses = 4 (mod 8) and "pad to 8, one s_nop" at = 0 (mod 8).
+//   0: wherever the code lands (it moved between 0 and 4 with every edit of the kernel)   1: = 4 (mod 8)   2: = 0 (mod 8)
+#ifndef WG_GEMM_ALIGN
+#define WG_GEMM_ALIGN 0
+#endif
+#if WG_GEMM_ALIGN == 1
+#define WG_GEMM_ALIGN_ASM ".p2align 3"
+#elif WG_GEMM_ALIGN == 2
+#define WG_GEMM_ALIGN_ASM ".p2align 3\n\ts_nop 0"
+#else
+#define WG_GEMM_ALIGN_ASM ""
+#endif
 #ifndef WG_GEMM_C_AUX
 #define WG_GEMM_C_AUX 0
 #endif
@@ -1084,7 +1097,10 @@ __device__ __forceinline__ i32x8 wg_i32x8_of(bf16x8 lo, bf16x8 hi) {
 //   * FP8: e4m3 operands with OCP-MX block scales on BOTH sides (GemmArgs::mx_a, mx_w), applied by the MFMA itself -- the
 //     accumulators come out dequantised and every epilogue above runs unchanged.  The scale bytes of a slab travel like its operands:
 //     by LDS-DMA with the early pieces of slab kt+1 (7 operations stay in flight at the first counted wait instead of 6).
-template <int LNMODE, bool STATS, bool FP8 = false>
+//   * SEAM (round 6): how the operand slabs are addressed and when a tile's first slab is requested -- see the comment at `piece` below.  true: every
+//     K with an even number of slabs (all shapes of the workload): 1 000-1 300 cycles less at every tile seam, +1.5 ... 6 % per GEMM
+//     (profiles/r06_gemm_seam.md); false: the round-1..5 form, kept for odd nk.
+template <int LNMODE, bool STATS, bool FP8 = false, bool SEAM = true>
 __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) {
     constexpr bool LN = LNMODE != 0;
     constexpr int BM = 256, BN = 256, BK = 64, WN = 4;
@@ -1125,8 +1141,25 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
         m0 = tm * BM;
         n0 = tn * BN;
     };
-    const bf16* srcA[4];
-    const bf16* srcW[4];
+    // SEAM: operand slabs come in by LDS-DMA through BUFFER descriptors: a lane's byte offset inside a 64-row round (row wave * 8 + lane / 8, its
+    // swizzled 16-byte chunk -- the swizzle depends on the row's bits 1-3 only, so it is the same in all four rounds) is a constant of the
+    // kernel, and everything that changes -- tile, round, slab -- travels in the instruction's SCALAR offset.  Two VGPRs instead of eight
+    // 64-bit pointers, no per-piece vector arithmetic, no per-tile source set-up; rows past M / N read as zero through the descriptor's range
+    // check (the scalar offset takes part in it on gfx950: tools/micro/buffer_soffset_range.hip), so ragged last tiles need no clamp.  That is
+    // what lets the NEXT tile's first slab be requested from inside this tile's last slab (below).
+    // !SEAM: eight per-lane 64-bit row pointers per tile (rows clamped to the matrix), a slab's column added per piece.
+    const __amdgpu_buffer_rsrc_t ars = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, g.a_bytes, WG_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.W, 0, g.w_bytes, WG_RSRC_FLAGS);
+    [[maybe_unused]] int voffA = 0, voffW = 0;
+    [[maybe_unused]] const bf16* srcA[4];
+    [[maybe_unused]] const bf16* srcW[4];
+    if constexpr (SEAM) {
+        const int ln = lane_now();
+        const int r = wave * RPI + (ln >> 3);
+        const int c = (ln & 7) ^ wg_swz<BK>(r);
+        voffA = (r * (int)g.lda + c * 8) * 2;
+        voffW = (r * (int)g.ldw + c * 8) * 2;
+    }
     auto set_sources = [&](int m0, int n0) {
         const int ln = FP8 ? lane_now() : lane;
 #pragma unroll
@@ -1140,18 +1173,28 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
             srcW[i] = g.W + (long)gw * g.ldw + c * 8;
         }
     };
-    auto piece = [&](int kt, int which) {   // which: 0,1 = W round pairs; 2 = A rounds 0,2 (early); 3 = A rounds 1,3 (late)
-        char* ldsA = smem + (kt & 1) * STAGE;
+    // two LDS-DMA instructions of a slab into buffer `stage`.  SEAM: offA / offW = scalar byte offsets of the slab's first A / W row (tile origin row
+    // * pitch + k column), the four 64-row rounds sit rsA / rsW bytes apart; !SEAM: offA = offW = the slab's k column (elements) on top of the
+    // tile's row pointers.  which: 0,1 = W round pairs; 2 = A rounds 0,2 (early); 3 = A rounds 1,3 (late)
+    const unsigned rsA = (unsigned)g.lda * (RPR * 2), rsW = (unsigned)g.ldw * (RPR * 2);
+    auto piece = [&](int stage, unsigned offA, unsigned offW, int which, int only = -1) {
+        char* ldsA = smem + stage * STAGE;
         char* ldsW = ldsA + BM * ROWB;
-        const int k0 = kt * BK;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
+            if (only >= 0 && u != only) continue;
             if (which < 2) {
                 const int i = which * 2 + u;
-                __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcW[i] + k0), WG_LDS_PTR(ldsW + (i * RPR + wave * RPI) * ROWB), 16, 0, WG_GEMM_W_AUX);
+                if constexpr (SEAM)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, WG_LDS_PTR(ldsW + (i * RPR + wave * RPI) * ROWB), 16, voffW, (int)(offW + i * rsW), 0, WG_GEMM_W_AUX);
+                else
+                    __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcW[i] + offW), WG_LDS_PTR(ldsW + (i * RPR + wave * RPI) * ROWB), 16, 0, WG_GEMM_W_AUX);
             } else {
                 const int i = (which - 2) + 2 * u;
-                __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcA[i] + k0), WG_LDS_PTR(ldsA + (i * RPR + wave * RPI) * ROWB), 16, 0, WG_GEMM_A_AUX);
+                if constexpr (SEAM)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(ars, WG_LDS_PTR(ldsA + (i * RPR + wave * RPI) * ROWB), 16, voffA, (int)(offA + i * rsA), 0, WG_GEMM_A_AUX);
+                else
+                    __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(srcA[i] + offA), WG_LDS_PTR(ldsA + (i * RPR + wave * RPI) * ROWB), 16, 0, WG_GEMM_A_AUX);
             }
         }
     };
@@ -1174,7 +1217,8 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
         const unsigned char* ub = wave < 4 ? g.mx_a + (long)(4 * kt + wave) * g.mx_a_pitch + tm0 : g.mx_w + (long)(4 * kt + wave - 4) * g.mx_w_pitch + tn0;
         __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(ub + (unsigned)(lane_now() * 4)), WG_LDS_PTR(mxbuf + (kt & 1) * 2048 + wave * 256), 4, 0, 0);
     };
-    auto first_slab = [&](int m0, int n0, int par) {
+    // the epilogue operands of a tile (bias row / LayerNorm fold vectors and row statistics), by LDS-DMA into parity `par`
+    auto first_ops = [&](int m0, int n0, int par) {
         const int lane = FP8 ? lane_now() : (tid & 63);   // (shadows the kernel's: see lane_now)
         if (LN) {
             if (wave == 0) {
@@ -1208,8 +1252,13 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
             n = n + 8 <= g.N ? n : 0;             // columns past N are never stored
             __builtin_amdgcn_global_load_lds(WG_GLOBAL_PTR(g.bias + n), WG_LDS_PTR(biasbuf + par * 512), 16, 0, 0);
         }
+    };
+    // a tile's first slab (into buffer 0)
+    auto first_pieces = [&](int m0, int n0) {
         if constexpr (FP8) scale_piece(m0, n0, 0);
-        piece(0, 0); piece(0, 1); piece(0, 2); piece(0, 3);
+        if constexpr (!SEAM) set_sources(m0, n0);
+        const unsigned oA = SEAM ? (unsigned)m0 * (unsigned)g.lda * 2u : 0u, oW = SEAM ? (unsigned)n0 * (unsigned)g.ldw * 2u : 0u;
+        piece(0, oA, oW, 0); piece(0, oA, oW, 1); piece(0, oA, oW, 2); piece(0, oA, oW, 3);
     };
     const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, g.c_bytes, WG_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc((void*)g.R, 0, g.r_bytes, WG_RSRC_FLAGS);
@@ -1220,8 +1269,8 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
     int v = blockIdx.x;
     int m0, n0;
     tile_of(v, m0, n0);
-    set_sources(m0, n0);
-    first_slab(m0, n0, 0);
+    first_ops(m0, n0, 0);
+    first_pieces(m0, n0);
     bool stores_in_flight = false;
     int par = 0;
 #ifdef WG_GEMM_STAMP
@@ -1233,6 +1282,15 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
     while (true) {
         WG_PSTAMP(0);
         const int nbase = n0 + wn * WTN;
+        // The next tile of this workgroup, known before the main loop starts (scalar arithmetic, off the seam between two tiles).  With an even
+        // number of slabs its first slab is requested INSIDE this tile's last slab, exactly where a slab kt + 1 would be (buffer 0 is free from
+        // slab nk - 2 on, and the epilogue stages through buffer 1): the operand pipeline never drains at a tile seam, and the epilogue starts
+        // with nothing to set up.  (Odd nk: buffer 0 holds the last slab; the first slab is then sent behind the loop, as before round 6.)
+        const int vn = v + gridDim.x;
+        const bool has_next = vn < nwg;
+        int m0n = m0, n0n = n0;
+        if (SEAM && has_next) tile_of(vn, m0n, n0n);      // (!SEAM: behind the main loop, where it always was -- nothing more live across the loop)
+        const bool seam = SEAM && has_next && !(nk & 1);
         f32x4 acc[8][FJ];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -1259,7 +1317,8 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                 }
         };
         // the whole first slab (older than the previous tile's stores) has landed; those stores may still be draining
-        if (stores_in_flight) wg_wait_vmcnt<NSTORE + (STATS ? 1 : 0)>(); else wg_wait_vmcnt<0>();
+        // (the slab's pieces are the oldest operations in the queue: behind them only the NSTORE output stores of the previous tile)
+        if (stores_in_flight) wg_wait_vmcnt<NSTORE>(); else wg_wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if constexpr (LNMODE == 2) {
             // this tile's row statistics from the partial sums that arrived with its first slab:  mean = S / K,
@@ -1285,17 +1344,60 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
         }
         WG_PSTAMP(1);
         if (grp == 1) __builtin_amdgcn_s_barrier();
-        for (int kt = 0; kt < nk; ++kt) {
+        // One slab.  While it computes it requests (more) slab kt + 1 of this tile or -- last slab, seam -- slab 0 of the NEXT tile; the last slab of
+        // the workgroup's last tile (or of an odd nk) requests nothing.  pA / pW: scalar byte offsets of the requested slab's first rows (tile
+        // origin + k column); (sm0, sn0, skt): the same slab for the fp8 scale bytes.  Two straight instances, loop body and last slab, in
+        // sequence: an if / else between two instances is a control-flow merge of 128 accumulators, which this hipcc resolves with spills.
+        auto slab = [&](int kt, auto lastc, auto morec, const bool more_rt, unsigned pA, unsigned pW, int sm0, int sn0, int skt) __attribute__((always_inline)) {
+            constexpr bool last = decltype(lastc)::value;
+            constexpr int MORE = decltype(morec)::value;      // 1: requests, 0: none (compile time: no branch around any request), 2: decided by more_rt
+            const bool more = MORE == 2 ? more_rt : MORE == 1;
             const char* ldsA = smem + (kt & 1) * STAGE;
             const char* ldsW = ldsA + BM * ROWB;
-            const bool more = kt + 1 < nk;
+            const int pst = (kt + 1) & 1;
 #pragma unroll
             for (int sc = 0; sc < 2; ++sc) {
-                read_a(ldsA, sc);
-                if (sc == 0) { read_w(ldsW, 0); read_w(ldsW, 1); }
-                if (more) {
-                    if (sc == 0) { piece(kt + 1, 0); piece(kt + 1, 1); piece(kt + 1, 2); }
-                    else piece(kt + 1, 3);
+                // M half-phase: the fragment reads of this cluster with the requests for the next slab BETWEEN them, one request per two or three
+                // reads.  Requests issued back to back (round 6 first had them behind the reads with only scalar instructions in between, where
+                // rounds 1-5 had happened to keep a 64-bit vector add between any two) cost the K >= 3072 shapes 2-6 %: profiles/r06_gemm_seam.md.
+                // (An LDS-DMA write and an LDS read may alias as far as hipcc knows, so it keeps this order.)
+                auto ra = [&](int i, int ks) __attribute__((always_inline)) {
+                    const int r = wm * WTM + (4 * sc + i) * 16 + fr;
+                    af[i][ks] = *(const bf16x8*)(ldsA + r * ROWB + (((ks * 4 + fq) ^ wg_swz<BK>(r)) << 4));
+                };
+                auto rw = [&](int cj, int j, int ks) __attribute__((always_inline)) {
+                    const int r = wn * WTN + (2 * cj + j) * 16 + fr;
+                    wf2[cj][j][ks] = *(const bf16x8*)(ldsW + r * ROWB + (((ks * 4 + fq) ^ wg_swz<BK>(r)) << 4));
+                };
+                if constexpr (!SEAM) {      // (odd nk only: the order of rounds 1-5; interleaved, its eight row pointers spill)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { ra(i, 0); ra(i, 1); }
+                    if (sc == 0) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) { rw(q >> 1, q & 1, 0); rw(q >> 1, q & 1, 1); }
+                    }
+                    if (more) {
+                        if (sc == 0) { piece(pst, pA, pW, 0); piece(pst, pA, pW, 1); piece(pst, pA, pW, 2); }
+                        else piece(pst, pA, pW, 3);
+                    }
+                } else if (sc == 0) {
+                    ra(0, 0); ra(0, 1); ra(1, 0);
+                    if (more) piece(pst, pA, pW, 0, 0);
+                    ra(1, 1); ra(2, 0); ra(2, 1);
+                    if (more) piece(pst, pA, pW, 0, 1);
+                    ra(3, 0); ra(3, 1);
+                    if (more) piece(pst, pA, pW, 1, 0);
+                    rw(0, 0, 0); rw(0, 0, 1); rw(0, 1, 0);
+                    if (more) piece(pst, pA, pW, 1, 1);
+                    rw(0, 1, 1); rw(1, 0, 0); rw(1, 0, 1);
+                    if (more) piece(pst, pA, pW, 2, 0);
+                    rw(1, 1, 0); rw(1, 1, 1);
+                    if (more) piece(pst, pA, pW, 2, 1);
+                } else {
+                    ra(0, 0); ra(0, 1); ra(1, 0); ra(1, 1);
+                    if (more) piece(pst, pA, pW, 3, 0);
+                    ra(2, 0); ra(2, 1); ra(3, 0); ra(3, 1);
+                    if (more) piece(pst, pA, pW, 3, 1);
                 }
                 if constexpr (FP8) {
                     const char* mxs = mxbuf + (kt & 1) * 2048;
@@ -1303,7 +1405,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                     sb = *(const unsigned*)(mxs + (ol >> 4) * 256 + wm * WTM + (ol & 15) * 8 + 4 * sc);
                     if (sc == 0) {
                         swc = *(const unsigned*)(mxs + 1024 + (ol >> 4) * 256 + wn * WTN + (ol & 15) * 4);
-                        if (more) scale_piece(m0, n0, kt + 1);
+                        if (more) scale_piece(sm0, sn0, skt);
                     }
                 }
                 if (sc == 0) {
@@ -1315,11 +1417,13 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                     else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
                 } else {
                     if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    else if (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (seam: nothing of THIS tile is outstanding any more)
                     else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_s_setprio(1);
+                if constexpr (!FP8) asm volatile(WG_GEMM_ALIGN_ASM);
                 if constexpr (FP8) {
                     const i32x8 w0 = wg_i32x8_of(wf2[0][0][0], wf2[0][0][1]), w1 = wg_i32x8_of(wf2[0][1][0], wf2[0][1][1]);
                     const i32x8 w2 = wg_i32x8_of(wf2[1][0][0], wf2[1][0][1]), w3 = wg_i32x8_of(wf2[1][1][0], wf2[1][1][1]);
@@ -1355,13 +1459,27 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                 __builtin_amdgcn_sched_barrier(0);
                 if (FP8 || WG_GEMM_TAIL == 0) __builtin_amdgcn_s_barrier();
             }
+        };
+        {
+            using I1_ = std::integral_constant<int, 1>;
+            using I2_ = std::integral_constant<int, 2>;
+            if constexpr (SEAM) {
+                unsigned pA = (unsigned)m0 * (unsigned)g.lda * 2u, pW = (unsigned)n0 * (unsigned)g.ldw * 2u;
+                int kt = 0;
+                for (; kt + 1 < nk; ++kt) {
+                    pA += BK * 2;
+                    pW += BK * 2;
+                    slab(kt, std::false_type{}, I1_{}, true, pA, pW, m0, n0, kt + 1);
+                }
+                slab(kt, std::true_type{}, I2_{}, seam, (unsigned)m0n * (unsigned)g.lda * 2u, (unsigned)n0n * (unsigned)g.ldw * 2u, m0n, n0n, 0);
+            } else {
+                for (int kt = 0; kt < nk; ++kt) slab(kt, std::false_type{}, I2_{}, kt + 1 < nk, (unsigned)(kt + 1) * BK, (unsigned)(kt + 1) * BK, m0, n0, kt + 1);
+            }
         }
         if (grp == 0) __builtin_amdgcn_s_barrier();
         // every wave is past its last LDS read of this tile (each M half-phase retired its reads before its barrier)
         WG_PSTAMP(2);
 
-        const int vn = v + gridDim.x;
-        const bool has_next = vn < nwg;
         const int cm0 = m0;
         // opaque copies of the lane coordinates: keeps hipcc from hoisting the epilogue's tile-invariant address arithmetic
         // out of the tile loop, where it would stay live across the main loop
@@ -1384,9 +1502,11 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
         }
         const char* lnbuf = biasbuf + par * EPIB;
         if (has_next) {
-            tile_of(vn, m0, n0);
-            set_sources(m0, n0);
-            first_slab(m0, n0, par ^ 1);
+            if constexpr (!SEAM) tile_of(vn, m0n, n0n);
+            m0 = m0n;
+            n0 = n0n;
+            first_ops(m0, n0, par ^ 1);
+            if (!seam) first_pieces(m0, n0);
         }
 #ifdef WG_GEMM_STAMP
         pst_e = pst_prev;
@@ -1566,9 +1686,18 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
     }
 }
 
+// The persistent kernel addresses A and W through 32-bit buffer offsets that reach up to 255 rows past the last one (those read as zero): both
+// operands, padded to whole tiles, must stay below 4 GiB.
+static bool wg_pp_operands_ok(int M, int N, long lda, long ldw) {
+    return (long)(M + 256) * lda < (1L << 31) && (long)(N + 256) * ldw < (1L << 31);
+}
+
 static int launch_pp_persist(GemmArgs& g, hipStream_t st) {
+    WG_REQUIRE(wg_pp_operands_ok(g.M, g.N, g.lda, g.ldw), "persistent gemm: an operand (padded to whole 256-row tiles) is larger than 4 GiB");
     g.tiles_m = (g.M + 255) / 256;
     g.tiles_n = (g.N + 255) / 256;
+    g.a_bytes = (unsigned)(((long)(g.M - 1) * g.lda + g.K) * 2);
+    g.w_bytes = (unsigned)(((long)(g.N - 1) * g.ldw + g.K) * 2);
     {
         const long panel = 256L * g.K * 2, wbytes = (long)g.N * g.K * 2;
         const int cb = (int)((3L << 19) / (panel > 0 ? panel : 1));
@@ -1591,25 +1720,36 @@ static int launch_pp_persist(GemmArgs& g, hipStream_t st) {
     static WgPerDevice once;
     int dev = 0;
     if (once.first(&dev)) {   // the attribute is per device (a process may drive several)
-        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_plain);
-        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_stats);
-        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_ln);
-        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_lnp);
-        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_plain + 4096);
-        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<0, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_stats + 4096);
-        (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<2, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_lnp + 4096);
+#define WG_PP_ATTR(LN_, ST_, F8_, BYTES_)                                                                                                                \
+    (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<LN_, ST_, F8_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES_);          \
+    (void)hipFuncSetAttribute((const void*)wg_gemm_pp_persist_kernel<LN_, ST_, F8_, false>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES_)
+        WG_PP_ATTR(0, false, false, lds_plain); WG_PP_ATTR(0, true, false, lds_stats); WG_PP_ATTR(1, false, false, lds_ln); WG_PP_ATTR(2, false, false, lds_lnp);
+        WG_PP_ATTR(0, false, true, lds_plain + 4096); WG_PP_ATTR(0, true, true, lds_stats + 4096); WG_PP_ATTR(2, false, true, lds_lnp + 4096);
+#undef WG_PP_ATTR
     }
     const int nwg = g.tiles_m * g.tiles_n;
     const int cus = wg_cu_count(dev);
     const int grid = nwg < cus ? nwg : cus;   // one resident workgroup per CU; a multiple of 8 keeps a workgroup's tiles on one XCD
+    // Which flow (template parameter SEAM): the seamless one whenever the number of slabs is even (its first-slab request lands in buffer 0
+    // during the last slab); the round-1..5 flow for odd nk.
+    const int nk = g.K / 64;
+    bool seam = (nk & 1) == 0;
+    static const char* force_seam = getenv("WG_GEMM_SEAM");      // =0: the round-1..5 flow everywhere (A/B runs)
+    if (force_seam && *force_seam) seam = seam && atoi(force_seam) != 0;
+#define WG_PP_LAUNCH(LN_, ST_, F8_, BYTES_)                                                                                           \
+    do {                                                                                                                              \
+        if (seam) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<LN_, ST_, F8_, true>), dim3(grid), dim3(512), BYTES_, st, g);         \
+        else hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<LN_, ST_, F8_, false>), dim3(grid), dim3(512), BYTES_, st, g);             \
+    } while (0)
     if (g.mx_w) {   // fp8 operands with MX block scales: the same three epilogue flavours (4 KiB more LDS for the slabs' scale bytes)
-        if (g.ln_part) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<2, false, true>), dim3(grid), dim3(512), lds_lnp + 4096, st, g);
-        else if (g.stats_part) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<0, true, true>), dim3(grid), dim3(512), lds_stats + 4096, st, g);
-        else hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<0, false, true>), dim3(grid), dim3(512), lds_plain + 4096, st, g);
-    } else if (g.ln_part) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<2, false>), dim3(grid), dim3(512), lds_lnp, st, g);
-    else if (g.ln_stats) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<1, false>), dim3(grid), dim3(512), lds_ln, st, g);
-    else if (g.stats_part) hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<0, true>), dim3(grid), dim3(512), lds_stats, st, g);
-    else hipLaunchKernelGGL((wg_gemm_pp_persist_kernel<0, false>), dim3(grid), dim3(512), lds_plain, st, g);
+        if (g.ln_part) WG_PP_LAUNCH(2, false, true, lds_lnp + 4096);
+        else if (g.stats_part) WG_PP_LAUNCH(0, true, true, lds_stats + 4096);
+        else WG_PP_LAUNCH(0, false, true, lds_plain + 4096);
+    } else if (g.ln_part) WG_PP_LAUNCH(2, false, false, lds_lnp);
+    else if (g.ln_stats) WG_PP_LAUNCH(1, false, false, lds_ln);
+    else if (g.stats_part) WG_PP_LAUNCH(0, true, false, lds_stats);
+    else WG_PP_LAUNCH(0, false, false, lds_plain);
+#undef WG_PP_LAUNCH
     return wg_check_launch("wg_gemm_bias_act_bf16(ping-pong persistent)");
 }
 
@@ -1815,7 +1955,7 @@ static int wg_gemm_dispatch(const void* A, long lda, const void* W, long ldw, co
 #endif
         tile = 16;
     }
-    if (tile == 16 && !(can_stage && small_ops && (!bias || ((uintptr_t)bias % 16 == 0 && N % 8 == 0)))) {
+    if (tile == 16 && !(can_stage && small_ops && wg_pp_operands_ok(M, N, lda, ldw) && (!bias || ((uintptr_t)bias % 16 == 0 && N % 8 == 0)))) {
         WG_REQUIRE(!(g.ln_part || g.stats_part || g.ln_stats), "gemm: this operand layout cannot take the persistent kernel's staged epilogue");
         tile = 14;
     }

@@ -22,6 +22,7 @@ struct GemmArgs {
     float* stats_part;           // producer side (persistent kernel, bf16 output, N % 256 == 0): [tiles_n][stats_mpad][2] fp32 =
     long stats_mpad;             //   {sum, sum of squares} of the STORED (bf16-rounded) values of each output row over the tile's 256 columns
     unsigned c_bytes, r_bytes;   // extents of C and R for the staged epilogue's buffer descriptors (0: not addressable in 32 bits)
+    unsigned a_bytes = 0, w_bytes = 0;   // persistent 256x256 kernel: extents of A and W for its LDS-DMA descriptors (set by launch_pp_persist)
     const float* scale_a;        // fp8 operands (wg_gemm_fp8_bias_act): per-row scale of A [M] and per-output-channel scale of W [N];
     const float* scale_w;        //   A, W then point at e4m3 bytes and lda / ldw / K count PAIRS of bytes (see the entry point)
     const unsigned char* mx_a = nullptr;   // persistent fp8 kernel, MX operand: E8M0 scale of every 32-value block of A's rows, [K/32][mx_a_pitch]
