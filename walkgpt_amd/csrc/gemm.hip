@@ -119,10 +119,24 @@ template <int CH, int NIT>
 __device__ __forceinline__ void wg_load_residual(u32x4* rres, __amdgpu_buffer_rsrc_t rrs, int ldr, int res_mod, int row0, int nbase, int el) {
     constexpr int RPS = 64 / CH;
     const int n = nbase + (el % CH) * 8;
+    // rows row0 .. row0 + 63 of the residual, modulo res_mod when it is set (a broadcast table: pos_embed, the decoder's positional rows).  The 64
+    // rows wrap at most once when res_mod >= 64: ONE scalar modulo for the slab's first row and a compare + subtract per load, instead of a vector
+    // integer division per load behind a branch (round 6: ~400 vector instructions per tile of every residual GEMM, whether or not res_mod was set)
+    const int base = res_mod > 0 ? __builtin_amdgcn_readfirstlane(row0) % res_mod : row0;
+    int off = ((base + el / CH) * ldr + n) * 2;
+    if (res_mod >= 64 || res_mod <= 0) {
+        const int wrap = res_mod > 0 ? res_mod - (base + el / CH) : 0x7FFFFFFF;      // rows until this lane's row index wraps
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-        const int m = row0 + it * RPS + el / CH;
-        rres[it] = __builtin_amdgcn_raw_buffer_load_b128(rrs, ((res_mod > 0 ? m % res_mod : m) * ldr + n) * 2, 0, 0);
+        for (int it = 0; it < NIT; ++it) {
+            const int o = off + it * RPS * ldr * 2;
+            rres[it] = __builtin_amdgcn_raw_buffer_load_b128(rrs, it * RPS >= wrap ? o - res_mod * ldr * 2 : o, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int m = row0 + it * RPS + el / CH;
+            rres[it] = __builtin_amdgcn_raw_buffer_load_b128(rrs, ((m % res_mod) * ldr + n) * 2, 0, 0);
+        }
     }
 }
 
@@ -139,6 +153,11 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 //   0: wherever the code lands (it moved between 0 and 4 with every edit of the kernel)   1: = 4 (mod 8)   2: = 0 (mod 8)
 #ifndef WG_GEMM_ALIGN
 #define WG_GEMM_ALIGN 0
+#endif
+// WG_GEMM_ILV (persistent bf16 kernel, seam flow): where a half-phase's LDS-DMA requests sit between its fragment reads (0 = product; the others
+// were measured against it: profiles/r06_gemm_seam.md)
+#ifndef WG_GEMM_ILV
+#define WG_GEMM_ILV 0
 #endif
 #if WG_GEMM_ALIGN == 1
 #define WG_GEMM_ALIGN_ASM ".p2align 3"
@@ -1381,6 +1400,47 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                         else piece(pst, pA, pW, 3);
                     }
                 } else if (sc == 0) {
+#if WG_GEMM_ILV == 1      // experiment: a request first, then two or three reads per request
+                    if (more) piece(pst, pA, pW, 0, 0);
+                    ra(0, 0); ra(0, 1);
+                    if (more) piece(pst, pA, pW, 0, 1);
+                    ra(1, 0); ra(1, 1); ra(2, 0);
+                    if (more) piece(pst, pA, pW, 1, 0);
+                    ra(2, 1); ra(3, 0); ra(3, 1);
+                    if (more) piece(pst, pA, pW, 1, 1);
+                    rw(0, 0, 0); rw(0, 0, 1); rw(0, 1, 0);
+                    if (more) piece(pst, pA, pW, 2, 0);
+                    rw(0, 1, 1); rw(1, 0, 0); rw(1, 0, 1);
+                    if (more) piece(pst, pA, pW, 2, 1);
+                    rw(1, 1, 0); rw(1, 1, 1);
+#elif WG_GEMM_ILV == 2    // experiment: two reads per request, the last four reads behind the last request
+                    ra(0, 0); ra(0, 1);
+                    if (more) piece(pst, pA, pW, 0, 0);
+                    ra(1, 0); ra(1, 1);
+                    if (more) piece(pst, pA, pW, 0, 1);
+                    ra(2, 0); ra(2, 1);
+                    if (more) piece(pst, pA, pW, 1, 0);
+                    ra(3, 0); ra(3, 1);
+                    if (more) piece(pst, pA, pW, 1, 1);
+                    rw(0, 0, 0); rw(0, 0, 1);
+                    if (more) piece(pst, pA, pW, 2, 0);
+                    rw(0, 1, 0); rw(0, 1, 1);
+                    if (more) piece(pst, pA, pW, 2, 1);
+                    rw(1, 0, 0); rw(1, 0, 1); rw(1, 1, 0); rw(1, 1, 1);
+#elif WG_GEMM_ILV == 3    // experiment: the W fragments (needed by every MFMA of the cluster) first, requests between the A reads
+                    rw(0, 0, 0); rw(0, 0, 1); rw(0, 1, 0);
+                    if (more) piece(pst, pA, pW, 0, 0);
+                    rw(0, 1, 1); rw(1, 0, 0); rw(1, 0, 1);
+                    if (more) piece(pst, pA, pW, 0, 1);
+                    rw(1, 1, 0); rw(1, 1, 1);
+                    if (more) piece(pst, pA, pW, 1, 0);
+                    ra(0, 0); ra(0, 1); ra(1, 0);
+                    if (more) piece(pst, pA, pW, 1, 1);
+                    ra(1, 1); ra(2, 0); ra(2, 1);
+                    if (more) piece(pst, pA, pW, 2, 0);
+                    ra(3, 0); ra(3, 1);
+                    if (more) piece(pst, pA, pW, 2, 1);
+#else
                     ra(0, 0); ra(0, 1); ra(1, 0);
                     if (more) piece(pst, pA, pW, 0, 0);
                     ra(1, 1); ra(2, 0); ra(2, 1);
@@ -1393,11 +1453,25 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                     if (more) piece(pst, pA, pW, 2, 0);
                     rw(1, 1, 0); rw(1, 1, 1);
                     if (more) piece(pst, pA, pW, 2, 1);
+#endif
                 } else {
+#if WG_GEMM_ILV == 1
+                    if (more) piece(pst, pA, pW, 3, 0);
+                    ra(0, 0); ra(0, 1); ra(1, 0); ra(1, 1);
+                    if (more) piece(pst, pA, pW, 3, 1);
+                    ra(2, 0); ra(2, 1); ra(3, 0); ra(3, 1);
+#elif WG_GEMM_ILV == 2
+                    ra(0, 0); ra(0, 1);
+                    if (more) piece(pst, pA, pW, 3, 0);
+                    ra(1, 0); ra(1, 1);
+                    if (more) piece(pst, pA, pW, 3, 1);
+                    ra(2, 0); ra(2, 1); ra(3, 0); ra(3, 1);
+#else
                     ra(0, 0); ra(0, 1); ra(1, 0); ra(1, 1);
                     if (more) piece(pst, pA, pW, 3, 0);
                     ra(2, 0); ra(2, 1); ra(3, 0); ra(3, 1);
                     if (more) piece(pst, pA, pW, 3, 1);
+#endif
                 }
                 if constexpr (FP8) {
                     const char* mxs = mxbuf + (kt & 1) * 2048;
