@@ -492,7 +492,7 @@ __global__ __launch_bounds__(WM* WN * 64, ((BM / WM) * (BN / WN) / 64 > 192 ? 1 
                 WG_ACT_SWITCH(g.act,
                     _Pragma("unroll") for (int i = 0; i < 4; ++i) {
                         _Pragma("unroll") for (int j = 0; j < FJ; ++j)
-                            *(bf16x4*)(stg + (i * 16 + fr) * SROW + (j * 16 + fq * 4) * 2) = wg_epi_pack<ACT>(acc[half * 4 + i][j], bv[j]);
+                            *(bf16x4*)(stg + (i * 16 + fr) * SROW + (j * 16 + fq * 4) * 2) = wg_epi_pack<ACT, FP8>(acc[half * 4 + i][j], bv[j]);
                     })
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();
@@ -1611,7 +1611,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                                 const f32x4 a4 = acc[half * 4 + i][j];
                                 f32x2 lo = {a4[0] * r + (b4[0] - mr * s4[0]), a4[1] * r + (b4[1] - mr * s4[1])};
                                 f32x2 hi = {a4[2] * r + (b4[2] - mr * s4[2]), a4[3] * r + (b4[3] - mr * s4[3])};
-                                lo = wg_act2<ACT>(lo); hi = wg_act2<ACT>(hi);
+                                lo = FP8 ? wg_act2<ACT>(lo) : wg_act2e<ACT>(lo); hi = FP8 ? wg_act2<ACT>(hi) : wg_act2e<ACT>(hi);
                                 *(bf16x4*)(stg + (i * 16 + efr) * SROW + (j * 16 + efq * 4) * 2) = (bf16x4){(bf16)lo.x, (bf16)lo.y, (bf16)hi.x, (bf16)hi.y};
                             }
                         })
@@ -1619,7 +1619,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                 WG_ACT_SWITCH(g.act,
                     _Pragma("unroll") for (int i = 0; i < 4; ++i) {
                         _Pragma("unroll") for (int j = 0; j < FJ; ++j)
-                            *(bf16x4*)(stg + (i * 16 + efr) * SROW + (j * 16 + efq * 4) * 2) = wg_epi_pack<ACT>(acc[half * 4 + i][j], bv[j]);
+                            *(bf16x4*)(stg + (i * 16 + efr) * SROW + (j * 16 + efq * 4) * 2) = wg_epi_pack<ACT, FP8>(acc[half * 4 + i][j], bv[j]);
                     })
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_wave_barrier();

@@ -178,11 +178,34 @@ template <int ACT> __device__ __forceinline__ f32x2 wg_act2(f32x2 x) {
     }
 }
 
+// The GEMM epilogues' form (bf16 outputs only: wg_epi_pack below, the persistent kernel's LayerNorm-fold epilogue).  (round 6)
+//   GELU(x) = x Phi(x),  Phi(x) = 1 / (1 + exp(-x (a + b x^2 + c x^4))),  x^2 clamped to 49
+// A minimax fit of the sigmoid form to the erf form over the whole line: |GELU_fit - GELU_erf| <= 2.6e-5 absolute (tools/fit_gelu.py prints the
+// fit and its fp32 error), i.e. 1/150 of a bf16 rounding step at |y| = 1, and every value that leaves through here is rounded to bf16.  Per PAIR of
+// values 6 packed multiplies / FMAs, 2 minima and 4 transcendentals against 15 + 2 + 4 for the A&S 7.1.26 form above (the lin1 GEMM spends a
+// third of every tile in this epilogue with the matrix pipe idle).  The A&S form stays wherever fp32 results leave the chip or a fused kernel is
+// compared bit for bit with an unfused chain (decoder.hip, norm.hip, wg_act); coefficients below are (a, b, c) * -log2(e).
+template <int ACT> __device__ __forceinline__ f32x2 wg_act2e(f32x2 x) {
+    if constexpr (ACT == WG_ACT_GELU_ERF) {
+        f32x2 x2 = x * x;
+        x2 = (f32x2){fminf(x2.x, 49.0f), fminf(x2.y, 49.0f)};
+        f32x2 p = x2 * 0.0010142630198970437f - 0.10677572339773178f;
+        p = p * x2 - 2.301121234893799f;
+        const f32x2 v = p * x;
+        const f32x2 d = (f32x2){__builtin_amdgcn_exp2f(v.x), __builtin_amdgcn_exp2f(v.y)} + 1.0f;      // (exp2 overflowing to +inf: rcp gives 0, the limit)
+        return x * (f32x2){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    } else {
+        return wg_act2<ACT>(x);
+    }
+}
+
 // four accumulator values (+ bias) -> activation -> packed bf16
-template <int ACT> __device__ __forceinline__ bf16x4 wg_epi_pack(f32x4 v, const float* b) {
+// (EXACT: the A&S form of GELU -- the fp8 kernels keep it: their end-to-end mask test sits at the edge of its 1e-3 IoU bound, and a 2.6e-5 change
+// in front of an e4m3 quantisation moves individual pixels)
+template <int ACT, bool EXACT = false> __device__ __forceinline__ bf16x4 wg_epi_pack(f32x4 v, const float* b) {
     f32x2 lo = {v[0] + b[0], v[1] + b[1]}, hi = {v[2] + b[2], v[3] + b[3]};
-    lo = wg_act2<ACT>(lo);
-    hi = wg_act2<ACT>(hi);
+    lo = EXACT ? wg_act2<ACT>(lo) : wg_act2e<ACT>(lo);
+    hi = EXACT ? wg_act2<ACT>(hi) : wg_act2e<ACT>(hi);
     return (bf16x4){(bf16)lo.x, (bf16)lo.y, (bf16)hi.x, (bf16)hi.y};
 }
 
