@@ -1342,9 +1342,10 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
         if constexpr (LNMODE == 2) {
             // this tile's row statistics from the partial sums that arrived with its first slab:  mean = S / K,
             // var = Q / K - mean^2 (fp32 sums of bf16 values; |mean| stays within a few sigma on a residual stream), rstd = (var + eps)^-1/2
-            int ct = FP8 ? wave * 64 + lane_now() : tid;
+            // (by the waves of group 1, which wait at their extra barrier anyway while group 0 is in its first load half-phase)
+            int ct = (FP8 ? wave * 64 + lane_now() : tid) - 256;
             asm volatile("" : "+v"(ct));
-            if (ct < 256) {
+            if (ct >= 0) {
                 float S = 0.f, Q = 0.f;
 #pragma unroll 1
                 for (int p = 0; p < g.ln_np; ++p) {
@@ -1359,7 +1360,8 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
         }
         if constexpr (STATS) {
             // the previous tile's row sums: the four column waves' shares meet here (their LDS writes are behind the barrier above)
-            if (stores_in_flight) wg_stats_combine(spart, FP8 ? wave * 64 + lane_now() : tid, g.stats_part, g.tiles_n * g.stats_mpad, sp_off);
+            // (group 1's threads carry the store -- see above; every wave issues it: the counted waits need the same number of operations per wave)
+            if (stores_in_flight) wg_stats_combine(spart, (FP8 ? wave * 64 + lane_now() : tid) ^ 256, g.stats_part, g.tiles_n * g.stats_mpad, sp_off);
         }
         WG_PSTAMP(1);
         if (grp == 1) __builtin_amdgcn_s_barrier();
@@ -1531,7 +1533,12 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                 }
                 __builtin_amdgcn_s_setprio(0);
                 __builtin_amdgcn_sched_barrier(0);
-                if (FP8 || WG_GEMM_TAIL == 0) __builtin_amdgcn_s_barrier();
+                // (the tile's last barrier -- group 1 behind its last cluster, group 0 one cluster earlier -- is left out in the seam flow: every LDS
+                // read of the tile was over at the barrier in front of that cluster, so group 0 starts its epilogue beside group 1's last
+                // MFMAs instead of idling through them)
+                if (FP8 || WG_GEMM_TAIL == 0) {
+                    if (!(SEAM && last && sc == 1 && grp == 1)) __builtin_amdgcn_s_barrier();
+                }
             }
         };
         {
@@ -1550,7 +1557,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                 for (int kt = 0; kt < nk; ++kt) slab(kt, std::false_type{}, I2_{}, kt + 1 < nk, (unsigned)(kt + 1) * BK, (unsigned)(kt + 1) * BK, m0, n0, kt + 1);
             }
         }
-        if (grp == 0) __builtin_amdgcn_s_barrier();
+        if (!SEAM && grp == 0) __builtin_amdgcn_s_barrier();
         // every wave is past its last LDS read of this tile (each M half-phase retired its reads before its barrier)
         WG_PSTAMP(2);
 
