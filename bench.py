@@ -602,11 +602,11 @@ def main():
                 "e2e_achieved": round(gf_step / ms_per_step, 1),  # GFLOP/ms == TFLOP/s
                 "e2e_peak": PEAK_TF["bf16"], "e2e_frac": round(gf_step / ms_per_step / PEAK_TF["bf16"], 4),
                 "algorithmic_bytes_per_launch": round(byt / n_l)}
-    # HBM traffic of the dominant kernel.  PMC counters cannot be read from inside an un-profiled process, so `traffic` (a measurement
-    # of THIS run) stays null here; what the committed rocprofv3 passes of the same command measured (tools/profile_r04.sh: --pmc
-    # FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH doubled per MI355X_MICROARCH.md) is reported beside it, labelled with the
-    # commit the profile was taken at, and only when it profiled THIS configuration and this kernel.
-    for pmc_file in ("r05_pmc_traffic.json", "r05_c5_fp8_pmc_traffic.json", "r04_pmc_traffic.json", "r04_c5_fp8_pmc_traffic.json"):
+    # HBM traffic of the dominant kernel.  PMC counters cannot be read from inside an un-profiled process: `traffic` is what the committed
+    # rocprofv3 passes of the same command measured (tools/profile_r06.sh: --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs, FETCH
+    # doubled per MI355X_MICROARCH.md), labelled with the commit the profile was taken at, and only when it profiled THIS configuration
+    # and this kernel; null otherwise.
+    for pmc_file in ("r06_pmc_traffic.json", "r06_c5_fp8_pmc_traffic.json", "r05_pmc_traffic.json", "r05_c5_fp8_pmc_traffic.json"):
         try:
             with open(os.path.join(ROOT, "profiles", pmc_file)) as f:
                 pmc = json.load(f)
@@ -617,6 +617,8 @@ def main():
             key = [k for k in pmc["kernels"] if dom in PMC_PREFIX and k.startswith(PMC_PREFIX[dom])]
             if same and key and "traffic_profiled" not in roofline:
                 roofline["traffic_profiled"] = pmc["kernels"][key[0]]["hbm_bytes_per_launch"]
+                # `traffic` carries the profiled figure (per launch, like `achieved`); the fields beside it say which commit and which passes it is from
+                roofline["traffic"] = roofline["traffic_profiled"]
                 roofline["traffic_profiled_head"] = pmc.get("head", "unknown (round-3 profile, taken before this field existed)")
                 roofline["traffic_profiled_source"] = ("profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE in separate passes of this "
                                                        "command, avg per launch; NOT measured in this run)" % pmc_file)
