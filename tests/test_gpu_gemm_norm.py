@@ -265,25 +265,3 @@ def test_row_partials_are_refused_for_shapes_the_kernel_cannot_take(dev):
     part = torch.empty(1, 256, 2, device=dev)
     rc = L.wg_gemm_bias_act_stats_bf16(x.data_ptr(), 64, w.data_ptr(), 64, None, None, 0, 0, y.data_ptr(), 256, 64, 256, 64, 0, part.data_ptr(), 256, None)
     assert rc != 0 and b"persistent" in L.wg_last_error()
-
-
-@pytest.mark.parametrize("M,N,K", [(1777, 520, 256), (256, 256, 128), (8200, 1024, 1024), (4096, 2304, 768), (3000, 776, 192), (70000, 256, 128)])
-@pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_GELU, ops.ACT_QUICK_GELU])
-def test_gemm_one_barrier_kernel_matches_the_ping_pong_kernel_bit_for_bit(dev, M, N, K, act):
-    """tile 17 (tools/micro/gemm_fr.hip, the experimental one-barrier-per-slab persistent kernel: the leading wave group's load half-phase runs beside the
-    trailing group's 64-MFMA burst by wave priority) sums in the same order as tile 16: identical bits on ragged M / N, several tiles per workgroup
-    and every activation; and both stay within the bf16 bound of fp32 torch.  The kernel is a probe: it is linked into diagnostic builds only
-    (tools/build_variant.py <tag> -DWG_GEMM_FR, run with WG_LIB=...); against the product library this test has nothing to compare and skips."""
-    from walkgpt_amd import _lib
-    if not hasattr(_lib.lib(), "wg_gemm_fr_present"):
-        pytest.skip("product library: the one-barrier probe kernel is not linked in")
-    g = torch.Generator().manual_seed(M + N + K + act)
-    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
-    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
-    b = torch.randn(N, generator=g).to(torch.bfloat16).to(dev)
-    o16 = ops.linear(a, w, b, act=act, tile=16)
-    o17 = torch.full_like(o16, float("nan"))
-    ops.linear(a, w, b, act=act, out=o17, tile=17)
-    assert torch.equal(o16, o17)
-    ref = _ref_act(a.float() @ w.float().t() + b.float(), act)
-    assert (o17.float() - ref).abs().max().item() <= 0.02 * max(1.0, ref.abs().max().item())

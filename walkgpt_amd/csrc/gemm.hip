@@ -148,24 +148,6 @@ typedef __attribute__((ext_vector_type(8))) int i32x8;
 #ifndef WG_GEMM_TAIL
 #define WG_GEMM_TAIL 0
 #endif
-// WG_GEMM_ALIGN (persistent bf16 kernel): placement of a cluster's 32 MFMAs (8-byte instructions) in the code.  hipcc puts ONE 4-byte s_waitcnt between
-// this statement and the first MFMA, so "pad to 8" leaves the MFMAs at addresses = 4 (mod 8) and "pad to 8, one s_nop" at = 0 (mod 8).
-//   0: wherever the code lands (it moved between 0 and 4 with every edit of the kernel)   1: = 4 (mod 8)   2: = 0 (mod 8)
-#ifndef WG_GEMM_ALIGN
-#define WG_GEMM_ALIGN 0
-#endif
-// WG_GEMM_ILV (persistent bf16 kernel, seam flow): where a half-phase's LDS-DMA requests sit between its fragment reads (0 = product; the others
-// were measured against it: profiles/r06_gemm_seam.md)
-#ifndef WG_GEMM_ILV
-#define WG_GEMM_ILV 0
-#endif
-#if WG_GEMM_ALIGN == 1
-#define WG_GEMM_ALIGN_ASM ".p2align 3"
-#elif WG_GEMM_ALIGN == 2
-#define WG_GEMM_ALIGN_ASM ".p2align 3\n\ts_nop 0"
-#else
-#define WG_GEMM_ALIGN_ASM ""
-#endif
 #ifndef WG_GEMM_C_AUX
 #define WG_GEMM_C_AUX 0
 #endif
@@ -1118,7 +1100,7 @@ __device__ __forceinline__ i32x8 wg_i32x8_of(bf16x8 lo, bf16x8 hi) {
 //     by LDS-DMA with the early pieces of slab kt+1 (7 operations stay in flight at the first counted wait instead of 6).
 //   * SEAM (round 6): how the operand slabs are addressed and when a tile's first slab is requested -- see the comment at `piece` below.  true: every
 //     K with an even number of slabs (all shapes of the workload): 1 000-1 300 cycles less at every tile seam, +1.5 ... 6 % per GEMM
-//     (profiles/r06_gemm_seam.md); false: the round-1..5 form, kept for odd nk.
+//     (profiles/r06_gemm_phases.md); false: the round-1..5 form, kept for odd nk.
 template <int LNMODE, bool STATS, bool FP8 = false, bool SEAM = true>
 __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) {
     constexpr bool LN = LNMODE != 0;
@@ -1380,7 +1362,7 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
             for (int sc = 0; sc < 2; ++sc) {
                 // M half-phase: the fragment reads of this cluster with the requests for the next slab BETWEEN them, one request per two or three
                 // reads.  Requests issued back to back (round 6 first had them behind the reads with only scalar instructions in between, where
-                // rounds 1-5 had happened to keep a 64-bit vector add between any two) cost the K >= 3072 shapes 2-6 %: profiles/r06_gemm_seam.md.
+                // rounds 1-5 had happened to keep a 64-bit vector add between any two) cost the K >= 3072 shapes 2-6 %: profiles/r06_gemm_phases.md.
                 // (An LDS-DMA write and an LDS read may alias as far as hipcc knows, so it keeps this order.)
                 auto ra = [&](int i, int ks) __attribute__((always_inline)) {
                     const int r = wm * WTM + (4 * sc + i) * 16 + fr;
@@ -1402,47 +1384,6 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                         else piece(pst, pA, pW, 3);
                     }
                 } else if (sc == 0) {
-#if WG_GEMM_ILV == 1      // experiment: a request first, then two or three reads per request
-                    if (more) piece(pst, pA, pW, 0, 0);
-                    ra(0, 0); ra(0, 1);
-                    if (more) piece(pst, pA, pW, 0, 1);
-                    ra(1, 0); ra(1, 1); ra(2, 0);
-                    if (more) piece(pst, pA, pW, 1, 0);
-                    ra(2, 1); ra(3, 0); ra(3, 1);
-                    if (more) piece(pst, pA, pW, 1, 1);
-                    rw(0, 0, 0); rw(0, 0, 1); rw(0, 1, 0);
-                    if (more) piece(pst, pA, pW, 2, 0);
-                    rw(0, 1, 1); rw(1, 0, 0); rw(1, 0, 1);
-                    if (more) piece(pst, pA, pW, 2, 1);
-                    rw(1, 1, 0); rw(1, 1, 1);
-#elif WG_GEMM_ILV == 2    // experiment: two reads per request, the last four reads behind the last request
-                    ra(0, 0); ra(0, 1);
-                    if (more) piece(pst, pA, pW, 0, 0);
-                    ra(1, 0); ra(1, 1);
-                    if (more) piece(pst, pA, pW, 0, 1);
-                    ra(2, 0); ra(2, 1);
-                    if (more) piece(pst, pA, pW, 1, 0);
-                    ra(3, 0); ra(3, 1);
-                    if (more) piece(pst, pA, pW, 1, 1);
-                    rw(0, 0, 0); rw(0, 0, 1);
-                    if (more) piece(pst, pA, pW, 2, 0);
-                    rw(0, 1, 0); rw(0, 1, 1);
-                    if (more) piece(pst, pA, pW, 2, 1);
-                    rw(1, 0, 0); rw(1, 0, 1); rw(1, 1, 0); rw(1, 1, 1);
-#elif WG_GEMM_ILV == 3    // experiment: the W fragments (needed by every MFMA of the cluster) first, requests between the A reads
-                    rw(0, 0, 0); rw(0, 0, 1); rw(0, 1, 0);
-                    if (more) piece(pst, pA, pW, 0, 0);
-                    rw(0, 1, 1); rw(1, 0, 0); rw(1, 0, 1);
-                    if (more) piece(pst, pA, pW, 0, 1);
-                    rw(1, 1, 0); rw(1, 1, 1);
-                    if (more) piece(pst, pA, pW, 1, 0);
-                    ra(0, 0); ra(0, 1); ra(1, 0);
-                    if (more) piece(pst, pA, pW, 1, 1);
-                    ra(1, 1); ra(2, 0); ra(2, 1);
-                    if (more) piece(pst, pA, pW, 2, 0);
-                    ra(3, 0); ra(3, 1);
-                    if (more) piece(pst, pA, pW, 2, 1);
-#else
                     ra(0, 0); ra(0, 1); ra(1, 0);
                     if (more) piece(pst, pA, pW, 0, 0);
                     ra(1, 1); ra(2, 0); ra(2, 1);
@@ -1455,25 +1396,11 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                     if (more) piece(pst, pA, pW, 2, 0);
                     rw(1, 1, 0); rw(1, 1, 1);
                     if (more) piece(pst, pA, pW, 2, 1);
-#endif
                 } else {
-#if WG_GEMM_ILV == 1
-                    if (more) piece(pst, pA, pW, 3, 0);
-                    ra(0, 0); ra(0, 1); ra(1, 0); ra(1, 1);
-                    if (more) piece(pst, pA, pW, 3, 1);
-                    ra(2, 0); ra(2, 1); ra(3, 0); ra(3, 1);
-#elif WG_GEMM_ILV == 2
-                    ra(0, 0); ra(0, 1);
-                    if (more) piece(pst, pA, pW, 3, 0);
-                    ra(1, 0); ra(1, 1);
-                    if (more) piece(pst, pA, pW, 3, 1);
-                    ra(2, 0); ra(2, 1); ra(3, 0); ra(3, 1);
-#else
                     ra(0, 0); ra(0, 1); ra(1, 0); ra(1, 1);
                     if (more) piece(pst, pA, pW, 3, 0);
                     ra(2, 0); ra(2, 1); ra(3, 0); ra(3, 1);
                     if (more) piece(pst, pA, pW, 3, 1);
-#endif
                 }
                 if constexpr (FP8) {
                     const char* mxs = mxbuf + (kt & 1) * 2048;
@@ -1499,7 +1426,6 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_s_setprio(1);
-                if constexpr (!FP8) asm volatile(WG_GEMM_ALIGN_ASM);
                 if constexpr (FP8) {
                     const i32x8 w0 = wg_i32x8_of(wf2[0][0][0], wf2[0][0][1]), w1 = wg_i32x8_of(wf2[0][1][0], wf2[0][1][1]);
                     const i32x8 w2 = wg_i32x8_of(wf2[1][0][0], wf2[1][0][1]), w3 = wg_i32x8_of(wf2[1][1][0], wf2[1][1][1]);
