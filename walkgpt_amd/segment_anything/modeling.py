@@ -14,6 +14,8 @@ import math
 from functools import partial
 from typing import Optional, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -128,7 +130,7 @@ class Block(nn.Module, _Prepared):
     def _prep_bf16(self):
         a, m = self.attn, self.mlp
         return self._prep_get(self._build, (self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias, self.norm2.weight, self.norm2.bias,
-                                            m.lin1.weight, m.lin1.bias))
+                                            m.lin1.weight, m.lin1.bias, m.lin2.weight))
 
     def _prep_mx(self):
         a, m = self.attn, self.mlp
@@ -197,12 +199,19 @@ class Block(nn.Module, _Prepared):
         # to them and ln_linear picks those up (no statistics pass in between)
         x = ops.linear(o, a.proj.weight, a.proj.bias, residual=x, row_partials=True)
         h = ops.ln_linear(x, p["lin1"], self.norm2.eps, act=self.mlp._act_code)
-        return ops.linear(h, self.mlp.lin2.weight, self.mlp.lin2.bias, residual=x, row_partials=True)
+        return ops.linear(h, p["lin2_w"], self.mlp.lin2.bias, residual=x, row_partials=True)
 
     def _build(self):
         a, m = self.attn, self.mlp
+        w2 = m.lin2.weight
+        if (w2.shape[1] * 2) % 10240 == 0 and w2.is_cuda and os.environ.get("WG_LIN2_PAD", "1") != "0":      # (=0: A/B runs)
+            # ViT-H's lin2 (K = 5120): weight rows on a 10 240-byte pitch camp on a few memory channels -- the same rows 128 bytes further apart run the
+            # GEMM 10 % faster (tools/bench_gemm_pitch.py, notes/r06_experiments.md section 7; K = 3072 / 4096 rows measured no difference)
+            buf = torch.empty(w2.shape[0], w2.shape[1] + 64, device=w2.device, dtype=w2.dtype)
+            buf[:, :w2.shape[1]].copy_(w2.detach())
+            w2 = buf[:, :w2.shape[1]]
         return {"qkv": ops.fold_layernorm(self.norm1.weight, self.norm1.bias, a.qkv.weight, a.qkv.bias),
-                "lin1": ops.fold_layernorm(self.norm2.weight, self.norm2.bias, m.lin1.weight, m.lin1.bias)}
+                "lin1": ops.fold_layernorm(self.norm2.weight, self.norm2.bias, m.lin1.weight, m.lin1.bias), "lin2_w": w2}
 
 
 class ImageEncoderViT(nn.Module, _Prepared):
