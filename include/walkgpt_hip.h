@@ -26,11 +26,14 @@ extern "C" {
 
 /* activation codes of fused epilogues */
 #define WG_ACT_NONE 0
-#define WG_ACT_GELU_ERF 1   /* nn.GELU()            model/segment_anything/modeling/common.py:13-26, utils/utils_walkgpt.py:173 */
+#define WG_ACT_GELU_ERF 1   /* nn.GELU()            model/segment_anything/modeling/common.py:13-26, utils/utils_walkgpt.py:173.
+                             * fp32 results and the fused decoder / norm kernels evaluate the erf form (A&S 7.1.26, 1.5e-7); the bf16 GEMM epilogues
+                             * (0.2.1) evaluate a minimax sigmoid-form fit of it, |error| <= 2.6e-5 absolute, and round to bf16 (csrc/wg_common.h wg_act2e) */
 #define WG_ACT_QUICK_GELU 2 /* x*sigmoid(1.702x)    HF CLIP MLP (custom_clip.py:50, third-party transformers) */
 #define WG_ACT_RELU 3       /* nn.ReLU()            model/segment_anything/modeling/transformer.py:23, mask_decoder.py:186 */
 
-int wg_version(void);               /* major*10000 + minor*100 + patch; 200 = 0.2.0: argument lists changed against 0.1.0 */
+int wg_version(void);               /* major*10000 + minor*100 + patch; 201 = 0.2.1: same entry points and argument lists as 0.2.0 (which changed them
+                                     * against 0.1.0: INTEGRATION.md section 3); 0.2.1 = round 6's kernels (GELU form of the bf16 epilogues, above) */
 const char* wg_last_error(void);    /* thread-local, valid until the next failing call on this thread */
 
 /* C[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) (+ R[m % res_row_mod or m, :]).  bf16 in, bf16 or fp32 out.

@@ -22,7 +22,7 @@ int wg_check_launch(const char* what) {
 }
 
 extern "C" const char* wg_last_error(void) { return g_err; }
-extern "C" int wg_version(void) { return 200; }  // 0.2.0 = major*10000 + minor*100 + patch (0.1.0 -> 0.2.0: see INTEGRATION.md, ABI rules)
+extern "C" int wg_version(void) { return 201; }  // 0.2.1 = major*10000 + minor*100 + patch (0.1.0 -> 0.2.0: see INTEGRATION.md, ABI rules; 0.2.1: no signature change)
 
 // Compute units of a device, cached per device index (a benign race: every thread writes the same value).  Persistent kernels size
 // their grids from it; one process per GPU sees one entry, a process that drives several devices one entry each.
