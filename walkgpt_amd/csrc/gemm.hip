@@ -1866,7 +1866,7 @@ extern "C" int wg_gemm_skinny_ln_bias_act_bf16(const void* A, long lda, const vo
 // 256x256 kernel only: wg_gemm_ln_supported() tells the caller whether this shape / alignment qualifies.
 extern "C" int wg_gemm_ln_supported(int M, int N, int K, long lda, long ldw, long ldc) {
     return (wg_gemm_pick_tile(M, N) == 16 && K % 64 == 0 && N % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 &&
-            (long)M * lda < (1L << 31) && (long)N * ldw < (1L << 31) && ((long)(M - 1) * ldc + N) * 2 < (1L << 31)) ? 1 : 0;
+            (long)(M + 256) * lda < (1L << 31) && (long)(N + 256) * ldw < (1L << 31) && ((long)(M - 1) * ldc + N) * 2 < (1L << 31)) ? 1 : 0;      // (operands: wg_pp_operands_ok)
 }
 extern "C" int wg_gemm_ln_bias_act_bf16(const void* A, long lda, const void* Wg, long ldw, const float* bias_f32, const float* colsum,
                                         const float* stats, void* C, long ldc, int M, int N, int K, int act, void* stream) {
