@@ -229,3 +229,38 @@ def test_hand_placed_streams_have_no_unpadded_mfma_operand(source):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lint_asm_hazards.py"), os.path.join(ROOT, *source.split("/"))],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_epilogue_gelu_fit_is_within_its_stated_error():
+    """csrc/wg_common.h wg_act2e<WG_ACT_GELU_ERF>: the coefficients in the source are the minimax fit tools/fit_gelu.py prints, and the formula as the
+    kernel evaluates it (fp32, exp2 form, x^2 clamped to 49) stays within 2.6e-5 of x Phi(x) on the whole line -- the figure the header, DESIGN.md and
+    INTEGRATION.md quote (common.py:13-26 / image_encoder.py:30 use nn.GELU's erf form)."""
+    from scipy.special import erf
+    txt = open(os.path.join(ROOT, "walkgpt_amd", "csrc", "wg_common.h")).read()
+    body = txt[txt.index("wg_act2e(f32x2 x)"):]
+    body = body[:body.index("} else {")]
+    c2 = float(re.search(r"x2 \* ([0-9.eE+-]+)f - ([0-9.eE+-]+)f", body).group(1))
+    c1 = -float(re.search(r"x2 \* ([0-9.eE+-]+)f - ([0-9.eE+-]+)f", body).group(2))
+    c0 = -float(re.search(r"p \* x2 - ([0-9.eE+-]+)f", body).group(1))
+    clamp = float(re.search(r"fminf\(x2\.x, ([0-9.]+)f\)", body).group(1))
+    x = np.linspace(-14, 14, 560001).astype(np.float32)
+    x2 = np.minimum(x * x, np.float32(clamp))
+    with np.errstate(over="ignore"):
+        y = x / (np.float32(1) + np.exp2(x * (np.float32(c0) + x2 * (np.float32(c1) + x2 * np.float32(c2)))))
+    ref = x.astype(np.float64) * 0.5 * (1 + erf(x.astype(np.float64) / np.sqrt(2)))
+    assert np.isfinite(y).all() and float(np.max(np.abs(y - ref))) <= 2.6e-5
+    # ... and they are the fit's: (a, b, c) * -log2(e) with the tanh form's well-known a, b as a sanity anchor (a = 1.5958 -> 1.5950, b = 0.0714 -> 0.0740)
+    a, b, c = -c0 / np.log2(np.e), -c1 / np.log2(np.e), -c2 / np.log2(np.e)
+    assert abs(a - 1.595) < 2e-3 and abs(b - 0.074) < 2e-3 and -1e-3 < c < 0
+
+
+def test_persistent_gemm_operand_bound_is_reported_by_the_supported_queries():
+    """The persistent kernel reads A and W through 32-bit buffer descriptors reaching up to 255 rows past the last one: the `supported` queries the host
+    asks before it plans a LayerNorm fold or a row-sum hand-over say no for operands that, padded to whole tiles, reach 4 GiB (pure host arithmetic)."""
+    from walkgpt_amd import _lib
+    L = _lib.lib()
+    assert L.wg_gemm_ln_supported(32768, 2304, 768, 768, 768, 2304) == 1
+    assert L.wg_gemm_ln_supported((1 << 20) - 256 - 1, 1024, 2048, 2048, 2048, 1024) == 1        # (M + 256) * lda just under 2^31
+    assert L.wg_gemm_ln_supported((1 << 20) - 256, 1024, 2048, 2048, 2048, 1024) == 0
+    assert L.wg_gemm_row_partials_supported((1 << 20) - 256, 1024, 2048, 2048, 2048, 1024) == 0
+

@@ -265,3 +265,21 @@ def test_row_partials_are_refused_for_shapes_the_kernel_cannot_take(dev):
     part = torch.empty(1, 256, 2, device=dev)
     rc = L.wg_gemm_bias_act_stats_bf16(x.data_ptr(), 64, w.data_ptr(), 64, None, None, 0, 0, y.data_ptr(), 256, 64, 256, 64, 0, part.data_ptr(), 256, None)
     assert rc != 0 and b"persistent" in L.wg_last_error()
+
+
+def test_epilogue_gelu_through_an_identity_gemm(dev):
+    """The bf16 epilogue's GELU alone: x @ I with the activation fused, on the persistent 256 x 256 kernel (plain and LayerNorm-free paths share
+    wg_act2e), against torch's erf GELU of the same bf16 inputs.  The fitted form is within 2.6e-5 of the erf form before the rounding to bf16, so the
+    stored value is within that + half a bf16 step of the exact one; |x| up to 12 covers both saturated ends and the clamp of x^2."""
+    M, K = 2048, 256
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(M, K, generator=g) * 3.0).to(torch.bfloat16)
+    x[0, :] = torch.linspace(-12, 12, K).to(torch.bfloat16)
+    x[1, :] = torch.linspace(-0.01, 0.01, K).to(torch.bfloat16)
+    eye = torch.eye(K).to(torch.bfloat16)
+    y = ops.linear(x.to(dev), eye.to(dev), act=ops.ACT_GELU, tile=16).float().cpu()
+    ref = torch.nn.functional.gelu(x.double())
+    half_step = ref.abs().clamp_min(2.0 ** -126).log2().floor().exp2() * 2.0 ** -8      # half a bf16 step at the reference's magnitude
+    assert bool(((y.double() - ref).abs() <= 2.6e-5 + half_step * 1.0001).all())
+    assert torch.isfinite(y).all() and abs(float(y[0, 0])) < 1e-12 and float(y[0, -1]) == 12.0
+
