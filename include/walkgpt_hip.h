@@ -238,6 +238,7 @@ int wg_dec_tokens_ctp_f32(int stages, int skip_pe, float* queries, float* query_
 int wg_dec_attn_partial_f32(const float* q, const void* Kimg, const void* Vimg, long ld_img, int head_stride, long img_rows_per_prompt,
                             const int* prompt_image, int hw,
                             float* partials, int n_splits, int P, void* stream);
+int wg_dec_mlp_slices(void);       /* S = slices of the MLP's 2048 hidden units in wg_dec_mlp_partial_f32 / wg_dec_tokens_f32 (partials [P, S, 6, 256]; lin2 tiled in S K-slices) */
 int wg_dec_mlp_partial_f32(const float* x, const void* const* combine, int n_splits, float eps, float* x_out, const void* lin1_w,
                            const void* lin1_b, const void* lin2_w, float* partials, int P, void* stream);
 int wg_dec_heads_f32(const float* x, const void* const* combine, int n_splits, float eps, const void* const* weights, int n_weights,

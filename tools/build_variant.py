@@ -19,7 +19,7 @@ def cc(src):
     obj = os.path.join(obj_dir, os.path.basename(src)[:-4] + ".o")
     # only gemm.hip / attn.hip read the experiment macros: every other object is shared with the product build
     base = os.path.join(_build.OBJ, os.path.basename(src)[:-4] + ".o")
-    if not any(m in open(src).read() for m in ("WG_GEMM_", "WG_ATTN_")) and os.path.exists(base):
+    if not any(m in open(src).read() for m in ("WG_GEMM_", "WG_ATTN_", "WG_DEC_")) and os.path.exists(base):
         return base
     subprocess.run([_build.HIPCC] + _build.FLAGS + extra + ["-c", src, "-o", obj], check=True, capture_output=True)
     return obj

@@ -93,6 +93,7 @@ SIGNATURES = {
     "wg_dec_tokens_ctp_f32": [c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_void_p, c_void_p, c_int,
                               c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p],
     "wg_dec_attn_partial_f32": [c_void_p, c_void_p, c_void_p, c_long, c_int, c_long, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p],
+    "wg_dec_mlp_slices": [],
     "wg_dec_mlp_partial_f32": [c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p],
     "wg_gemm_skinny_ln_supported": [c_int, c_int, c_int, c_long, c_long, c_long],
     "wg_gemm_skinny_ln_bias_act_bf16": [c_void_p, c_long, c_void_p, c_void_p, c_float, c_void_p, c_long, c_int, c_void_p, c_void_p, c_long, c_int,

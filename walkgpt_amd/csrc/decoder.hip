@@ -402,7 +402,11 @@ constexpr int TK_THREADS = 512;
 constexpr int TK_N = 6;          // tokens per prompt: iou + 4 mask tokens + 1 text prompt (mask_decoder.py:125-132)
 constexpr int TK_C = 256;        // transformer_dim
 constexpr int TK_HID = 2048;     // MLP width
-constexpr int TK_SLICES = 8;     // MLP slices (256 hidden units each)
+#ifndef WG_DEC_MLP_SLICES
+#define WG_DEC_MLP_SLICES 16
+#endif
+constexpr int TK_SLICES = WG_DEC_MLP_SLICES;     // MLP slices (2048 / TK_SLICES hidden units each: 8 or 16)
+constexpr int TK_SLW = 2048 / TK_SLICES;         // hidden units per slice
 constexpr int TK_PART = TK_N * 18;   // floats of one attention partial: m[6] | l[6] | o[6][16]
 
 struct LinW { const bf16* w; const bf16* b; };
@@ -891,10 +895,10 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_mlp_partial_kernel(MlpArgs 
         if (slice == 0)
             for (int i = threadIdx.x; i < TK_N * TK_C; i += TK_THREADS) a.x_out[(long)p * TK_N * TK_C + i] = xs[i];
     }
-    const LinW l1{a.lin1.w + (long)slice * 256 * TK_C, a.lin1.b + slice * 256};   // rows slice*256 .. +255 of lin1.weight = 16 column blocks
-    tok_linear<TK_C>(xs, TK_C, TK_N, l1, 256, hs, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
-    const LinW l2{a.lin2_w + (long)slice * 256 * TK_C, nullptr};     // columns slice*256 .. +255 of lin2.weight [256, 2048], tiled per slice
-    tok_linear<TK_C>(hs, TK_C, TK_N, l2, TK_C, ys, TK_C, 0, nullptr, 0, sh, sl);
+    const LinW l1{a.lin1.w + (long)slice * TK_SLW * TK_C, a.lin1.b + slice * TK_SLW};   // rows slice*TK_SLW .. of lin1.weight = TK_SLW / 16 column blocks
+    tok_linear<TK_C>(xs, TK_C, TK_N, l1, TK_SLW, hs, TK_C, WG_ACT_RELU, nullptr, 0, sh, sl);
+    const LinW l2{a.lin2_w + (long)slice * TK_SLW * TK_C, nullptr};     // columns slice*TK_SLW .. of lin2.weight [256, 2048], tiled per slice
+    tok_linear<TK_SLW>(hs, TK_C, TK_N, l2, TK_C, ys, TK_C, 0, nullptr, 0, sh, sl);
     float* out = a.part + ((long)p * TK_SLICES + slice) * TK_N * TK_C;
     for (int i = threadIdx.x; i < TK_N * TK_C; i += TK_THREADS) out[i] = ys[i];
 }
@@ -1034,10 +1038,12 @@ static bool wg_parse_combine(const void* const* combine, int n_splits, float eps
     return true;
 }
 
-// x [P,6,256] fp32; lin1 [2048,256] + bias, lin2 weight [256,2048] (bias added by the SUM_MLP stage); partials [P, 8, 6, 256] fp32.
+// x [P,6,256] fp32; lin1 [2048,256] + bias, lin2 weight [256,2048] tiled in S = wg_dec_mlp_slices() K-slices (bias added by the SUM_MLP stage); partials [P, S, 6, 256] fp32.
 // combine == null: x holds the tokens after norm2.  combine != null (5 pointers: attention partials, token->image out_proj weight, bias,
 // norm2 gamma, beta): x holds the tokens BEFORE the COMBINE stage, which this launch runs itself; the tokens after norm2 go to x_out
 // (a buffer other than x).
+extern "C" int wg_dec_mlp_slices(void) { return TK_SLICES; }      // slices of wg_dec_mlp_partial_f32's partials (the host sizes its buffers and tiles lin2 by it)
+
 extern "C" int wg_dec_mlp_partial_f32(const float* x, const void* const* combine, int n_splits, float eps, float* x_out, const void* lin1_w,
                                       const void* lin1_b, const void* lin2_w, float* partials, int P, void* stream) {
     WG_REQUIRE(x && lin1_w && lin1_b && lin2_w && partials && P > 0, "dec_mlp_partial: bad arguments");

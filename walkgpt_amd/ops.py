@@ -642,7 +642,7 @@ def dec_tokens(stages, skip_pe, queries, query_pe, weights, q_t2i=None, attn_par
         assert attn_partials.shape[0] == P and attn_partials.shape[1] == 8 and attn_partials.shape[3] == _TOK_PART
         n_splits = attn_partials.shape[2]
     if stages & TOK_SUM_MLP:
-        assert mlp_partials.dtype == torch.float32 and mlp_partials.is_contiguous() and mlp_partials.shape == (P, 8, 6, 256)
+        assert mlp_partials.dtype == torch.float32 and mlp_partials.is_contiguous() and mlp_partials.shape == (P, dec_mlp_slices(), 6, 256)
         for t in (k_i2t, v_i2t):
             assert t.dtype == _BF16 and t.is_contiguous() and t.shape == (P, 6, 128)
     table = (ctypes.c_void_p * 24)(*[None if w is None else w.data_ptr() for w in weights])
@@ -705,16 +705,22 @@ def _combine_table(combine, P):
     return (ctypes.c_void_p * 5)(part.data_ptr(), wo.data_ptr(), bo.data_ptr(), g.data_ptr(), b.data_ptr()), part.shape[2]
 
 
+def dec_mlp_slices():
+    """Slices the library cuts the decoder MLP's 2048 hidden units into (wg_dec_mlp_slices): lin2 is tiled in that many K-slices."""
+    return int(_lib.lib().wg_dec_mlp_slices())
+
+
 def dec_mlp_partial(x, lin1_w, lin1_b, lin2_w, combine=None, eps=1e-5):
-    """The eight 256-unit slices of mlp(x) for x [P, 6, 256] fp32 (wg_dec_mlp_partial_f32) -> fp32 [P, 8, 6, 256]; lin2's bias is added
+    """The S = dec_mlp_slices() slices of mlp(x) for x [P, 6, 256] fp32 (wg_dec_mlp_partial_f32) -> fp32 [P, S, 6, 256]; lin2's bias is added
     by dec_tokens(TOK_SUM_MLP).  With `combine` (see _combine_table) x holds the tokens before the COMBINE stage, which the launch runs
     itself: returns (partials, tokens after the LayerNorm -- a new buffer)."""
     _need_gpu(x, lin1_w, lin1_b, lin2_w)
     P = x.shape[0]
     _f32_tokens(x, P, 256)
-    assert _tiled_ok(lin1_w, 2048, 256) and _tiled_ok(lin2_w, 256, 2048, 8) and lin1_b.shape == (2048,)     # ops.tile_weight(w), (w, 8)
+    S = dec_mlp_slices()
+    assert _tiled_ok(lin1_w, 2048, 256) and _tiled_ok(lin2_w, 256, 2048, S) and lin1_b.shape == (2048,)     # ops.tile_weight(w), (w, S)
     assert lin1_b.dtype == _BF16 and lin1_b.is_contiguous()
-    out = torch.empty(P, 8, 6, 256, device=x.device, dtype=torch.float32)
+    out = torch.empty(P, S, 6, 256, device=x.device, dtype=torch.float32)
     table, n_splits = _combine_table(combine, P)
     x_out = torch.empty_like(x) if combine is not None else None
     rc = _lib.lib().wg_dec_mlp_partial_f32(x.data_ptr(), table, n_splits, float(eps), _ptr(x_out), lin1_w.data_ptr(), lin1_b.data_ptr(),

@@ -502,7 +502,7 @@ class TwoWayAttentionBlock(nn.Module):
         return ops.layernorm(keys, self.norm4.weight, self.norm4.bias, self.norm4.eps)
 
     def mlp_partials(self, queries, combine=None):
-        return ops.dec_mlp_partial(queries, _tiled(self.mlp.lin1.weight), self.mlp.lin1.bias, _tiled(self.mlp.lin2.weight, 8), combine=combine,
+        return ops.dec_mlp_partial(queries, _tiled(self.mlp.lin1.weight), self.mlp.lin1.bias, _tiled(self.mlp.lin2.weight, ops.dec_mlp_slices()), combine=combine,
                                    eps=self.norm2.eps)
 
     def check_fused(self):
