@@ -198,7 +198,7 @@ int wg_upscale_mask_bf16(const void* x, long ldx, const void* w1, const void* b1
  * tokens, the 2048-wide MLP) are spread over the chip and hand fp32 partials across kernel boundaries.
  *
  * wg_dec_tokens_f32: one workgroup per prompt runs the stages named by the bit mask `stages`, in this order:
- *   1 SUM_MLP  x += mlp.lin2.bias + sum of the 8 MLP partials (:169-171); norm3; k / v of the image->token attention (:173-176)
+ *   1 SUM_MLP  x += mlp.lin2.bias + sum of the S = wg_dec_mlp_slices() MLP partials (:169-171); norm3; k / v of the image->token attention (:173-176)
  *              -> k_i2t / v_i2t [P,6,128] bf16
  *   2 SELF     self attention (+ query_pe unless skip_pe) and norm1 (:153-160)
  *   4 Q_T2I    q_proj(x + query_pe) of the token->image attention (:162-165; tail :96-99) -> q_t2i [P,6,128] fp32
@@ -214,7 +214,7 @@ int wg_upscale_mask_bf16(const void* x, long ldx, const void* w1, const void* b1
  *   (16: two plain 128-column blocks; 32: columns ordered [K_h | V_h] per head, Vimg = Kimg + 16: one 64-byte piece per key and head)
  *   (img_rows_per_prompt = 0 when all prompts share one image; prompt_image [P] int32 != null: prompt p reads image prompt_image[p] --
  *   the first block, whose image tokens are those of the image for every one of its prompts); partials [P, 8, n_splits, 108] fp32 = {running max[6], sum[6], o[6][16]}, n_splits = ceil(hw / 1024).
- * wg_dec_mlp_partial_f32: slice s of 8 of mlp(x): relu(x lin1[256 s .. +255]^T + b1) lin2[:, 256 s .. +255]^T -> partials [P,8,6,256].
+ * wg_dec_mlp_partial_f32: slice s of S = wg_dec_mlp_slices() (16 since 0.2.1; 8 before) of mlp(x), w = 2048 / S: relu(x lin1[w s .. +w-1]^T + b1) lin2[:, w s .. +w-1]^T -> partials [P,S,6,256].
  * wg_dec_heads_f32: output_hypernetworks_mlps[i](x[:, 1 + i]) -> hyper_out [P,4,32]; iou_prediction_head(x[:, 0]) -> iou_out [P,4];
  *   weights: 30 bf16 pointers = (hypernetwork 0..3, IoU head) x layers[0..2] x (weight, bias).
  * Both take an optional `combine` table of 5 pointers {attention partials, out_proj weight [256,128], out_proj bias, LayerNorm gamma, beta}:
