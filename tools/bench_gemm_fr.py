@@ -1,4 +1,4 @@
-"""Free-running persistent GEMM (tile 17, csrc/gemm_fr.hip) against the ping-pong persistent kernel (tile 16): bit-exactness, then timing on the hot-path shapes."""
+"""Free-running persistent GEMM (tile 17, tools/micro/gemm_fr.hip; needs a -DWG_GEMM_FR build: tools/build_variant.py fr -DWG_GEMM_FR, WG_LIB=walkgpt_amd/_abl/lib_fr.so) against the ping-pong persistent kernel (tile 16): bit-exactness, then timing on the hot-path shapes."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,4 @@
-"""Where a slab of the free-running persistent GEMM (csrc/gemm_fr.hip) goes: needs a library built with -DWG_GEMM_STAMP
+"""Where a slab of the free-running persistent GEMM (tools/micro/gemm_fr.hip) goes: needs a library built with -DWG_GEMM_FR -DWG_GEMM_STAMP
 (python tools/build_variant.py gstamp -DWG_GEMM_STAMP), run with WG_LIB=walkgpt_amd/_abl/lib_gstamp.so."""
 import sys, os, ctypes, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
