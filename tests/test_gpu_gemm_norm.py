@@ -35,7 +35,7 @@ def test_gemm_exact_integer_asymmetric(dev, tile):
                                         (77, 256, 256, 1), (1, 512, 4096, 1), (1000, 2304, 768, 0),
                                         (8200, 3072, 1024, 14), (4096, 768, 3072, 14), (300, 512, 64, 14), (700, 256, 128, 14),
                                         (5000, 1024, 192, 11), (8200, 3072, 1024, 16), (4096, 768, 3072, 16), (300, 512, 64, 16),
-                                        (33000, 1280, 256, 16)])
+                                        (33000, 1280, 256, 16), (66000, 512, 128, 16)])      # (the last two: several tiles per workgroup at 4 and at 2 slabs)
 @pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_GELU, ops.ACT_QUICK_GELU, ops.ACT_RELU])
 def test_gemm_epilogues(dev, M, N, K, tile, act):
     g = torch.Generator().manual_seed(M + N + K + act)

@@ -1347,23 +1347,37 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
         }
         WG_PSTAMP(1);
         if (grp == 1) __builtin_amdgcn_s_barrier();
-        // One slab.  While it computes it requests (more) slab kt + 1 of this tile or -- last slab, seam -- slab 0 of the NEXT tile; the last slab of
-        // the workgroup's last tile (or of an odd nk) requests nothing.  pA / pW: scalar byte offsets of the requested slab's first rows (tile
-        // origin + k column); (sm0, sn0, skt): the same slab for the fp8 scale bytes.  Two straight instances, loop body and last slab, in
-        // sequence: an if / else between two instances is a control-flow merge of 128 accumulators, which this hipcc resolves with spills.
-        auto slab = [&](int kt, auto lastc, auto morec, const bool more_rt, unsigned pA, unsigned pW, int sm0, int sn0, int skt) __attribute__((always_inline)) {
+        // One slab = two clusters; each cluster an M half-phase (fragment reads + requests for later slabs, then the counted wait and the hand-over
+        // barrier) and its 64 MFMAs.  Requests of the seam flow (even nk; E(s) = the six "early" pieces of slab s: all of W and the A rows of the
+        // waves' first clusters, L(s) = the two "late" pieces: the A rows of their second clusters):
+        //     M(kt, first cluster):  L(kt + 1)            -- those rows of buffer (kt + 1) & 1 were last read in slab kt - 1's second cluster
+        //     M(kt, second cluster): E(kt + 2)            -- into the buffer slab kt itself sits in: W and the first clusters' A rows were read in
+        //                                                    M(kt, first cluster) by both groups, one barrier ago
+        // so every piece has a whole slab (~1.2 us) between request and first use.  Rounds 1-6 sent E(kt + 1) in M(kt, first) -- three quarters of the
+        // operand bytes with HALF a slab of lead, which is what the K >= 3072 shapes (A from beyond L2) paid 2800 instead of 2350 cycles per slab for.
+        // Slab 0 also sends E(1) (nothing could send it earlier: the previous tile's epilogue stages through buffer 1); past the tile's end the
+        // same slots carry the NEXT tile's slab 0 (E'(0) in slab nk - 2, L'(0) in slab nk - 1, both into buffer 0).  fp8: the slab's scale bytes
+        // S(kt + 1) go first in M(kt, first cluster) (their buffer is read in both clusters, so they keep the old timing).
+        // Queue, oldest first, at the wait that ends M(kt, first): .. L(kt) | E(kt+1) | [S] L(kt+1)  -> L(kt) is in at vmcnt(8) (fp8: 9);
+        // at the wait that ends M(kt, second): E(kt+1) | [S] L(kt+1) | E(kt+2)  -> E(kt+1) and S(kt+1) are in at vmcnt(8), or vmcnt(2) when no
+        // E(kt+2) was sent.  Slab 0's first wait needs nothing (the tile-start wait covered slab 0; the queue may still hold the previous tile's stores).
+        // Odd nk (tests only) keeps the flow of rounds 1-5: E(kt + 1) and L(kt + 1) both sent in slab kt, first slab sent behind the previous tile's loop.
+        // Straight instances in sequence (first slab, loop body, last slab): an if / else between two instances is a control-flow merge of 128
+        // accumulators, which this hipcc resolves with spills.
+        auto slab = [&](int kt, auto firstc, auto lastc, const bool more, unsigned lA, unsigned lW, unsigned eA, unsigned eW, int sm0, int sn0, int skt) __attribute__((always_inline)) {
             constexpr bool last = decltype(lastc)::value;
-            constexpr int MORE = decltype(morec)::value;      // 1: requests, 0: none (compile time: no branch around any request), 2: decided by more_rt
-            const bool more = MORE == 2 ? more_rt : MORE == 1;
+            const bool first = kt == 0;      // (last: nk >= 2)
+            // SEAM: `more` = E is sent in the second cluster (first / loop instances; L always is) | the next tile's L'(0) is sent (last instance)
+            // !SEAM: `more` = slab kt + 1 exists (eA / eW its k offset)
             const char* ldsA = smem + (kt & 1) * STAGE;
             const char* ldsW = ldsA + BM * ROWB;
             const int pst = (kt + 1) & 1;
 #pragma unroll
             for (int sc = 0; sc < 2; ++sc) {
-                // M half-phase: the fragment reads of this cluster with the requests for the next slab BETWEEN them, one request per two or three
-                // reads.  Requests issued back to back (round 6 first had them behind the reads with only scalar instructions in between, where
-                // rounds 1-5 had happened to keep a 64-bit vector add between any two) cost the K >= 3072 shapes 2-6 %: profiles/r06_gemm_phases.md.
-                // (An LDS-DMA write and an LDS read may alias as far as hipcc knows, so it keeps this order.)
+                // Requests sit BETWEEN the fragment reads, at most one per read: issued back to back (round 6 first had them behind the reads with only
+                // scalar instructions in between, where rounds 1-5 had happened to keep a 64-bit vector add between any two) they cost the
+                // K >= 3072 shapes 2-6 %: profiles/r06_gemm_phases.md.  (An LDS-DMA write and an LDS read may alias as far as hipcc knows, so it
+                // keeps this order.)
                 auto ra = [&](int i, int ks) __attribute__((always_inline)) {
                     const int r = wm * WTM + (4 * sc + i) * 16 + fr;
                     af[i][ks] = *(const bf16x8*)(ldsA + r * ROWB + (((ks * 4 + fq) ^ wg_swz<BK>(r)) << 4));
@@ -1380,27 +1394,45 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                         for (int q = 0; q < 4; ++q) { rw(q >> 1, q & 1, 0); rw(q >> 1, q & 1, 1); }
                     }
                     if (more) {
-                        if (sc == 0) { piece(pst, pA, pW, 0); piece(pst, pA, pW, 1); piece(pst, pA, pW, 2); }
-                        else piece(pst, pA, pW, 3);
+                        if (sc == 0) { piece(pst, eA, eW, 0); piece(pst, eA, eW, 1); piece(pst, eA, eW, 2); }
+                        else piece(pst, eA, eW, 3);
                     }
                 } else if (sc == 0) {
+                    const bool sendL = !last || more;
+                    if constexpr (FP8) {
+                        if (sendL) scale_piece(sm0, sn0, skt);
+                    }
                     ra(0, 0); ra(0, 1); ra(1, 0);
-                    if (more) piece(pst, pA, pW, 0, 0);
+                    if (first) piece(pst, lA, lW, 0, 0);         // (slab 0: E(1) rides here, in front of L(1); its k offset is L's)
                     ra(1, 1); ra(2, 0); ra(2, 1);
-                    if (more) piece(pst, pA, pW, 0, 1);
+                    if (first) piece(pst, lA, lW, 0, 1);
                     ra(3, 0); ra(3, 1);
-                    if (more) piece(pst, pA, pW, 1, 0);
-                    rw(0, 0, 0); rw(0, 0, 1); rw(0, 1, 0);
-                    if (more) piece(pst, pA, pW, 1, 1);
-                    rw(0, 1, 1); rw(1, 0, 0); rw(1, 0, 1);
-                    if (more) piece(pst, pA, pW, 2, 0);
+                    if (first) piece(pst, lA, lW, 1, 0);
+                    rw(0, 0, 0); rw(0, 0, 1);
+                    if (first) piece(pst, lA, lW, 1, 1);
+                    rw(0, 1, 0); rw(0, 1, 1);
+                    if (first) piece(pst, lA, lW, 2, 0);
+                    rw(1, 0, 0);
+                    if (first) piece(pst, lA, lW, 2, 1);
+                    rw(1, 0, 1);
+                    if (sendL) piece(pst, lA, 0, 3, 0);
                     rw(1, 1, 0); rw(1, 1, 1);
-                    if (more) piece(pst, pA, pW, 2, 1);
+                    if (sendL) piece(pst, lA, 0, 3, 1);
                 } else {
-                    ra(0, 0); ra(0, 1); ra(1, 0); ra(1, 1);
-                    if (more) piece(pst, pA, pW, 3, 0);
-                    ra(2, 0); ra(2, 1); ra(3, 0); ra(3, 1);
-                    if (more) piece(pst, pA, pW, 3, 1);
+                    const bool sendE = !last && more;
+                    const int est = kt & 1;      // E(kt + 2) goes into this slab's own buffer
+                    ra(0, 0);
+                    if (sendE) piece(est, eA, eW, 0, 0);
+                    ra(0, 1);
+                    if (sendE) piece(est, eA, eW, 0, 1);
+                    ra(1, 0);
+                    if (sendE) piece(est, eA, eW, 1, 0);
+                    ra(1, 1);
+                    if (sendE) piece(est, eA, eW, 1, 1);
+                    ra(2, 0); ra(2, 1);
+                    if (sendE) piece(est, eA, eW, 2, 0);
+                    ra(3, 0); ra(3, 1);
+                    if (sendE) piece(est, eA, eW, 2, 1);
                 }
                 if constexpr (FP8) {
                     const char* mxs = mxbuf + (kt & 1) * 2048;
@@ -1408,10 +1440,25 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                     sb = *(const unsigned*)(mxs + (ol >> 4) * 256 + wm * WTM + (ol & 15) * 8 + 4 * sc);
                     if (sc == 0) {
                         swc = *(const unsigned*)(mxs + 1024 + (ol >> 4) * 256 + wn * WTN + (ol & 15) * 4);
-                        if (more) scale_piece(sm0, sn0, skt);
+                        if constexpr (!SEAM) {
+                            if (more) scale_piece(sm0, sn0, skt);
+                        }
                     }
                 }
-                if (sc == 0) {
+                if constexpr (SEAM) {
+                    if (sc == 0) {
+                        if (first) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        else if (last && !more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        else if (FP8) asm volatile("s_waitcnt vmcnt(9) lgkmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                    } else {
+                        if (last) {
+                            if (more) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (seam: nothing of THIS tile is outstanding any more)
+                            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                        } else if (more) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+                        else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                    }
+                } else if (sc == 0) {
                     // late A rows of this slab must be in.  In slab 0 they are (first-slab wait above) and the queue may still hold
                     // the previous tile's stores in front of the six pieces just sent: do not wait for those here.
                     if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1420,7 +1467,6 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
                     else asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
                 } else {
                     if (!more) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                    else if (last) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (seam: nothing of THIS tile is outstanding any more)
                     else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -1468,19 +1514,22 @@ __global__ __launch_bounds__(512, 2) void wg_gemm_pp_persist_kernel(GemmArgs g) 
             }
         };
         {
-            using I1_ = std::integral_constant<int, 1>;
-            using I2_ = std::integral_constant<int, 2>;
+            using T_ = std::true_type;
+            using F_ = std::false_type;
             if constexpr (SEAM) {
-                unsigned pA = (unsigned)m0 * (unsigned)g.lda * 2u, pW = (unsigned)n0 * (unsigned)g.ldw * 2u;
+                // (one call per instance, their arguments chosen by selects: a branch around an instance is the merge described above)
+                const unsigned nA = (unsigned)m0n * (unsigned)g.lda * 2u, nW = (unsigned)n0n * (unsigned)g.ldw * 2u;      // the next tile's slab 0
+                unsigned pA = (unsigned)m0 * (unsigned)g.lda * 2u + BK * 2, pW = (unsigned)n0 * (unsigned)g.ldw * 2u + BK * 2;      // slab kt + 1
                 int kt = 0;
                 for (; kt + 1 < nk; ++kt) {
+                    const bool inner = kt + 2 < nk;
+                    slab(kt, F_{}, F_{}, inner || seam, pA, pW, inner ? pA + BK * 2 : nA, inner ? pW + BK * 2 : nW, m0, n0, kt + 1);
                     pA += BK * 2;
                     pW += BK * 2;
-                    slab(kt, std::false_type{}, I1_{}, true, pA, pW, m0, n0, kt + 1);
                 }
-                slab(kt, std::true_type{}, I2_{}, seam, (unsigned)m0n * (unsigned)g.lda * 2u, (unsigned)n0n * (unsigned)g.ldw * 2u, m0n, n0n, 0);
+                slab(kt, F_{}, T_{}, seam, nA, nW, 0, 0, m0n, n0n, 0);
             } else {
-                for (int kt = 0; kt < nk; ++kt) slab(kt, std::false_type{}, I2_{}, kt + 1 < nk, (unsigned)(kt + 1) * BK, (unsigned)(kt + 1) * BK, m0, n0, kt + 1);
+                for (int kt = 0; kt < nk; ++kt) slab(kt, F_{}, F_{}, kt + 1 < nk, 0, 0, (unsigned)(kt + 1) * BK, (unsigned)(kt + 1) * BK, m0, n0, kt + 1);
             }
         }
         if (!SEAM && grp == 0) __builtin_amdgcn_s_barrier();
