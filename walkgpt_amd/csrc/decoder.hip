@@ -398,7 +398,13 @@ extern "C" int wg_upscale_mask_bf16(const void* x, long ldx, const void* w1, con
 // =====================================================================================================================================
 namespace {
 
-constexpr int TK_THREADS = 512;
+// 1024 threads: the token kernels are chains of short phases on ONE compute unit (stage, weight pass, LDS arithmetic, LayerNorm); their weight passes
+// keep the same bytes in flight at 8 or 16 waves, but everything between the passes is per-thread serial work, and 16 waves halve it.  Round 6,
+// one-image decode 198.5 -> 185.3 us, B = 8: 286 -> 272, T = 14: 356 -> 343, B = 8 at T = 14 unchanged (notes/r06_experiments.md section 14).
+#ifndef WG_DEC_THREADS
+#define WG_DEC_THREADS 1024
+#endif
+constexpr int TK_THREADS = WG_DEC_THREADS;
 constexpr int TK_N = 6;          // tokens per prompt: iou + 4 mask tokens + 1 text prompt (mask_decoder.py:125-132)
 constexpr int TK_C = 256;        // transformer_dim
 constexpr int TK_HID = 2048;     // MLP width
