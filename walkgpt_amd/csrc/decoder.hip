@@ -506,7 +506,12 @@ __device__ void tok_mm(const TokJob (&jobs)[NJ], int rows) {
         const bf16* wpb = jq.W.w + (long)nb[1] * (K / 32) * 512 + lane * 8;
         const bf16* aha = ja.sh + arow * PITCH + 8 * kg, *ala = ja.sl + arow * PITCH + 8 * kg;
         const bf16* ahb = jq.sh + arow * PITCH + 8 * kg, *alb = jq.sl + arow * PITCH + 8 * kg;
-        f32x4 acc_a = {0.f, 0.f, 0.f, 0.f}, acc_b = {0.f, 0.f, 0.f, 0.f};
+        // The columns' bias values travel WITH the weight fragments: requested in front of them, no branch (a missing bias reads a weight word and
+        // is dropped by a select), and they are what the accumulators start from -- so the first MFMA's wait covers them.  Added behind the loop,
+        // hipcc sank the load to its use: one more dependent trip to L2 in every pass of every token kernel (round 6).
+        const bf16 bra = *((ja.W.b ? ja.W.b : ja.W.w) + (n_a < ja.N ? n_a : 0)), brb = *((jq.W.b ? jq.W.b : jq.W.w) + (n_b < jq.N ? n_b : 0));
+        const float bias_a = ja.W.b ? (float)bra : 0.f, bias_b = jq.W.b ? (float)brb : 0.f;
+        f32x4 acc_a = {bias_a, bias_a, bias_a, bias_a}, acc_b = {bias_b, bias_b, bias_b, bias_b};
 #pragma unroll 8
         for (int ks = 0; ks < K / 32; ++ks) {
             const bf16x8 fa = *(const bf16x8*)(wpa + 512 * ks);
@@ -527,12 +532,11 @@ __device__ void tok_mm(const TokJob (&jobs)[NJ], int rows) {
             const int n = u == 0 ? n_a : n_b;
             const f32x4 acc = u == 0 ? acc_a : acc_b;
             if (n < jj.N) {
-                const float bias = jj.W.b ? (float)jj.W.b[n] : 0.f;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int r = 4 * kg + i;
                     if (r < rows) {
-                        float v = acc[i] + bias;
+                        float v = acc[i];
                         if (jj.act == WG_ACT_RELU) v = fmaxf(v, 0.f);
                         if (jj.res) v += jj.res[r * jj.ldres + n];
                         jj.y[r * jj.ldy + n] = v;
@@ -554,9 +558,22 @@ __device__ void tok_linear(const float* x, int ldx, int rows, LinW W, int N, flo
     tok_mm<K, 1, THREADS>(job, rows);
 }
 
-// LayerNorm over the last dimension (256) of `rows` LDS rows, in place; one wave per row.
+// LayerNorm over the last dimension (256) of `rows` LDS rows, in place; one wave per row.  Its gamma / beta come from memory: tok_ln_load requests
+// them EARLY -- in front of the Linear whose output the LayerNorm reads (a barrier inside keeps the loads there) -- so that the trip to L2 passes
+// under that Linear's weight pass instead of standing alone behind it (round 6: every token kernel is a chain of such trips).
+struct LnRegs { float g[4], b[4]; };
+__device__ __forceinline__ LnRegs tok_ln_load(NormW nw) {
+    const int lane = threadIdx.x & 63;
+    LnRegs r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        r.g[j] = (float)nw.g[lane + 64 * j];
+        r.b[j] = (float)nw.b[lane + 64 * j];
+    }
+    return r;
+}
 template <int THREADS = TK_THREADS>
-__device__ void tok_layernorm(float* x, int rows, NormW nw, float eps) {
+__device__ void tok_layernorm(float* x, int rows, const LnRegs& p, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int r = wave; r < rows; r += THREADS / 64) {
         float v[4], s = 0.f;
@@ -574,9 +591,13 @@ __device__ void tok_layernorm(float* x, int rows, NormW nw, float eps) {
         }
         const float rstd = 1.0f / sqrtf(wg_wave_sum(sq) * (1.0f / TK_C) + eps);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[r * TK_C + lane + 64 * j] = v[j] * rstd * (float)nw.g[lane + 64 * j] + (float)nw.b[lane + 64 * j];
+        for (int j = 0; j < 4; ++j) x[r * TK_C + lane + 64 * j] = v[j] * rstd * p.g[j] + p.b[j];
     }
     __syncthreads();
+}
+template <int THREADS = TK_THREADS>
+__device__ void tok_layernorm(float* x, int rows, NormW nw, float eps) {
+    tok_layernorm<THREADS>(x, rows, tok_ln_load(nw), eps);
 }
 
 // softmax(q k^T / sqrt(32)) v over the six tokens themselves: q, k, v [6][256] LDS fp32 (8 heads x 32) -> o [6][256]
@@ -646,8 +667,9 @@ __device__ void tok_combine(const CombineW& c, long p, int row0, int rows, float
         ao[r * 128 + h * 16 + d] = o / L;
     }
     __syncthreads();
+    const LnRegs ln = tok_ln_load(c.nw);
     tok_linear<128, THREADS>(ao, 128, rows, c.wo, TK_C, x, TK_C, 0, x, TK_C, sh, sl);
-    tok_layernorm<THREADS>(x, rows, c.nw, c.eps);
+    tok_layernorm<THREADS>(x, rows, ln, c.eps);
 }
 
 __global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
@@ -656,6 +678,8 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
     const int p = blockIdx.x;
     const int tid = threadIdx.x;
     const bool tail = (a.stages & ST_INIT) && a.tail_g;
+    LnRegs ln3 = {};
+    if (a.stages & ST_SUM_MLP) ln3 = tok_ln_load(a.norm3);      // (with the loads of the token rows and the MLP partials below, not behind them)
     if (tail) {                           // the text projector's tail on this prompt's row: one launch (4.6 us of a decode) less
         if (tid < 64) {
             float v[8];
@@ -693,7 +717,7 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
     const bool self_in_sum = sum && self, q_in_sum = sum && !self && q_t2i;
     if (sum) {
         // ---- norm3, then k / v of the image -> token attention (:172-178) ------------------------------------------------------------------
-        tok_layernorm(qs, TK_N, a.norm3, a.eps);
+        tok_layernorm(qs, TK_N, ln3, a.eps);
         tok_stage<TK_C>(qs, TK_C, pes, TK_N, sh[0], sl[0]);
         tok_stage<TK_C>(qs, TK_C, nullptr, TK_N, sh[1], sl[1]);
         __syncthreads();
@@ -733,8 +757,9 @@ __global__ __launch_bounds__(TK_THREADS) void wg_dec_tokens_kernel(TokArgs a) {
             tok_mm<TK_C, 3>(qkv, TK_N);
         }
         tok_self_attention(t0, t1, t2, t3);
+        const LnRegs ln1 = tok_ln_load(a.norm1);
         tok_linear<TK_C>(t3, TK_C, TK_N, a.self_attn.o, TK_C, qs, TK_C, 0, a.skip_pe ? nullptr : qs, TK_C, sh[0], sl[0]);
-        tok_layernorm(qs, TK_N, a.norm1, a.eps);
+        tok_layernorm(qs, TK_N, ln1, a.eps);
     }
     if (q_t2i && !q_in_sum) {
         // ---- q of the token -> image attention (:162-165; tail: :96-101), internal width 128 ------------------------------------------------
