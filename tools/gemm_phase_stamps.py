@@ -35,6 +35,9 @@ shapes = [("SAM qkv (LN fold)", 32768, 2304, 768, "ln"), ("SAM lin1 (LN fold + G
           ("CLIP q,k,v (LN fold)", 8200, 3072, 1024, "ln"), ("CLIP fc1 (LN fold + quick-GELU)", 8200, 4096, 1024, "ln_qgelu"),
           ("CLIP out_proj (+ residual, row sums)", 8200, 1024, 1024, "res"), ("CLIP fc2 (+ residual, row sums)", 8200, 1024, 4096, "res"),
           ("8192^3 (bias only)", 8192, 8192, 8192, "bias")]
+if "--vit-h" in sys.argv:      # config C3 / C5's SAM ViT-H at bs = 32 (131 072 token rows)
+    shapes = [("ViT-H qkv (LN fold)", 131072, 3840, 1280, "ln"), ("ViT-H lin1 (LN fold + GELU)", 131072, 5120, 1280, "ln_gelu"),
+              ("ViT-H proj (+ residual, row sums)", 131072, 1280, 1280, "res"), ("ViT-H lin2 (+ residual, row sums)", 131072, 1280, 5120, "res")]
 print("# Persistent 256 x 256 GEMM: phases of a tile's life and operand fetch per shape (round 4)\n")
 print("`tools/gemm_phase_stamps.py` on a `-DWG_GEMM_STAMP` build: `s_memtime` sums over every tile of workgroups 0-31, waves 0 and 4 (the two halves of "
       "the ping-pong), in scalar registers; in-kernel clock = core cycles / 100 MHz ticks over the workgroup's life after >= 1 s of back-to-back "

@@ -1758,6 +1758,18 @@ static int launch_pp_persist(GemmArgs& g, hipStream_t st) {
         const long panel = 256L * g.K * 2, wbytes = (long)g.N * g.K * 2;
         const int cb = (int)((3L << 19) / (panel > 0 ? panel : 1));
         g.col_block = (wbytes > (3L << 20) && cb >= 2 && cb < g.tiles_n) ? cb : 0;
+        if (g.col_block && (long)g.M * g.K * 2 > (128L << 20)) {
+            // A (ViT-H at bs = 32: 335 MB) does not stay in the 256 MB Infinity Cache from one column block to the next, and its panels are 640 KiB:
+            // narrow blocks then make every XCD stream 16 row panels at a time, at different rows than its neighbours.  What measured best on those
+            // shapes (tools/bench_gemm_colblock.py, notes/r06_experiments.md section 16): blocks of 4-10 tile columns that are a whole number of XCD
+            // ranges (an XCD owns nwg / 8 consecutive tiles of the order: the XCDs then walk the SAME row panels at the same time, in different
+            // column blocks, and share them through the Infinity Cache) -- lin1 (20 tile columns): 5, -6.6 % -- and plain row-major when no such
+            // width exists (qkv, proj: -2 ... -3 % against blocks of 2).
+            const long nwg = (long)g.tiles_m * g.tiles_n;
+            g.col_block = 0;
+            for (int c = 4; c <= 10 && c < g.tiles_n; ++c)
+                if (((long)g.tiles_m * c * 8) % nwg == 0) { g.col_block = c; break; }
+        }
         static const char* force = getenv("WG_GEMM_COLBLOCK");      // experiments: tile order override (0 = row-major)
         if (force && *force) {
             g.col_block = atoi(force);
