@@ -53,6 +53,22 @@ def test_gemm_epilogues(dev, M, N, K, tile, act):
     assert err32 <= 2e-3, err32
 
 
+def test_gemm_tile_order_for_operands_larger_than_the_infinity_cache(dev):
+    """A > 128 MB with weights past 3 MB: the persistent kernel walks XCD-aligned column blocks (here 4 tile columns of 8) instead of the L2-sized ones;
+    a tile order is a permutation of the same tiles, so every order must give the same bits as the plain row-major one of a smaller row count."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 66000, 2048, 1024
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).to(torch.bfloat16).to(dev)
+    b = torch.randn(N, generator=g).to(torch.bfloat16).to(dev)
+    out = ops.linear(a, w, b, tile=16)
+    ref = a.float() @ w.float().t() + b.float()
+    assert (out.float() - ref).abs().max().item() <= 0.02 * max(1.0, ref.abs().max().item())
+    # rows 0 .. 32767 alone are 67 MB: the old rule (blocks of 3) -- same tiles, same arithmetic per tile
+    part = ops.linear(a[:32768], w, b, tile=16)
+    assert torch.equal(part, out[:32768])
+
+
 @pytest.mark.parametrize("M,N,K", [(8200, 1024, 1024), (129, 128, 64), (144, 256, 128), (263, 384, 192), (8200, 3072, 1024)])
 @pytest.mark.parametrize("act", [ops.ACT_NONE, ops.ACT_QUICK_GELU])
 def test_gemm_tail_absorbing_tiles(dev, M, N, K, act):
